@@ -1,0 +1,350 @@
+"""CPU ORACLE bindings -- TEST INFRASTRUCTURE ONLY.
+
+ctypes/numpy wrapper over ``oracle/_build/libpdx_oracle.so`` (built from ``pdx_oracle.c``,
+a plain-C restatement of the Arrow-CPU behaviour the reference forwards to; see the header
+of ``pdx_oracle.h``).  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this package.  The product (``pandasarrow_amd``) never does.
+
+Conventions: values are numpy arrays; ``valid`` is an optional numpy bool array (True =
+valid) that is packed LSB-first into an Arrow validity bitmap before the C call; ``offset``
+shifts both the values and the bitmap (Arrow slice semantics).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libpdx_oracle.so")
+
+ADD, SUB, MUL, DIV = 0, 1, 2, 3
+EQ, NE, LT, LE, GT, GE = 0, 1, 2, 3, 4, 5
+AND, OR = 0, 1
+AGG_SUM, AGG_MEAN, AGG_MIN, AGG_MAX, AGG_COUNT = 0, 1, 2, 3, 4
+OK, INVALID, INDEX_ERROR = 0, 1, 2
+ORIGIN_EPOCH, ORIGIN_START_DAY, ORIGIN_START, ORIGIN_END, ORIGIN_END_DAY, ORIGIN_CUSTOM = range(6)
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement (gcc).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "pdx_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(
+        os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "pdx_oracle.h"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_splitmix64.restype = C.c_uint64
+        _lib.orc_splitmix64.argtypes = [C.c_uint64]
+        for name in ("orc_count", "orc_filter_count", "orc_group_ids_i64", "orc_groupby_sum_mean_count",
+                     "orc_resample_group_info"):
+            getattr(_lib, name).restype = C.c_int64
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _i64(x):
+    return C.c_int64(int(x))
+
+
+def pack_bits(b, offset=0):
+    """bool array -> LSB-first bitmap whose bit ``offset`` is b[0]."""
+    if b is None:
+        return None
+    b = np.asarray(b, dtype=bool)
+    if offset:
+        b = np.concatenate([np.zeros(offset, dtype=bool), b])
+    out = np.packbits(b, bitorder="little")
+    return np.ascontiguousarray(np.concatenate([out, np.zeros(8, np.uint8)]))
+
+
+def unpack_bits(bits, n, offset=0):
+    return np.unpackbits(np.asarray(bits, dtype=np.uint8), bitorder="little")[offset:offset + n].astype(bool)
+
+
+def _shift(a, offset):
+    """values with ``offset`` junk elements in front (to exercise Arrow slice offsets)."""
+    a = np.ascontiguousarray(a)
+    if not offset:
+        return a
+    pad = np.full(offset, 77, dtype=a.dtype) if a.dtype.kind in "iu" else np.full(offset, 7.5, dtype=a.dtype)
+    return np.ascontiguousarray(np.concatenate([pad, a]))
+
+
+# ------------------------------------------------------------------ synthetic inputs
+def splitmix64(x):
+    return lib().orc_splitmix64(C.c_uint64(int(x) & 0xFFFFFFFFFFFFFFFF))
+
+
+def synth_keys(start, n, num_keys):
+    out = np.empty(n, np.int64)
+    lib().orc_synth_keys(_i64(start), _i64(n), _i64(num_keys), _p(out))
+    return out
+
+
+def synth_vals(start, n, seed_off=0):
+    out = np.empty(n, np.float64)
+    lib().orc_synth_vals(_i64(start), _i64(n), C.c_uint64(seed_off), _p(out))
+    return out
+
+
+def synth_ts(start, n, t0_ns, step_ns):
+    out = np.empty(n, np.int64)
+    lib().orc_synth_ts(_i64(start), _i64(n), _i64(t0_ns), _i64(step_ns), _p(out))
+    return out
+
+
+# ------------------------------------------------------------------ aggregates
+def _is_float(a):
+    return np.asarray(a).dtype == np.float64
+
+
+def agg(kind, v, valid=None, offset=0):
+    """Whole-array aggregate.  Returns (value, count); value is None when Arrow returns null."""
+    v = np.asarray(v)
+    n = len(v)
+    vs = _shift(v.astype(np.float64 if _is_float(v) else np.int64), offset)
+    vb = pack_bits(valid, offset)
+    cnt = C.c_int64(0)
+    L = lib()
+    if kind == AGG_COUNT:
+        return int(L.orc_count(_p(vb), _i64(offset), _i64(n))), None
+    if _is_float(v):
+        if kind in (AGG_SUM, AGG_MEAN):
+            out = C.c_double(0)
+            (L.orc_sum_f64 if kind == AGG_SUM else L.orc_mean_f64)(_p(vs), _p(vb), _i64(offset), _i64(n), C.byref(out), C.byref(cnt))
+            return (out.value if cnt.value else None), cnt.value
+        mn, mx = C.c_double(0), C.c_double(0)
+        L.orc_minmax_f64(_p(vs), _p(vb), _i64(offset), _i64(n), C.byref(mn), C.byref(mx), C.byref(cnt))
+        return ((mn.value if kind == AGG_MIN else mx.value) if cnt.value else None), cnt.value
+    if kind == AGG_SUM:
+        out = C.c_int64(0)
+        L.orc_sum_i64(_p(vs), _p(vb), _i64(offset), _i64(n), C.byref(out), C.byref(cnt))
+        return (out.value if cnt.value else None), cnt.value
+    if kind == AGG_MEAN:
+        out = C.c_double(0)
+        L.orc_mean_i64(_p(vs), _p(vb), _i64(offset), _i64(n), C.byref(out), C.byref(cnt))
+        return (out.value if cnt.value else None), cnt.value
+    mn, mx = C.c_int64(0), C.c_int64(0)
+    L.orc_minmax_i64(_p(vs), _p(vb), _i64(offset), _i64(n), C.byref(mn), C.byref(mx), C.byref(cnt))
+    return ((mn.value if kind == AGG_MIN else mx.value) if cnt.value else None), cnt.value
+
+
+# ------------------------------------------------------------------ element-wise
+def _binary_like(fn_f64, fn_i64, op, a, b, va, vb, offset, out_dtype, bits):
+    a = np.asarray(a)
+    scalar = np.ndim(b) == 0
+    b = np.atleast_1d(np.asarray(b))
+    isf = a.dtype == np.float64 or b.dtype == np.float64  # implicit promotion int64 (+) double -> double
+    dt = np.float64 if isf else np.int64
+    n = len(a)
+    A = _shift(a.astype(dt), offset)
+    B = b.astype(dt) if scalar else _shift(b.astype(dt), offset)
+    VA = pack_bits(va, offset)
+    VB = pack_bits(vb, 0 if scalar else offset)
+    need_valid = va is not None or vb is not None
+    out_valid = np.zeros((n + 7) // 8 + 8, np.uint8) if need_valid else None
+    if bits:
+        out = np.zeros((n + 7) // 8 + 8, np.uint8)
+    else:
+        out = np.empty(n, dt if out_dtype is None else out_dtype)
+    rc = (fn_f64 if isf else fn_i64)(C.c_int(op), _p(A), _p(VA), _i64(offset), _p(B), _p(VB), _i64(0 if scalar else offset),
+                                     C.c_int(1 if scalar else 0), _i64(n), _p(out), _p(out_valid))
+    if rc == INVALID:
+        raise OracleError(INVALID, "divide by zero")
+    res = unpack_bits(out, n) if bits else out
+    return res, (unpack_bits(out_valid, n) if need_valid else None)
+
+
+def binary(op, a, b, va=None, vb=None, offset=0):
+    """a (op) b; b may be a python scalar.  Returns (values, valid|None)."""
+    L = lib()
+    return _binary_like(L.orc_binary_f64, L.orc_binary_i64, op, a, b, va, vb, offset, None, False)
+
+
+def compare(op, a, b, va=None, vb=None, offset=0):
+    L = lib()
+    return _binary_like(L.orc_compare_f64, L.orc_compare_i64, op, a, b, va, vb, offset, None, True)
+
+
+def logical(op, a, b, va=None, vb=None, offset=0):
+    n = len(a)
+    out = np.zeros((n + 7) // 8 + 8, np.uint8)
+    need_valid = va is not None or vb is not None
+    out_valid = np.zeros((n + 7) // 8 + 8, np.uint8) if need_valid else None
+    lib().orc_logical(C.c_int(op), _p(pack_bits(a, offset)), _p(pack_bits(va, offset)), _i64(offset), _p(pack_bits(b, offset)),
+                      _p(pack_bits(vb, offset)), _i64(offset), _i64(n), _p(out), _p(out_valid))
+    return unpack_bits(out, n), (unpack_bits(out_valid, n) if need_valid else None)
+
+
+def invert(a, offset=0):
+    n = len(a)
+    out = np.zeros((n + 7) // 8 + 8, np.uint8)
+    lib().orc_invert(_p(pack_bits(a, offset)), _i64(offset), _i64(n), _p(out))
+    return unpack_bits(out, n)
+
+
+# ------------------------------------------------------------------ filter / take
+def _as_u64(v):
+    v = np.ascontiguousarray(v)
+    assert v.dtype.itemsize == 8
+    return v.view(np.uint64)
+
+
+def filter(v, mask, valid=None, mask_valid=None, emit_null=True, offset=0):
+    """Returns (values, valid|None)."""
+    v = np.ascontiguousarray(v)
+    n = len(v)
+    L = lib()
+    mb, mv = pack_bits(mask, offset), pack_bits(mask_valid, offset)
+    m = int(L.orc_filter_count(_p(mb), _p(mv), _i64(offset), _i64(n), C.c_int(emit_null)))
+    out = np.zeros(m, np.uint64)
+    ov = np.zeros((m + 7) // 8 + 8, np.uint8)
+    nulls = C.c_int64(0)
+    L.orc_filter_64(_p(_shift(_as_u64(v), offset)), _p(pack_bits(valid, offset)), _i64(offset), _p(mb), _p(mv), _i64(offset),
+                    _i64(n), C.c_int(emit_null), _p(out), _p(ov), C.byref(nulls))
+    return out.view(v.dtype), (unpack_bits(ov, m) if (valid is not None or mask_valid is not None) else None)
+
+
+def take(v, idx, valid=None, idx_valid=None, offset=0):
+    v = np.ascontiguousarray(v)
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    n, m = len(v), len(idx)
+    out = np.zeros(m, np.uint64)
+    ov = np.zeros((m + 7) // 8 + 8, np.uint8)
+    nulls, bad = C.c_int64(0), C.c_int64(0)
+    rc = lib().orc_take_64(_p(_shift(_as_u64(v), offset)), _p(pack_bits(valid, offset)), _i64(offset), _i64(n), _p(idx),
+                           _p(pack_bits(idx_valid)), _i64(0), _i64(m), _p(out), _p(ov), C.byref(nulls), C.byref(bad))
+    if rc == INDEX_ERROR:
+        raise OracleError(INDEX_ERROR, f"Index {bad.value} out of bounds")
+    return out.view(v.dtype), (unpack_bits(ov, m) if (valid is not None or idx_valid is not None) else None)
+
+
+# ------------------------------------------------------------------ group-by
+def group_ids(keys, valid=None, offset=0):
+    """Returns (ids uint32[n], uniques int64[G], unique_is_null bool[G], first_row int64[G])."""
+    keys = np.asarray(keys, dtype=np.int64)
+    n = len(keys)
+    ids = np.zeros(n, np.uint32)
+    uniq = np.zeros(max(n, 1), np.int64)
+    isnull = np.zeros(max(n, 1), np.uint8)
+    first = np.zeros(max(n, 1), np.int64)
+    G = int(lib().orc_group_ids_i64(_p(_shift(keys, offset)), _p(pack_bits(valid, offset)), _i64(offset), _i64(n), _p(ids), _p(uniq),
+                                    _p(isnull), _p(first)))
+    return ids, uniq[:G].copy(), isnull[:G].astype(bool), first[:G].copy()
+
+
+def groupings(ids, G):
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    offsets = np.zeros(G + 1, np.int64)
+    rows = np.zeros(max(len(ids), 1), np.int64)
+    lib().orc_make_groupings(_p(ids), _i64(len(ids)), _i64(G), _p(offsets), _p(rows))
+    return offsets, rows[:len(ids)]
+
+
+def groupby_agg(kind, ids, G, v, valid=None, offset=0, nthreads=1):
+    """Per-group aggregate in group-id order.  Returns (values, valid bool[G])."""
+    v = np.asarray(v)
+    offsets, rows = groupings(ids, G)
+    out_f = np.zeros(max(G, 1), np.float64)
+    out_i = np.zeros(max(G, 1), np.int64)
+    ov = np.zeros(max(G, 1), np.uint8)
+    isf = v.dtype == np.float64
+    fn = lib().orc_groupby_agg_f64 if isf else lib().orc_groupby_agg_i64
+    vs = _shift(v.astype(np.float64 if isf else np.int64), offset)
+    fn(C.c_int(kind), _p(offsets), _p(rows), _i64(G), _p(vs), _p(pack_bits(valid, offset)), _i64(offset), _p(out_f), _p(out_i), _p(ov),
+       C.c_int(nthreads))
+    if kind == AGG_COUNT or (not isf and kind != AGG_MEAN):
+        return out_i[:G], ov[:G].astype(bool)
+    return out_f[:G], ov[:G].astype(bool)
+
+
+def groupby_sum_mean_count(keys, vals, nthreads=1):
+    keys = np.ascontiguousarray(keys, dtype=np.int64)
+    vals = np.ascontiguousarray(vals, dtype=np.float64)
+    n = len(keys)
+    ok = np.zeros(max(n, 1), np.int64)
+    os_ = np.zeros(max(n, 1), np.float64)
+    om = np.zeros(max(n, 1), np.float64)
+    oc = np.zeros(max(n, 1), np.int64)
+    G = int(lib().orc_groupby_sum_mean_count(_p(keys), _p(vals), _i64(n), _p(ok), _p(os_), _p(om), _p(oc), C.c_int(nthreads)))
+    return ok[:G], os_[:G], om[:G], oc[:G]
+
+
+# ------------------------------------------------------------------ resample
+def resample_group_info(ts, freq_ns, closed_right=False, label_right=False, origin=ORIGIN_START_DAY, origin_custom_ns=0,
+                        offset_ns=0):
+    """Returns (bins int64[nb], labels int64[nb])."""
+    ts = np.ascontiguousarray(ts, dtype=np.int64)
+    n = len(ts)
+    if n == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64)
+    cap = int((int(ts.max()) - int(ts.min())) // freq_ns + 4)
+    bins = np.zeros(cap, np.int64)
+    labels = np.zeros(cap, np.int64)
+    nb = int(lib().orc_resample_group_info(_p(ts), _i64(n), _i64(freq_ns), C.c_int(closed_right), C.c_int(label_right), C.c_int(origin),
+                                           _i64(origin_custom_ns), _i64(offset_ns), _p(bins), _p(labels), _i64(cap)))
+    if nb < 0:
+        raise OracleError(INVALID, {-1: "Invalid length for values or for binner", -2: "Values falls before first bin",
+                                    -3: "Values falls after last bin", -4: "cap", -5: "start date has to be less than end date"}[nb])
+    return bins[:nb].copy(), labels[:nb].copy()
+
+
+def resample_row_labels(ts, freq_ns, **kw):
+    bins, labels = resample_group_info(ts, freq_ns, **kw)
+    out = np.zeros(len(ts), np.int64)
+    if len(bins):
+        if bins[-1] < len(labels):
+            raise OracleError(INVALID, "upSampling is not implemented.")
+        lib().orc_resample_expand(_p(bins), _p(labels), _i64(len(bins)), _p(out))
+    return out
+
+
+def resample_agg(kind, ts, v, freq_ns, valid=None, **kw):
+    """Resampler::<agg> (src/group_by.h:249-299): group on per-row labels; empty bins vanish.
+    Returns (labels int64[G], values, valid bool[G])."""
+    row_labels = resample_row_labels(ts, freq_ns, **kw)
+    ids, uniq, _, _ = group_ids(row_labels)
+    vals, ok = groupby_agg(kind, ids, len(uniq), v, valid)
+    return uniq, vals, ok
+
+
+# ------------------------------------------------------------------ concat
+def concat(parts, valids=None):
+    """Row-concat of 8-byte columns.  Returns (values, valid|None)."""
+    parts = [np.ascontiguousarray(p) for p in parts]
+    k = len(parts)
+    total = sum(len(p) for p in parts)
+    dtype = parts[0].dtype if parts else np.dtype(np.float64)
+    u = [_as_u64(p) for p in parts]
+    vb = [None if (valids is None or valids[i] is None) else pack_bits(valids[i]) for i in range(k)]
+    pp = (C.c_void_p * max(k, 1))(*[x.ctypes.data for x in u])
+    pv = (C.c_void_p * max(k, 1))(*[(None if b is None else b.ctypes.data) for b in vb])
+    offs = np.zeros(max(k, 1), np.int64)
+    lens = np.array([len(p) for p in parts] + ([0] if not k else []), np.int64)
+    out = np.zeros(total, np.uint64)
+    ov = np.zeros((total + 7) // 8 + 8, np.uint8)
+    nulls = C.c_int64(0)
+    lib().orc_concat_64(pp, pv, _p(offs), _p(lens), C.c_int(k), _p(out), _p(ov), C.byref(nulls))
+    return out.view(dtype), (None if valids is None else unpack_bits(ov, total))

@@ -1,0 +1,630 @@
+/*
+ * pdx_oracle.c -- CPU ORACLE (test infrastructure only; see pdx_oracle.h).
+ *
+ * Plain-C restatement of the Arrow C++ 25.0.0 behaviour that EPOCHDevs/PandasArrow
+ * forwards to on its vectorized operator path.  Every function cites the reference
+ * call site it follows (file:line relative to /root/reference).  No code is copied
+ * from the reference or from Arrow: algorithms are restated from their observable
+ * behaviour and pinned by tests/golden/.
+ */
+#include "pdx_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static inline int bit_get(const uint8_t* bits, int64_t i) { return (bits[i >> 3] >> (i & 7)) & 1; }
+static inline void bit_set_to(uint8_t* bits, int64_t i, int v) {
+  if (v) bits[i >> 3] |= (uint8_t)(1u << (i & 7));
+  else bits[i >> 3] &= (uint8_t)~(1u << (i & 7));
+}
+static inline int is_valid(const uint8_t* valid, int64_t off, int64_t i) { return valid ? bit_get(valid, off + i) : 1; }
+
+/* ------------------------------------------------------------------ synthetic inputs */
+uint64_t orc_splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+/* key[i] = mix(i ^ 0x5EED0001) % num_keys   */
+void orc_synth_keys(int64_t start, int64_t n, int64_t num_keys, int64_t* out) {
+  for (int64_t k = 0; k < n; ++k) {
+    uint64_t i = (uint64_t)(start + k);
+    out[k] = (int64_t)(orc_splitmix64(i ^ 0x5EED0001ull) % (uint64_t)num_keys);
+  }
+}
+/* val[i] = (mix(i + 0x5EED0002 + seed_off) >> 11) * 2^-53 in [0,1) */
+void orc_synth_vals(int64_t start, int64_t n, uint64_t seed_off, double* out) {
+  for (int64_t k = 0; k < n; ++k) {
+    uint64_t i = (uint64_t)(start + k);
+    out[k] = (double)(orc_splitmix64(i + 0x5EED0002ull + seed_off) >> 11) * 0x1.0p-53;
+  }
+}
+void orc_synth_ts(int64_t start, int64_t n, int64_t t0_ns, int64_t step_ns, int64_t* out) {
+  for (int64_t k = 0; k < n; ++k) out[k] = t0_ns + (start + k) * step_ns;
+}
+
+/* ------------------------------------------------------------------ pairwise fp64 sum
+ * Reference call sites: NDFrame::sum (src/ndframe.cpp:220 via macro 26-31) and every
+ * per-group CallFunction("sum"/"mean") in src/pd_core_macros.h:31,66,103,132.
+ * Arrow's floating-point scalar `sum`: sequential 16-value leaves per run of valid
+ * values, binary-counter merge of leaf sums, final low->high fold. */
+typedef struct {
+  double sum[64];
+  uint64_t mask;
+  int root;
+} pw_state;
+
+static void pw_init(pw_state* s) {
+  for (int i = 0; i < 64; ++i) s->sum[i] = 0.0;
+  s->mask = 0;
+  s->root = 0;
+}
+static void pw_reduce(pw_state* s, double block) {
+  int cur = 0;
+  uint64_t m = 1;
+  s->sum[0] += block;
+  s->mask ^= m;
+  while ((s->mask & m) == 0) {
+    block = s->sum[cur];
+    s->sum[cur] = 0.0;
+    ++cur;
+    m <<= 1;
+    s->sum[cur] += block;
+    s->mask ^= m;
+  }
+  if (cur > s->root) s->root = cur;
+}
+static double pw_finish(pw_state* s) {
+  for (int i = 1; i <= s->root; ++i) s->sum[i] += s->sum[i - 1];
+  return s->sum[s->root];
+}
+/* feed one run of consecutive valid values */
+static void pw_run(pw_state* s, const double* v, int64_t len) {
+  int64_t blocks = len / 16, rem = len % 16;
+  for (int64_t b = 0; b < blocks; ++b) {
+    double acc = 0.0;
+    for (int j = 0; j < 16; ++j) acc += v[j];
+    pw_reduce(s, acc);
+    v += 16;
+  }
+  if (rem > 0) {
+    double acc = 0.0;
+    for (int64_t j = 0; j < rem; ++j) acc += v[j];
+    pw_reduce(s, acc);
+  }
+}
+
+int orc_sum_f64(const double* v, const uint8_t* valid, int64_t off, int64_t n, double* out, int64_t* count) {
+  pw_state s;
+  pw_init(&s);
+  int64_t cnt = 0;
+  if (!valid) {
+    cnt = n;
+    if (n > 0) pw_run(&s, v + off, n);
+  } else {
+    int64_t i = 0;
+    while (i < n) {
+      while (i < n && !bit_get(valid, off + i)) ++i;
+      int64_t st = i;
+      while (i < n && bit_get(valid, off + i)) ++i;
+      if (i > st) {
+        pw_run(&s, v + off + st, i - st);
+        cnt += i - st;
+      }
+    }
+  }
+  *count = cnt;
+  *out = cnt ? pw_finish(&s) : 0.0; /* min_count=1: count==0 -> null (caller checks count) */
+  return ORC_OK;
+}
+
+/* integer sum wraps (two's complement); int64 -> int64 */
+int orc_sum_i64(const int64_t* v, const uint8_t* valid, int64_t off, int64_t n, int64_t* out, int64_t* count) {
+  uint64_t acc = 0;
+  int64_t cnt = 0;
+  for (int64_t i = 0; i < n; ++i)
+    if (is_valid(valid, off, i)) {
+      acc += (uint64_t)v[off + i];
+      ++cnt;
+    }
+  *out = (int64_t)acc;
+  *count = cnt;
+  return ORC_OK;
+}
+/* mean = pairwise sum / count (NDFrame::mean src/ndframe.cpp:162) */
+int orc_mean_f64(const double* v, const uint8_t* valid, int64_t off, int64_t n, double* out, int64_t* count) {
+  double s;
+  orc_sum_f64(v, valid, off, n, &s, count);
+  *out = *count ? s / (double)*count : 0.0;
+  return ORC_OK;
+}
+/* integer mean (Arrow 25.0.0): values are converted to double one by one and summed with the SAME pairwise
+ * algorithm as fp64 (no int64 wrap-around), then divided by the valid count.  Pinned by tests/golden (agg_i64_*). */
+int orc_mean_i64(const int64_t* v, const uint8_t* valid, int64_t off, int64_t n, double* out, int64_t* count) {
+  double* d = (double*)malloc((size_t)(n ? n : 1) * sizeof(double));
+  for (int64_t i = 0; i < n; ++i) d[i] = (double)v[off + i];
+  /* validity bitmap is addressed with `off`, the converted values start at 0: shift by re-walking runs */
+  pw_state s;
+  pw_init(&s);
+  int64_t cnt = 0, i = 0;
+  while (i < n) {
+    while (i < n && !is_valid(valid, off, i)) ++i;
+    int64_t st = i;
+    while (i < n && is_valid(valid, off, i)) ++i;
+    if (i > st) {
+      pw_run(&s, d + st, i - st);
+      cnt += i - st;
+    }
+  }
+  free(d);
+  *count = cnt;
+  *out = cnt ? pw_finish(&s) / (double)cnt : 0.0;
+  return ORC_OK;
+}
+/* min/max: nulls skipped; NaN skipped unless every valid value is NaN; first value wins ties
+ * (NDFrame::min/max src/ndframe.cpp:163-166; MinMax in src/resample.cpp:223) */
+int orc_minmax_f64(const double* v, const uint8_t* valid, int64_t off, int64_t n, double* mn, double* mx, int64_t* count) {
+  int64_t cnt = 0;
+  int have = 0;
+  double lo = 0, hi = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (!is_valid(valid, off, i)) continue;
+    ++cnt;
+    double x = v[off + i];
+    if (x != x) continue;
+    if (!have) {
+      lo = hi = x;
+      have = 1;
+    } else {
+      if (x < lo) lo = x;
+      if (x > hi) hi = x;
+    }
+  }
+  *count = cnt;
+  if (cnt && !have) lo = hi = NAN;
+  *mn = lo;
+  *mx = hi;
+  return ORC_OK;
+}
+int orc_minmax_i64(const int64_t* v, const uint8_t* valid, int64_t off, int64_t n, int64_t* mn, int64_t* mx, int64_t* count) {
+  int64_t cnt = 0, lo = 0, hi = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (!is_valid(valid, off, i)) continue;
+    int64_t x = v[off + i];
+    if (!cnt) lo = hi = x;
+    else {
+      if (x < lo) lo = x;
+      if (x > hi) hi = x;
+    }
+    ++cnt;
+  }
+  *count = cnt;
+  *mn = lo;
+  *mx = hi;
+  return ORC_OK;
+}
+int64_t orc_count(const uint8_t* valid, int64_t off, int64_t n) {
+  if (!valid) return n;
+  int64_t c = 0;
+  for (int64_t i = 0; i < n; ++i) c += bit_get(valid, off + i);
+  return c;
+}
+
+/* ------------------------------------------------------------------ element-wise */
+void orc_validity_and(const uint8_t* va, int64_t aoff, const uint8_t* vb, int64_t boff, int64_t n, uint8_t* out_valid) {
+  if (!out_valid) return;
+  memset(out_valid, 0, (size_t)((n + 7) / 8));
+  for (int64_t i = 0; i < n; ++i) bit_set_to(out_valid, i, is_valid(va, aoff, i) && is_valid(vb, boff, i));
+}
+static void valid_and_scalar(const uint8_t* va, int64_t aoff, const uint8_t* vb, int64_t boff, int b_is_scalar, int64_t n,
+                             uint8_t* out_valid) {
+  if (!out_valid) return;
+  memset(out_valid, 0, (size_t)((n + 7) / 8));
+  for (int64_t i = 0; i < n; ++i)
+    bit_set_to(out_valid, i, is_valid(va, aoff, i) && (b_is_scalar ? is_valid(vb, boff, 0) : is_valid(vb, boff, i)));
+}
+
+/* Series::operator+,-,*,/ (src/series.cpp:19-33,229-235): "add/subtract/multiply/divide", null if either side null. */
+int orc_binary_f64(int op, const double* a, const uint8_t* va, int64_t aoff, const double* b, const uint8_t* vb, int64_t boff,
+                   int b_is_scalar, int64_t n, double* out, uint8_t* out_valid) {
+  for (int64_t i = 0; i < n; ++i) {
+    double x = a[aoff + i], y = b_is_scalar ? b[boff] : b[boff + i];
+    double r;
+    switch (op) {
+      case ORC_ADD: r = x + y; break;
+      case ORC_SUB: r = x - y; break;
+      case ORC_MUL: r = x * y; break;
+      case ORC_DIV: r = x / y; break; /* IEEE: 1/0=inf, 0/0=NaN */
+      default: return ORC_INVALID;
+    }
+    out[i] = r;
+  }
+  valid_and_scalar(va, aoff, vb, boff, b_is_scalar, n, out_valid);
+  return ORC_OK;
+}
+/* unchecked integer arithmetic: wraps; divide truncates toward zero, INT64_MIN/-1 -> 0,
+ * divisor 0 at a VALID slot -> ArrowInvalid "divide by zero" for the whole call */
+int orc_binary_i64(int op, const int64_t* a, const uint8_t* va, int64_t aoff, const int64_t* b, const uint8_t* vb, int64_t boff,
+                   int b_is_scalar, int64_t n, int64_t* out, uint8_t* out_valid) {
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t x = a[aoff + i], y = b_is_scalar ? b[boff] : b[boff + i];
+    int ok = is_valid(va, aoff, i) && (b_is_scalar ? is_valid(vb, boff, 0) : is_valid(vb, boff, i));
+    int64_t r;
+    switch (op) {
+      case ORC_ADD: r = (int64_t)((uint64_t)x + (uint64_t)y); break;
+      case ORC_SUB: r = (int64_t)((uint64_t)x - (uint64_t)y); break;
+      case ORC_MUL: r = (int64_t)((uint64_t)x * (uint64_t)y); break;
+      case ORC_DIV:
+        if (!ok) { r = 0; break; }
+        if (y == 0) return ORC_INVALID;
+        if (x == INT64_MIN && y == -1) r = 0;
+        else r = x / y;
+        break;
+      default: return ORC_INVALID;
+    }
+    out[i] = r;
+  }
+  valid_and_scalar(va, aoff, vb, boff, b_is_scalar, n, out_valid);
+  return ORC_OK;
+}
+
+#define CMP_BODY(T)                                                                          \
+  memset(out_bits, 0, (size_t)((n + 7) / 8));                                                \
+  for (int64_t i = 0; i < n; ++i) {                                                          \
+    T x = a[aoff + i], y = b_is_scalar ? b[boff] : b[boff + i];                              \
+    int r;                                                                                   \
+    switch (op) {                                                                            \
+      case ORC_EQ: r = x == y; break;                                                        \
+      case ORC_NE: r = x != y; break;                                                        \
+      case ORC_LT: r = x < y; break;                                                         \
+      case ORC_LE: r = x <= y; break;                                                        \
+      case ORC_GT: r = x > y; break;                                                         \
+      case ORC_GE: r = x >= y; break;                                                        \
+      default: return ORC_INVALID;                                                           \
+    }                                                                                        \
+    bit_set_to(out_bits, i, r);                                                              \
+  }                                                                                          \
+  valid_and_scalar(va, aoff, vb, boff, b_is_scalar, n, out_valid);                           \
+  return ORC_OK;
+
+/* Series::operator{>,>=,<,<=,==,!=} (src/series.cpp:247-257): bit-packed LSB-first; NaN false except != */
+int orc_compare_f64(int op, const double* a, const uint8_t* va, int64_t aoff, const double* b, const uint8_t* vb, int64_t boff,
+                    int b_is_scalar, int64_t n, uint8_t* out_bits, uint8_t* out_valid) {
+  CMP_BODY(double)
+}
+int orc_compare_i64(int op, const int64_t* a, const uint8_t* va, int64_t aoff, const int64_t* b, const uint8_t* vb, int64_t boff,
+                    int b_is_scalar, int64_t n, uint8_t* out_bits, uint8_t* out_valid) {
+  CMP_BODY(int64_t)
+}
+/* "and"/"or" are the non-Kleene kernels (src/series.cpp:259-260): null if either side null */
+int orc_logical(int op, const uint8_t* a, const uint8_t* va, int64_t aoff, const uint8_t* b, const uint8_t* vb, int64_t boff,
+                int64_t n, uint8_t* out_bits, uint8_t* out_valid) {
+  memset(out_bits, 0, (size_t)((n + 7) / 8));
+  for (int64_t i = 0; i < n; ++i) {
+    int x = bit_get(a, aoff + i), y = bit_get(b, boff + i);
+    bit_set_to(out_bits, i, op == ORC_AND ? (x & y) : (x | y));
+  }
+  orc_validity_and(va, aoff, vb, boff, n, out_valid);
+  return ORC_OK;
+}
+void orc_invert(const uint8_t* a, int64_t aoff, int64_t n, uint8_t* out_bits) {
+  memset(out_bits, 0, (size_t)((n + 7) / 8));
+  for (int64_t i = 0; i < n; ++i) bit_set_to(out_bits, i, !bit_get(a, aoff + i));
+}
+
+/* ------------------------------------------------------------------ filter / take */
+/* DataFrame::where (src/dataframe.cpp:461-475): "filter" with EMIT_NULL; Series::where index uses DROP (src/series.cpp:130-144) */
+int64_t orc_filter_count(const uint8_t* mask, const uint8_t* mask_valid, int64_t moff, int64_t n, int emit_null) {
+  int64_t c = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    int mv = is_valid(mask_valid, moff, i);
+    if (mv ? bit_get(mask, moff + i) : emit_null) ++c;
+  }
+  return c;
+}
+int orc_filter_64(const uint64_t* v, const uint8_t* valid, int64_t off, const uint8_t* mask, const uint8_t* mask_valid,
+                  int64_t moff, int64_t n, int emit_null, uint64_t* out, uint8_t* out_valid, int64_t* out_nulls) {
+  int64_t o = 0, nulls = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    int mv = is_valid(mask_valid, moff, i);
+    if (mv) {
+      if (!bit_get(mask, moff + i)) continue;
+      int ok = is_valid(valid, off, i);
+      out[o] = ok ? v[off + i] : 0;
+      if (out_valid) bit_set_to(out_valid, o, ok);
+      nulls += !ok;
+      ++o;
+    } else if (emit_null) {
+      out[o] = 0;
+      if (out_valid) bit_set_to(out_valid, o, 0);
+      ++nulls;
+      ++o;
+    }
+  }
+  if (out_nulls) *out_nulls = nulls;
+  return ORC_OK;
+}
+/* DataFrame::take (src/dataframe.cpp:477-492): bounds-checked gather; null index -> null row */
+int orc_take_64(const uint64_t* v, const uint8_t* valid, int64_t off, int64_t n, const int64_t* idx, const uint8_t* idx_valid,
+                int64_t ioff, int64_t m, uint64_t* out, uint8_t* out_valid, int64_t* out_nulls, int64_t* bad_index) {
+  int64_t nulls = 0;
+  for (int64_t j = 0; j < m; ++j) {
+    if (!is_valid(idx_valid, ioff, j)) continue;
+    int64_t k = idx[ioff + j];
+    if (k < 0 || k >= n) {
+      if (bad_index) *bad_index = k;
+      return ORC_INDEX_ERROR;
+    }
+  }
+  for (int64_t j = 0; j < m; ++j) {
+    if (!is_valid(idx_valid, ioff, j)) {
+      out[j] = 0;
+      if (out_valid) bit_set_to(out_valid, j, 0);
+      ++nulls;
+      continue;
+    }
+    int64_t k = idx[ioff + j];
+    int ok = is_valid(valid, off, k);
+    out[j] = ok ? v[off + k] : 0;
+    if (out_valid) bit_set_to(out_valid, j, ok);
+    nulls += !ok;
+  }
+  if (out_nulls) *out_nulls = nulls;
+  return ORC_OK;
+}
+
+/* ------------------------------------------------------------------ group-by */
+/* GroupBy::makeGroups -> Grouper::Consume (src/dataframe.cpp:1580-1584): ids dense, first-occurrence order. */
+int64_t orc_group_ids_i64(const int64_t* keys, const uint8_t* valid, int64_t off, int64_t n, uint32_t* ids, int64_t* uniques,
+                          uint8_t* unique_is_null, int64_t* first_row) {
+  uint64_t cap = 16;
+  while (cap < (uint64_t)n * 2 + 2) cap <<= 1;
+  int64_t* slot_gid = (int64_t*)malloc(cap * sizeof(int64_t));
+  for (uint64_t i = 0; i < cap; ++i) slot_gid[i] = -1;
+  int64_t G = 0, null_gid = -1;
+  for (int64_t i = 0; i < n; ++i) {
+    if (!is_valid(valid, off, i)) {
+      if (null_gid < 0) {
+        null_gid = G;
+        uniques[G] = 0;
+        if (unique_is_null) unique_is_null[G] = 1;
+        if (first_row) first_row[G] = i;
+        ++G;
+      }
+      ids[i] = (uint32_t)null_gid;
+      continue;
+    }
+    int64_t k = keys[off + i];
+    uint64_t h = orc_splitmix64((uint64_t)k) & (cap - 1);
+    for (;;) {
+      int64_t g = slot_gid[h];
+      if (g < 0) {
+        slot_gid[h] = G;
+        uniques[G] = k;
+        if (unique_is_null) unique_is_null[G] = 0;
+        if (first_row) first_row[G] = i;
+        ids[i] = (uint32_t)G;
+        ++G;
+        break;
+      }
+      if (uniques[g] == k && !(unique_is_null && unique_is_null[g])) {
+        ids[i] = (uint32_t)g;
+        break;
+      }
+      h = (h + 1) & (cap - 1);
+    }
+  }
+  free(slot_gid);
+  return G;
+}
+/* Grouper::MakeGroupings (src/dataframe.cpp:1586-1588): row ids ascending within each group */
+void orc_make_groupings(const uint32_t* ids, int64_t n, int64_t G, int64_t* offsets, int64_t* rows) {
+  for (int64_t g = 0; g <= G; ++g) offsets[g] = 0;
+  for (int64_t i = 0; i < n; ++i) offsets[ids[i] + 1]++;
+  for (int64_t g = 0; g < G; ++g) offsets[g + 1] += offsets[g];
+  int64_t* cur = (int64_t*)malloc((size_t)(G + 1) * sizeof(int64_t));
+  memcpy(cur, offsets, (size_t)(G + 1) * sizeof(int64_t));
+  for (int64_t i = 0; i < n; ++i) rows[cur[ids[i]]++] = i;
+  free(cur);
+}
+
+/* GROUPBY_AGG / GROUPBY_NUMERIC_AGG (src/pd_core_macros.h:5-147): for every group, gather the group's rows
+ * (Grouper::ApplyGroupings, src/dataframe.cpp:1546) then CallFunction(kind) on that array. */
+int orc_groupby_agg_f64(int kind, const int64_t* offsets, const int64_t* rows, int64_t G, const double* v, const uint8_t* valid,
+                        int64_t off, double* out_f64, int64_t* out_i64, uint8_t* out_valid, int nthreads) {
+  (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+  for (int64_t g = 0; g < G; ++g) {
+    int64_t len = offsets[g + 1] - offsets[g];
+    double* gv = (double*)malloc((size_t)(len ? len : 1) * sizeof(double));
+    uint8_t* gb = valid ? (uint8_t*)calloc((size_t)(len / 8 + 1), 1) : NULL;
+    for (int64_t j = 0; j < len; ++j) {
+      int64_t r = rows[offsets[g] + j];
+      gv[j] = v[off + r];
+      if (gb) bit_set_to(gb, j, bit_get(valid, off + r));
+    }
+    int64_t cnt = 0;
+    double s = 0, lo = 0, hi = 0;
+    switch (kind) {
+      case ORC_AGG_SUM: orc_sum_f64(gv, gb, 0, len, &s, &cnt); out_f64[g] = s; break;
+      case ORC_AGG_MEAN: orc_mean_f64(gv, gb, 0, len, &s, &cnt); out_f64[g] = s; break;
+      case ORC_AGG_MIN: orc_minmax_f64(gv, gb, 0, len, &lo, &hi, &cnt); out_f64[g] = lo; break;
+      case ORC_AGG_MAX: orc_minmax_f64(gv, gb, 0, len, &lo, &hi, &cnt); out_f64[g] = hi; break;
+      case ORC_AGG_COUNT: cnt = orc_count(gb, 0, len); out_i64[g] = cnt; break;
+    }
+    if (out_valid) out_valid[g] = (kind == ORC_AGG_COUNT) ? 1 : (cnt > 0);
+    free(gv);
+    free(gb);
+  }
+  return ORC_OK;
+}
+int orc_groupby_agg_i64(int kind, const int64_t* offsets, const int64_t* rows, int64_t G, const int64_t* v, const uint8_t* valid,
+                        int64_t off, double* out_f64, int64_t* out_i64, uint8_t* out_valid, int nthreads) {
+  (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+  for (int64_t g = 0; g < G; ++g) {
+    int64_t len = offsets[g + 1] - offsets[g];
+    int64_t* gv = (int64_t*)malloc((size_t)(len ? len : 1) * sizeof(int64_t));
+    uint8_t* gb = valid ? (uint8_t*)calloc((size_t)(len / 8 + 1), 1) : NULL;
+    for (int64_t j = 0; j < len; ++j) {
+      int64_t r = rows[offsets[g] + j];
+      gv[j] = v[off + r];
+      if (gb) bit_set_to(gb, j, bit_get(valid, off + r));
+    }
+    int64_t cnt = 0, s = 0, lo = 0, hi = 0;
+    double m = 0;
+    switch (kind) {
+      case ORC_AGG_SUM: orc_sum_i64(gv, gb, 0, len, &s, &cnt); out_i64[g] = s; break;
+      case ORC_AGG_MEAN: orc_mean_i64(gv, gb, 0, len, &m, &cnt); out_f64[g] = m; break;
+      case ORC_AGG_MIN: orc_minmax_i64(gv, gb, 0, len, &lo, &hi, &cnt); out_i64[g] = lo; break;
+      case ORC_AGG_MAX: orc_minmax_i64(gv, gb, 0, len, &lo, &hi, &cnt); out_i64[g] = hi; break;
+      case ORC_AGG_COUNT: cnt = orc_count(gb, 0, len); out_i64[g] = cnt; break;
+    }
+    if (out_valid) out_valid[g] = (kind == ORC_AGG_COUNT) ? 1 : (cnt > 0);
+    free(gv);
+    free(gb);
+  }
+  return ORC_OK;
+}
+
+/* The reference's whole group-by call sequence for df.group_by("k").{sum,mean,count}("v"), no nulls:
+ *   Grouper::Consume -> MakeGroupings -> ApplyGroupings(index, key col, value col) (src/dataframe.cpp:1571-1600)
+ *   -> per group CallFunction("sum"), ("mean"), ("count") (src/pd_core_macros.h:5-147; TBB over groups = OpenMP here).
+ * It omits the reference's unordered_map<ScalarPtr,...> bookkeeping, so it flatters the reference. */
+int64_t orc_groupby_sum_mean_count(const int64_t* keys, const double* vals, int64_t n, int64_t* out_keys, double* out_sum,
+                                   double* out_mean, int64_t* out_count, int nthreads) {
+  uint32_t* ids = (uint32_t*)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
+  int64_t* uniq = (int64_t*)malloc((size_t)(n ? n : 1) * sizeof(int64_t));
+  int64_t G = orc_group_ids_i64(keys, NULL, 0, n, ids, uniq, NULL, NULL);
+  int64_t* offsets = (int64_t*)malloc((size_t)(G + 1) * sizeof(int64_t));
+  int64_t* rows = (int64_t*)malloc((size_t)(n ? n : 1) * sizeof(int64_t));
+  orc_make_groupings(ids, n, G, offsets, rows);
+  /* ApplyGroupings of the index (uint64 range), the key column and the value column: three gathers */
+  uint64_t* g_index = (uint64_t*)malloc((size_t)(n ? n : 1) * sizeof(uint64_t));
+  int64_t* g_keys = (int64_t*)malloc((size_t)(n ? n : 1) * sizeof(int64_t));
+  double* g_vals = (double*)malloc((size_t)(n ? n : 1) * sizeof(double));
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+  for (int64_t j = 0; j < n; ++j) {
+    int64_t r = rows[j];
+    g_index[j] = (uint64_t)r;
+    g_keys[j] = keys[r];
+    g_vals[j] = vals[r];
+  }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+  for (int64_t g = 0; g < G; ++g) {
+    int64_t len = offsets[g + 1] - offsets[g], c1, c2;
+    double s, m;
+    orc_sum_f64(g_vals + offsets[g], NULL, 0, len, &s, &c1);  /* sum   */
+    orc_mean_f64(g_vals + offsets[g], NULL, 0, len, &m, &c2); /* mean  */
+    out_sum[g] = s;
+    out_mean[g] = m;
+    out_count[g] = len; /* count */
+    out_keys[g] = uniq[g];
+  }
+  free(ids); free(uniq); free(offsets); free(rows); free(g_index); free(g_keys); free(g_vals);
+  return G;
+}
+
+/* ------------------------------------------------------------------ resample */
+static int64_t floor_div(int64_t a, int64_t b) {
+  int64_t q = a / b, r = a % b;
+  return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q;
+}
+#define NS_PER_DAY 86400000000000LL
+
+/* adjustDatesAnchored (src/resample.cpp:85-178), tz == "" path */
+int orc_adjust_dates_anchored(int64_t min_ns, int64_t max_ns, int64_t freq_ns, int closed_right, int origin_type,
+                              int64_t origin_custom_ns, int64_t offset_ns, int64_t* first_out, int64_t* last_out) {
+  int64_t first = min_ns, last = max_ns, origin = 0;
+  switch (origin_type) {
+    case ORC_ORIGIN_EPOCH: origin = 0; break;
+    case ORC_ORIGIN_START_DAY: origin = floor_div(first, NS_PER_DAY) * NS_PER_DAY; break;
+    case ORC_ORIGIN_START: origin = first; break;
+    case ORC_ORIGIN_END: origin = last; break;
+    case ORC_ORIGIN_END_DAY: origin = floor_div(last, NS_PER_DAY) * NS_PER_DAY; break;
+    default: origin = origin_custom_ns; break;
+  }
+  origin += offset_ns;
+  int64_t foffset = (first - origin) % freq_ns; /* C++ % : sign follows the dividend */
+  int64_t loffset = (last - origin) % freq_ns;
+  if (closed_right) {
+    if (foffset > 0) first -= foffset;
+    else first -= freq_ns;
+    if (loffset > 0) last += freq_ns - loffset;
+  } else {
+    if (foffset > 0) first -= foffset;
+    if (loffset > 0) last += freq_ns - loffset;
+    else last += freq_ns;
+  }
+  *first_out = first;
+  *last_out = last;
+  return ORC_OK;
+}
+
+/* makeGroupInfo for a fixed-duration rule (src/resample.cpp:202-295):
+ *   MinMax -> adjustDatesAnchored -> date_range edges (src/core.cpp:308-331) -> generate_bins_dt64 (src/resample.cpp:11-83)
+ *   -> label slicing (269-292). Requires sorted, null-free timestamps. Returns #bins, or -1 invalid length, -2 value before
+ *   first bin, -3 value after last bin, -4 cap too small, -5 start >= end. */
+int64_t orc_resample_group_info(const int64_t* ts, int64_t n, int64_t freq_ns, int closed_right, int label_right, int origin_type,
+                                int64_t origin_custom_ns, int64_t offset_ns, int64_t* bins, int64_t* labels, int64_t cap) {
+  if (n == 0) return 0;
+  int64_t mn = ts[0], mx = ts[0];
+  for (int64_t i = 1; i < n; ++i) {
+    if (ts[i] < mn) mn = ts[i];
+    if (ts[i] > mx) mx = ts[i];
+  }
+  int64_t first, last;
+  orc_adjust_dates_anchored(mn, mx, freq_ns, closed_right, origin_type, origin_custom_ns, offset_ns, &first, &last);
+  if (first >= last || freq_ns <= 0) return -5;
+  int64_t nedges = (last - first) / freq_ns + 1; /* edges first + k*freq <= last */
+  if (nedges - 1 > cap) return -4;
+  if (nedges <= 0) return -1;
+  if (ts[0] < first) return -2;
+  if (ts[n - 1] > first + (nedges - 1) * freq_ns) return -3;
+  int64_t j = 0, nb = nedges - 1;
+  for (int64_t i = 0; i < nb; ++i) {
+    int64_t r_bin = first + (i + 1) * freq_ns;
+    if (closed_right) while (j < n && ts[j] <= r_bin) ++j;
+    else while (j < n && ts[j] < r_bin) ++j;
+    bins[i] = j;
+  }
+  /* labels = edges, sliced by one when label_right; truncated to bins.size() */
+  for (int64_t i = 0; i < nb; ++i) labels[i] = first + (i + (label_right ? 1 : 0)) * freq_ns;
+  return nb;
+}
+/* GroupInfo::downsample (src/resample.h:19-43) */
+void orc_resample_expand(const int64_t* bins, const int64_t* labels, int64_t nb, int64_t* row_labels) {
+  int64_t last = 0;
+  for (int64_t b = 0; b < nb; ++b) {
+    for (int64_t i = last; i < bins[b]; ++i) row_labels[i] = labels[b];
+    last = bins[b];
+  }
+}
+
+/* ------------------------------------------------------------------ concat rows (src/concat.cpp:135-189) */
+void orc_concat_64(const uint64_t* const* parts, const uint8_t* const* valids, const int64_t* offs, const int64_t* lens,
+                   int nparts, uint64_t* out, uint8_t* out_valid, int64_t* out_nulls) {
+  int64_t o = 0, nulls = 0;
+  for (int p = 0; p < nparts; ++p) {
+    for (int64_t i = 0; i < lens[p]; ++i) {
+      int ok = valids && valids[p] ? bit_get(valids[p], offs[p] + i) : 1;
+      out[o] = parts[p][offs[p] + i];
+      if (out_valid) bit_set_to(out_valid, o, ok);
+      nulls += !ok;
+      ++o;
+    }
+  }
+  if (out_nulls) *out_nulls = nulls;
+}
