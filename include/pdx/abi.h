@@ -1,0 +1,196 @@
+/*
+ * pdx/abi.h -- C ABI of libpdx_hip.so: the MI355X (gfx950) execution backend that replaces the
+ * Arrow-CPU compute underneath PandasArrow's vectorized operator path.
+ *
+ * Drop-in boundary.  In the reference every numeric operation on this
+ * path is a forward to
+ *     arrow::compute::CallFunction("<kernel-name>", {Datum...}, FunctionOptions*)
+ * or to arrow::compute::Grouper::{Make,Consume,MakeGroupings,ApplyGroupings,GetUniques}.
+ * Each entry point below cites the reference call site(s) it replaces (file:line relative to the
+ * reference repository).  INTEGRATION.md shows the binding a maintainer adds at those sites.
+ *
+ * Conventions
+ *   - Columns are Arrow-layout raw buffers that live in DEVICE memory (HBM): a contiguous values
+ *     buffer plus an optional validity bitmap (1 bit/row, LSB first), both addressed with an element
+ *     `offset` exactly like a sliced arrow::ArrayData.  PDX_BOOL values are bit-packed.
+ *   - Inputs are borrowed and never mutated.  Outputs whose size is known up front are written into
+ *     caller-provided buffers (pdx_mut_column); data-dependent results (group-by, resample) live in
+ *     an opaque handle owned by the library until pdx_*_destroy.
+ *   - Every function returns a pdx_status.  No exception crosses this boundary; the C++ facade
+ *     (pandasarrow_amd/cpp) rethrows std::runtime_error(pdx_last_error()) the way the reference's
+ *     ReturnOrThrowOnFailure does (src/core.h:181-194).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are ordered on
+ *     that stream; entry points that return host-visible results (scalars, counts) synchronise it.
+ *   - Re-entrant: no global mutable state besides the per-device scratch pool (mutex protected).
+ */
+#ifndef PDX_ABI_H
+#define PDX_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDX_ABI_VERSION 1
+
+typedef enum pdx_status {
+  PDX_OK = 0,
+  PDX_INVALID = 1,      /* arrow::Status::Invalid: type/length mismatch, integer divide by zero, bad argument */
+  PDX_INDEX_ERROR = 2,  /* arrow::Status::IndexError: take index out of bounds */
+  PDX_OOM = 3,          /* device allocation failed */
+  PDX_DEVICE = 4,       /* HIP runtime error */
+  PDX_NOT_IMPLEMENTED = 5
+} pdx_status;
+
+typedef enum pdx_dtype {
+  PDX_INT64 = 0,
+  PDX_FLOAT64 = 1,
+  PDX_BOOL = 2,         /* bit-packed, LSB first */
+  PDX_UINT64 = 3,
+  PDX_TIMESTAMP_NS = 4  /* int64 nanoseconds since epoch */
+} pdx_dtype;
+
+/* immutable input column (mirrors the fields of arrow::ArrayData the kernels read) */
+typedef struct pdx_column {
+  int32_t dtype;        /* pdx_dtype */
+  int32_t reserved;
+  int64_t length;       /* rows */
+  int64_t offset;       /* element offset into values; bit offset into validity (and bool values) */
+  int64_t null_count;   /* 0 => validity may be NULL; -1 => unknown */
+  const void* validity; /* device pointer or NULL */
+  const void* values;   /* device pointer */
+} pdx_column;
+
+/* caller-allocated output column; offset is always 0.  validity may be NULL when the caller knows the
+ * result cannot contain nulls (then a would-be null is an error PDX_INVALID). */
+typedef struct pdx_mut_column {
+  int32_t dtype;
+  int32_t reserved;
+  int64_t length;       /* capacity in rows on input; rows written on output */
+  int64_t null_count;   /* written by the library (exact), -1 if not computed */
+  void* validity;       /* device pointer to (length+7)/8 bytes (+8 bytes slack), or NULL */
+  void* values;         /* device pointer */
+} pdx_mut_column;
+
+/* host-visible scalar result (arrow::Scalar analogue) */
+typedef struct pdx_scalar {
+  int32_t dtype;
+  int32_t is_valid;     /* 0 => null (e.g. sum of an empty / all-null array, min_count = 1) */
+  union {
+    int64_t i64;
+    uint64_t u64;
+    double f64;
+  } v;
+  int64_t count;        /* number of valid inputs that produced it */
+} pdx_scalar;
+
+typedef enum pdx_binary_op { PDX_ADD = 0, PDX_SUB = 1, PDX_MUL = 2, PDX_DIV = 3 } pdx_binary_op;
+typedef enum pdx_compare_op { PDX_EQ = 0, PDX_NE = 1, PDX_LT = 2, PDX_LE = 3, PDX_GT = 4, PDX_GE = 5 } pdx_compare_op;
+typedef enum pdx_logical_op { PDX_AND = 0, PDX_OR = 1 } pdx_logical_op;
+typedef enum pdx_agg_kind { PDX_AGG_SUM = 0, PDX_AGG_MEAN = 1, PDX_AGG_MIN = 2, PDX_AGG_MAX = 3, PDX_AGG_COUNT = 4 } pdx_agg_kind;
+typedef enum pdx_origin {
+  PDX_ORIGIN_EPOCH = 0, PDX_ORIGIN_START_DAY = 1, PDX_ORIGIN_START = 2, PDX_ORIGIN_END = 3, PDX_ORIGIN_END_DAY = 4, PDX_ORIGIN_CUSTOM = 5
+} pdx_origin;
+
+/* ---------------------------------------------------------------- runtime */
+int pdx_abi_version(void);
+/* Select the HIP device for the calling thread and create the scratch pool.  Idempotent. */
+int pdx_init(int device);
+int pdx_shutdown(void);
+/* Thread-local message of the last non-OK status returned on this thread ("" if none). */
+const char* pdx_last_error(void);
+/* Device memory helpers for callers that hand over HOST buffers (the reference builds everything from
+ * host std::vector / arrow builders; cudf precedent: src/cudf/cudf_utils.h:118-141). */
+int pdx_malloc(void** dptr, size_t bytes);
+int pdx_free(void* dptr);
+int pdx_to_device(void* dst_device, const void* src_host, size_t bytes, void* stream);
+int pdx_to_host(void* dst_host, const void* src_device, size_t bytes, void* stream);
+int pdx_stream_synchronize(void* stream);
+/* Release cached scratch memory back to the driver. */
+int pdx_trim_pool(void);
+
+/* ---------------------------------------------------------------- synthetic inputs
+ * Counter-based generators, bit-identical to oracle/pdx_oracle.c orc_synth_*; used by bench.py/tests. */
+int pdx_synth_keys(int64_t start, int64_t n, int64_t num_keys, int64_t* out, void* stream);
+int pdx_synth_vals(int64_t start, int64_t n, uint64_t seed_off, double* out, void* stream);
+int pdx_synth_ts(int64_t start, int64_t n, int64_t t0_ns, int64_t step_ns, int64_t* out, void* stream);
+
+/* ---------------------------------------------------------------- element-wise
+ * Replaces CallFunction("add"|"subtract"|"multiply"|"divide", {lhs, rhs}) at src/series.cpp:19-33 (macro
+ * BINARY_OPERATOR, instantiated 229-235), src/scalar.cpp:24-36 (Scalar rhs/lhs) and the DataFrame form
+ * src/dataframe.cpp:233-275.  a,b: PDX_INT64 or PDX_FLOAT64 (mixed => float64 result, like Arrow's implicit
+ * promotion).  b_is_scalar != 0: b has length 1 and is broadcast.  Integer arithmetic wraps; integer divide
+ * truncates toward zero, INT64_MIN / -1 == 0, a zero divisor at a valid slot fails the whole call with
+ * PDX_INVALID "divide by zero".  out null where either input is null. */
+int pdx_binary(int op, const pdx_column* a, const pdx_column* b, int b_is_scalar, pdx_mut_column* out, void* stream);
+/* Replaces CallFunction("equal"|"not_equal"|"less"|"less_equal"|"greater"|"greater_equal") at
+ * src/series.cpp:247-257.  out: PDX_BOOL (bit-packed). */
+int pdx_compare(int op, const pdx_column* a, const pdx_column* b, int b_is_scalar, pdx_mut_column* out, void* stream);
+/* Replaces CallFunction("and"|"or") (non-Kleene) at src/series.cpp:259-260 and "invert" at src/series.cpp:319. */
+int pdx_logical(int op, const pdx_column* a, const pdx_column* b, pdx_mut_column* out, void* stream);
+int pdx_invert(const pdx_column* a, pdx_mut_column* out, void* stream);
+
+/* ---------------------------------------------------------------- whole-array aggregates
+ * Replaces CallFunction("sum"|"mean"|"min"|"max"|"count", {array}, ScalarAggregateOptions{skip_nulls=true,
+ * min_count=1}) at src/ndframe.cpp:26-31 (macro), 119, 162-166, 220, and MinMax at src/resample.cpp:223.
+ * fp64 sum reproduces Arrow's pairwise tree bit-for-bit (16-value leaves per valid run, binary-counter merge).
+ * Synchronises `stream`. */
+int pdx_aggregate(int kind, const pdx_column* a, pdx_scalar* out, void* stream);
+
+/* ---------------------------------------------------------------- filter / take
+ * Replaces CallFunction("filter", {RecordBatch, mask}, FilterOptions{EMIT_NULL}) + CallFunction("array_filter",
+ * {index, mask}) at src/dataframe.cpp:461-475 and src/series.cpp:130-144.  mask: PDX_BOOL of the same length as
+ * every column (else PDX_INVALID).  Two calls: count (host-visible) then fill; the facade hides the pair. */
+int pdx_filter_count(const pdx_column* mask, int emit_null, int64_t* out_count, void* stream);
+int pdx_filter(const pdx_column* cols, int ncols, const pdx_column* mask, int emit_null, pdx_mut_column* outs, void* stream);
+/* Replaces CallFunction("take", {RecordBatch, indices}) + "array_take" at src/dataframe.cpp:477-492 and
+ * src/series.cpp:146-159.  indices: PDX_INT64.  Out-of-range index => PDX_INDEX_ERROR "Index k out of bounds". */
+int pdx_take(const pdx_column* cols, int ncols, const pdx_column* indices, pdx_mut_column* outs, void* stream);
+
+/* ---------------------------------------------------------------- group-by
+ * pdx_groupby_create replaces GroupBy::makeGroups (src/dataframe.cpp:1571-1600): Grouper::Make + Consume
+ * (dense group ids in FIRST-OCCURRENCE order, a null key is its own group) + GetUniques.  The reference's eager
+ * MakeGroupings/ApplyGroupings of every column (src/dataframe.cpp:1539-1569) is deferred to pdx_groupby_agg.
+ * key: PDX_INT64 / PDX_TIMESTAMP_NS / PDX_UINT64.  Limit: length < 2^32 rows per call. */
+typedef struct pdx_groupby pdx_groupby;
+int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out);
+int pdx_groupby_destroy(pdx_groupby* gb);
+int64_t pdx_groupby_num_groups(const pdx_groupby* gb);
+int64_t pdx_groupby_num_rows(const pdx_groupby* gb);
+/* uniqueKeys (GroupBy::unique(), src/group_by.h:52-55): G rows, first-occurrence order; validity marks the null key. */
+int pdx_groupby_unique_keys(const pdx_groupby* gb, pdx_mut_column* out, void* stream);
+/* Grouper::Consume output: uint32 group id per input row (out_ids: device pointer to num_rows uint32). */
+int pdx_groupby_group_ids(pdx_groupby* gb, uint32_t* out_ids, void* stream);
+/* first_row[g] = index of the first row of group g (device pointer to G int64) */
+int pdx_groupby_first_rows(const pdx_groupby* gb, int64_t* out_rows, void* stream);
+/* Replaces GROUPBY_AGG(sum|min|max) and GROUPBY_NUMERIC_AGG(mean|count) (src/pd_core_macros.h:5-147, instantiated
+ * src/dataframe.cpp:1512-1534): for every group, the scalar aggregate over the group's rows IN ROW ORDER.
+ * `kinds`/`outs` have nk entries and are all computed from one grouped pass over `values` (sum/mean/count of the
+ * headline query share one pass).  Output dtypes: SUM -> dtype of values (int64 wraps), MEAN -> FLOAT64, MIN/MAX ->
+ * dtype of values, COUNT -> INT64.  outs[k].length must be >= G.  A group with no valid value yields a null
+ * (validity required in that case) except COUNT. */
+int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds, int nk, pdx_mut_column* outs, void* stream);
+
+/* ---------------------------------------------------------------- resample
+ * Replaces pd::resample<> / makeGroupInfo / generate_bins_dt64 / GroupInfo::downsample + the Resampler's GroupBy on
+ * the per-row labels (src/resample.h:19-43,91-122; src/resample.cpp:11-83,85-178,202-295; src/core.cpp:308-331;
+ * src/group_by.h:255-299).  ts: sorted PDX_TIMESTAMP_NS without nulls.  The handle behaves like a pdx_groupby whose
+ * unique keys are the labels of the NON-EMPTY bins (empty bins vanish, as in the reference).
+ * Errors (PDX_INVALID): "Values falls before first bin", "Values falls after last bin",
+ * "upSampling is not implemented.", unsorted input. */
+int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right, int label_right, int origin_type,
+                        int64_t origin_custom_ns, int64_t offset_ns, void* stream, pdx_groupby** out);
+/* per-row labels (GroupInfo::downsample): device pointer to num_rows int64 */
+int pdx_resample_row_labels(pdx_groupby* gb, int64_t* out_labels, void* stream);
+
+/* ---------------------------------------------------------------- concat (rows)
+ * Replaces arrow::ConcatenateTables + CombineChunksToBatch at src/concat.cpp:152-154 for same-dtype parts
+ * (the all-gatherv merge of sharded results).  out->length must be >= sum of part lengths. */
+int pdx_concat(const pdx_column* parts, int nparts, pdx_mut_column* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDX_ABI_H */

@@ -1,0 +1,113 @@
+"""ctypes binding of the C ABI declared in include/pdx/abi.h (libpdx_hip.so).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is NO
+fallback: if the library is missing or a call fails, an exception is raised -- the product path never
+routes through the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpdx_hip.so")
+
+# enums (include/pdx/abi.h)
+OK, INVALID, INDEX_ERROR, OOM, DEVICE, NOT_IMPLEMENTED = range(6)
+INT64, FLOAT64, BOOL, UINT64, TIMESTAMP_NS = range(5)
+ADD, SUB, MUL, DIV = range(4)
+EQ, NE, LT, LE, GT, GE = range(6)
+AND, OR = range(2)
+AGG_SUM, AGG_MEAN, AGG_MIN, AGG_MAX, AGG_COUNT = range(5)
+ORIGIN_EPOCH, ORIGIN_START_DAY, ORIGIN_START, ORIGIN_END, ORIGIN_END_DAY, ORIGIN_CUSTOM = range(6)
+
+
+class PdxColumn(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("reserved", C.c_int32), ("length", C.c_int64), ("offset", C.c_int64),
+                ("null_count", C.c_int64), ("validity", C.c_void_p), ("values", C.c_void_p)]
+
+
+class PdxMutColumn(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("reserved", C.c_int32), ("length", C.c_int64), ("null_count", C.c_int64),
+                ("validity", C.c_void_p), ("values", C.c_void_p)]
+
+
+class _ScalarValue(C.Union):
+    _fields_ = [("i64", C.c_int64), ("u64", C.c_uint64), ("f64", C.c_double)]
+
+
+class PdxScalar(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("is_valid", C.c_int32), ("v", _ScalarValue), ("count", C.c_int64)]
+
+
+class PdxError(RuntimeError):
+    """Mirror of the reference's std::runtime_error(status.ToString()) (src/core.h:181-194)."""
+
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+# every symbol include/pdx/abi.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_COL = C.POINTER(PdxColumn)
+_MUT = C.POINTER(PdxMutColumn)
+ABI_SYMBOLS = {
+    "pdx_abi_version": (C.c_int, []),
+    "pdx_init": (C.c_int, [C.c_int]),
+    "pdx_shutdown": (C.c_int, []),
+    "pdx_last_error": (C.c_char_p, []),
+    "pdx_malloc": (C.c_int, [C.POINTER(_P), C.c_size_t]),
+    "pdx_free": (C.c_int, [_P]),
+    "pdx_to_device": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "pdx_to_host": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "pdx_stream_synchronize": (C.c_int, [_P]),
+    "pdx_trim_pool": (C.c_int, []),
+    "pdx_synth_keys": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, _P, _P]),
+    "pdx_synth_vals": (C.c_int, [C.c_int64, C.c_int64, C.c_uint64, _P, _P]),
+    "pdx_synth_ts": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
+    "pdx_binary": (C.c_int, [C.c_int, _COL, _COL, C.c_int, _MUT, _P]),
+    "pdx_compare": (C.c_int, [C.c_int, _COL, _COL, C.c_int, _MUT, _P]),
+    "pdx_logical": (C.c_int, [C.c_int, _COL, _COL, _MUT, _P]),
+    "pdx_invert": (C.c_int, [_COL, _MUT, _P]),
+    "pdx_aggregate": (C.c_int, [C.c_int, _COL, C.POINTER(PdxScalar), _P]),
+    "pdx_filter_count": (C.c_int, [_COL, C.c_int, C.POINTER(C.c_int64), _P]),
+    "pdx_filter": (C.c_int, [_COL, C.c_int, _COL, C.c_int, _MUT, _P]),
+    "pdx_take": (C.c_int, [_COL, C.c_int, _COL, _MUT, _P]),
+    "pdx_groupby_create": (C.c_int, [_COL, _P, C.POINTER(_P)]),
+    "pdx_groupby_destroy": (C.c_int, [_P]),
+    "pdx_groupby_num_groups": (C.c_int64, [_P]),
+    "pdx_groupby_num_rows": (C.c_int64, [_P]),
+    "pdx_groupby_unique_keys": (C.c_int, [_P, _MUT, _P]),
+    "pdx_groupby_group_ids": (C.c_int, [_P, _P, _P]),
+    "pdx_groupby_first_rows": (C.c_int, [_P, _P, _P]),
+    "pdx_groupby_agg": (C.c_int, [_P, _COL, C.POINTER(C.c_int), C.c_int, _MUT, _P]),
+    "pdx_resample_create": (C.c_int, [_COL, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _P, C.POINTER(_P)]),
+    "pdx_resample_row_labels": (C.c_int, [_P, _P, _P]),
+    "pdx_concat": (C.c_int, [_COL, C.c_int, _MUT, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libpdx_hip.so and bind every ABI symbol.  Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PdxError(DEVICE, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in ABI_SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != OK:
+        msg = load().pdx_last_error().decode("utf-8", "replace")
+        raise PdxError(status, msg)

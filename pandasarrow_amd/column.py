@@ -1,0 +1,349 @@
+"""Device-resident Arrow-layout columns and the thin Python calls into the C ABI.
+
+A ``Column`` owns torch CUDA tensors (PyTorch is used only for device memory and streams): a contiguous
+values buffer, an optional validity bitmap (1 bit/row, LSB first) and an element ``offset`` -- the fields
+of ``arrow::ArrayData`` the reference's kernels read (src/ndframe.h:140-157).  Every operation below is one
+call through ``libpdx_hip.so``; nothing is computed in Python/torch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+_TORCH_DT = {L.INT64: torch.int64, L.FLOAT64: torch.float64, L.UINT64: torch.int64, L.TIMESTAMP_NS: torch.int64, L.BOOL: torch.uint8}
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise L.PdxError(L.DEVICE, "no GPU visible: pandasarrow_amd runs on MI355X (gfx950) only; there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _bitmap_bytes(n):
+    return (n + 7) // 8 + 16  # slack so kernels may store whole 64-bit words
+
+
+def pack_bits_host(b, offset=0):
+    b = np.asarray(b, dtype=bool)
+    if offset:
+        b = np.concatenate([np.zeros(offset, bool), b])
+    bits = np.packbits(b, bitorder="little")
+    return np.concatenate([bits, np.zeros(16, np.uint8)])
+
+
+def unpack_bits_host(bits, n, offset=0):
+    return np.unpackbits(np.asarray(bits, np.uint8), bitorder="little")[offset:offset + n].astype(bool)
+
+
+class Column:
+    """One Arrow-layout column in HBM."""
+
+    __slots__ = ("dtype", "length", "offset", "values", "validity", "null_count")
+
+    def __init__(self, dtype, length, values, validity=None, offset=0, null_count=None):
+        self.dtype = dtype
+        self.length = int(length)
+        self.offset = int(offset)
+        self.values = values      # torch tensor (int64/float64, or uint8 bitmap for BOOL)
+        self.validity = validity  # torch uint8 bitmap or None
+        self.null_count = (0 if validity is None else -1) if null_count is None else int(null_count)
+
+    # ---- construction -------------------------------------------------------------------------------------
+    @staticmethod
+    def from_numpy(a, valid=None, dtype=None, offset=0):
+        """Host -> device.  ``offset`` prepends junk rows to exercise Arrow slice offsets."""
+        a = np.asarray(a)
+        dev = _device()
+        if dtype is None:
+            if a.dtype == np.bool_:
+                dtype = L.BOOL
+            elif a.dtype == np.float64:
+                dtype = L.FLOAT64
+            elif a.dtype == np.uint64:
+                dtype = L.UINT64
+            elif a.dtype.kind in "iu":
+                dtype = L.INT64
+            elif a.dtype.kind == "M":
+                dtype = L.TIMESTAMP_NS
+                a = a.astype("datetime64[ns]").astype(np.int64)
+            else:
+                raise L.PdxError(L.INVALID, f"unsupported numpy dtype {a.dtype}")
+        n = len(a)
+        if dtype == L.BOOL:
+            vals = torch.from_numpy(pack_bits_host(a.astype(bool), offset)).to(dev)
+        else:
+            host = a.astype(np.float64 if dtype == L.FLOAT64 else np.int64 if dtype != L.UINT64 else np.uint64)
+            if offset:
+                host = np.concatenate([np.full(offset, 77, host.dtype), host])
+            vals = torch.from_numpy(np.ascontiguousarray(host).view(np.float64 if dtype == L.FLOAT64 else np.int64).copy()).to(dev)
+        vbits = None
+        if valid is not None:
+            vbits = torch.from_numpy(pack_bits_host(valid, offset)).to(dev)
+        return Column(dtype, n, vals, vbits, offset)
+
+    @staticmethod
+    def empty(dtype, n, with_validity=False):
+        dev = _device()
+        if dtype == L.BOOL:
+            vals = torch.zeros(_bitmap_bytes(n), dtype=torch.uint8, device=dev)
+        else:
+            vals = torch.empty(max(n, 1), dtype=_TORCH_DT[dtype], device=dev)
+        vb = torch.zeros(_bitmap_bytes(n), dtype=torch.uint8, device=dev) if with_validity else None
+        return Column(dtype, n, vals, vb)
+
+    # ---- host views ---------------------------------------------------------------------------------------
+    def to_numpy(self):
+        """-> (values ndarray, valid bool ndarray | None)."""
+        torch.cuda.current_stream().synchronize()
+        if self.dtype == L.BOOL:
+            vals = unpack_bits_host(self.values.cpu().numpy(), self.length, self.offset)
+        else:
+            host = self.values[self.offset:self.offset + self.length].cpu().numpy()
+            vals = host.view(np.uint64) if self.dtype == L.UINT64 else host
+        valid = None
+        if self.validity is not None:
+            valid = unpack_bits_host(self.validity.cpu().numpy(), self.length, self.offset)
+        return vals, valid
+
+    # ---- ABI structs --------------------------------------------------------------------------------------
+    def c(self):
+        return L.PdxColumn(self.dtype, 0, self.length, self.offset, self.null_count,
+                           None if self.validity is None else self.validity.data_ptr(), self.values.data_ptr())
+
+    def mut(self):
+        return L.PdxMutColumn(self.dtype, 0, self.length, -1, None if self.validity is None else self.validity.data_ptr(),
+                              self.values.data_ptr())
+
+    def _adopt(self, m):
+        self.length = int(m.length)
+        self.null_count = int(m.null_count)
+        return self
+
+    def has_nulls(self):
+        return self.validity is not None and self.null_count != 0
+
+    def slice(self, start, length):
+        return Column(self.dtype, length, self.values, self.validity, self.offset + start, None if self.validity is not None else 0)
+
+
+def _scalar_column(x, like_float):
+    if isinstance(x, Column):
+        return x
+    if x is None:
+        return Column.from_numpy(np.zeros(1, np.float64 if like_float else np.int64), valid=np.zeros(1, bool))
+    if isinstance(x, (float, np.floating)):
+        return Column.from_numpy(np.array([x], np.float64))
+    return Column.from_numpy(np.array([x], np.int64))
+
+
+def _promoted(a, b):
+    return L.FLOAT64 if L.FLOAT64 in (a.dtype, b.dtype) else L.INT64
+
+
+# ---------------------------------------------------------------- element-wise
+def binary(op, a: Column, b, scalar=False) -> Column:
+    lib = L.load()
+    if not isinstance(b, Column):
+        b, scalar = _scalar_column(b, a.dtype == L.FLOAT64), True
+    out = Column.empty(_promoted(a, b), a.length, with_validity=a.has_nulls() or b.has_nulls())
+    ca, cb, m = a.c(), b.c(), out.mut()
+    L.check(lib.pdx_binary(op, C.byref(ca), C.byref(cb), int(scalar), C.byref(m), _stream()))
+    return out._adopt(m)
+
+
+def compare(op, a: Column, b, scalar=False) -> Column:
+    lib = L.load()
+    if not isinstance(b, Column):
+        b, scalar = _scalar_column(b, a.dtype == L.FLOAT64), True
+    out = Column.empty(L.BOOL, a.length, with_validity=a.has_nulls() or b.has_nulls())
+    ca, cb, m = a.c(), b.c(), out.mut()
+    L.check(lib.pdx_compare(op, C.byref(ca), C.byref(cb), int(scalar), C.byref(m), _stream()))
+    return out._adopt(m)
+
+
+def logical(op, a: Column, b: Column) -> Column:
+    lib = L.load()
+    out = Column.empty(L.BOOL, a.length, with_validity=a.has_nulls() or b.has_nulls())
+    ca, cb, m = a.c(), b.c(), out.mut()
+    L.check(lib.pdx_logical(op, C.byref(ca), C.byref(cb), C.byref(m), _stream()))
+    return out._adopt(m)
+
+
+def invert(a: Column) -> Column:
+    lib = L.load()
+    out = Column.empty(L.BOOL, a.length, with_validity=a.has_nulls())
+    ca, m = a.c(), out.mut()
+    L.check(lib.pdx_invert(C.byref(ca), C.byref(m), _stream()))
+    return out._adopt(m)
+
+
+# ---------------------------------------------------------------- aggregates
+def aggregate(kind, a: Column):
+    """-> (python value | None, count)."""
+    lib = L.load()
+    s = L.PdxScalar()
+    ca = a.c()
+    L.check(lib.pdx_aggregate(kind, C.byref(ca), C.byref(s), _stream()))
+    if not s.is_valid:
+        return None, int(s.count)
+    if s.dtype == L.FLOAT64:
+        return float(s.v.f64), int(s.count)
+    return int(s.v.i64), int(s.count)
+
+
+# ---------------------------------------------------------------- filter / take / concat
+def _col_array(cols):
+    arr = (L.PdxColumn * len(cols))(*[c.c() for c in cols])
+    return arr
+
+
+def _mut_array(cols):
+    return (L.PdxMutColumn * len(cols))(*[c.mut() for c in cols])
+
+
+def filter_count(mask: Column, emit_null=True) -> int:
+    lib = L.load()
+    out = C.c_int64(0)
+    cm = mask.c()
+    L.check(lib.pdx_filter_count(C.byref(cm), int(emit_null), C.byref(out), _stream()))
+    return int(out.value)
+
+
+def filter(cols, mask: Column, emit_null=True):
+    lib = L.load()
+    cm = mask.c()
+    if cols and cols[0].length != mask.length:  # same check the kernel would make, before sizing outputs
+        L.check(lib.pdx_filter(_col_array(cols), len(cols), C.byref(cm), int(emit_null), _mut_array(cols), _stream()))
+    m = filter_count(mask, emit_null)
+    nullable = mask.has_nulls() and emit_null
+    outs = [Column.empty(c.dtype, m, with_validity=c.has_nulls() or nullable) for c in cols]
+    marr = _mut_array(outs)
+    L.check(lib.pdx_filter(_col_array(cols), len(cols), C.byref(cm), int(emit_null), marr, _stream()))
+    return [o._adopt(marr[i]) for i, o in enumerate(outs)]
+
+
+def take(cols, idx: Column):
+    lib = L.load()
+    outs = [Column.empty(c.dtype, idx.length, with_validity=c.has_nulls() or idx.has_nulls()) for c in cols]
+    marr = _mut_array(outs)
+    ci = idx.c()
+    L.check(lib.pdx_take(_col_array(cols), len(cols), C.byref(ci), marr, _stream()))
+    return [o._adopt(marr[i]) for i, o in enumerate(outs)]
+
+
+def concat(parts) -> Column:
+    lib = L.load()
+    total = sum(p.length for p in parts)
+    out = Column.empty(parts[0].dtype, total, with_validity=any(p.has_nulls() for p in parts))
+    m = out.mut()
+    L.check(lib.pdx_concat(_col_array(parts), len(parts), C.byref(m), _stream()))
+    return out._adopt(m)
+
+
+# ---------------------------------------------------------------- group-by / resample handles
+_AGG_OUT_DT = {L.AGG_MEAN: lambda dt: L.FLOAT64, L.AGG_COUNT: lambda dt: L.INT64, L.AGG_SUM: lambda dt: dt, L.AGG_MIN: lambda dt: dt,
+               L.AGG_MAX: lambda dt: dt}
+
+
+class GroupByHandle:
+    """Owner of a pdx_groupby* (hash group-by or resample segments)."""
+
+    def __init__(self, handle, key_dtype, keep_alive=None):
+        self._h = handle
+        self.key_dtype = key_dtype
+        self._keep = keep_alive  # the resample handle reads the timestamp buffer lazily
+
+    @staticmethod
+    def create(key: Column):
+        lib = L.load()
+        h = C.c_void_p()
+        ck = key.c()
+        L.check(lib.pdx_groupby_create(C.byref(ck), _stream(), C.byref(h)))
+        return GroupByHandle(h, key.dtype)
+
+    @staticmethod
+    def resample(ts: Column, freq_ns, closed_right=False, label_right=False, origin=L.ORIGIN_START_DAY, origin_custom_ns=0, offset_ns=0):
+        lib = L.load()
+        h = C.c_void_p()
+        ct = ts.c()
+        L.check(lib.pdx_resample_create(C.byref(ct), int(freq_ns), int(closed_right), int(label_right), int(origin), int(origin_custom_ns),
+                                        int(offset_ns), _stream(), C.byref(h)))
+        return GroupByHandle(h, L.TIMESTAMP_NS, keep_alive=ts)
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            L.load().pdx_groupby_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_groups(self):
+        return int(L.load().pdx_groupby_num_groups(self._h))
+
+    @property
+    def num_rows(self):
+        return int(L.load().pdx_groupby_num_rows(self._h))
+
+    def unique_keys(self) -> Column:
+        out = Column.empty(self.key_dtype if self.key_dtype != L.BOOL else L.INT64, self.num_groups, with_validity=True)
+        m = out.mut()
+        L.check(L.load().pdx_groupby_unique_keys(self._h, C.byref(m), _stream()))
+        return out._adopt(m)
+
+    def group_ids(self) -> torch.Tensor:
+        out = torch.empty(max(self.num_rows, 1), dtype=torch.int32, device=_device())
+        L.check(L.load().pdx_groupby_group_ids(self._h, out.data_ptr(), _stream()))
+        return out[: self.num_rows]
+
+    def first_rows(self) -> torch.Tensor:
+        out = torch.empty(max(self.num_groups, 1), dtype=torch.int64, device=_device())
+        L.check(L.load().pdx_groupby_first_rows(self._h, out.data_ptr(), _stream()))
+        return out[: self.num_groups]
+
+    def row_labels(self) -> torch.Tensor:
+        out = torch.empty(max(self.num_rows, 1), dtype=torch.int64, device=_device())
+        L.check(L.load().pdx_resample_row_labels(self._h, out.data_ptr(), _stream()))
+        return out[: self.num_rows]
+
+    def agg(self, values: Column, kinds):
+        """All `kinds` from one grouped pass.  -> list of Columns (G rows, group-id order)."""
+        kinds = list(kinds)
+        G = self.num_groups
+        outs = [Column.empty(_AGG_OUT_DT[k](values.dtype), G, with_validity=values.has_nulls() and k != L.AGG_COUNT) for k in kinds]
+        marr = _mut_array(outs)
+        karr = (C.c_int * len(kinds))(*kinds)
+        cv = values.c()
+        L.check(L.load().pdx_groupby_agg(self._h, C.byref(cv), karr, len(kinds), marr, _stream()))
+        return [o._adopt(marr[i]) for i, o in enumerate(outs)]
+
+
+# ---------------------------------------------------------------- synthetic inputs (bench / tests)
+def synth_keys(start, n, num_keys) -> Column:
+    out = Column.empty(L.INT64, n)
+    L.check(L.load().pdx_synth_keys(int(start), int(n), int(num_keys), out.values.data_ptr(), _stream()))
+    return out
+
+
+def synth_vals(start, n, seed_off=0) -> Column:
+    out = Column.empty(L.FLOAT64, n)
+    L.check(L.load().pdx_synth_vals(int(start), int(n), int(seed_off), out.values.data_ptr(), _stream()))
+    return out
+
+
+def synth_ts(start, n, t0_ns, step_ns) -> Column:
+    out = Column.empty(L.TIMESTAMP_NS, n)
+    L.check(L.load().pdx_synth_ts(int(start), int(n), int(t0_ns), int(step_ns), out.values.data_ptr(), _stream()))
+    return out

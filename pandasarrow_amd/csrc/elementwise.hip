@@ -1,0 +1,382 @@
+// elementwise.hip -- element-wise arithmetic, comparison and logical kernels for gfx950.
+//
+// Replaces the Arrow kernels reached from Series::operator{+,-,*,/,<,<=,...,&&,||,!}
+// (reference src/series.cpp:19-33,229-261,319; src/scalar.cpp:24-36) and the DataFrame
+// forms (src/dataframe.cpp:233-275).  All kernels are HBM-bound streams:
+//   binary  : 2 x 8 B read + 8 B write per row  (24 B/row, + 3/8 B with validity)
+//   compare : 2 x 8 B read + 1/8 B write per row
+// Layout: grid-stride over coalesced 8-byte lanes (a wave moves 512 B per instruction, 4 independent
+// instructions in flight per thread); bit-packed outputs are assembled with wave-wide ballots so every
+// wave stores whole 64-bit words, 64 words (512 B) at a time.
+#include "pdx_common.hpp"
+
+namespace pdx {
+
+// ---------------------------------------------------------------- validity: out = va & vb (bit offsets honoured)
+// one thread per output 64-bit word
+__global__ void k_validity_and(const uint8_t* __restrict__ va, int64_t aoff, int64_t alimit, const uint8_t* __restrict__ vb,
+                               int64_t boff, int64_t blimit, int b_broadcast, int64_t n, uint8_t* __restrict__ out) {
+  int64_t nwords = (n + 63) >> 6;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool b_all = true;
+  if (vb && b_broadcast) b_all = bit_get(vb, boff);
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += stride) {
+    int64_t base = w << 6;
+    uint64_t x = va ? load_bits64(va, aoff + base, alimit) : ~0ull;
+    uint64_t y = ~0ull;
+    if (vb) y = b_broadcast ? (b_all ? ~0ull : 0ull) : load_bits64(vb, boff + base, blimit);
+    uint64_t r = x & y;
+    int64_t remain = n - base;
+    if (remain >= 64) {
+      reinterpret_cast<uint64_t*>(out)[w] = r;
+    } else {
+      r &= (1ull << remain) - 1ull;
+      int nbytes = (int)((remain + 7) >> 3);
+      for (int k = 0; k < nbytes; ++k) out[(w << 3) + k] = (uint8_t)(r >> (8 * k));
+    }
+  }
+}
+
+int launch_validity_and(const pdx_column* a, const pdx_column* b, int b_is_scalar, int64_t n, uint8_t* out, hipStream_t st) {
+  const uint8_t* va = validity_or_null(a);
+  const uint8_t* vb = b ? validity_or_null(b) : nullptr;
+  if (n == 0) return PDX_OK;
+  int64_t nwords = (n + 63) >> 6;
+  hipLaunchKernelGGL(k_validity_and, dim3(grid_for(nwords, 256)), dim3(256), 0, st, va, a->offset, a->offset + a->length, vb,
+                     b ? b->offset : 0, b ? b->offset + b->length : 0, b_is_scalar, n, out);
+  PDX_LAUNCH_CHECK();
+  return PDX_OK;
+}
+
+// ---------------------------------------------------------------- binary arithmetic
+template <typename T>
+struct Conv;
+template <>
+struct Conv<double> {
+  template <typename S>
+  __device__ static double from(S x) { return (double)x; }
+};
+template <>
+struct Conv<int64_t> {
+  template <typename S>
+  __device__ static int64_t from(S x) { return (int64_t)x; }
+};
+
+template <typename TO, int OP>
+__device__ __forceinline__ TO apply_op(TO x, TO y, bool valid, unsigned long long* err) {
+  if constexpr (sizeof(TO) == 8 && OP == PDX_ADD) {
+    if constexpr (__is_same(TO, double)) return x + y;
+    else return (int64_t)((uint64_t)x + (uint64_t)y);
+  } else if constexpr (OP == PDX_SUB) {
+    if constexpr (__is_same(TO, double)) return x - y;
+    else return (int64_t)((uint64_t)x - (uint64_t)y);
+  } else if constexpr (OP == PDX_MUL) {
+    if constexpr (__is_same(TO, double)) return x * y;
+    else return (int64_t)((uint64_t)x * (uint64_t)y);
+  } else {
+    if constexpr (__is_same(TO, double)) {
+      return x / y;
+    } else {
+      // Arrow "divide" (unchecked): truncation toward zero; INT64_MIN / -1 -> 0; zero divisor at a valid slot is an error
+      if (!valid) return 0;
+      if (y == 0) {
+        *err = 1ull;
+        return 0;
+      }
+      if (x == INT64_MIN && y == -1) return 0;
+      return x / y;
+    }
+  }
+}
+
+template <typename TA, typename TB, typename TO, int OP, bool SCALAR_B>
+__global__ void __launch_bounds__(256) k_binary(const TA* __restrict__ a, const TB* __restrict__ b, TO* __restrict__ out, int64_t n,
+                                                const uint8_t* __restrict__ va, int64_t aoff, const uint8_t* __restrict__ vb,
+                                                int64_t boff, unsigned long long* __restrict__ err) {
+  constexpr bool kNeedValid = (OP == PDX_DIV) && !__is_same(TO, double);
+  int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  TO ys = 0;
+  bool ys_valid = true;
+  if constexpr (SCALAR_B) {
+    ys = Conv<TO>::from(b[0]);
+    if (kNeedValid && vb) ys_valid = bit_get(vb, boff);
+  }
+  unsigned long long local_err = 0;
+  // 4 independent 8-byte streams per thread
+  int64_t i = tid;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    TO x[4], y[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      x[k] = Conv<TO>::from(a[i + k * stride]);
+      y[k] = SCALAR_B ? ys : Conv<TO>::from(b[i + k * stride]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      bool valid = true;
+      if constexpr (kNeedValid) {
+        int64_t j = i + k * stride;
+        valid = (!va || bit_get(va, aoff + j)) && (SCALAR_B ? ys_valid : (!vb || bit_get(vb, boff + j)));
+      }
+      out[i + k * stride] = apply_op<TO, OP>(x[k], y[k], valid, &local_err);
+    }
+  }
+  for (; i < n; i += stride) {
+    TO x = Conv<TO>::from(a[i]);
+    TO y = SCALAR_B ? ys : Conv<TO>::from(b[i]);
+    bool valid = true;
+    if constexpr (kNeedValid) valid = (!va || bit_get(va, aoff + i)) && (SCALAR_B ? ys_valid : (!vb || bit_get(vb, boff + i)));
+    out[i] = apply_op<TO, OP>(x, y, valid, &local_err);
+  }
+  if constexpr (kNeedValid) {
+    if (local_err) atomicMax(err, local_err);
+  }
+}
+
+template <typename TA, typename TB, typename TO, int OP>
+static void launch_binary_sb(const pdx_column* a, const pdx_column* b, int scalar, TO* out, unsigned long long* err, hipStream_t st) {
+  int64_t n = a->length;
+  const TA* pa = static_cast<const TA*>(a->values) + a->offset;
+  const TB* pb = static_cast<const TB*>(b->values) + b->offset;
+  dim3 grid(grid_for(n, 256, 4)), block(256);
+  if (scalar)
+    hipLaunchKernelGGL((k_binary<TA, TB, TO, OP, true>), grid, block, 0, st, pa, pb, out, n, validity_or_null(a), a->offset,
+                       validity_or_null(b), b->offset, err);
+  else
+    hipLaunchKernelGGL((k_binary<TA, TB, TO, OP, false>), grid, block, 0, st, pa, pb, out, n, validity_or_null(a), a->offset,
+                       validity_or_null(b), b->offset, err);
+}
+template <typename TA, typename TB, typename TO>
+static void launch_binary_op(int op, const pdx_column* a, const pdx_column* b, int scalar, TO* out, unsigned long long* err,
+                             hipStream_t st) {
+  switch (op) {
+    case PDX_ADD: launch_binary_sb<TA, TB, TO, PDX_ADD>(a, b, scalar, out, err, st); break;
+    case PDX_SUB: launch_binary_sb<TA, TB, TO, PDX_SUB>(a, b, scalar, out, err, st); break;
+    case PDX_MUL: launch_binary_sb<TA, TB, TO, PDX_MUL>(a, b, scalar, out, err, st); break;
+    default: launch_binary_sb<TA, TB, TO, PDX_DIV>(a, b, scalar, out, err, st); break;
+  }
+}
+
+// ---------------------------------------------------------------- comparisons -> bit-packed bools
+template <typename T, int OP>
+__device__ __forceinline__ bool cmp_op(T x, T y) {
+  if constexpr (OP == PDX_EQ) return x == y;
+  else if constexpr (OP == PDX_NE) return x != y;
+  else if constexpr (OP == PDX_LT) return x < y;
+  else if constexpr (OP == PDX_LE) return x <= y;
+  else if constexpr (OP == PDX_GT) return x > y;
+  else return x >= y;
+}
+
+// each wave owns tiles of 4096 rows: 64 ballots -> lane k keeps word k -> one 512-byte store
+template <typename TA, typename TB, typename TC, int OP, bool SCALAR_B>
+__global__ void __launch_bounds__(256) k_compare(const TA* __restrict__ a, const TB* __restrict__ b, uint8_t* __restrict__ out,
+                                                 int64_t n) {
+  const int lane = threadIdx.x & 63;
+  int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int64_t ntiles = (n + 4095) >> 12;
+  TC ys = 0;
+  if constexpr (SCALAR_B) ys = Conv<TC>::from(b[0]);
+  for (int64_t t = wave; t < ntiles; t += nwaves) {
+    int64_t base = t << 12;
+    uint64_t myword = 0;
+    if (base + 4096 <= n) {
+#pragma unroll 8
+      for (int k = 0; k < 64; ++k) {
+        int64_t i = base + (k << 6) + lane;
+        TC x = Conv<TC>::from(a[i]);
+        TC y = SCALAR_B ? ys : Conv<TC>::from(b[i]);
+        uint64_t bal = __ballot(cmp_op<TC, OP>(x, y));
+        if (lane == k) myword = bal;
+      }
+      reinterpret_cast<uint64_t*>(out)[(base >> 6) + lane] = myword;
+    } else {
+      for (int k = 0; k < 64; ++k) {
+        int64_t i = base + (k << 6) + lane;
+        bool p = false;
+        if (i < n) {
+          TC x = Conv<TC>::from(a[i]);
+          TC y = SCALAR_B ? ys : Conv<TC>::from(b[i]);
+          p = cmp_op<TC, OP>(x, y);
+        }
+        uint64_t bal = __ballot(p);
+        if (lane == k) myword = bal;
+      }
+      // ragged tail: byte-granular store of the words that hold rows < n
+      int64_t wbase = (base >> 6) + lane;
+      int64_t first_row = wbase << 6;
+      if (first_row < n) {
+        int64_t remain = n - first_row;
+        int nbytes = remain >= 64 ? 8 : (int)((remain + 7) >> 3);
+        for (int q = 0; q < nbytes; ++q) out[(wbase << 3) + q] = (uint8_t)(myword >> (8 * q));
+      }
+    }
+  }
+}
+
+template <typename TA, typename TB, typename TC, int OP>
+static void launch_compare_sb(const pdx_column* a, const pdx_column* b, int scalar, uint8_t* out, hipStream_t st) {
+  int64_t n = a->length;
+  const TA* pa = static_cast<const TA*>(a->values) + a->offset;
+  const TB* pb = static_cast<const TB*>(b->values) + b->offset;
+  int64_t ntiles = (n + 4095) >> 12;
+  dim3 grid(grid_for(ntiles * 64, 256)), block(256);
+  if (scalar) hipLaunchKernelGGL((k_compare<TA, TB, TC, OP, true>), grid, block, 0, st, pa, pb, out, n);
+  else hipLaunchKernelGGL((k_compare<TA, TB, TC, OP, false>), grid, block, 0, st, pa, pb, out, n);
+}
+template <typename TA, typename TB, typename TC>
+static void launch_compare_op(int op, const pdx_column* a, const pdx_column* b, int scalar, uint8_t* out, hipStream_t st) {
+  switch (op) {
+    case PDX_EQ: launch_compare_sb<TA, TB, TC, PDX_EQ>(a, b, scalar, out, st); break;
+    case PDX_NE: launch_compare_sb<TA, TB, TC, PDX_NE>(a, b, scalar, out, st); break;
+    case PDX_LT: launch_compare_sb<TA, TB, TC, PDX_LT>(a, b, scalar, out, st); break;
+    case PDX_LE: launch_compare_sb<TA, TB, TC, PDX_LE>(a, b, scalar, out, st); break;
+    case PDX_GT: launch_compare_sb<TA, TB, TC, PDX_GT>(a, b, scalar, out, st); break;
+    default: launch_compare_sb<TA, TB, TC, PDX_GE>(a, b, scalar, out, st); break;
+  }
+}
+
+// ---------------------------------------------------------------- logical on bit-packed bools
+// mode 0: and, 1: or, 2: invert(a)
+__global__ void k_logical(const uint8_t* __restrict__ a, int64_t aoff, int64_t alimit, const uint8_t* __restrict__ b, int64_t boff,
+                          int64_t blimit, int mode, int64_t n, uint8_t* __restrict__ out) {
+  int64_t nwords = (n + 63) >> 6;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += stride) {
+    int64_t base = w << 6;
+    uint64_t x = load_bits64(a, aoff + base, alimit);
+    uint64_t r;
+    if (mode == 2) r = ~x;
+    else {
+      uint64_t y = load_bits64(b, boff + base, blimit);
+      r = mode == 0 ? (x & y) : (x | y);
+    }
+    int64_t remain = n - base;
+    if (remain >= 64) {
+      reinterpret_cast<uint64_t*>(out)[w] = r;
+    } else {
+      r &= (1ull << remain) - 1ull;
+      int nbytes = (int)((remain + 7) >> 3);
+      for (int k = 0; k < nbytes; ++k) out[(w << 3) + k] = (uint8_t)(r >> (8 * k));
+    }
+  }
+}
+
+static int check_numeric_pair(const pdx_column* a, const pdx_column* b, int b_is_scalar, const char* what) {
+  PDX_TRY(check_column(a, what));
+  PDX_TRY(check_column(b, what));
+  auto ok = [](int dt) { return dt == PDX_INT64 || dt == PDX_FLOAT64; };
+  if (!ok(a->dtype) || !ok(b->dtype)) return fail(PDX_NOT_IMPLEMENTED, std::string(what) + ": only int64/float64 operands are supported");
+  if (b_is_scalar) {
+    if (b->length != 1) return fail(PDX_INVALID, std::string(what) + ": scalar operand must have length 1");
+  } else if (a->length != b->length) {
+    return fail(PDX_INVALID, std::string(what) + ": array lengths differ: " + std::to_string(a->length) + " vs " + std::to_string(b->length));
+  }
+  return PDX_OK;
+}
+
+}  // namespace pdx
+
+using namespace pdx;
+
+extern "C" {
+
+int pdx_binary(int op, const pdx_column* a, const pdx_column* b, int b_is_scalar, pdx_mut_column* out, void* stream) {
+  PDX_TRY(check_numeric_pair(a, b, b_is_scalar, "pdx_binary"));
+  if (op < PDX_ADD || op > PDX_DIV) return fail(PDX_INVALID, "pdx_binary: unknown op");
+  if (!out || out->length < a->length) return fail(PDX_INVALID, "pdx_binary: output too small");
+  const bool is_f = a->dtype == PDX_FLOAT64 || b->dtype == PDX_FLOAT64;
+  const int out_dt = is_f ? PDX_FLOAT64 : PDX_INT64;
+  if (out->dtype != out_dt) return fail(PDX_INVALID, "pdx_binary: output dtype must be the promoted input dtype");
+  const bool has_nulls = validity_or_null(a) || validity_or_null(b);
+  if (has_nulls && !out->validity) return fail(PDX_INVALID, "pdx_binary: inputs carry nulls but output has no validity buffer");
+  hipStream_t st = as_stream(stream);
+  int64_t n = a->length;
+  out->length = n;
+  out->null_count = has_nulls ? -1 : 0;
+  if (n == 0) return PDX_OK;
+  if (!out->values) return fail(PDX_INVALID, "pdx_binary: null output buffer");
+  const bool need_err = (op == PDX_DIV) && !is_f;
+  Scratch scratch;
+  unsigned long long* err = nullptr;
+  if (need_err) {
+    err = scratch.get<unsigned long long>(1);
+    PDX_SCRATCH_CHECK(scratch);
+    PDX_HIP(hipMemsetAsync(err, 0, sizeof(unsigned long long), st));
+  }
+  if (is_f) {
+    double* o = static_cast<double*>(out->values);
+    if (a->dtype == PDX_FLOAT64 && b->dtype == PDX_FLOAT64) launch_binary_op<double, double, double>(op, a, b, b_is_scalar, o, err, st);
+    else if (a->dtype == PDX_FLOAT64) launch_binary_op<double, int64_t, double>(op, a, b, b_is_scalar, o, err, st);
+    else launch_binary_op<int64_t, double, double>(op, a, b, b_is_scalar, o, err, st);
+  } else {
+    launch_binary_op<int64_t, int64_t, int64_t>(op, a, b, b_is_scalar, static_cast<int64_t*>(out->values), err, st);
+  }
+  PDX_LAUNCH_CHECK();
+  if (out->validity) PDX_TRY(launch_validity_and(a, b, b_is_scalar, n, static_cast<uint8_t*>(out->validity), st));
+  if (need_err) {
+    unsigned long long h = 0;
+    PDX_HIP(hipMemcpyAsync(&h, err, sizeof(h), hipMemcpyDeviceToHost, st));
+    PDX_HIP(hipStreamSynchronize(st));
+    if (h) return fail(PDX_INVALID, "divide by zero");
+  }
+  return PDX_OK;
+}
+
+int pdx_compare(int op, const pdx_column* a, const pdx_column* b, int b_is_scalar, pdx_mut_column* out, void* stream) {
+  PDX_TRY(check_numeric_pair(a, b, b_is_scalar, "pdx_compare"));
+  if (op < PDX_EQ || op > PDX_GE) return fail(PDX_INVALID, "pdx_compare: unknown op");
+  if (!out || out->length < a->length || out->dtype != PDX_BOOL) return fail(PDX_INVALID, "pdx_compare: output must be PDX_BOOL of the input length");
+  const bool has_nulls = validity_or_null(a) || validity_or_null(b);
+  if (has_nulls && !out->validity) return fail(PDX_INVALID, "pdx_compare: inputs carry nulls but output has no validity buffer");
+  hipStream_t st = as_stream(stream);
+  int64_t n = a->length;
+  out->length = n;
+  out->null_count = has_nulls ? -1 : 0;
+  if (n == 0) return PDX_OK;
+  if (!out->values) return fail(PDX_INVALID, "pdx_compare: null output buffer");
+  uint8_t* o = static_cast<uint8_t*>(out->values);
+  if (a->dtype == PDX_FLOAT64 && b->dtype == PDX_FLOAT64) launch_compare_op<double, double, double>(op, a, b, b_is_scalar, o, st);
+  else if (a->dtype == PDX_FLOAT64) launch_compare_op<double, int64_t, double>(op, a, b, b_is_scalar, o, st);
+  else if (b->dtype == PDX_FLOAT64) launch_compare_op<int64_t, double, double>(op, a, b, b_is_scalar, o, st);
+  else launch_compare_op<int64_t, int64_t, int64_t>(op, a, b, b_is_scalar, o, st);
+  PDX_LAUNCH_CHECK();
+  if (out->validity) PDX_TRY(launch_validity_and(a, b, b_is_scalar, n, static_cast<uint8_t*>(out->validity), st));
+  return PDX_OK;
+}
+
+static int logical_impl(int mode, const pdx_column* a, const pdx_column* b, pdx_mut_column* out, void* stream, const char* what) {
+  PDX_TRY(check_column(a, what));
+  if (a->dtype != PDX_BOOL) return fail(PDX_INVALID, std::string(what) + ": operands must be PDX_BOOL");
+  if (b) {
+    PDX_TRY(check_column(b, what));
+    if (b->dtype != PDX_BOOL) return fail(PDX_INVALID, std::string(what) + ": operands must be PDX_BOOL");
+    if (a->length != b->length) return fail(PDX_INVALID, std::string(what) + ": array lengths differ");
+  }
+  if (!out || out->length < a->length || out->dtype != PDX_BOOL) return fail(PDX_INVALID, std::string(what) + ": output must be PDX_BOOL of the input length");
+  const bool has_nulls = validity_or_null(a) || (b && validity_or_null(b));
+  if (has_nulls && !out->validity) return fail(PDX_INVALID, std::string(what) + ": inputs carry nulls but output has no validity buffer");
+  hipStream_t st = as_stream(stream);
+  int64_t n = a->length;
+  out->length = n;
+  out->null_count = has_nulls ? -1 : 0;
+  if (n == 0) return PDX_OK;
+  int64_t nwords = (n + 63) >> 6;
+  hipLaunchKernelGGL(k_logical, dim3(grid_for(nwords, 256)), dim3(256), 0, st, static_cast<const uint8_t*>(a->values), a->offset,
+                     a->offset + a->length, b ? static_cast<const uint8_t*>(b->values) : nullptr, b ? b->offset : 0,
+                     b ? b->offset + b->length : 0, mode, n, static_cast<uint8_t*>(out->values));
+  PDX_LAUNCH_CHECK();
+  if (out->validity) PDX_TRY(launch_validity_and(a, b, 0, n, static_cast<uint8_t*>(out->validity), st));
+  return PDX_OK;
+}
+
+int pdx_logical(int op, const pdx_column* a, const pdx_column* b, pdx_mut_column* out, void* stream) {
+  if (op != PDX_AND && op != PDX_OR) return fail(PDX_INVALID, "pdx_logical: unknown op");
+  if (!b) return fail(PDX_INVALID, "pdx_logical: null column");
+  return logical_impl(op == PDX_AND ? 0 : 1, a, b, out, stream, "pdx_logical");
+}
+int pdx_invert(const pdx_column* a, pdx_mut_column* out, void* stream) { return logical_impl(2, a, nullptr, out, stream, "pdx_invert"); }
+
+}  // extern "C"

@@ -1,0 +1,828 @@
+// groupby.hip -- hash group-by with sum/mean/min/max/count, and the resample front-end, for gfx950.
+//
+// Replaces (reference file:line)
+//   GroupBy::makeGroups  src/dataframe.cpp:1571-1600   Grouper::Make/Consume/GetUniques  -> pdx_groupby_create
+//   processIndex/processEach (MakeGroupings + ApplyGroupings of every column, 1539-1569)  -> deferred, per aggregated
+//                                                                                            column, to pdx_groupby_agg
+//   GROUPBY_AGG / GROUPBY_NUMERIC_AGG  src/pd_core_macros.h:5-147 (one CallFunction per group)  -> pdx_groupby_agg
+//   pd::resample / makeGroupInfo / generate_bins_dt64 / GroupInfo::downsample
+//        src/resample.h:19-43,91-122  src/resample.cpp:11-83,85-178,202-295               -> pdx_resample_create
+//
+// Data path for N rows, G groups (all arrays in HBM):
+//   1. k_hash_insert   keys (8 B/row, coalesced) -> open-addressing table of 16-byte slots {key, first_row, gid}
+//                      (lock-free: 64-bit CAS on the key, atomicMin on first_row); writes slot_of_row (4 B/row).
+//   2. occupied slots are compacted (slot order) and sorted by first_row -> dense gid in FIRST-OCCURRENCE order.
+//   3. per aggregated column: stable LSD radix sort of (slot, value) by slot (radix_sort.hpp) -> every group's values
+//      contiguous IN ROW ORDER; group offsets by binary search of the G slot values in the sorted keys.
+//   4. k_seg_reduce: one wave per group: coalesced loads staged through LDS, 16-value sequential leaves per lane,
+//      shuffle tree + binary counter == Arrow's pairwise sum bit-for-bit; min/max/count/int-sum from the same pass.
+// Algorithmic bytes: 16 B/row (8 key + 8 value).  Actual traffic is higher (sort passes); see DESIGN.md.
+#include <vector>
+#include <algorithm>
+#include "compact.hpp"
+#include "minmax.hpp"
+#include "pairwise.hpp"
+#include "radix_sort.hpp"
+#include "scan.hpp"
+
+namespace pdx {
+
+struct Slot {
+  long long key;
+  unsigned int first;  // first row with this key (0xFFFFFFFF = slot never used)
+  unsigned int gid;    // dense group id in first-occurrence order
+};
+static_assert(sizeof(Slot) == 16, "slot layout");
+constexpr long long kEmptyKey = (long long)0x8000000000000000ull;  // INT64_MIN is routed to a dedicated slot
+constexpr unsigned int kNoRow = 0xFFFFFFFFu;
+
+struct HashCtl {
+  unsigned int inserted;
+  unsigned int overflow;
+};
+
+__global__ void k_table_init(Slot* __restrict__ table, int64_t nslots) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += stride) {
+    table[i].key = kEmptyKey;
+    table[i].first = kNoRow;
+    table[i].gid = kNoRow;
+  }
+}
+
+// Lock-free insert-or-find.  A stale (cached) read of an EMPTY key only costs a CAS: the CAS result is authoritative.
+__global__ void __launch_bounds__(256) k_hash_insert(const long long* __restrict__ keys, const uint8_t* __restrict__ valid,
+                                                     int64_t off, int64_t n, Slot* table, unsigned int cap, unsigned int limit,
+                                                     uint32_t* __restrict__ slot_of_row, HashCtl* ctl) {
+  const unsigned int mask = cap - 1;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (__hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    unsigned int s;
+    long long key = keys[i];
+    if (valid && !bit_get(valid, off + i)) {
+      s = cap;  // the null key is its own group
+    } else if (key == kEmptyKey) {
+      s = cap + 1;
+    } else {
+      unsigned int h = (unsigned int)splitmix64((uint64_t)key) & mask;
+      unsigned int probes = 0;
+      for (;;) {
+        long long cur = table[h].key;
+        if (cur == key) { s = h; break; }
+        if (cur == kEmptyKey) {
+          unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[h].key), (unsigned long long)kEmptyKey,
+                                             (unsigned long long)key);
+          if (old == (unsigned long long)kEmptyKey) {
+            unsigned int c = atomicAdd(&ctl->inserted, 1u);
+            if (c >= limit) atomicExch(&ctl->overflow, 1u);
+            s = h;
+            break;
+          }
+          if (old == (unsigned long long)key) { s = h; break; }
+        }
+        h = (h + 1) & mask;
+        if (++probes > cap) {
+          atomicExch(&ctl->overflow, 1u);
+          s = cap;
+          break;
+        }
+      }
+    }
+    if ((unsigned int)i < table[s].first) atomicMin(&table[s].first, (unsigned int)i);
+    slot_of_row[i] = s;
+  }
+}
+
+struct OccPred {
+  const Slot* table;
+  __device__ bool operator()(int64_t i) const { return table[i].first != kNoRow; }
+};
+struct OccEmit {
+  const Slot* table;
+  uint32_t* occ_slot;
+  uint32_t* occ_first;
+  __device__ void operator()(int64_t pos, int64_t i) const {
+    occ_slot[pos] = (uint32_t)i;
+    occ_first[pos] = table[i].first;
+  }
+};
+
+// sorted_slot[r] = slot of the r-th group in first-occurrence order
+__global__ void k_assign_gids(Slot* table, const uint32_t* __restrict__ sorted_first, const uint32_t* __restrict__ sorted_slot, int64_t G,
+                              unsigned int cap, int64_t* __restrict__ uniques, uint8_t* __restrict__ unique_ok,
+                              int64_t* __restrict__ first_rows) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < G; r += stride) {
+    unsigned int s = sorted_slot[r];
+    table[s].gid = (unsigned int)r;
+    long long k = table[s].key;
+    if (s == cap) k = 0;
+    if (s == cap + 1) k = kEmptyKey;
+    uniques[r] = k;
+    unique_ok[r] = s != cap;
+    first_rows[r] = (int64_t)sorted_first[r];
+  }
+}
+__global__ void k_gid_of_occ(const Slot* __restrict__ table, const uint32_t* __restrict__ occ_slot, int64_t G, uint32_t* __restrict__ out) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < G; k += stride) out[k] = table[occ_slot[k]].gid;
+}
+__global__ void k_row_gids(const Slot* __restrict__ table, const uint32_t* __restrict__ slot_of_row, int64_t n, uint32_t* __restrict__ out) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = table[slot_of_row[i]].gid;
+}
+
+// keys for the value sort when the value column has nulls: bit 31 = row is null
+__global__ void k_flag_keys(const uint32_t* __restrict__ slot_of_row, const uint8_t* __restrict__ valid, int64_t off, int64_t n,
+                            uint32_t* __restrict__ out) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = slot_of_row[i] | (bit_get(valid, off + i) ? 0u : 0x80000000u);
+}
+
+// seg_start[k] = first position in sorted keys whose (masked) key >= occ_slot[k]; seg_start[G] = n
+__global__ void k_seg_starts(const uint32_t* __restrict__ sorted_keys, int64_t n, const uint32_t* __restrict__ occ_slot, int64_t G,
+                             uint32_t* __restrict__ seg_start) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= G; k += stride) {
+    if (k == G) {
+      seg_start[k] = (uint32_t)n;
+      continue;
+    }
+    uint32_t target = occ_slot[k];
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      int64_t mid = (lo + hi) >> 1;
+      if ((sorted_keys[mid] & kSortKeyMask) < target) lo = mid + 1;
+      else hi = mid;
+    }
+    seg_start[k] = (uint32_t)lo;
+  }
+}
+
+// ---------------------------------------------------------------- segmented reduce (dense values: no nulls)
+struct SegOut {
+  double* sum_f;     // SUM of float64 values, or nullptr
+  long long* sum_i;  // SUM of int64 values (wrapping)
+  double* mean;
+  void* vmin;        // T*
+  void* vmax;        // T*
+  long long* count;
+};
+
+constexpr int kSegWaves = 4;
+constexpr int kSegChunk = 1024;  // values per wave-chunk = 64 leaves
+
+template <typename T>
+__device__ __forceinline__ double seg_to_f64(T x) { return (double)x; }
+
+// uniform (whole-wave) replay of Arrow's counter with the level sums in LDS; lane 0 stores, every lane reads
+__device__ __forceinline__ void lds_counter_push(double* csum, uint64_t& mask, int& root, double x, int level, int lane) {
+  int cur = level;
+  uint64_t mb = 1ull << level;
+  double v = csum[cur] + x;
+  mask ^= mb;
+  while ((mask & mb) == 0) {
+    if (lane == 0) csum[cur] = 0.0;
+    ++cur;
+    mb <<= 1;
+    v = csum[cur] + v;
+    mask ^= mb;
+  }
+  if (lane == 0) csum[cur] = v;
+  if (cur > root) root = cur;
+}
+
+template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM>
+__global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restrict__ vals, const uint32_t* __restrict__ seg_start,
+                                                               int64_t nseg, const uint32_t* __restrict__ out_index, SegOut out) {
+  __shared__ double stage[kSegWaves][64 * 17];
+  __shared__ double csum_all[kSegWaves][48];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* lds = stage[wave];
+  double* csum = csum_all[wave];
+  int64_t gw = (int64_t)blockIdx.x * kSegWaves + wave;
+  int64_t nw = (int64_t)gridDim.x * kSegWaves;
+  for (int64_t k = gw; k < nseg; k += nw) {
+    const int64_t s = seg_start[k], e = seg_start[k + 1];
+    const int64_t len = e - s;
+    const uint32_t oi = out_index ? out_index[k] : (uint32_t)k;
+    Extreme<T> ext;
+    ext.init();
+    unsigned long long isum = 0;
+    uint64_t mask = 0;
+    int root = 0;
+    double single = 0.0;  // result when the group fits one chunk
+    const bool multi = len > kSegChunk;
+    if (WANT_PAIRWISE && multi) {
+      if (lane < 48) csum[lane] = 0.0;
+    }
+    for (int64_t c0 = 0; c0 < len; c0 += kSegChunk) {
+      const int cl = (int)((len - c0) < kSegChunk ? (len - c0) : kSegChunk);
+      // coalesced loads: 16 wave-instructions of 64 consecutive values
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        int idx = q * 64 + lane;
+        if (idx < cl) {
+          T x = vals[s + c0 + idx];
+          if (WANT_PAIRWISE) lds[idx + (idx >> 4)] = seg_to_f64(x);
+          if (WANT_MINMAX) {
+            if (x == x) ext.add(x, (long long)(c0 + idx));
+          }
+          if (WANT_ISUM) isum += (unsigned long long)x;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // the LDS image is wave-private: in-order LDS issue makes it visible to all lanes
+      if (WANT_PAIRWISE) {
+        const int m = (cl + 15) >> 4;  // leaves in this chunk (wave-uniform)
+        double x = 0.0;
+        const int first = lane * 16;
+        if (first < cl) {
+          int cnt = cl - first < 16 ? cl - first : 16;
+          x = leaf_sum(&lds[lane * 17], cnt);
+        }
+        // butterfly; pick the perfect subtrees that tile [0, m)
+        double node[7];
+#pragma unroll
+        for (int sft = 0; sft < 6; ++sft) {
+          node[sft] = 0.0;
+          if ((m >> sft) & 1) node[sft] = __shfl(x, m & ~((2 << sft) - 1), 64);
+          double y = __shfl_down(x, 1 << sft, 64);
+          x = x + y;
+        }
+        node[6] = __shfl(x, 0, 64);
+        if (!multi) {
+          // fold ascending: acc = lowest node; acc = higher + acc
+          bool have = false;
+          double acc = 0.0;
+#pragma unroll
+          for (int sft = 0; sft <= 6; ++sft) {
+            if ((m >> sft) & 1) {
+              acc = have ? node[sft] + acc : node[sft];
+              have = true;
+            }
+          }
+          single = acc;
+        } else {
+#pragma unroll
+          for (int sft = 6; sft >= 0; --sft)
+            if ((m >> sft) & 1) lds_counter_push(csum, mask, root, node[sft], sft, lane);
+        }
+      }
+    }
+    double total = single;
+    if (WANT_PAIRWISE && multi) {
+      double acc = csum[0];
+      for (int i = 1; i <= root; ++i) acc = csum[i] + acc;
+      total = acc;
+    }
+    if (WANT_MINMAX) {
+      for (int d = 32; d > 0; d >>= 1) {
+        T omin = __shfl_down(ext.vmin, d, 64), omax = __shfl_down(ext.vmax, d, 64);
+        long long ormin = __shfl_down(ext.rmin, d, 64), ormax = __shfl_down(ext.rmax, d, 64);
+        ext.merge(omin, ormin, omax, ormax);
+      }
+    }
+    if (WANT_ISUM) {
+      for (int d = 32; d > 0; d >>= 1) isum += __shfl_down(isum, d, 64);
+    }
+    if (lane == 0) {
+      if (WANT_PAIRWISE) {
+        if (out.sum_f) out.sum_f[oi] = total;
+        if (out.mean) out.mean[oi] = total / (double)len;
+      }
+      if (WANT_ISUM && out.sum_i) out.sum_i[oi] = (long long)isum;
+      if (WANT_MINMAX) {
+        T nanv = T(0);
+        if constexpr (__is_same(T, double)) nanv = __builtin_nan("");
+        if (out.vmin) static_cast<T*>(out.vmin)[oi] = ext.rmin < 0 ? nanv : ext.vmin;
+        if (out.vmax) static_cast<T*>(out.vmax)[oi] = ext.rmax < 0 ? nanv : ext.vmax;
+      }
+      if (out.count) out.count[oi] = (long long)len;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- segmented reduce (nullable values): one thread per group,
+// literal replay of the per-group scalar kernels (runs of valid rows restart the 16-value leaves)
+template <typename T>
+__global__ void __launch_bounds__(256) k_seg_reduce_nullable(const T* __restrict__ vals, const uint32_t* __restrict__ sorted_keys,
+                                                             const uint8_t* __restrict__ row_valid, int64_t valid_off,
+                                                             const uint32_t* __restrict__ seg_start, int64_t nseg,
+                                                             const uint32_t* __restrict__ out_index, SegOut out, uint8_t* __restrict__ ok) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += stride) {
+    const int64_t s = seg_start[k], e = seg_start[k + 1];
+    const uint32_t oi = out_index ? out_index[k] : (uint32_t)k;
+    PairwiseCounter c;
+    c.init();
+    int run = 0;
+    double acc = 0.0;
+    long long cnt = 0;
+    unsigned long long isum = 0;
+    Extreme<T> ext;
+    ext.init();
+    for (int64_t i = s; i < e; ++i) {
+      bool valid = sorted_keys ? !(sorted_keys[i] >> 31) : (!row_valid || bit_get(row_valid, valid_off + i));
+      if (valid) {
+        T x = vals[i];
+        acc += (double)x;
+        ++cnt;
+        isum += (unsigned long long)x;
+        if (x == x) ext.add(x, (long long)(i - s));
+        if (++run == 16) {
+          c.push(acc, 0);
+          acc = 0.0;
+          run = 0;
+        }
+      } else if (run) {
+        c.push(acc, 0);
+        acc = 0.0;
+        run = 0;
+      }
+    }
+    if (run) c.push(acc, 0);
+    double total = cnt ? c.finish() : 0.0;
+    if (out.sum_f) out.sum_f[oi] = total;
+    if (out.mean) out.mean[oi] = cnt ? total / (double)cnt : 0.0;
+    if (out.sum_i) out.sum_i[oi] = (long long)isum;
+    T nanv = T(0);
+    if constexpr (__is_same(T, double)) nanv = __builtin_nan("");
+    if (out.vmin) static_cast<T*>(out.vmin)[oi] = ext.rmin < 0 ? nanv : ext.vmin;
+    if (out.vmax) static_cast<T*>(out.vmax)[oi] = ext.rmax < 0 ? nanv : ext.vmax;
+    if (out.count) out.count[oi] = cnt;
+    ok[oi] = cnt > 0;
+  }
+}
+
+// ---------------------------------------------------------------- resample helpers
+struct BinParams {
+  const long long* ts;
+  long long first, freq;
+  int closed_right;
+  __device__ long long bin(int64_t i) const {
+    long long v = ts[i];
+    return closed_right ? (v - first - 1) / freq : (v - first) / freq;
+  }
+};
+struct BinStartPred {
+  BinParams p;
+  __device__ bool operator()(int64_t i) const { return i == 0 || p.bin(i) != p.bin(i - 1); }
+};
+struct BinStartEmit {
+  BinParams p;
+  long long label_base;  // first + label_right * freq
+  uint32_t* seg_start;
+  int64_t* labels;
+  int64_t* first_rows;
+  __device__ void operator()(int64_t pos, int64_t i) const {
+    seg_start[pos] = (uint32_t)i;
+    labels[pos] = label_base + p.bin(i) * p.freq;
+    first_rows[pos] = i;
+  }
+};
+__global__ void k_check_sorted(const long long* __restrict__ ts, int64_t n, unsigned int* __restrict__ bad) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; i < n; i += stride)
+    if (ts[i] < ts[i - 1]) atomicExch(bad, 1u);
+}
+__global__ void k_row_labels(BinParams p, long long label_base, int64_t n, int64_t* __restrict__ out) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = label_base + p.bin(i) * p.freq;
+}
+__global__ void k_seg_row_ids(const uint32_t* __restrict__ seg_start, int64_t G, int64_t n, uint32_t* __restrict__ out) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int64_t lo = 0, hi = G;  // last segment with start <= i
+    while (hi - lo > 1) {
+      int64_t mid = (lo + hi) >> 1;
+      if (seg_start[mid] <= (uint32_t)i) lo = mid;
+      else hi = mid;
+    }
+    out[i] = (uint32_t)lo;
+  }
+}
+__global__ void k_set_last(uint32_t* p, int64_t idx, uint32_t v) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) p[idx] = v;
+}
+
+}  // namespace pdx
+
+using namespace pdx;
+
+struct pdx_groupby {
+  int mode = 0;  // 0 = hash group-by, 1 = contiguous segments (resample)
+  int64_t n = 0, G = 0;
+  int key_dtype = PDX_INT64;
+  // hash mode
+  Slot* table = nullptr;
+  unsigned int cap = 0;
+  int slot_bits = 0;
+  uint32_t* slot_of_row = nullptr;  // n
+  uint32_t* occ_slot = nullptr;     // G, slot order
+  uint32_t* gid_of_occ = nullptr;   // G
+  // both modes
+  int64_t* uniques = nullptr;      // G (labels in resample mode)
+  uint8_t* unique_ok = nullptr;    // G bytes
+  int64_t* first_rows = nullptr;   // G
+  // segments mode
+  uint32_t* seg_start = nullptr;   // G + 1
+  BinParams bin{};
+  long long label_base = 0;
+  std::vector<void*> owned;
+  template <typename T>
+  T* own(size_t count) {
+    T* p = static_cast<T*>(pool_alloc((count ? count : 1) * sizeof(T)));
+    if (p) owned.push_back(p);
+    return p;
+  }
+  ~pdx_groupby() {
+    for (void* p : owned) pool_free(p);
+  }
+};
+
+namespace pdx {
+
+int minmax_i64_host(const long long* v, int64_t n, long long* mn, long long* mx, Scratch& s, hipStream_t st);  // aggregate.hip
+
+static unsigned int next_pow2(uint64_t x) {
+  uint64_t p = 16;
+  while (p < x) p <<= 1;
+  return (unsigned int)p;
+}
+static int ilog2(uint64_t x) {
+  int b = 0;
+  while ((1ull << b) < x) ++b;
+  return b;
+}
+
+template <typename T>
+static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int64_t nseg, const uint32_t* out_index, const SegOut& o,
+                                   bool want_pw, bool want_mm, bool want_is, hipStream_t st) {
+  if (nseg == 0) return PDX_OK;
+  int grid = (int)std::min<int64_t>(ceil_div(nseg, kSegWaves), (int64_t)kCUs * 8);
+  dim3 g(grid), b(kSegWaves * 64);
+#define SEG_LAUNCH(PW, MM, IS) hipLaunchKernelGGL((k_seg_reduce<T, PW, MM, IS>), g, b, 0, st, vals, seg_start, nseg, out_index, o)
+  if (want_pw && !want_mm && !want_is) SEG_LAUNCH(true, false, false);
+  else if (!want_pw && want_mm && !want_is) SEG_LAUNCH(false, true, false);
+  else if (!want_pw && !want_mm && want_is) SEG_LAUNCH(false, false, true);
+  else if (!want_pw && !want_mm && !want_is) SEG_LAUNCH(false, false, false);
+  else SEG_LAUNCH(true, true, true);
+#undef SEG_LAUNCH
+  PDX_LAUNCH_CHECK();
+  return PDX_OK;
+}
+
+}  // namespace pdx
+
+extern "C" {
+
+int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
+  PDX_TRY(check_column(key, "pdx_groupby_create"));
+  if (!out) return fail(PDX_INVALID, "pdx_groupby_create: null output");
+  if (!is_int_like(key->dtype)) return fail(PDX_NOT_IMPLEMENTED, "pdx_groupby_create: key must be int64/uint64/timestamp");
+  const int64_t n = key->length;
+  if (n > 0x7FFFFFFFll) return fail(PDX_NOT_IMPLEMENTED, "pdx_groupby_create: more than 2^31-1 rows per call is not supported yet");
+  hipStream_t st = as_stream(stream);
+  pdx_groupby* gb = new pdx_groupby();
+  gb->n = n;
+  gb->key_dtype = key->dtype;
+  *out = nullptr;
+  if (n == 0) {
+    *out = gb;
+    return PDX_OK;
+  }
+  Scratch s;
+  const long long* keys = static_cast<const long long*>(key->values) + key->offset;
+  const uint8_t* valid = validity_or_null(key);
+  gb->slot_of_row = gb->own<uint32_t>((size_t)n);
+  HashCtl* ctl = s.get<HashCtl>(1);
+  if (!gb->slot_of_row || s.failed) {
+    delete gb;
+    return PDX_OOM;
+  }
+  // table capacity: start at min(2^21, pow2 >= 2n) and grow x8 whenever more than 70 % of the slots fill up
+  uint64_t want = next_pow2((uint64_t)n * 2);
+  unsigned int cap = (unsigned int)std::min<uint64_t>(want, 1u << 21);
+  Slot* table = nullptr;
+  for (;;) {
+    table = static_cast<Slot*>(pool_alloc(((size_t)cap + 2) * sizeof(Slot)));
+    if (!table) {
+      delete gb;
+      return PDX_OOM;
+    }
+    hipLaunchKernelGGL(k_table_init, dim3(grid_for((int64_t)cap + 2, 256, 4)), dim3(256), 0, st, table, (int64_t)cap + 2);
+    hipMemsetAsync(ctl, 0, sizeof(HashCtl), st);
+    unsigned int limit = (unsigned int)((uint64_t)cap * 7 / 10);
+    if (cap >= want) limit = cap;  // a table of >= 2n slots can never overflow
+    hipLaunchKernelGGL(k_hash_insert, dim3(grid_for(n, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, n, table, cap, limit,
+                       gb->slot_of_row, ctl);
+    HashCtl h;
+    hipError_t e = hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+      pool_free(table);
+      delete gb;
+      return hip_fail(e, "k_hash_insert");
+    }
+    if (!h.overflow) break;
+    pool_free(table);
+    if (cap >= want) {
+      delete gb;
+      return fail(PDX_DEVICE, "pdx_groupby_create: hash table overflow at maximum capacity");
+    }
+    cap = (unsigned int)std::min<uint64_t>((uint64_t)cap * 8, want);
+  }
+  gb->table = table;
+  gb->owned.push_back(table);
+  gb->cap = cap;
+  gb->slot_bits = ilog2((uint64_t)cap + 2);
+  // occupied slots in slot order
+  const int64_t nslots = (int64_t)cap + 2;
+  uint32_t* occ_slot_tmp = s.get<uint32_t>((size_t)std::min<int64_t>(nslots, n + 2));
+  uint32_t* occ_first_tmp = s.get<uint32_t>((size_t)std::min<int64_t>(nslots, n + 2));
+  if (s.failed) {
+    delete gb;
+    return PDX_OOM;
+  }
+  int64_t G = 0;
+  int rc = compact_indices(nslots, OccPred{table}, OccEmit{table, occ_slot_tmp, occ_first_tmp}, &G, s, st);
+  if (rc != PDX_OK) {
+    delete gb;
+    return rc;
+  }
+  gb->G = G;
+  gb->occ_slot = gb->own<uint32_t>((size_t)G);
+  gb->gid_of_occ = gb->own<uint32_t>((size_t)G);
+  gb->uniques = gb->own<int64_t>((size_t)G);
+  gb->unique_ok = gb->own<uint8_t>((size_t)G);
+  gb->first_rows = gb->own<int64_t>((size_t)G);
+  uint32_t* k0 = s.get<uint32_t>((size_t)G);
+  uint32_t* v0 = s.get<uint32_t>((size_t)G);
+  uint32_t* k1 = s.get<uint32_t>((size_t)G);
+  uint32_t* v1 = s.get<uint32_t>((size_t)G);
+  if (s.failed || !gb->occ_slot || !gb->gid_of_occ || !gb->uniques || !gb->unique_ok || !gb->first_rows) {
+    delete gb;
+    return PDX_OOM;
+  }
+  hipMemcpyAsync(gb->occ_slot, occ_slot_tmp, (size_t)G * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
+  // order groups by first occurrence: sort (first_row -> slot); first rows are distinct so any order of ties is moot
+  const uint32_t *ks = nullptr, *vs = nullptr;
+  rc = radix_sort_pairs<uint32_t>(occ_first_tmp, occ_slot_tmp, k0, v0, k1, v1, G, ilog2((uint64_t)n + 1) < 31 ? ilog2((uint64_t)n + 1) : 31,
+                                  &ks, &vs, true, s, st);
+  if (rc != PDX_OK) {
+    delete gb;
+    return rc;
+  }
+  int g = grid_for(G, 256);
+  hipLaunchKernelGGL(k_assign_gids, dim3(g), dim3(256), 0, st, table, ks, vs, G, cap, gb->uniques, gb->unique_ok, gb->first_rows);
+  hipLaunchKernelGGL(k_gid_of_occ, dim3(g), dim3(256), 0, st, table, gb->occ_slot, G, gb->gid_of_occ);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    delete gb;
+    return hip_fail(e, "pdx_groupby_create");
+  }
+  *out = gb;
+  return PDX_OK;
+}
+
+int pdx_groupby_destroy(pdx_groupby* gb) {
+  delete gb;
+  return PDX_OK;
+}
+int64_t pdx_groupby_num_groups(const pdx_groupby* gb) { return gb ? gb->G : -1; }
+int64_t pdx_groupby_num_rows(const pdx_groupby* gb) { return gb ? gb->n : -1; }
+
+int pdx_groupby_unique_keys(const pdx_groupby* gb, pdx_mut_column* out, void* stream) {
+  if (!gb || !out) return fail(PDX_INVALID, "pdx_groupby_unique_keys: null argument");
+  if (out->length < gb->G) return fail(PDX_INVALID, "pdx_groupby_unique_keys: output too small");
+  hipStream_t st = as_stream(stream);
+  out->length = gb->G;
+  out->null_count = -1;
+  if (gb->G == 0) return PDX_OK;
+  PDX_HIP(hipMemcpyAsync(out->values, gb->uniques, (size_t)gb->G * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+  if (out->validity) {
+    hipLaunchKernelGGL(k_pack_bytes, dim3(grid_for((gb->G + 7) / 8, 256)), dim3(256), 0, st, gb->unique_ok, gb->G,
+                       static_cast<uint8_t*>(out->validity));
+    PDX_LAUNCH_CHECK();
+  }
+  PDX_HIP(hipStreamSynchronize(st));
+  return PDX_OK;
+}
+
+int pdx_groupby_first_rows(const pdx_groupby* gb, int64_t* out_rows, void* stream) {
+  if (!gb || !out_rows) return fail(PDX_INVALID, "pdx_groupby_first_rows: null argument");
+  hipStream_t st = as_stream(stream);
+  if (gb->G) PDX_HIP(hipMemcpyAsync(out_rows, gb->first_rows, (size_t)gb->G * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+  PDX_HIP(hipStreamSynchronize(st));
+  return PDX_OK;
+}
+
+int pdx_groupby_group_ids(pdx_groupby* gb, uint32_t* out_ids, void* stream) {
+  if (!gb || !out_ids) return fail(PDX_INVALID, "pdx_groupby_group_ids: null argument");
+  hipStream_t st = as_stream(stream);
+  if (gb->n == 0) return PDX_OK;
+  if (gb->mode == 0)
+    hipLaunchKernelGGL(k_row_gids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->table, gb->slot_of_row, gb->n, out_ids);
+  else
+    hipLaunchKernelGGL(k_seg_row_ids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->seg_start, gb->G, gb->n, out_ids);
+  PDX_LAUNCH_CHECK();
+  PDX_HIP(hipStreamSynchronize(st));
+  return PDX_OK;
+}
+
+int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds, int nk, pdx_mut_column* outs, void* stream) {
+  if (!gb || !kinds || !outs || nk <= 0) return fail(PDX_INVALID, "pdx_groupby_agg: null argument");
+  PDX_TRY(check_column(values, "pdx_groupby_agg"));
+  if (values->length != gb->n) return fail(PDX_INVALID, "pdx_groupby_agg: values length differs from the grouped key length");
+  const bool is_f = values->dtype == PDX_FLOAT64;
+  if (!is_f && values->dtype != PDX_INT64) return fail(PDX_NOT_IMPLEMENTED, "pdx_groupby_agg: values must be int64 or float64");
+  hipStream_t st = as_stream(stream);
+  const int64_t n = gb->n, G = gb->G;
+  const uint8_t* vvalid = validity_or_null(values);
+  SegOut o{};
+  bool want_pw = false, want_mm = false, want_is = false;
+  for (int k = 0; k < nk; ++k) {
+    pdx_mut_column* oc = &outs[k];
+    if (oc->length < G) return fail(PDX_INVALID, "pdx_groupby_agg: output too small");
+    if (G && !oc->values) return fail(PDX_INVALID, "pdx_groupby_agg: null output buffer");
+    int want_dt;
+    switch (kinds[k]) {
+      case PDX_AGG_SUM:
+        want_dt = is_f ? PDX_FLOAT64 : PDX_INT64;
+        if (is_f) { o.sum_f = static_cast<double*>(oc->values); want_pw = true; }
+        else { o.sum_i = static_cast<long long*>(oc->values); want_is = true; }
+        break;
+      case PDX_AGG_MEAN: want_dt = PDX_FLOAT64; o.mean = static_cast<double*>(oc->values); want_pw = true; break;
+      case PDX_AGG_MIN: want_dt = values->dtype; o.vmin = oc->values; want_mm = true; break;
+      case PDX_AGG_MAX: want_dt = values->dtype; o.vmax = oc->values; want_mm = true; break;
+      case PDX_AGG_COUNT: want_dt = PDX_INT64; o.count = static_cast<long long*>(oc->values); break;
+      default: return fail(PDX_INVALID, "pdx_groupby_agg: unknown aggregate kind");
+    }
+    if (oc->dtype != want_dt) return fail(PDX_INVALID, "pdx_groupby_agg: output dtype does not match the aggregate's result type");
+    if (vvalid && kinds[k] != PDX_AGG_COUNT && !oc->validity)
+      return fail(PDX_INVALID, "pdx_groupby_agg: values carry nulls but an output has no validity buffer");
+    oc->length = G;
+    oc->null_count = vvalid && kinds[k] != PDX_AGG_COUNT ? -1 : 0;
+  }
+  if (G == 0) return PDX_OK;
+  Scratch s;
+  const void* vals_sorted = nullptr;
+  const uint32_t* keys_sorted = nullptr;
+  const uint32_t* seg_start = nullptr;
+  const uint32_t* out_index = nullptr;
+  const uint8_t* row_valid = nullptr;  // segments mode reads validity in place
+  if (gb->mode == 0) {
+    // stable sort of (slot, value) by slot: each group's values become contiguous in row order
+    const uint32_t* kin = gb->slot_of_row;
+    if (vvalid) {
+      uint32_t* fk = s.get<uint32_t>((size_t)n);
+      PDX_SCRATCH_CHECK(s);
+      hipLaunchKernelGGL(k_flag_keys, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, gb->slot_of_row, vvalid, values->offset, n, fk);
+      kin = fk;
+    }
+    uint32_t* k0 = s.get<uint32_t>((size_t)n);
+    uint32_t* k1 = s.get<uint32_t>((size_t)n);
+    uint64_t* v0 = s.get<uint64_t>((size_t)n);
+    uint64_t* v1 = s.get<uint64_t>((size_t)n);
+    uint32_t* ss = s.get<uint32_t>((size_t)G + 1);
+    PDX_SCRATCH_CHECK(s);
+    const uint64_t* vin = static_cast<const uint64_t*>(values->values) + values->offset;
+    const uint64_t* vs = nullptr;
+    PDX_TRY(radix_sort_pairs<uint64_t>(kin, vin, k0, v0, k1, v1, n, gb->slot_bits, &keys_sorted, &vs, true, s, st));
+    vals_sorted = vs;
+    hipLaunchKernelGGL(k_seg_starts, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, keys_sorted, n, gb->occ_slot, G, ss);
+    PDX_LAUNCH_CHECK();
+    seg_start = ss;
+    out_index = gb->gid_of_occ;
+  } else {
+    vals_sorted = static_cast<const uint64_t*>(values->values) + values->offset;
+    seg_start = gb->seg_start;
+    row_valid = vvalid;
+  }
+  if (!vvalid) {
+    if (is_f) PDX_TRY(launch_seg_reduce_dense<double>(static_cast<const double*>(vals_sorted), seg_start, G, out_index, o, want_pw, want_mm, want_is, st));
+    else PDX_TRY(launch_seg_reduce_dense<long long>(static_cast<const long long*>(vals_sorted), seg_start, G, out_index, o, want_pw, want_mm, want_is, st));
+    for (int k = 0; k < nk; ++k)
+      if (outs[k].validity) PDX_HIP(hipMemsetAsync(outs[k].validity, 0xFF, (size_t)((G + 7) / 8), st));
+  } else {
+    uint8_t* ok = s.get<uint8_t>((size_t)G);
+    PDX_SCRATCH_CHECK(s);
+    int grid = grid_for(G, 256);
+    const uint32_t* fk = gb->mode == 0 ? keys_sorted : nullptr;
+    if (is_f)
+      hipLaunchKernelGGL((k_seg_reduce_nullable<double>), dim3(grid), dim3(256), 0, st, static_cast<const double*>(vals_sorted), fk, row_valid,
+                         values->offset, seg_start, G, out_index, o, ok);
+    else
+      hipLaunchKernelGGL((k_seg_reduce_nullable<long long>), dim3(grid), dim3(256), 0, st, static_cast<const long long*>(vals_sorted), fk,
+                         row_valid, values->offset, seg_start, G, out_index, o, ok);
+    PDX_LAUNCH_CHECK();
+    for (int k = 0; k < nk; ++k) {
+      if (!outs[k].validity) continue;
+      if (kinds[k] == PDX_AGG_COUNT) PDX_HIP(hipMemsetAsync(outs[k].validity, 0xFF, (size_t)((G + 7) / 8), st));
+      else hipLaunchKernelGGL(k_pack_bytes, dim3(grid_for((G + 7) / 8, 256)), dim3(256), 0, st, ok, G, static_cast<uint8_t*>(outs[k].validity));
+    }
+    PDX_LAUNCH_CHECK();
+  }
+  PDX_HIP(hipStreamSynchronize(st));  // scratch is returned to the pool on exit
+  return PDX_OK;
+}
+
+int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right, int label_right, int origin_type,
+                        int64_t origin_custom_ns, int64_t offset_ns, void* stream, pdx_groupby** out) {
+  PDX_TRY(check_column(ts, "pdx_resample_create"));
+  if (!out) return fail(PDX_INVALID, "pdx_resample_create: null output");
+  if (ts->dtype != PDX_TIMESTAMP_NS && ts->dtype != PDX_INT64) return fail(PDX_INVALID, "axis must be a TimestampArray");
+  if (validity_or_null(ts)) return fail(PDX_NOT_IMPLEMENTED, "pdx_resample_create: null timestamps are not supported");
+  if (freq_ns <= 0) return fail(PDX_INVALID, "FREQ must be positive");
+  const int64_t n = ts->length;
+  if (n > 0x7FFFFFFFll) return fail(PDX_NOT_IMPLEMENTED, "pdx_resample_create: more than 2^31-1 rows per call is not supported yet");
+  hipStream_t st = as_stream(stream);
+  pdx_groupby* gb = new pdx_groupby();
+  gb->mode = 1;
+  gb->n = n;
+  gb->key_dtype = PDX_TIMESTAMP_NS;
+  *out = nullptr;
+  if (n == 0) {
+    *out = gb;
+    return PDX_OK;
+  }
+  Scratch s;
+  const long long* t = static_cast<const long long*>(ts->values) + ts->offset;
+  unsigned int* bad = s.get<unsigned int>(1);
+  if (s.failed) { delete gb; return PDX_OOM; }
+  hipMemsetAsync(bad, 0, sizeof(unsigned int), st);
+  hipLaunchKernelGGL(k_check_sorted, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, t, n, bad);
+  long long mn = 0, mx = 0;
+  int rc = minmax_i64_host(t, n, &mn, &mx, s, st);
+  unsigned int hbad = 0;
+  if (rc == PDX_OK) {
+    hipError_t e = hipMemcpyAsync(&hbad, bad, sizeof(hbad), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = hip_fail(e, "pdx_resample_create");
+  }
+  if (rc != PDX_OK) { delete gb; return rc; }
+  if (hbad) { delete gb; return fail(PDX_INVALID, "pdx_resample_create: timestamps must be sorted ascending"); }
+  // adjustDatesAnchored (src/resample.cpp:85-178), tz == ""
+  auto floor_div = [](long long a, long long b) { long long q = a / b, r = a % b; return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q; };
+  const long long day = 86400000000000LL;
+  long long first = mn, last = mx, origin = 0;
+  switch (origin_type) {
+    case PDX_ORIGIN_EPOCH: origin = 0; break;
+    case PDX_ORIGIN_START_DAY: origin = floor_div(first, day) * day; break;
+    case PDX_ORIGIN_START: origin = first; break;
+    case PDX_ORIGIN_END: origin = last; break;
+    case PDX_ORIGIN_END_DAY: origin = floor_div(last, day) * day; break;
+    default: origin = origin_custom_ns; break;
+  }
+  origin += offset_ns;
+  long long foffset = (first - origin) % freq_ns, loffset = (last - origin) % freq_ns;
+  if (closed_right) {
+    if (foffset > 0) first -= foffset; else first -= freq_ns;
+    if (loffset > 0) last += freq_ns - loffset;
+  } else {
+    if (foffset > 0) first -= foffset;
+    if (loffset > 0) last += freq_ns - loffset; else last += freq_ns;
+  }
+  if (first >= last) { delete gb; return fail(PDX_INVALID, "start date has to be less than end date"); }
+  long long nedges = (last - first) / freq_ns + 1;  // date_range: first + k*freq <= last (src/core.cpp:308-331)
+  long long last_edge = first + (nedges - 1) * freq_ns;
+  if (mn < first) { delete gb; return fail(PDX_INVALID, "Values falls before first bin"); }
+  if (mx > last_edge) { delete gb; return fail(PDX_INVALID, "Values falls after last bin"); }
+  long long nbins = nedges - 1;
+  if (n < nbins) { delete gb; return fail(PDX_INVALID, "upSampling is not implemented."); }  // GroupInfo::upsampling, src/resample.h:14-17
+  gb->bin = BinParams{t, first, freq_ns, closed_right};
+  gb->label_base = first + (label_right ? freq_ns : 0);
+  // non-empty bins: boundaries where the bin index changes (timestamps are sorted)
+  int64_t maxg = std::min<int64_t>(n, nbins);
+  gb->seg_start = gb->own<uint32_t>((size_t)maxg + 1);
+  gb->uniques = gb->own<int64_t>((size_t)maxg);
+  gb->first_rows = gb->own<int64_t>((size_t)maxg);
+  gb->unique_ok = gb->own<uint8_t>((size_t)maxg);
+  if (!gb->seg_start || !gb->uniques || !gb->first_rows || !gb->unique_ok) { delete gb; return PDX_OOM; }
+  int64_t G = 0;
+  rc = compact_indices(n, BinStartPred{gb->bin}, BinStartEmit{gb->bin, gb->label_base, gb->seg_start, gb->uniques, gb->first_rows}, &G, s, st);
+  if (rc != PDX_OK) { delete gb; return rc; }
+  gb->G = G;
+  hipLaunchKernelGGL(k_set_last, dim3(1), dim3(64), 0, st, gb->seg_start, G, (uint32_t)n);
+  hipMemsetAsync(gb->unique_ok, 1, (size_t)G, st);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { delete gb; return hip_fail(e, "pdx_resample_create"); }
+  *out = gb;
+  return PDX_OK;
+}
+
+int pdx_resample_row_labels(pdx_groupby* gb, int64_t* out_labels, void* stream) {
+  if (!gb || !out_labels) return fail(PDX_INVALID, "pdx_resample_row_labels: null argument");
+  if (gb->mode != 1) return fail(PDX_INVALID, "pdx_resample_row_labels: handle was not created by pdx_resample_create");
+  hipStream_t st = as_stream(stream);
+  if (gb->n) hipLaunchKernelGGL(k_row_labels, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->bin, gb->label_base, gb->n, out_labels);
+  PDX_LAUNCH_CHECK();
+  PDX_HIP(hipStreamSynchronize(st));
+  return PDX_OK;
+}
+
+}  // extern "C"

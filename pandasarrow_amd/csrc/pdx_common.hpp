@@ -1,0 +1,122 @@
+// pdx_common.hpp -- shared plumbing for the gfx950 kernels behind include/pdx/abi.h.
+// Error convention, scratch pool, bitmap helpers, launch geometry.  CDNA4 only (wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "pdx/abi.h"
+
+namespace pdx {
+
+// ---------------------------------------------------------------- errors (thread-local message, no exceptions)
+void set_error(const std::string& msg);
+int fail(int status, const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+#define PDX_HIP(expr)                                            \
+  do {                                                           \
+    hipError_t _e = (expr);                                      \
+    if (_e != hipSuccess) return ::pdx::hip_fail(_e, #expr);     \
+  } while (0)
+#define PDX_TRY(expr)               \
+  do {                              \
+    int _s = (expr);                \
+    if (_s != PDX_OK) return _s;    \
+  } while (0)
+#define PDX_LAUNCH_CHECK() PDX_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------- scratch pool
+// Size-bucketed caching allocator over hipMalloc: group-by needs tens of GB of workspace per call and
+// hipMalloc/hipFree of that size costs milliseconds.  Blocks are reused across calls; pdx_trim_pool frees them.
+void* pool_alloc(size_t bytes);  // nullptr on failure (error set)
+void pool_free(void* p);
+void pool_trim();
+
+struct Scratch {  // RAII: everything allocated through it is returned to the pool on scope exit
+  static constexpr int kMax = 64;
+  void* ptrs[kMax];
+  int n = 0;
+  bool failed = false;
+  ~Scratch() { release(); }
+  void release() {
+    for (int i = 0; i < n; ++i) pool_free(ptrs[i]);
+    n = 0;
+  }
+  template <typename T>
+  T* get(size_t count) {
+    void* p = pool_alloc((count ? count : 1) * sizeof(T));
+    if (!p || n >= kMax) {
+      failed = true;
+      return nullptr;
+    }
+    ptrs[n++] = p;
+    return static_cast<T*>(p);
+  }
+};
+#define PDX_SCRATCH_CHECK(s) \
+  if ((s).failed) return PDX_OOM
+
+inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+
+// ---------------------------------------------------------------- geometry
+constexpr int kWave = 64;
+constexpr int kCUs = 256;
+// memory-bound grid-stride kernels: enough workgroups to fill 256 CUs x 8 blocks, never more than the work
+inline int grid_for(int64_t work_items, int block, int items_per_thread = 1, int max_blocks = kCUs * 8) {
+  int64_t per_block = (int64_t)block * items_per_thread;
+  int64_t b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (int)b;
+}
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+// ---------------------------------------------------------------- device helpers
+// Arrow bitmap: bit i lives in byte i>>3, position i&7 (LSB first).
+__device__ __forceinline__ bool bit_get(const uint8_t* bits, int64_t i) { return (bits[i >> 3] >> (i & 7)) & 1; }
+// 64 consecutive bits starting at bit position `bitpos` (may be unaligned).  Reads up to 9 bytes; callers guarantee
+// that reading bytes up to (bitpos+63)>>3 is in bounds or pass `limit_bits` to clamp.
+__device__ __forceinline__ uint64_t load_bits64(const uint8_t* bits, int64_t bitpos, int64_t limit_bits) {
+  // limit_bits: total number of addressable bits from bit 0 of `bits` (exclusive end); bits past it read as 0
+  int64_t byte0 = bitpos >> 3;
+  int sh = (int)(bitpos & 7);
+  int64_t last_byte = (limit_bits + 7) >> 3;  // exclusive
+  uint64_t lo = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int64_t b = byte0 + k;
+    uint64_t v = (b < last_byte) ? (uint64_t)bits[b] : 0ull;
+    lo |= v << (8 * k);
+  }
+  uint64_t res = lo >> sh;
+  if (sh) {
+    int64_t b = byte0 + 8;
+    uint64_t v = (b < last_byte) ? (uint64_t)bits[b] : 0ull;
+    res |= v << (64 - sh);
+  }
+  int64_t remain = limit_bits - bitpos;
+  if (remain < 64) res &= (remain <= 0) ? 0ull : ((1ull << remain) - 1ull);
+  return res;
+}
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// device-side error flag block (one per call, in scratch): [0]=code, [1]=payload
+struct ErrFlag {
+  unsigned long long code;
+  long long payload;
+};
+
+int check_column(const pdx_column* c, const char* what);
+inline bool is_int_like(int dt) { return dt == PDX_INT64 || dt == PDX_UINT64 || dt == PDX_TIMESTAMP_NS; }
+inline const uint8_t* validity_or_null(const pdx_column* c) {
+  return (c->validity && c->null_count != 0) ? static_cast<const uint8_t*>(c->validity) : nullptr;
+}
+
+}  // namespace pdx

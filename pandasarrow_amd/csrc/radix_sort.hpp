@@ -1,0 +1,288 @@
+// radix_sort.hpp -- stable LSD radix sort of (uint32 key, payload) pairs for gfx950, header-only templates.
+//
+// Why a sort sits on the group-by path: the reference's per-group fp64 `sum` is Arrow's pairwise tree over the group's
+// rows IN ROW ORDER (src/pd_core_macros.h:103 after Grouper::ApplyGroupings, src/dataframe.cpp:1546), so a bit-exact
+// device result needs every group's values contiguous and in row order == a stable sort by group slot.
+//
+// One pass = three kernels, all HBM-streaming:
+//   k_radix_hist    : per 4096-row tile, LDS-atomic digit histogram                  (reads 4 B/row)
+//   column scan     : hist[tile][digit] -> global output offsets (3 tiny kernels)
+//   k_radix_scatter : per tile, stable rank by wave-wide match-any (ballot per digit bit) + per-wave LDS counters,
+//                     rows staged in LDS in output order, written back as contiguous runs (reads 12 B, writes 12 B/row)
+// Wave = 64 lanes; a tile is 4 waves x 16 steps x 64 rows, so row order == (wave, step, lane) order.
+#pragma once
+#include "pdx_common.hpp"
+#include "scan.hpp"
+
+namespace pdx {
+
+constexpr int kSortBlock = 256;
+constexpr int kSortItems = 16;
+constexpr int kSortTile = kSortBlock * kSortItems;  // 4096 rows
+constexpr int kSortWaves = kSortBlock / 64;
+constexpr uint32_t kSortKeyMask = 0x7FFFFFFFu;      // bit 31 of a key is a caller flag and never sorted on
+
+template <int BITS>
+__global__ void __launch_bounds__(kSortBlock) k_radix_hist(const uint32_t* __restrict__ keys, int64_t n, int shift,
+                                                           uint32_t* __restrict__ hist /* [tiles][1<<BITS] */) {
+  constexpr int R = 1 << BITS;
+  __shared__ uint32_t h[R];
+  for (int d = threadIdx.x; d < R; d += kSortBlock) h[d] = 0;
+  __syncthreads();
+  int64_t base = (int64_t)blockIdx.x * kSortTile;
+#pragma unroll
+  for (int k = 0; k < kSortItems; ++k) {
+    int64_t i = base + k * kSortBlock + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & (R - 1)], 1u);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < R; d += kSortBlock) hist[(int64_t)blockIdx.x * R + d] = h[d];
+}
+
+// ---- column scan of hist[tiles][R]: afterwards hist[t][d] = global output offset of tile t's first row with digit d
+constexpr int kColChunk = 256;  // tiles per chunk
+template <int BITS>
+__global__ void __launch_bounds__(256) k_col_chunk_sums(const uint32_t* __restrict__ hist, int64_t ntiles,
+                                                        uint32_t* __restrict__ chunk_sum /* [chunks][R] */) {
+  constexpr int R = 1 << BITS;
+  int64_t t0 = (int64_t)blockIdx.x * kColChunk;
+  int64_t t1 = t0 + kColChunk < ntiles ? t0 + kColChunk : ntiles;
+  for (int d = threadIdx.x; d < R; d += 256) {
+    uint32_t acc = 0;
+    for (int64_t t = t0; t < t1; ++t) acc += hist[t * R + d];
+    chunk_sum[(int64_t)blockIdx.x * R + d] = acc;
+  }
+}
+template <int BITS>
+__global__ void __launch_bounds__(256) k_col_chunk_scan(uint32_t* __restrict__ chunk_sum, int64_t nchunks) {
+  constexpr int R = 1 << BITS;
+  constexpr int DPT = (R + 255) / 256;  // digits per thread, contiguous
+  __shared__ uint32_t smem[8];
+  uint32_t tot[DPT];
+  uint32_t tsum = 0;
+#pragma unroll
+  for (int j = 0; j < DPT; ++j) {
+    int d = threadIdx.x * DPT + j;
+    uint32_t acc = 0;
+    if (d < R)
+      for (int64_t c = 0; c < nchunks; ++c) {
+        uint32_t v = chunk_sum[c * R + d];
+        chunk_sum[c * R + d] = acc;  // exclusive over chunks (per digit)
+        acc += v;
+      }
+    tot[j] = acc;
+    tsum += acc;
+  }
+  uint32_t total;
+  uint32_t pre = block_exclusive_scan(tsum, SumOp(), &total, smem);  // exclusive over digits
+#pragma unroll
+  for (int j = 0; j < DPT; ++j) {
+    int d = threadIdx.x * DPT + j;
+    if (d < R)
+      for (int64_t c = 0; c < nchunks; ++c) chunk_sum[c * R + d] += pre;
+    pre += tot[j];
+  }
+}
+template <int BITS>
+__global__ void __launch_bounds__(256) k_col_apply(uint32_t* __restrict__ hist, int64_t ntiles, const uint32_t* __restrict__ chunk_off) {
+  constexpr int R = 1 << BITS;
+  int64_t t0 = (int64_t)blockIdx.x * kColChunk;
+  int64_t t1 = t0 + kColChunk < ntiles ? t0 + kColChunk : ntiles;
+  for (int d = threadIdx.x; d < R; d += 256) {
+    uint32_t off = chunk_off[(int64_t)blockIdx.x * R + d];
+    for (int64_t t = t0; t < t1; ++t) {
+      uint32_t v = hist[t * R + d];
+      hist[t * R + d] = off;
+      off += v;
+    }
+  }
+}
+
+// ---- scatter
+template <int BITS, typename V, bool WRITE_KEYS>
+__global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals_in,
+                                                              uint32_t* __restrict__ keys_out, V* __restrict__ vals_out, int64_t n,
+                                                              int shift, const uint32_t* __restrict__ offsets /* [tiles][R] */) {
+  constexpr int R = 1 << BITS;
+  constexpr int DPT = (R + kSortBlock - 1) / kSortBlock;
+  __shared__ uint32_t cnt[kSortWaves][R];   // per-wave digit counters, later per-(wave,digit) local base
+  __shared__ uint32_t gbase[R];             // global offset minus local start, per digit
+  __shared__ uint32_t skeys[kSortTile];
+  __shared__ V svals[kSortTile];
+  __shared__ uint32_t scan_smem[8];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t tile_base = (int64_t)blockIdx.x * kSortTile;
+  const int tile_rows = (int)((n - tile_base) < kSortTile ? (n - tile_base) : kSortTile);
+
+  for (int d = tid; d < kSortWaves * R; d += kSortBlock) (&cnt[0][0])[d] = 0;
+  __syncthreads();
+
+  uint32_t key[kSortItems];
+  V val[kSortItems];
+  uint32_t rank[kSortItems];
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  // each wave owns rows [wave*1024, wave*1024+1024) of the tile; step s covers 64 consecutive rows
+#pragma unroll
+  for (int s = 0; s < kSortItems; ++s) {
+    int r = wave * (64 * kSortItems) + s * 64 + lane;
+    bool active = r < tile_rows;
+    key[s] = active ? keys_in[tile_base + r] : 0u;
+    if (active) val[s] = vals_in[tile_base + r];
+  }
+#pragma unroll
+  for (int s = 0; s < kSortItems; ++s) {
+    int r = wave * (64 * kSortItems) + s * 64 + lane;
+    bool active = r < tile_rows;
+    uint32_t d = (key[s] >> shift) & (R - 1);
+    uint64_t peers = __ballot(active);
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+      bool bit = (d >> b) & 1;
+      uint64_t m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    uint32_t base = 0;
+    if (active) {
+      int leader = __ffsll((unsigned long long)peers) - 1;
+      if (lane == leader) {
+        base = cnt[wave][d];
+        cnt[wave][d] = base + (uint32_t)__popcll(peers);
+      }
+      base = __shfl(base, leader, 64);
+      rank[s] = base + (uint32_t)__popcll(peers & lt_mask);
+    }
+  }
+  __syncthreads();
+  // per digit: exclusive prefix over waves, tile totals, exclusive scan over digits
+  uint32_t dsum[DPT];
+  uint32_t tsum = 0;
+#pragma unroll
+  for (int j = 0; j < DPT; ++j) {
+    int d = tid * DPT + j;
+    uint32_t acc = 0;
+    if (d < R) {
+#pragma unroll
+      for (int w = 0; w < kSortWaves; ++w) {
+        uint32_t c = cnt[w][d];
+        cnt[w][d] = acc;
+        acc += c;
+      }
+    }
+    dsum[j] = acc;
+    tsum += acc;
+  }
+  uint32_t total;
+  uint32_t pre = block_exclusive_scan(tsum, SumOp(), &total, scan_smem);
+#pragma unroll
+  for (int j = 0; j < DPT; ++j) {
+    int d = tid * DPT + j;
+    if (d < R) {
+#pragma unroll
+      for (int w = 0; w < kSortWaves; ++w) cnt[w][d] += pre;
+      gbase[d] = offsets[(int64_t)blockIdx.x * R + d] - pre;
+    }
+    pre += dsum[j];
+  }
+  __syncthreads();
+  // stage rows in output order
+#pragma unroll
+  for (int s = 0; s < kSortItems; ++s) {
+    int r = wave * (64 * kSortItems) + s * 64 + lane;
+    if (r < tile_rows) {
+      uint32_t d = (key[s] >> shift) & (R - 1);
+      uint32_t p = cnt[wave][d] + rank[s];
+      skeys[p] = key[s];
+      svals[p] = val[s];
+    }
+  }
+  __syncthreads();
+  // contiguous runs per digit -> coalesced stores
+  for (int p = tid; p < tile_rows; p += kSortBlock) {
+    uint32_t k = skeys[p];
+    uint32_t d = (k >> shift) & (R - 1);
+    uint32_t g = gbase[d] + (uint32_t)p;
+    if (WRITE_KEYS) keys_out[g] = k;
+    vals_out[g] = svals[p];
+  }
+}
+
+// ---- host driver -----------------------------------------------------------------------------------------------
+struct SortPlan {
+  int npasses;
+  int bits[8];
+};
+inline SortPlan make_sort_plan(int total_bits, int max_bits_per_pass = 8) {
+  SortPlan p;
+  if (total_bits < 1) total_bits = 1;
+  p.npasses = (total_bits + max_bits_per_pass - 1) / max_bits_per_pass;
+  int left = total_bits;
+  for (int i = 0; i < p.npasses; ++i) {
+    int b = (left + (p.npasses - i) - 1) / (p.npasses - i);
+    if (b < 4) b = 4;
+    p.bits[i] = b;
+    left -= b;
+    if (left < 0) left = 0;
+  }
+  return p;
+}
+
+template <int BITS, typename V>
+int radix_pass(const uint32_t* kin, const V* vin, uint32_t* kout, V* vout, int64_t n, int shift, bool write_keys, uint32_t* hist,
+               uint32_t* chunk_sum, hipStream_t st) {
+  int64_t ntiles = ceil_div(n, kSortTile);
+  int64_t nchunks = ceil_div(ntiles, kColChunk);
+  hipLaunchKernelGGL((k_radix_hist<BITS>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, n, shift, hist);
+  hipLaunchKernelGGL((k_col_chunk_sums<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum);
+  hipLaunchKernelGGL((k_col_chunk_scan<BITS>), dim3(1), dim3(256), 0, st, chunk_sum, nchunks);
+  hipLaunchKernelGGL((k_col_apply<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum);
+  if (write_keys)
+    hipLaunchKernelGGL((k_radix_scatter<BITS, V, true>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, vin, kout, vout, n, shift, hist);
+  else
+    hipLaunchKernelGGL((k_radix_scatter<BITS, V, false>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, vin, kout, vout, n, shift, hist);
+  PDX_LAUNCH_CHECK();
+  return PDX_OK;
+}
+
+template <typename V>
+int radix_pass_dispatch(int bits, const uint32_t* kin, const V* vin, uint32_t* kout, V* vout, int64_t n, int shift, bool write_keys,
+                        uint32_t* hist, uint32_t* chunk_sum, hipStream_t st) {
+  switch (bits) {
+    case 4: return radix_pass<4, V>(kin, vin, kout, vout, n, shift, write_keys, hist, chunk_sum, st);
+    case 5: return radix_pass<5, V>(kin, vin, kout, vout, n, shift, write_keys, hist, chunk_sum, st);
+    case 6: return radix_pass<6, V>(kin, vin, kout, vout, n, shift, write_keys, hist, chunk_sum, st);
+    case 7: return radix_pass<7, V>(kin, vin, kout, vout, n, shift, write_keys, hist, chunk_sum, st);
+    case 8: return radix_pass<8, V>(kin, vin, kout, vout, n, shift, write_keys, hist, chunk_sum, st);
+    default: return fail(PDX_INVALID, "radix sort: unsupported digit width");
+  }
+}
+
+// Sorts (keys_in, vals_in) by key bits [0, total_bits) into (*keys_sorted, *vals_sorted), which point into the
+// caller's ping-pong buffers (k0,v0)/(k1,v1).  Inputs are never written.  n must be < 2^32.
+template <typename V>
+int radix_sort_pairs(const uint32_t* keys_in, const V* vals_in, uint32_t* k0, V* v0, uint32_t* k1, V* v1, int64_t n, int total_bits,
+                     const uint32_t** keys_sorted, const V** vals_sorted, bool need_sorted_keys, Scratch& s, hipStream_t st) {
+  SortPlan plan = make_sort_plan(total_bits);
+  int64_t ntiles = ceil_div(n, kSortTile);
+  int64_t nchunks = ceil_div(ntiles, kColChunk);
+  uint32_t* hist = s.get<uint32_t>((size_t)ntiles * 256);
+  uint32_t* chunk_sum = s.get<uint32_t>((size_t)nchunks * 256);
+  PDX_SCRATCH_CHECK(s);
+  const uint32_t* kin = keys_in;
+  const V* vin = vals_in;
+  int shift = 0;
+  for (int p = 0; p < plan.npasses; ++p) {
+    uint32_t* kout = (p & 1) ? k1 : k0;
+    V* vout = (p & 1) ? v1 : v0;
+    bool last = p == plan.npasses - 1;
+    PDX_TRY(radix_pass_dispatch<V>(plan.bits[p], kin, vin, kout, vout, n, shift, !last || need_sorted_keys, hist, chunk_sum, st));
+    shift += plan.bits[p];
+    kin = kout;
+    vin = vout;
+  }
+  *keys_sorted = kin;
+  *vals_sorted = vin;
+  return PDX_OK;
+}
+
+}  // namespace pdx

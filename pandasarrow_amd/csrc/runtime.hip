@@ -1,0 +1,192 @@
+// runtime.hip -- status/error plumbing, scratch pool, host<->device helpers, synthetic input generators.
+#include <map>
+#include <mutex>
+#include <vector>
+#include "pdx_common.hpp"
+
+namespace pdx {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int status, const std::string& msg) {
+  g_last_error = msg;
+  return status;
+}
+int hip_fail(hipError_t e, const char* what) {
+  g_last_error = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what;
+  return e == hipErrorOutOfMemory ? PDX_OOM : PDX_DEVICE;
+}
+
+int check_column(const pdx_column* c, const char* what) {
+  if (!c) return fail(PDX_INVALID, std::string(what) + ": null column");
+  if (c->length < 0 || c->offset < 0) return fail(PDX_INVALID, std::string(what) + ": negative length/offset");
+  if (c->length > 0 && !c->values) return fail(PDX_INVALID, std::string(what) + ": null values pointer");
+  return PDX_OK;
+}
+
+// ---------------------------------------------------------------- pool
+namespace {
+struct Pool {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_blocks;  // size -> ptr
+  std::map<void*, size_t> live;              // ptr -> size
+};
+Pool& pool() {
+  static Pool p;
+  return p;
+}
+size_t bucket(size_t bytes) {
+  // round up to 256 B below 1 MiB, to 1/8 of the next power of two above (bounded internal fragmentation)
+  if (bytes < (1u << 20)) return (bytes + 255) & ~size_t(255);
+  size_t p2 = 1;
+  while (p2 < bytes) p2 <<= 1;
+  size_t step = p2 >> 3;
+  return (bytes + step - 1) / step * step;
+}
+}  // namespace
+
+void* pool_alloc(size_t bytes) {
+  size_t sz = bucket(bytes);
+  Pool& p = pool();
+  {
+    std::lock_guard<std::mutex> lk(p.mu);
+    auto it = p.free_blocks.lower_bound(sz);
+    if (it != p.free_blocks.end() && it->first <= sz + sz / 4) {
+      void* ptr = it->second;
+      size_t got = it->first;
+      p.free_blocks.erase(it);
+      p.live[ptr] = got;
+      return ptr;
+    }
+  }
+  void* ptr = nullptr;
+  hipError_t e = hipMalloc(&ptr, sz);
+  if (e != hipSuccess) {
+    // give cached blocks back and retry once
+    pool_trim();
+    (void)hipGetLastError();
+    e = hipMalloc(&ptr, sz);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      fail(PDX_OOM, "device allocation of " + std::to_string(sz) + " bytes failed");
+      return nullptr;
+    }
+  }
+  std::lock_guard<std::mutex> lk(p.mu);
+  p.live[ptr] = sz;
+  return ptr;
+}
+void pool_free(void* ptr) {
+  if (!ptr) return;
+  Pool& p = pool();
+  std::lock_guard<std::mutex> lk(p.mu);
+  auto it = p.live.find(ptr);
+  if (it == p.live.end()) return;
+  p.free_blocks.emplace(it->second, ptr);
+  p.live.erase(it);
+}
+void pool_trim() {
+  Pool& p = pool();
+  std::vector<void*> to_free;
+  {
+    std::lock_guard<std::mutex> lk(p.mu);
+    for (auto& kv : p.free_blocks) to_free.push_back(kv.second);
+    p.free_blocks.clear();
+  }
+  for (void* q : to_free) (void)hipFree(q);
+}
+
+// ---------------------------------------------------------------- synthetic generators
+__global__ void k_synth_keys(int64_t start, int64_t n, uint64_t num_keys, int64_t* __restrict__ out) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+    uint64_t i = (uint64_t)(start + k);
+    out[k] = (int64_t)(splitmix64(i ^ 0x5EED0001ull) % num_keys);
+  }
+}
+__global__ void k_synth_vals(int64_t start, int64_t n, uint64_t seed_off, double* __restrict__ out) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+    uint64_t i = (uint64_t)(start + k);
+    out[k] = (double)(splitmix64(i + 0x5EED0002ull + seed_off) >> 11) * 0x1.0p-53;
+  }
+}
+__global__ void k_synth_ts(int64_t start, int64_t n, int64_t t0, int64_t step, int64_t* __restrict__ out) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) out[k] = t0 + (start + k) * step;
+}
+
+}  // namespace pdx
+
+using namespace pdx;
+
+extern "C" {
+
+int pdx_abi_version(void) { return PDX_ABI_VERSION; }
+
+int pdx_init(int device) {
+  int count = 0;
+  PDX_HIP(hipGetDeviceCount(&count));
+  if (count <= 0) return fail(PDX_DEVICE, "no HIP device visible: libpdx_hip needs an MI355X (gfx950)");
+  if (device < 0 || device >= count) return fail(PDX_INVALID, "pdx_init: device index out of range");
+  PDX_HIP(hipSetDevice(device));
+  return PDX_OK;
+}
+int pdx_shutdown(void) {
+  pool_trim();
+  return PDX_OK;
+}
+const char* pdx_last_error(void) { return g_last_error.c_str(); }
+
+int pdx_malloc(void** dptr, size_t bytes) {
+  if (!dptr) return fail(PDX_INVALID, "pdx_malloc: null out pointer");
+  PDX_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+  return PDX_OK;
+}
+int pdx_free(void* dptr) {
+  if (dptr) PDX_HIP(hipFree(dptr));
+  return PDX_OK;
+}
+int pdx_to_device(void* dst, const void* src, size_t bytes, void* stream) {
+  if (bytes) PDX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+  PDX_HIP(hipStreamSynchronize(as_stream(stream)));
+  return PDX_OK;
+}
+int pdx_to_host(void* dst, const void* src, size_t bytes, void* stream) {
+  if (bytes) PDX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+  PDX_HIP(hipStreamSynchronize(as_stream(stream)));
+  return PDX_OK;
+}
+int pdx_stream_synchronize(void* stream) {
+  PDX_HIP(hipStreamSynchronize(as_stream(stream)));
+  return PDX_OK;
+}
+int pdx_trim_pool(void) {
+  pool_trim();
+  return PDX_OK;
+}
+
+int pdx_synth_keys(int64_t start, int64_t n, int64_t num_keys, int64_t* out, void* stream) {
+  if (n < 0 || num_keys <= 0) return fail(PDX_INVALID, "pdx_synth_keys: bad arguments");
+  if (n == 0) return PDX_OK;
+  hipLaunchKernelGGL(k_synth_keys, dim3(grid_for(n, 256, 4)), dim3(256), 0, as_stream(stream), start, n, (uint64_t)num_keys, out);
+  PDX_LAUNCH_CHECK();
+  return PDX_OK;
+}
+int pdx_synth_vals(int64_t start, int64_t n, uint64_t seed_off, double* out, void* stream) {
+  if (n < 0) return fail(PDX_INVALID, "pdx_synth_vals: bad arguments");
+  if (n == 0) return PDX_OK;
+  hipLaunchKernelGGL(k_synth_vals, dim3(grid_for(n, 256, 4)), dim3(256), 0, as_stream(stream), start, n, seed_off, out);
+  PDX_LAUNCH_CHECK();
+  return PDX_OK;
+}
+int pdx_synth_ts(int64_t start, int64_t n, int64_t t0_ns, int64_t step_ns, int64_t* out, void* stream) {
+  if (n < 0) return fail(PDX_INVALID, "pdx_synth_ts: bad arguments");
+  if (n == 0) return PDX_OK;
+  hipLaunchKernelGGL(k_synth_ts, dim3(grid_for(n, 256, 4)), dim3(256), 0, as_stream(stream), start, n, t0_ns, step_ns, out);
+  PDX_LAUNCH_CHECK();
+  return PDX_OK;
+}
+
+}  // extern "C"

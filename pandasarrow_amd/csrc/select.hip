@@ -1,0 +1,278 @@
+// select.hip -- boolean-mask filter, take (gather) and row concat for gfx950.
+//
+// Replaces (reference file:line)
+//   DataFrame::where / Series::where : CallFunction("filter"/"array_filter", {.., mask}, FilterOptions{EMIT_NULL})
+//        src/dataframe.cpp:461-475, src/series.cpp:130-144, reached from NDFrame::operator[](Series) src/ndframe.cpp:347-350
+//   DataFrame::take / Series::take   : CallFunction("take"/"array_take")   src/dataframe.cpp:477-492, src/series.cpp:146-159
+//   pd::concat rows                  : arrow::ConcatenateTables + CombineChunksToBatch   src/concat.cpp:152-154
+//
+// filter = ordered compaction of the selected row ids (wave ballot + popcount ranks, compact.hpp) followed by ONE fused
+// gather over all columns (the index list is read once for up to 16 columns; source reads are monotonic so every cache
+// line is fetched once).  take is the same gather with caller indices plus a bounds check that reports through a device
+// flag.  Output validity words are assembled with wave ballots: a wave owns 64 consecutive output rows.
+// Algorithmic bytes: filter (1/8 + 8(C+1)(1+s)) B/row, take (8 + 16(C+1)) B per output row.
+#include "compact.hpp"
+
+namespace pdx {
+
+constexpr int kMaxCols = 16;
+struct GatherCols {
+  const uint64_t* src[kMaxCols];      // values + offset applied
+  const uint8_t* src_valid[kMaxCols]; // or nullptr
+  int64_t src_off[kMaxCols];
+  uint64_t* dst[kMaxCols];
+  uint8_t* dst_valid[kMaxCols];       // or nullptr
+  int ncols;
+};
+
+// idx[j] < 0  => emit a null row.  idx_valid (bitmap, optional) marks null indices.  Bounds are checked against n_src.
+template <typename IDX>
+__global__ void __launch_bounds__(256) k_gather(GatherCols c, const IDX* __restrict__ idx, const uint8_t* __restrict__ idx_valid,
+                                                int64_t idx_off, int64_t m, int64_t n_src, int check_bounds, ErrFlag* err,
+                                                unsigned long long* __restrict__ null_counts) {
+  const int lane = threadIdx.x & 63;
+  int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int64_t nwords = (m + 63) >> 6;
+  for (int64_t w = wave; w < nwords; w += nwaves) {
+    int64_t j = (w << 6) + lane;
+    bool in = j < m;
+    long long k = -1;
+    if (in) {
+      bool iv = !idx_valid || bit_get(idx_valid, idx_off + j);
+      if (iv) {
+        k = (long long)idx[j];
+        if (check_bounds && (k < 0 || k >= n_src)) {
+          atomicMax(&err->code, 1ull);
+          err->payload = k;
+          k = -1;
+        }
+      }
+    }
+    for (int col = 0; col < c.ncols; ++col) {
+      bool ok = k >= 0 && (!c.src_valid[col] || bit_get(c.src_valid[col], c.src_off[col] + k));
+      if (in) c.dst[col][j] = ok ? c.src[col][k] : 0ull;
+      if (c.dst_valid[col]) {
+        uint64_t bal = __ballot(ok);
+        if (lane == 0) {
+          int64_t remain = m - (w << 6);
+          if (remain >= 64) reinterpret_cast<uint64_t*>(c.dst_valid[col])[w] = bal;
+          else {
+            int nbytes = (int)((remain + 7) >> 3);
+            for (int q = 0; q < nbytes; ++q) c.dst_valid[col][(w << 3) + q] = (uint8_t)(bal >> (8 * q));
+          }
+          int valid_rows = (int)(remain >= 64 ? 64 : remain);
+          unsigned long long nulls = (unsigned long long)(valid_rows - __popcll(bal));
+          if (nulls) atomicAdd(&null_counts[col], nulls);
+        }
+      }
+    }
+  }
+}
+
+struct MaskPred {
+  const uint8_t* mask;
+  const uint8_t* mvalid;
+  int64_t off;
+  int emit_null;
+  __device__ bool operator()(int64_t i) const {
+    bool mv = !mvalid || bit_get(mvalid, off + i);
+    return mv ? bit_get(mask, off + i) : (emit_null != 0);
+  }
+};
+struct MaskEmit {
+  const uint8_t* mvalid;
+  int64_t off;
+  int64_t* sel;
+  __device__ void operator()(int64_t pos, int64_t i) const {
+    bool mv = !mvalid || bit_get(mvalid, off + i);
+    sel[pos] = mv ? i : -1;  // a null mask slot emits a null row (FilterOptions::EMIT_NULL)
+  }
+};
+
+static int fill_cols(GatherCols& g, const pdx_column* cols, int ncols, pdx_mut_column* outs, int64_t out_len, int64_t src_len,
+                     bool forced_nulls, const char* what) {
+  if (ncols < 1 || ncols > kMaxCols) return fail(PDX_INVALID, std::string(what) + ": between 1 and 16 columns per call");
+  g.ncols = ncols;
+  for (int c = 0; c < ncols; ++c) {
+    PDX_TRY(check_column(&cols[c], what));
+    if (cols[c].dtype == PDX_BOOL) return fail(PDX_NOT_IMPLEMENTED, std::string(what) + ": boolean columns are not supported yet");
+    if (cols[c].length != src_len) return fail(PDX_INVALID, std::string(what) + ": all columns must have the same length");
+    if (outs[c].length < out_len) return fail(PDX_INVALID, std::string(what) + ": output too small");
+    if (outs[c].dtype != cols[c].dtype) return fail(PDX_INVALID, std::string(what) + ": output dtype must equal the column dtype");
+    if (out_len && !outs[c].values) return fail(PDX_INVALID, std::string(what) + ": null output buffer");
+    const uint8_t* sv = validity_or_null(&cols[c]);
+    if ((sv || forced_nulls) && !outs[c].validity) return fail(PDX_INVALID, std::string(what) + ": nulls possible but an output has no validity buffer");
+    g.src[c] = static_cast<const uint64_t*>(cols[c].values) + cols[c].offset;
+    g.src_valid[c] = sv;
+    g.src_off[c] = cols[c].offset;
+    g.dst[c] = static_cast<uint64_t*>(outs[c].values);
+    g.dst_valid[c] = static_cast<uint8_t*>(outs[c].validity);
+  }
+  return PDX_OK;
+}
+
+template <typename IDX>
+static int run_gather(GatherCols& g, const IDX* idx, const uint8_t* idx_valid, int64_t idx_off, int64_t m, int64_t n_src, int check,
+                      pdx_mut_column* outs, Scratch& s, hipStream_t st, long long* bad_index) {
+  ErrFlag* err = s.get<ErrFlag>(1);
+  unsigned long long* nulls = s.get<unsigned long long>(kMaxCols);
+  PDX_SCRATCH_CHECK(s);
+  PDX_HIP(hipMemsetAsync(err, 0, sizeof(ErrFlag), st));
+  PDX_HIP(hipMemsetAsync(nulls, 0, sizeof(unsigned long long) * kMaxCols, st));
+  if (m > 0) {
+    int64_t nwords = (m + 63) >> 6;
+    hipLaunchKernelGGL((k_gather<IDX>), dim3(grid_for(nwords * 64, 256)), dim3(256), 0, st, g, idx, idx_valid, idx_off, m, n_src, check, err, nulls);
+    PDX_LAUNCH_CHECK();
+  }
+  ErrFlag h;
+  unsigned long long hn[kMaxCols];
+  PDX_HIP(hipMemcpyAsync(&h, err, sizeof(h), hipMemcpyDeviceToHost, st));
+  PDX_HIP(hipMemcpyAsync(hn, nulls, sizeof(hn), hipMemcpyDeviceToHost, st));
+  PDX_HIP(hipStreamSynchronize(st));
+  if (h.code) {
+    *bad_index = h.payload;
+    return PDX_INDEX_ERROR;
+  }
+  for (int c = 0; c < g.ncols; ++c) {
+    outs[c].length = m;
+    outs[c].null_count = g.dst_valid[c] ? (int64_t)hn[c] : 0;
+  }
+  return PDX_OK;
+}
+
+// ---------------------------------------------------------------- concat validity: one thread per output word
+struct ConcatParts {
+  const uint8_t* valid[64];
+  int64_t off[64];
+  int64_t start[65];  // output row where each part begins; start[nparts] = total
+  int nparts;
+};
+__global__ void k_concat_validity(ConcatParts p, int64_t total, uint8_t* __restrict__ out, unsigned long long* __restrict__ nulls) {
+  int64_t nwords = (total + 63) >> 6;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned long long nc = 0;
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += stride) {
+    int64_t base = w << 6;
+    int64_t end = base + 64 < total ? base + 64 : total;
+    uint64_t r = 0;
+    for (int q = 0; q < p.nparts; ++q) {
+      int64_t lo = p.start[q] > base ? p.start[q] : base;
+      int64_t hi = p.start[q + 1] < end ? p.start[q + 1] : end;
+      if (lo >= hi) continue;
+      int cnt = (int)(hi - lo);
+      uint64_t bits = ~0ull;
+      if (p.valid[q]) bits = load_bits64(p.valid[q], p.off[q] + (lo - p.start[q]), p.off[q] + (p.start[q + 1] - p.start[q]));
+      if (cnt < 64) bits &= (1ull << cnt) - 1ull;
+      r |= bits << (lo - base);
+    }
+    int rows = (int)(end - base);
+    nc += (unsigned long long)(rows - __popcll(r));
+    if (rows == 64) reinterpret_cast<uint64_t*>(out)[w] = r;
+    else {
+      int nbytes = (rows + 7) >> 3;
+      for (int k = 0; k < nbytes; ++k) out[(w << 3) + k] = (uint8_t)(r >> (8 * k));
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) nc += __shfl_down(nc, d, 64);
+  if ((threadIdx.x & 63) == 0 && nc) atomicAdd(nulls, nc);
+}
+
+}  // namespace pdx
+
+using namespace pdx;
+
+extern "C" {
+
+int pdx_filter_count(const pdx_column* mask, int emit_null, int64_t* out_count, void* stream) {
+  PDX_TRY(check_column(mask, "pdx_filter_count"));
+  if (mask->dtype != PDX_BOOL) return fail(PDX_INVALID, "filter mask must be boolean");
+  if (!out_count) return fail(PDX_INVALID, "pdx_filter_count: null output");
+  Scratch s;
+  MaskPred pred{static_cast<const uint8_t*>(mask->values), validity_or_null(mask), mask->offset, emit_null};
+  return count_if(mask->length, pred, out_count, s, as_stream(stream));
+}
+
+int pdx_filter(const pdx_column* cols, int ncols, const pdx_column* mask, int emit_null, pdx_mut_column* outs, void* stream) {
+  PDX_TRY(check_column(mask, "pdx_filter"));
+  if (mask->dtype != PDX_BOOL) return fail(PDX_INVALID, "filter mask must be boolean");
+  if (!cols || !outs) return fail(PDX_INVALID, "pdx_filter: null argument");
+  if (ncols >= 1 && cols[0].length != mask->length)
+    return fail(PDX_INVALID, "Filter inputs must all be the same length: " + std::to_string(cols[0].length) + " vs " + std::to_string(mask->length));
+  hipStream_t st = as_stream(stream);
+  Scratch s;
+  const int64_t n = mask->length;
+  const uint8_t* mvalid = validity_or_null(mask);
+  int64_t* sel = s.get<int64_t>((size_t)n);
+  PDX_SCRATCH_CHECK(s);
+  MaskPred pred{static_cast<const uint8_t*>(mask->values), mvalid, mask->offset, emit_null};
+  MaskEmit emit{mvalid, mask->offset, sel};
+  int64_t m = 0;
+  PDX_TRY(compact_indices(n, pred, emit, &m, s, st));
+  GatherCols g;
+  PDX_TRY(fill_cols(g, cols, ncols, outs, m, n, mvalid && emit_null, "pdx_filter"));
+  long long bad = 0;
+  return run_gather<int64_t>(g, sel, nullptr, 0, m, n, 0, outs, s, st, &bad);
+}
+
+int pdx_take(const pdx_column* cols, int ncols, const pdx_column* indices, pdx_mut_column* outs, void* stream) {
+  PDX_TRY(check_column(indices, "pdx_take"));
+  if (indices->dtype == PDX_BOOL) return fail(PDX_INVALID, "take indices must be integers, not boolean");
+  if (indices->dtype != PDX_INT64 && indices->dtype != PDX_UINT64) return fail(PDX_NOT_IMPLEMENTED, "pdx_take: indices must be int64");
+  if (!cols || !outs || ncols < 1) return fail(PDX_INVALID, "pdx_take: null argument");
+  hipStream_t st = as_stream(stream);
+  Scratch s;
+  const int64_t m = indices->length, n = cols[0].length;
+  GatherCols g;
+  const uint8_t* iv = validity_or_null(indices);
+  PDX_TRY(fill_cols(g, cols, ncols, outs, m, n, iv != nullptr, "pdx_take"));
+  long long bad = 0;
+  int rc = run_gather<int64_t>(g, static_cast<const int64_t*>(indices->values) + indices->offset, iv, indices->offset, m, n, 1, outs, s, st, &bad);
+  if (rc == PDX_INDEX_ERROR) return fail(PDX_INDEX_ERROR, "Index " + std::to_string(bad) + " out of bounds");
+  return rc;
+}
+
+int pdx_concat(const pdx_column* parts, int nparts, pdx_mut_column* out, void* stream) {
+  if (!parts || !out || nparts < 1 || nparts > 64) return fail(PDX_INVALID, "pdx_concat: between 1 and 64 parts per call");
+  hipStream_t st = as_stream(stream);
+  ConcatParts cp;
+  cp.nparts = nparts;
+  int64_t total = 0;
+  bool any_valid = false;
+  for (int q = 0; q < nparts; ++q) {
+    PDX_TRY(check_column(&parts[q], "pdx_concat"));
+    if (parts[q].dtype != parts[0].dtype) return fail(PDX_INVALID, "pdx_concat: parts must share one dtype (promote first)");
+    if (parts[q].dtype == PDX_BOOL) return fail(PDX_NOT_IMPLEMENTED, "pdx_concat: boolean columns are not supported yet");
+    cp.valid[q] = validity_or_null(&parts[q]);
+    cp.off[q] = parts[q].offset;
+    cp.start[q] = total;
+    any_valid = any_valid || cp.valid[q];
+    total += parts[q].length;
+  }
+  cp.start[nparts] = total;
+  if (out->length < total) return fail(PDX_INVALID, "pdx_concat: output too small");
+  if (out->dtype != parts[0].dtype) return fail(PDX_INVALID, "pdx_concat: output dtype must equal the parts' dtype");
+  if (any_valid && !out->validity) return fail(PDX_INVALID, "pdx_concat: parts carry nulls but output has no validity buffer");
+  out->length = total;
+  out->null_count = 0;
+  if (total == 0) return PDX_OK;
+  for (int q = 0; q < nparts; ++q)
+    if (parts[q].length)
+      PDX_HIP(hipMemcpyAsync(static_cast<uint64_t*>(out->values) + cp.start[q], static_cast<const uint64_t*>(parts[q].values) + parts[q].offset,
+                             (size_t)parts[q].length * 8, hipMemcpyDeviceToDevice, st));
+  if (out->validity) {
+    Scratch s;
+    unsigned long long* nulls = s.get<unsigned long long>(1);
+    PDX_SCRATCH_CHECK(s);
+    PDX_HIP(hipMemsetAsync(nulls, 0, sizeof(*nulls), st));
+    hipLaunchKernelGGL(k_concat_validity, dim3(grid_for((total + 63) >> 6, 256)), dim3(256), 0, st, cp, total, static_cast<uint8_t*>(out->validity), nulls);
+    PDX_LAUNCH_CHECK();
+    unsigned long long h = 0;
+    PDX_HIP(hipMemcpyAsync(&h, nulls, sizeof(h), hipMemcpyDeviceToHost, st));
+    PDX_HIP(hipStreamSynchronize(st));
+    out->null_count = (int64_t)h;
+  }
+  return PDX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,429 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X).  Every check goes HIP kernels -> C ABI (libpdx_hip.so) -> ctypes,
+and is compared bit-for-bit with the CPU oracle and with the committed golden vectors (Arrow 25.0.0 outputs and the
+reference's own known-answer tests).  Tolerances: none -- integer, index and fp64 results must be bit-identical."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from conftest import assert_f64_bits, golden
+
+pytestmark = pytest.mark.gpu
+
+G = golden()
+
+
+@pytest.fixture(scope="module")
+def px():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from pandasarrow_amd import _lib as L
+    from pandasarrow_amd import api, column
+
+    L.check(L.load().pdx_init(0))
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.L, ns.K, ns.api, ns.Column, ns.torch = L, column, api, column.Column, torch
+    return ns
+
+
+def _valid_or_none(v):
+    return None if v is None or np.all(v) else v
+
+
+# ------------------------------------------------------------------ synthetic generators
+def test_synth_matches_oracle(px):
+    n = 100_003
+    assert np.array_equal(px.K.synth_keys(5, n, 1000).to_numpy()[0], orc.synth_keys(5, n, 1000))
+    assert_f64_bits(px.K.synth_vals(7, n, 3).to_numpy()[0], orc.synth_vals(7, n, 3))
+    assert np.array_equal(px.K.synth_ts(2, n, 946684800 * 10**9, 10**8).to_numpy()[0], orc.synth_ts(2, n, 946684800 * 10**9, 10**8))
+
+
+# ------------------------------------------------------------------ element-wise
+OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3}
+CMPS = {"eq": 0, "ne": 1, "lt": 2, "le": 3, "gt": 4, "ge": 5}
+
+
+@pytest.mark.parametrize("name", [c for c in G.cases("elementwise") if c.startswith("ew_")])
+@pytest.mark.parametrize("offset", [0, 5])
+def test_elementwise_golden(px, name, offset):
+    c = G.case(name)
+    scalar = c["b"].ndim == 0
+    va, vb = _valid_or_none(c["va"]), (None if scalar else _valid_or_none(c["vb"]))
+    A = px.Column.from_numpy(c["a"], va, offset=offset)
+    B = c["b"].item() if scalar else px.Column.from_numpy(c["b"], vb, offset=offset)
+    for k, op in OPS.items():
+        out = px.K.binary(op, A, B)
+        vals, valid = out.to_numpy()
+        ev = c[f"{k}_valid"]
+        if valid is not None:
+            assert np.array_equal(valid, ev), f"{name} {k} validity"
+        else:
+            assert ev.all()
+        if vals.dtype == np.float64:
+            assert_f64_bits(vals, c[k], valid=ev, what=f"{name} {k}")
+        else:
+            assert np.array_equal(vals[ev], c[k][ev]), f"{name} {k}"
+    for k, op in CMPS.items():
+        vals, valid = px.K.compare(op, A, B).to_numpy()
+        ev = c[f"{k}_valid"]
+        assert np.array_equal(vals[ev], c[k][ev]), f"{name} {k}"
+        if valid is not None:
+            assert np.array_equal(valid, ev)
+
+
+@pytest.mark.parametrize("name", [c for c in G.cases("elementwise") if c.startswith("logic_")])
+def test_logical_golden(px, name):
+    c = G.case(name)
+    A = px.Column.from_numpy(c["a"], c["va"], offset=3)
+    B = px.Column.from_numpy(c["b"], c["vb"], offset=11)
+    for k, op in (("and_", 0), ("or_", 1)):
+        vals, valid = px.K.logical(op, A, B).to_numpy()
+        ev = c[f"{k}valid"]
+        assert np.array_equal(valid, ev)
+        assert np.array_equal(vals[ev], c[k][ev])
+    vals, valid = px.K.invert(A).to_numpy()
+    assert np.array_equal(valid, c["inv_valid"])
+    assert np.array_equal(vals[c["inv_valid"]], c["inv"][c["inv_valid"]])
+
+
+def test_elementwise_errors_and_kat(px, kat):
+    S = px.api.Series
+    with pytest.raises(RuntimeError, match="divide by zero"):
+        S(np.array([7, 1])) / S(np.array([2, 0]))
+    r = S(np.array([7, 1])) / S(np.array([2, 0]), valid=np.array([True, False]))  # the zero hides under a null
+    vals, valid = r.to_numpy()
+    assert vals[0] == 3 and list(valid) == [True, False]
+    with pytest.raises(RuntimeError):
+        S(np.arange(5)) + S(np.arange(3))
+    for k in kat["binary"]:
+        if k["dtype"] == "int64":
+            a = S(np.array(k["a"], np.int64))
+            b = k["b_scalar"] if "b_scalar" in k else S(np.array(k["b"], np.int64))
+            for name, res in (("add", a + b), ("sub", a - b), ("mul", a * b), ("div", a / b)):
+                assert res.dtype() == px.L.INT64 and res.name == "" and list(res.values()) == k[name], (k["src"], name)
+        else:
+            res = S(np.array(k["a"])) - S(np.array(k["b"], np.int64))
+            assert res.dtype() == px.L.FLOAT64 and np.allclose(res.values(), k["sub_approx"])
+    assert list((-S(np.array([1, 2, 3]))).values()) == [-1, -2, -3]
+
+
+def test_elementwise_large_vs_oracle(px):
+    n = 3_000_017
+    a, b = orc.synth_vals(0, n, 1), orc.synth_vals(0, n, 2) - 0.5
+    A, B = px.K.synth_vals(0, n, 1), px.Column.from_numpy(b)
+    for op in OPS.values():
+        assert_f64_bits(px.K.binary(op, A, B).to_numpy()[0], orc.binary(op, a, b)[0], what=f"op{op}")
+    for op in CMPS.values():
+        assert np.array_equal(px.K.compare(op, A, B).to_numpy()[0], orc.compare(op, a, b)[0])
+    m1, m2 = px.K.compare(4, A, 0.5), px.K.compare(2, B, 0.0)
+    assert np.array_equal(px.K.logical(0, m1, m2).to_numpy()[0], (a > 0.5) & (b < 0.0))
+
+
+# ------------------------------------------------------------------ whole-array aggregates
+AGG = {"sum": 0, "mean": 1, "min": 2, "max": 3}
+
+
+@pytest.mark.parametrize("name", [c for c in G.cases("aggregate") if c.startswith("agg_f64") and "synth" not in c])
+@pytest.mark.parametrize("offset", [0, 3])
+def test_aggregate_f64_golden(px, name, offset):
+    c = G.case(name)
+    col = px.Column.from_numpy(c["v"], _valid_or_none(c["valid"]), offset=offset)
+    for j, kind in enumerate(AGG.values()):
+        val, cnt = px.K.aggregate(kind, col)
+        assert cnt == int(c["count"])
+        if c["isnull"][j]:
+            assert val is None
+        else:
+            assert_f64_bits([val], [c["exp"][j]], what=f"{name} kind={kind}")
+    assert px.K.aggregate(4, col)[0] == int(c["count"])
+
+
+@pytest.mark.parametrize("name", [c for c in G.cases("aggregate") if c.startswith("agg_i64")])
+def test_aggregate_i64_golden(px, name):
+    c = G.case(name)
+    col = px.Column.from_numpy(c["v"], _valid_or_none(c["valid"]), offset=2)
+    s, cnt = px.K.aggregate(0, col)
+    m, _ = px.K.aggregate(1, col)
+    lo, _ = px.K.aggregate(2, col)
+    hi, _ = px.K.aggregate(3, col)
+    assert cnt == int(c["count"])
+    if c["isnull"][0]:
+        assert s is None and m is None and lo is None and hi is None
+    else:
+        assert (s, lo, hi) == tuple(int(x) for x in c["exp_i"])
+        assert_f64_bits([m], [c["exp_mean"]])
+
+
+@pytest.mark.parametrize("name", [c for c in G.cases("aggregate") if "synth" in c])
+def test_aggregate_synth_golden(px, name):
+    c = G.case(name)
+    col = px.K.synth_vals(0, int(c["n"]), int(c["seed_off"]))
+    got = [px.K.aggregate(k, col)[0] for k in AGG.values()]
+    assert_f64_bits(got, c["exp"], what=name)
+
+
+@pytest.mark.parametrize("n", [4096, 4097, 65536 + 17, 256 * 4096, 256 * 4096 + 4095, 20_000_003])
+def test_aggregate_sum_sizes_vs_oracle(px, n):
+    v = orc.synth_vals(0, n, 5) - 0.25
+    col = px.Column.from_numpy(v)
+    for kind in AGG.values():
+        assert_f64_bits([px.K.aggregate(kind, col)[0]], [orc.agg(kind, v)[0]], what=f"n={n} kind={kind}")
+    if n <= 2_000_000:
+        valid = (orc.synth_keys(0, n, 10) != 3)
+        colv = px.Column.from_numpy(v, valid, offset=7)
+        for kind in AGG.values():
+            assert_f64_bits([px.K.aggregate(kind, colv)[0]], [orc.agg(kind, v, valid)[0]], what=f"nulls n={n} kind={kind}")
+        # long valid runs with isolated nulls + int64 mean
+        valid2 = np.ones(n, bool)
+        valid2[::1013] = False
+        vi = orc.synth_keys(0, n, 1 << 40) - (1 << 39)
+        coli = px.Column.from_numpy(vi, valid2)
+        for kind in (0, 1, 2, 3, 4):
+            assert px.K.aggregate(kind, coli)[0] == orc.agg(kind, vi, valid2)[0]
+
+
+def test_aggregate_kat(px, kat):
+    S = px.api.Series
+    for k in kat["aggregate"]:
+        s = S(np.array(k["v"], np.int64), valid=np.array(k["valid"], bool))
+        if "min" in k:
+            assert s.min() == k["min"] and s.max() == k["max"]
+        if "mean" in k:
+            assert s.mean() == k["mean"]
+
+
+# ------------------------------------------------------------------ filter / take / concat
+@pytest.mark.parametrize("name", [c for c in G.cases("filter_take") if c.startswith("filter_")])
+def test_filter_golden(px, name):
+    c = G.case(name)
+    col = px.Column.from_numpy(c["v"], _valid_or_none(c["valid"]), offset=3)
+    mask = px.Column.from_numpy(c["mask"], _valid_or_none(c["mvalid"]), offset=9)
+    for emit, key in ((True, "emit"), (False, "drop")):
+        assert px.K.filter_count(mask, emit) == len(c[key])
+        (out,) = px.K.filter([col], mask, emit)
+        vals, ok = out.to_numpy()
+        ev = c[f"{key}_valid"]
+        assert len(vals) == len(c[key])
+        if ok is not None:
+            assert np.array_equal(ok, ev)
+            assert out.null_count == int((~ev).sum())
+        else:
+            assert ev.all()
+        assert_f64_bits(vals, c[key], valid=ev, what=name)
+
+
+@pytest.mark.parametrize("name", [c for c in G.cases("filter_take") if c.startswith("take_")])
+def test_take_golden(px, name):
+    c = G.case(name)
+    col = px.Column.from_numpy(c["v"], _valid_or_none(c["valid"]), offset=2)
+    idx = px.Column.from_numpy(c["idx"], _valid_or_none(c["ivalid"]), offset=1)
+    (out,) = px.K.take([col], idx)
+    vals, ok = out.to_numpy()
+    if ok is not None:
+        assert np.array_equal(ok, c["out_valid"])
+    assert np.array_equal(vals[c["out_valid"]], c["out"][c["out_valid"]])
+
+
+def test_filter_take_errors_and_kat(px, kat):
+    S, DF = px.api.Series, px.api.DataFrame
+    s1 = S(np.array([1, 2, 3, 4, 5]))
+    with pytest.raises(RuntimeError):  # tests/series_indexing_test.cpp:27-36: mask of a different size
+        s1.where(S(np.array([False, True, True])))
+    with pytest.raises(RuntimeError):  # tests/series_indexing_test.cpp:57-60: take with a boolean mask
+        s1.take(S(np.array([False, True, True, True, False])))
+    with pytest.raises(RuntimeError):  # tests/series_indexing_test.cpp:17-25: where on an index Series
+        S(np.array([1, 2, 3, 4, 5]), is_index=True).where(S(np.array([True, False, True, False, True])))
+    with pytest.raises(RuntimeError, match=G.manifest["take_oob_message"]):
+        S(np.array([1, 2, 3])).take(S(np.array([0, 5])))
+    with pytest.raises(RuntimeError, match="out of bounds"):
+        S(np.array([1, 2, 3])).take(S(np.array([-1])))
+    for k in kat["take"]:
+        assert list(S(np.array(k["v"], np.int64)).take(S(np.array(k["idx"]))).values()) == k["out"]
+    # DataFrame mask filter + take over 8 fp64 columns + explicit index (config C2 shape, small)
+    n = 200_003
+    cols = {f"c{j}": orc.synth_vals(0, n, 20 + j) for j in range(8)}
+    df = DF(cols, index=np.arange(n, dtype=np.uint64) * 3)
+    mask = df["c0"] > 0.5
+    out = df[mask]
+    mh = cols["c0"] > 0.5
+    for j in range(8):
+        assert_f64_bits(out[f"c{j}"].values(), cols[f"c{j}"][mh])
+    assert np.array_equal(out.index.to_numpy()[0], (np.arange(n, dtype=np.uint64) * 3)[mh])
+    idx = (orc.synth_keys(0, n // 2, n)).astype(np.int64)
+    tk = df.take(S(idx))
+    for j in range(8):
+        assert_f64_bits(tk[f"c{j}"].values(), cols[f"c{j}"][idx])
+
+
+def test_concat(px, kat):
+    DF = px.api.DataFrame
+    for k in kat["concat"]:
+        a, b = (DF({"number": np.array(p, np.int64)}) for p in k["parts"])
+        r = px.api.concat([a, b])
+        assert list(r["number"].values()) == k["out"]
+        assert list(r.index.to_numpy()[0]) == k["index"]
+    rng = np.random.default_rng(5)
+    parts, valids = [], []
+    for n in (0, 1, 63, 64, 65, 1000, 7):
+        parts.append(rng.standard_normal(n))
+        valids.append(rng.random(n) > 0.3 if n % 2 else None)
+    cols = [px.Column.from_numpy(p, v, offset=i) for i, (p, v) in enumerate(zip(parts, valids))]
+    out = px.K.concat(cols)
+    vals, ok = out.to_numpy()
+    ev, eok = orc.concat(parts, valids)
+    assert np.array_equal(ok, eok) and out.null_count == int((~eok).sum())
+    assert_f64_bits(vals, ev, valid=eok)
+
+
+# ------------------------------------------------------------------ group-by
+GB = {"sum": 0, "mean": 1, "min": 2, "max": 3, "count": 4}
+
+
+@pytest.mark.parametrize("name", [c for c in G.cases("groupby") if "synth" not in c])
+def test_groupby_golden(px, name):
+    c = G.case(name)
+    kvalid = _valid_or_none(c["kvalid"]) if "kvalid" in c else None
+    key = px.Column.from_numpy(c["keys"], kvalid, offset=1)
+    gb = px.K.GroupByHandle.create(key)
+    Gn = len(c["uniq"])
+    assert gb.num_groups == Gn
+    if Gn == 0:
+        return
+    assert np.array_equal(gb.group_ids().cpu().numpy().astype(np.uint32), c["ids"])
+    uk, uok = gb.unique_keys().to_numpy()
+    if "uniq_valid" in c:
+        assert np.array_equal(uok, c["uniq_valid"])
+        assert np.array_equal(uk[uok], c["uniq"][c["uniq_valid"]])
+    else:
+        assert uok.all() and np.array_equal(uk, c["uniq"])
+    vvalid = _valid_or_none(c["vvalid"]) if "vvalid" in c else None
+    for col, keyname in (("f", "vf"), ("i", "vi")):
+        if keyname not in c:
+            continue
+        vcol = px.Column.from_numpy(c[keyname], vvalid, offset=2)
+        outs = gb.agg(vcol, list(GB.values()))  # all five from one grouped pass
+        for (k, kind), out in zip(GB.items(), outs):
+            vals, ok = out.to_numpy()
+            exp = c[f"{col}_{k}"]
+            eok = np.ones(Gn, bool) if k == "count" else c[f"{col}_ok"]
+            if ok is not None:
+                assert np.array_equal(ok, eok), f"{name} {col} {k} validity"
+            else:
+                assert eok.all()
+            if vals.dtype == np.float64:
+                assert_f64_bits(vals, exp, valid=eok, what=f"{name} {col} {k}")
+            else:
+                assert np.array_equal(vals[eok], exp[eok]), f"{name} {col} {k}"
+        # single-kind calls take the specialised kernels
+        for k in ("sum", "min"):
+            vals, ok = gb.agg(vcol, [GB[k]])[0].to_numpy()
+            eok = c[f"{col}_ok"]
+            if vals.dtype == np.float64:
+                assert_f64_bits(vals, c[f"{col}_{k}"], valid=eok, what=f"{name} {col} {k} single")
+            else:
+                assert np.array_equal(vals[eok], c[f"{col}_{k}"][eok])
+
+
+def test_groupby_synth_golden(px):
+    c = G.case("gb_synth_300000_1000")
+    n, nk = int(c["n"]), int(c["num_keys"])
+    gb = px.K.GroupByHandle.create(px.K.synth_keys(0, n, nk))
+    outs = gb.agg(px.K.synth_vals(0, n), [0, 1, 4, 2, 3])
+    assert np.array_equal(gb.unique_keys().to_numpy()[0], c["uniq"])
+    for out, k in zip(outs, ("sum", "mean", "count", "min", "max")):
+        vals = out.to_numpy()[0]
+        if k == "count":
+            assert np.array_equal(vals, c["f_count"])
+        else:
+            assert_f64_bits(vals, c[f"f_{k}"], what=k)
+
+
+def test_groupby_kat(px, kat):
+    DF = px.api.DataFrame
+    for k in kat["groupby"]:
+        cols = {"__key": np.array(k["keys"], np.int64)}
+        cols.update({nm: np.array(v, np.int64) for nm, v in k["cols"].items()})
+        gb = DF(cols).group_by("__key")
+        assert gb.groupSize() == len(k["uniques"])
+        assert list(gb.unique().to_numpy()[0]) == k["uniques"], k["src"]
+        for agg in ("sum", "mean", "min", "max", "count"):
+            for cname, exp in k.get(agg, {}).items():
+                got = getattr(gb, agg)(cname).values()
+                assert list(got) == exp, (k["src"], agg, cname)
+        if "frame_sum" in k:
+            r = gb.sum(list(k["cols"].keys()))
+            tot = sum(r[c].values() for c in k["cols"])
+            assert list(tot) == k["frame_sum"]
+
+
+@pytest.mark.parametrize("n,nk", [(1, 1), (70_001, 1), (1_000_003, 100_003), (2_500_000, 7), (5_000_000, 1_000_000)])
+def test_groupby_sizes_vs_oracle(px, n, nk):
+    """group sizes from 1 row to millions of rows (multi-chunk counter path) and table growth (nk > initial capacity / 2)."""
+    keys, vals = orc.synth_keys(0, n, nk), orc.synth_vals(0, n) - 0.5
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys))
+    s, m, cnt, lo, hi = gb.agg(px.Column.from_numpy(vals), [0, 1, 4, 2, 3])
+    ek, es, em, ec = orc.groupby_sum_mean_count(keys, vals, nthreads=8)
+    assert np.array_equal(gb.unique_keys().to_numpy()[0], ek)
+    assert np.array_equal(cnt.to_numpy()[0], ec)
+    assert_f64_bits(s.to_numpy()[0], es, what="sum")
+    assert_f64_bits(m.to_numpy()[0], em, what="mean")
+    ids, uniq, _, first = orc.group_ids(keys)
+    assert np.array_equal(gb.first_rows().cpu().numpy(), first)
+    assert_f64_bits(lo.to_numpy()[0], orc.groupby_agg(orc.AGG_MIN, ids, len(uniq), vals, nthreads=8)[0], what="min")
+    assert_f64_bits(hi.to_numpy()[0], orc.groupby_agg(orc.AGG_MAX, ids, len(uniq), vals, nthreads=8)[0], what="max")
+
+
+def test_groupby_special_keys(px):
+    keys = np.array([np.iinfo(np.int64).min, 5, np.iinfo(np.int64).min, 0, 5, np.iinfo(np.int64).max, 0], np.int64)
+    valid = np.array([1, 1, 1, 0, 1, 1, 1], bool)
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys, valid))
+    ids, uniq, isnull, _ = orc.group_ids(keys, valid)
+    assert np.array_equal(gb.group_ids().cpu().numpy().astype(np.uint32), ids)
+    uk, uok = gb.unique_keys().to_numpy()
+    assert np.array_equal(uok, ~isnull) and np.array_equal(uk[uok], uniq[~isnull])
+
+
+# ------------------------------------------------------------------ resample
+@pytest.mark.parametrize("name", G.cases("resample"))
+def test_resample_golden(px, name):
+    c = G.case(name)
+    S = px.api.Series
+    ts = px.Column.from_numpy(c["ts"], dtype=px.L.TIMESTAMP_NS)
+    ser = S(c["v"], index=ts, name="v")
+    kw = dict(closed_right=bool(c["closed_right"]), label_right=bool(c["label_right"]))
+    if bool(c["upsampling"]):
+        with pytest.raises(RuntimeError, match="upSampling"):
+            ser.resample(int(c["freq"]), **kw)
+        return
+    r = ser.resample(int(c["freq"]), **kw)
+    assert np.array_equal(r.index().to_numpy()[0], c["labels"]), name
+    assert_f64_bits(r.mean()["v"].values(), c["mean"], what=name)
+    assert_f64_bits(r.sum()["v"].values(), c["sum"], what=name)
+    assert np.array_equal(r.count()["v"].values(), c["counts"])
+    assert np.array_equal(r._h.row_labels().cpu().numpy(), orc.resample_row_labels(c["ts"], int(c["freq"]), **kw))
+
+
+def test_resample_kat_and_errors(px, kat):
+    S = px.api.Series
+    for k in kat["resample"]:
+        ts = px.K.synth_ts(0, k["n"], k["t0_ns"], k["step_ns"])
+        ser = S(np.array(k["values"], np.int64), index=ts, name="i")
+        r = ser.resample("3T", closed_right=k["closed_right"], label_right=k["label_right"])
+        assert list(r.index().to_numpy()[0]) == k["labels"], k["src"]
+        assert list(r.sum()["i"].values()) == k["sum"], k["src"]
+    with pytest.raises(RuntimeError, match="sorted"):
+        S(np.arange(4.0), index=px.Column.from_numpy(np.array([5, 4, 7, 8]) * 10**9, dtype=px.L.TIMESTAMP_NS)).resample("1S")
+
+
+def test_resample_large_vs_oracle(px):
+    n = 2_000_000  # C5 shape: 100 ms spacing, 1-minute bins -> 600 rows per bin
+    t0, step = 946_684_800 * 10**9, 100_000_000
+    ts, v = orc.synth_ts(0, n, t0, step), orc.synth_vals(0, n)
+    r = px.api.Series(px.K.synth_vals(0, n), index=px.K.synth_ts(0, n, t0, step), name="v").resample("1min")
+    labels, means, _ = orc.resample_agg(orc.AGG_MEAN, ts, v, 60 * 10**9)
+    assert np.array_equal(r.index().to_numpy()[0], labels)
+    assert_f64_bits(r.mean()["v"].values(), means)
