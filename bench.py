@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: hash group-by (sum, mean, count) of 1e9 int64-key rows x 1e6 keys (BASELINE.json
+configs[2], "group_by(int64 key).agg(sum,mean,count), 1e9 rows / 1e6 keys, 1 GPU"; configs[3] at N > 1).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one full pass of the hot path over the resident synthetic columns: pdx_groupby_create (hash keys ->
+first-occurrence group ids) + pdx_groupby_agg(sum, mean, count) (stable sort by group + Arrow-order pairwise reduce),
+inputs already in HBM, results left in HBM.  Rank 0 prints ONE JSON line (see README/DESIGN.md for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+ALGO_BYTES_PER_ROW = 16.0  # 8 B int64 key + 8 B fp64 value per row
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=float, default=1e9, help="total rows (strong scaling: split by row range over the ranks)")
+    ap.add_argument("--keys", type=float, default=1e6)
+    ap.add_argument("--cpu-sample-rows", type=float, default=3e7, help="rows of the same workload timed on the host cores (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the size-independent result checks after the timed region")
+    return ap.parse_args()
+
+
+def profile_report(lib):
+    buf = C.create_string_buffer(1 << 16)
+    from pandasarrow_amd import _lib as L
+
+    L.check(lib.pdx_profile_report(buf, len(buf)))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        tag, cnt, ms = line.split()
+        out[tag] = (int(cnt), float(ms))
+    return out
+
+
+def cpu_baseline(sample_rows, nkeys):
+    """The oracle's restatement of the reference's Arrow-CPU call sequence, timed on this host ("port")."""
+    import oracle as orc
+
+    threads = max(1, min(16, os.cpu_count() or 1))
+    keys = orc.synth_keys(0, sample_rows, nkeys)
+    vals = orc.synth_vals(0, sample_rows)
+    t0 = time.perf_counter()
+    uk, *_ = orc.groupby_sum_mean_count(keys, vals, nthreads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": sample_rows / dt / 1e9, "unit": "Grows/s", "cores": threads, "kind": "port",
+            "sample": f"first {sample_rows:.3g} rows of the same synthetic workload ({len(uk)} groups), "
+                      f"oracle/pdx_oracle.c orc_groupby_sum_mean_count, {dt:.1f} s"}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from pandasarrow_amd import _lib as L
+    from pandasarrow_amd import column as K
+
+    lib = L.load()
+    L.check(lib.pdx_init(local_rank))
+
+    n_total, nkeys = int(args.rows), int(args.keys)
+    lo = n_total * rank // world
+    hi = n_total * (rank + 1) // world
+    n_local = hi - lo
+    keys = K.synth_keys(lo, n_local, nkeys)   # resident in HBM before the timed region
+    vals = K.synth_vals(lo, n_local)
+    kinds = [L.AGG_SUM, L.AGG_MEAN, L.AGG_COUNT]
+
+    if world == 1:
+        def step():
+            gb = K.GroupByHandle.create(keys)
+            outs = gb.agg(vals, kinds)
+            return gb, outs
+    else:
+        from pandasarrow_amd import dist as pdist
+
+        engine = pdist.HipEngine()
+
+        def step():
+            return pdist.groupby_agg_sharded(engine, keys, vals, kinds, row_offset=lo)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        r = step()
+        del r
+    lib.pdx_profile_reset()
+    lib.pdx_profile_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    lib.pdx_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = profile_report(lib)
+
+    ms_per_step = dt / args.steps * 1e3
+    value = n_total / (dt / args.steps) / 1e9
+
+    # dominant kernel family (by device time inside the timed region), priced against the HBM roofline with the
+    # ALGORITHMIC bytes of the rows one launch processes (16 B/row x local rows)
+    dom, roof = None, None
+    if prof:
+        dom = max(prof.items(), key=lambda kv: kv[1][1])
+        tag, (cnt, ms) = dom
+        avg_ms = ms / cnt
+        achieved = ALGO_BYTES_PER_ROW * n_local / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": tag, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "launches_per_step": cnt / args.steps, "avg_launch_ms": avg_ms,
+                "whole_step_frac": ALGO_BYTES_PER_ROW * n_local / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items())}}
+
+    # size-independent checks on the last result (outside the timed region)
+    check = None
+    if not args.no_check:
+        if world == 1:
+            gb, outs = res
+            G = gb.num_groups
+            cnt = outs[2].values[:G]
+            sm, mean = outs[0].values[:G], outs[1].values[:G]
+            ok_counts = int(cnt.sum().item()) == n_local
+            ok_mean = bool(torch.equal(mean, sm / cnt.to(torch.float64)))
+            fr = gb.first_rows()
+            ok_order = bool((fr[1:] > fr[:-1]).all().item()) if G > 1 else True
+            check = {"groups": G, "counts_sum_to_rows": ok_counts, "mean_is_sum_over_count": ok_mean, "first_occurrence_order": ok_order}
+        else:
+            check = pdist.check_result(res, n_total)
+        if rank == 0 and not all(v for k, v in check.items() if isinstance(v, bool)):
+            raise SystemExit(f"result check failed: {check}")
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(int(min(args.cpu_sample_rows, n_total)), nkeys)
+
+    if rank == 0:
+        line = {
+            "metric": "Grows/sec hash group-by-sum, 1e9 int64 rows x 1e6 keys", "value": value, "unit": "Grows/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"group_by(int64 key).agg(sum,mean,count), {n_total:.3g} rows / {nkeys:.3g} keys"
+                                   + (", 1 GPU" if world == 1 else f", row-range sharded over {world} GPUs (RCCL exchange)"),
+                       "rows": n_total, "keys": nkeys, "rows_per_gpu": n_local, "parity": "bit-exact vs Arrow-order pairwise sum"},
+            "roofline": roof, "cpu_baseline": cpu, "check": check,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

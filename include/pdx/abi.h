@@ -111,6 +111,12 @@ int pdx_stream_synchronize(void* stream);
 /* Release cached scratch memory back to the driver. */
 int pdx_trim_pool(void);
 
+/* Optional per-kernel timing: when enabled, HIP events bracket each kernel family on its launch stream.
+ * pdx_profile_report writes one "tag count total_ms" line per kernel family. Used by bench.py for the roofline line. */
+int pdx_profile_enable(int on);
+int pdx_profile_reset(void);
+int pdx_profile_report(char* buf, size_t buf_len);
+
 /* ---------------------------------------------------------------- synthetic inputs
  * Counter-based generators, bit-identical to oracle/pdx_oracle.c orc_synth_*; used by bench.py/tests. */
 int pdx_synth_keys(int64_t start, int64_t n, int64_t num_keys, int64_t* out, void* stream);

@@ -63,6 +63,9 @@ ABI_SYMBOLS = {
     "pdx_to_host": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "pdx_stream_synchronize": (C.c_int, [_P]),
     "pdx_trim_pool": (C.c_int, []),
+    "pdx_profile_enable": (C.c_int, [C.c_int]),
+    "pdx_profile_reset": (C.c_int, []),
+    "pdx_profile_report": (C.c_int, [C.c_char_p, C.c_size_t]),
     "pdx_synth_keys": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "pdx_synth_vals": (C.c_int, [C.c_int64, C.c_int64, C.c_uint64, _P, _P]),
     "pdx_synth_ts": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P]),

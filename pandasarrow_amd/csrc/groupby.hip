@@ -516,8 +516,11 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     hipMemsetAsync(ctl, 0, sizeof(HashCtl), st);
     unsigned int limit = (unsigned int)((uint64_t)cap * 7 / 10);
     if (cap >= want) limit = cap;  // a table of >= 2n slots can never overflow
-    hipLaunchKernelGGL(k_hash_insert, dim3(grid_for(n, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, n, table, cap, limit,
-                       gb->slot_of_row, ctl);
+    {
+      PDX_PROFILE("hash_insert", st);
+      hipLaunchKernelGGL(k_hash_insert, dim3(grid_for(n, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, n, table, cap, limit,
+                         gb->slot_of_row, ctl);
+    }
     HashCtl h;
     hipError_t e = hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -693,7 +696,10 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
     const uint64_t* vs = nullptr;
     PDX_TRY(radix_sort_pairs<uint64_t>(kin, vin, k0, v0, k1, v1, n, gb->slot_bits, &keys_sorted, &vs, true, s, st));
     vals_sorted = vs;
-    hipLaunchKernelGGL(k_seg_starts, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, keys_sorted, n, gb->occ_slot, G, ss);
+    {
+      PDX_PROFILE("seg_starts", st);
+      hipLaunchKernelGGL(k_seg_starts, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, keys_sorted, n, gb->occ_slot, G, ss);
+    }
     PDX_LAUNCH_CHECK();
     seg_start = ss;
     out_index = gb->gid_of_occ;
@@ -702,6 +708,7 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
     seg_start = gb->seg_start;
     row_valid = vvalid;
   }
+  PDX_PROFILE("seg_reduce", st);
   if (!vvalid) {
     if (is_f) PDX_TRY(launch_seg_reduce_dense<double>(static_cast<const double*>(vals_sorted), seg_start, G, out_index, o, want_pw, want_mm, want_is, st));
     else PDX_TRY(launch_seg_reduce_dense<long long>(static_cast<const long long*>(vals_sorted), seg_start, G, out_index, o, want_pw, want_mm, want_is, st));

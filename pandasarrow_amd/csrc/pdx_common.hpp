@@ -58,6 +58,20 @@ struct Scratch {  // RAII: everything allocated through it is returned to the po
 
 inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 
+// ---------------------------------------------------------------- optional per-kernel timing (pdx_profile_*)
+// When enabled, a HIP event pair brackets the launches inside the scope ON THE LAUNCH STREAM; bench.py reads the
+// per-tag totals to report the dominant kernel's achieved bandwidth.  Disabled: one relaxed load per scope.
+bool profile_enabled();
+struct ProfileScope {
+  int slot;
+  hipStream_t st;
+  ProfileScope(const char* tag, hipStream_t s);
+  ~ProfileScope();
+};
+#define PDX_CONCAT2(a, b) a##b
+#define PDX_CONCAT(a, b) PDX_CONCAT2(a, b)
+#define PDX_PROFILE(tag, st) ::pdx::ProfileScope PDX_CONCAT(_pdx_prof_scope_, __LINE__)(tag, st)
+
 // ---------------------------------------------------------------- geometry
 constexpr int kWave = 64;
 constexpr int kCUs = 256;

@@ -232,10 +232,15 @@ int radix_pass(const uint32_t* kin, const V* vin, uint32_t* kout, V* vout, int64
                uint32_t* chunk_sum, hipStream_t st) {
   int64_t ntiles = ceil_div(n, kSortTile);
   int64_t nchunks = ceil_div(ntiles, kColChunk);
-  hipLaunchKernelGGL((k_radix_hist<BITS>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, n, shift, hist);
+  {
+    PDX_PROFILE(sizeof(V) == 8 ? "radix_hist" : "radix_hist_small", st);
+    hipLaunchKernelGGL((k_radix_hist<BITS>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, n, shift, hist);
+  }
+  PDX_PROFILE(sizeof(V) == 8 ? "radix_scan_scatter" : "radix_scan_scatter_small", st);
   hipLaunchKernelGGL((k_col_chunk_sums<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum);
   hipLaunchKernelGGL((k_col_chunk_scan<BITS>), dim3(1), dim3(256), 0, st, chunk_sum, nchunks);
   hipLaunchKernelGGL((k_col_apply<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum);
+  PDX_PROFILE(sizeof(V) == 8 ? "radix_scatter" : "radix_scatter_small", st);
   if (write_keys)
     hipLaunchKernelGGL((k_radix_scatter<BITS, V, true>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, vin, kout, vout, n, shift, hist);
   else

@@ -1,6 +1,9 @@
 // runtime.hip -- status/error plumbing, scratch pool, host<->device helpers, synthetic input generators.
+#include <string.h>
 #include <map>
 #include <mutex>
+#include <string>
+#include <utility>
 #include <vector>
 #include "pdx_common.hpp"
 
@@ -97,6 +100,48 @@ void pool_trim() {
   for (void* q : to_free) (void)hipFree(q);
 }
 
+// ---------------------------------------------------------------- profiling
+namespace {
+struct ProfRecord {
+  const char* tag;
+  hipEvent_t start, stop;
+};
+struct Profiler {
+  std::mutex mu;
+  bool enabled = false;
+  std::vector<ProfRecord> records;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+};
+Profiler& profiler() {
+  static Profiler p;
+  return p;
+}
+}  // namespace
+bool profile_enabled() { return profiler().enabled; }
+ProfileScope::ProfileScope(const char* tag, hipStream_t s) : slot(-1), st(s) {
+  Profiler& p = profiler();
+  if (!p.enabled) return;
+  std::lock_guard<std::mutex> lk(p.mu);
+  ProfRecord r;
+  r.tag = tag;
+  if (!p.free_events.empty()) {
+    r.start = p.free_events.back().first;
+    r.stop = p.free_events.back().second;
+    p.free_events.pop_back();
+  } else {
+    if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+  }
+  (void)hipEventRecord(r.start, st);
+  slot = (int)p.records.size();
+  p.records.push_back(r);
+}
+ProfileScope::~ProfileScope() {
+  if (slot < 0) return;
+  Profiler& p = profiler();
+  std::lock_guard<std::mutex> lk(p.mu);
+  (void)hipEventRecord(p.records[slot].stop, st);
+}
+
 // ---------------------------------------------------------------- synthetic generators
 __global__ void k_synth_keys(int64_t start, int64_t n, uint64_t num_keys, int64_t* __restrict__ out) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -164,6 +209,40 @@ int pdx_stream_synchronize(void* stream) {
 }
 int pdx_trim_pool(void) {
   pool_trim();
+  return PDX_OK;
+}
+
+int pdx_profile_enable(int on) {
+  Profiler& p = profiler();
+  std::lock_guard<std::mutex> lk(p.mu);
+  p.enabled = on != 0;
+  return PDX_OK;
+}
+int pdx_profile_reset(void) {
+  Profiler& p = profiler();
+  std::lock_guard<std::mutex> lk(p.mu);
+  for (auto& r : p.records) p.free_events.emplace_back(r.start, r.stop);
+  p.records.clear();
+  return PDX_OK;
+}
+// Writes "tag count total_ms\n" lines (aggregated per tag) into buf; synchronises the device first.
+int pdx_profile_report(char* buf, size_t buf_len) {
+  if (!buf || buf_len == 0) return fail(PDX_INVALID, "pdx_profile_report: null buffer");
+  PDX_HIP(hipDeviceSynchronize());
+  Profiler& p = profiler();
+  std::lock_guard<std::mutex> lk(p.mu);
+  std::map<std::string, std::pair<long, double>> agg;
+  for (auto& r : p.records) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) continue;
+    auto& a = agg[r.tag];
+    a.first += 1;
+    a.second += ms;
+  }
+  std::string out;
+  for (auto& kv : agg) out += kv.first + " " + std::to_string(kv.second.first) + " " + std::to_string(kv.second.second) + "\n";
+  if (out.size() + 1 > buf_len) return fail(PDX_INVALID, "pdx_profile_report: buffer too small");
+  memcpy(buf, out.c_str(), out.size() + 1);
   return PDX_OK;
 }
 
