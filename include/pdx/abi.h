@@ -155,6 +155,10 @@ int pdx_filter(const pdx_column* cols, int ncols, const pdx_column* mask, int em
  * src/series.cpp:146-159.  indices: PDX_INT64.  Out-of-range index => PDX_INDEX_ERROR "Index k out of bounds". */
 int pdx_take(const pdx_column* cols, int ncols, const pdx_column* indices, pdx_mut_column* outs, void* stream);
 
+/* Inverse of take: outs[c][indices[j]] = cols[c][j] (indices must be distinct and in [0, outs[c].length)); rows of outs
+ * that no index names are left untouched.  Used to place per-owner group results by global group id. */
+int pdx_scatter(const pdx_column* cols, int ncols, const pdx_column* indices, pdx_mut_column* outs, void* stream);
+
 /* ---------------------------------------------------------------- group-by
  * pdx_groupby_create replaces GroupBy::makeGroups (src/dataframe.cpp:1571-1600): Grouper::Make + Consume
  * (dense group ids in FIRST-OCCURRENCE order, a null key is its own group) + GetUniques.  The reference's eager
@@ -169,6 +173,9 @@ int64_t pdx_groupby_num_rows(const pdx_groupby* gb);
 int pdx_groupby_unique_keys(const pdx_groupby* gb, pdx_mut_column* out, void* stream);
 /* Grouper::Consume output: uint32 group id per input row (out_ids: device pointer to num_rows uint32). */
 int pdx_groupby_group_ids(pdx_groupby* gb, uint32_t* out_ids, void* stream);
+/* out[i] = map[group_id(i)] for every input row: routes rows by a per-group attribute (global id, owner rank) in the
+ * multi-GPU merge.  map: device pointer to G int64; out: device pointer to num_rows int64. */
+int pdx_groupby_map_ids(pdx_groupby* gb, const int64_t* map, int64_t* out, void* stream);
 /* first_row[g] = index of the first row of group g (device pointer to G int64) */
 int pdx_groupby_first_rows(const pdx_groupby* gb, int64_t* out_rows, void* stream);
 /* Replaces GROUPBY_AGG(sum|min|max) and GROUPBY_NUMERIC_AGG(mean|count) (src/pd_core_macros.h:5-147, instantiated

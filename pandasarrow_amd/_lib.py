@@ -77,12 +77,14 @@ ABI_SYMBOLS = {
     "pdx_filter_count": (C.c_int, [_COL, C.c_int, C.POINTER(C.c_int64), _P]),
     "pdx_filter": (C.c_int, [_COL, C.c_int, _COL, C.c_int, _MUT, _P]),
     "pdx_take": (C.c_int, [_COL, C.c_int, _COL, _MUT, _P]),
+    "pdx_scatter": (C.c_int, [_COL, C.c_int, _COL, _MUT, _P]),
     "pdx_groupby_create": (C.c_int, [_COL, _P, C.POINTER(_P)]),
     "pdx_groupby_destroy": (C.c_int, [_P]),
     "pdx_groupby_num_groups": (C.c_int64, [_P]),
     "pdx_groupby_num_rows": (C.c_int64, [_P]),
     "pdx_groupby_unique_keys": (C.c_int, [_P, _MUT, _P]),
     "pdx_groupby_group_ids": (C.c_int, [_P, _P, _P]),
+    "pdx_groupby_map_ids": (C.c_int, [_P, _P, _P, _P]),
     "pdx_groupby_first_rows": (C.c_int, [_P, _P, _P]),
     "pdx_groupby_agg": (C.c_int, [_P, _COL, C.POINTER(C.c_int), C.c_int, _MUT, _P]),
     "pdx_resample_create": (C.c_int, [_COL, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _P, C.POINTER(_P)]),

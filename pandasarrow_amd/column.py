@@ -239,6 +239,15 @@ def take(cols, idx: Column):
     return [o._adopt(marr[i]) for i, o in enumerate(outs)]
 
 
+def scatter(cols, idx: Column, outs):
+    """outs[c][idx[j]] = cols[c][j] in place (distinct indices)."""
+    lib = L.load()
+    marr = _mut_array(outs)
+    ci = idx.c()
+    L.check(lib.pdx_scatter(_col_array(cols), len(cols), C.byref(ci), marr, _stream()))
+    return outs
+
+
 def concat(parts) -> Column:
     lib = L.load()
     total = sum(p.length for p in parts)
@@ -307,6 +316,12 @@ class GroupByHandle:
         out = torch.empty(max(self.num_rows, 1), dtype=torch.int32, device=_device())
         L.check(L.load().pdx_groupby_group_ids(self._h, out.data_ptr(), _stream()))
         return out[: self.num_rows]
+
+    def map_ids(self, mapping: torch.Tensor) -> Column:
+        """per-row map[group_id(row)] (int64)."""
+        out = Column.empty(L.INT64, self.num_rows)
+        L.check(L.load().pdx_groupby_map_ids(self._h, mapping.data_ptr(), out.values.data_ptr(), _stream()))
+        return out
 
     def first_rows(self) -> torch.Tensor:
         out = torch.empty(max(self.num_groups, 1), dtype=torch.int64, device=_device())

@@ -133,6 +133,25 @@ __global__ void k_row_gids(const Slot* __restrict__ table, const uint32_t* __res
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = table[slot_of_row[i]].gid;
 }
 
+__global__ void k_map_ids(const Slot* __restrict__ table, const uint32_t* __restrict__ slot_of_row, const uint32_t* __restrict__ seg_start,
+                          int64_t G, int64_t n, const int64_t* __restrict__ map, int64_t* __restrict__ out) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    uint32_t g;
+    if (table) g = table[slot_of_row[i]].gid;
+    else {
+      int64_t lo = 0, hi = G;
+      while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (seg_start[mid] <= (uint32_t)i) lo = mid;
+        else hi = mid;
+      }
+      g = (uint32_t)lo;
+    }
+    out[i] = map[g];
+  }
+}
+
 // keys for the value sort when the value column has nulls: bit 31 = row is null
 __global__ void k_flag_keys(const uint32_t* __restrict__ slot_of_row, const uint8_t* __restrict__ valid, int64_t off, int64_t n,
                             uint32_t* __restrict__ out) {
@@ -631,6 +650,17 @@ int pdx_groupby_group_ids(pdx_groupby* gb, uint32_t* out_ids, void* stream) {
     hipLaunchKernelGGL(k_row_gids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->table, gb->slot_of_row, gb->n, out_ids);
   else
     hipLaunchKernelGGL(k_seg_row_ids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->seg_start, gb->G, gb->n, out_ids);
+  PDX_LAUNCH_CHECK();
+  PDX_HIP(hipStreamSynchronize(st));
+  return PDX_OK;
+}
+
+int pdx_groupby_map_ids(pdx_groupby* gb, const int64_t* map, int64_t* out, void* stream) {
+  if (!gb || !map || !out) return fail(PDX_INVALID, "pdx_groupby_map_ids: null argument");
+  hipStream_t st = as_stream(stream);
+  if (gb->n == 0) return PDX_OK;
+  hipLaunchKernelGGL(k_map_ids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->mode == 0 ? gb->table : nullptr, gb->slot_of_row,
+                     gb->seg_start, gb->G, gb->n, map, out);
   PDX_LAUNCH_CHECK();
   PDX_HIP(hipStreamSynchronize(st));
   return PDX_OK;

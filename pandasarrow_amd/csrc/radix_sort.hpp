@@ -11,6 +11,7 @@
 //                     rows staged in LDS in output order, written back as contiguous runs (reads 12 B, writes 12 B/row)
 // Wave = 64 lanes; a tile is 4 waves x 16 steps x 64 rows, so row order == (wave, step, lane) order.
 #pragma once
+#include <stdlib.h>
 #include "pdx_common.hpp"
 #include "scan.hpp"
 
@@ -258,6 +259,9 @@ int radix_pass_dispatch(int bits, const uint32_t* kin, const V* vin, uint32_t* k
     case 6: return radix_pass<6, V>(kin, vin, kout, vout, n, shift, write_keys, hist, chunk_sum, st);
     case 7: return radix_pass<7, V>(kin, vin, kout, vout, n, shift, write_keys, hist, chunk_sum, st);
     case 8: return radix_pass<8, V>(kin, vin, kout, vout, n, shift, write_keys, hist, chunk_sum, st);
+    case 9: return radix_pass<9, V>(kin, vin, kout, vout, n, shift, write_keys, hist, chunk_sum, st);
+    case 10: return radix_pass<10, V>(kin, vin, kout, vout, n, shift, write_keys, hist, chunk_sum, st);
+    case 11: return radix_pass<11, V>(kin, vin, kout, vout, n, shift, write_keys, hist, chunk_sum, st);
     default: return fail(PDX_INVALID, "radix sort: unsupported digit width");
   }
 }
@@ -267,11 +271,13 @@ int radix_pass_dispatch(int bits, const uint32_t* kin, const V* vin, uint32_t* k
 template <typename V>
 int radix_sort_pairs(const uint32_t* keys_in, const V* vals_in, uint32_t* k0, V* v0, uint32_t* k1, V* v1, int64_t n, int total_bits,
                      const uint32_t** keys_sorted, const V** vals_sorted, bool need_sorted_keys, Scratch& s, hipStream_t st) {
-  SortPlan plan = make_sort_plan(total_bits);
+  int max_bits = 8;
+  if (const char* e = getenv("PDX_SORT_MAX_BITS")) max_bits = atoi(e) >= 4 && atoi(e) <= 11 ? atoi(e) : 8;
+  SortPlan plan = make_sort_plan(total_bits, max_bits);
   int64_t ntiles = ceil_div(n, kSortTile);
   int64_t nchunks = ceil_div(ntiles, kColChunk);
-  uint32_t* hist = s.get<uint32_t>((size_t)ntiles * 256);
-  uint32_t* chunk_sum = s.get<uint32_t>((size_t)nchunks * 256);
+  uint32_t* hist = s.get<uint32_t>((size_t)ntiles * ((size_t)1 << max_bits));
+  uint32_t* chunk_sum = s.get<uint32_t>((size_t)nchunks * ((size_t)1 << max_bits));
   PDX_SCRATCH_CHECK(s);
   const uint32_t* kin = keys_in;
   const V* vin = vals_in;

@@ -70,6 +70,29 @@ __global__ void __launch_bounds__(256) k_gather(GatherCols c, const IDX* __restr
   }
 }
 
+// scatter: dst[idx[j]] = src[j]; validity bits are set/cleared with atomics (distinct rows may share a byte)
+__global__ void __launch_bounds__(256) k_scatter(GatherCols c, const int64_t* __restrict__ idx, int64_t m, int64_t n_dst, ErrFlag* err) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+    long long k = idx[j];
+    if (k < 0 || k >= n_dst) {
+      atomicMax(&err->code, 1ull);
+      err->payload = k;
+      continue;
+    }
+    for (int col = 0; col < c.ncols; ++col) {
+      bool ok = !c.src_valid[col] || bit_get(c.src_valid[col], c.src_off[col] + j);
+      c.dst[col][k] = c.src[col][j];
+      if (c.dst_valid[col]) {
+        unsigned int* word = reinterpret_cast<unsigned int*>(c.dst_valid[col]) + (k >> 5);
+        unsigned int bit = 1u << (k & 31);
+        if (ok) atomicOr(word, bit);
+        else atomicAnd(word, ~bit);
+      }
+    }
+  }
+}
+
 struct MaskPred {
   const uint8_t* mask;
   const uint8_t* mvalid;
@@ -230,6 +253,44 @@ int pdx_take(const pdx_column* cols, int ncols, const pdx_column* indices, pdx_m
   int rc = run_gather<int64_t>(g, static_cast<const int64_t*>(indices->values) + indices->offset, iv, indices->offset, m, n, 1, outs, s, st, &bad);
   if (rc == PDX_INDEX_ERROR) return fail(PDX_INDEX_ERROR, "Index " + std::to_string(bad) + " out of bounds");
   return rc;
+}
+
+int pdx_scatter(const pdx_column* cols, int ncols, const pdx_column* indices, pdx_mut_column* outs, void* stream) {
+  PDX_TRY(check_column(indices, "pdx_scatter"));
+  if (indices->dtype != PDX_INT64) return fail(PDX_INVALID, "pdx_scatter: indices must be int64");
+  if (validity_or_null(indices)) return fail(PDX_INVALID, "pdx_scatter: null indices are not allowed");
+  if (!cols || !outs || ncols < 1 || ncols > kMaxCols) return fail(PDX_INVALID, "pdx_scatter: between 1 and 16 columns per call");
+  hipStream_t st = as_stream(stream);
+  const int64_t m = indices->length;
+  GatherCols g;
+  g.ncols = ncols;
+  int64_t n_dst = outs[0].length;
+  for (int c = 0; c < ncols; ++c) {
+    PDX_TRY(check_column(&cols[c], "pdx_scatter"));
+    if (cols[c].length != m) return fail(PDX_INVALID, "pdx_scatter: columns and indices must have the same length");
+    if (outs[c].dtype != cols[c].dtype || cols[c].dtype == PDX_BOOL) return fail(PDX_INVALID, "pdx_scatter: dtype mismatch / boolean unsupported");
+    if (outs[c].length != n_dst || (n_dst && !outs[c].values)) return fail(PDX_INVALID, "pdx_scatter: bad output column");
+    const uint8_t* sv = validity_or_null(&cols[c]);
+    if (sv && !outs[c].validity) return fail(PDX_INVALID, "pdx_scatter: nulls possible but an output has no validity buffer");
+    g.src[c] = static_cast<const uint64_t*>(cols[c].values) + cols[c].offset;
+    g.src_valid[c] = sv;
+    g.src_off[c] = cols[c].offset;
+    g.dst[c] = static_cast<uint64_t*>(outs[c].values);
+    g.dst_valid[c] = static_cast<uint8_t*>(outs[c].validity);
+    outs[c].null_count = -1;
+  }
+  if (m == 0) return PDX_OK;
+  Scratch s;
+  ErrFlag* err = s.get<ErrFlag>(1);
+  PDX_SCRATCH_CHECK(s);
+  PDX_HIP(hipMemsetAsync(err, 0, sizeof(ErrFlag), st));
+  hipLaunchKernelGGL(k_scatter, dim3(grid_for(m, 256, 4)), dim3(256), 0, st, g, static_cast<const int64_t*>(indices->values) + indices->offset, m, n_dst, err);
+  PDX_LAUNCH_CHECK();
+  ErrFlag h;
+  PDX_HIP(hipMemcpyAsync(&h, err, sizeof(h), hipMemcpyDeviceToHost, st));
+  PDX_HIP(hipStreamSynchronize(st));
+  if (h.code) return fail(PDX_INDEX_ERROR, "Index " + std::to_string(h.payload) + " out of bounds");
+  return PDX_OK;
 }
 
 int pdx_concat(const pdx_column* parts, int nparts, pdx_mut_column* out, void* stream) {
