@@ -1,0 +1,625 @@
+// pdx.hpp -- C++ host facade over the C ABI (include/pdx/abi.h): the same names, argument meaning and error behaviour as the
+// reference's pd::Series / pd::DataFrame / pd::GroupBy / pd::Resampler / pd::concat for the hot path, with the data resident
+// in HBM.  Header-only; link with -lpdx_hip.  Errors are std::runtime_error(pdx_last_error()), the reference's
+// ReturnOrThrowOnFailure convention (src/core.h:181-194).
+//
+// Reference surface mirrored (file:line relative to the reference repository):
+//   pd::Series      src/series.h:20-516   operators src/series.cpp:19-33,229-261; where/take 130-159; aggregations src/ndframe.cpp:119-220
+//   pd::DataFrame   src/dataframe.h:75-709   BinaryFunction src/dataframe.cpp:233-275; where/take 461-492; group_by 1227-1235
+//   pd::GroupBy     src/group_by.h:22-299    aggregations src/pd_core_macros.h:5-147
+//   pd::Resampler   src/group_by.h:255-299   pd::resample src/resample.h:51-122
+//   pd::concat      src/concat.h:56-64
+// Differences kept deliberately small: values are constructed from host std::vector (like the reference) and uploaded once
+// (pd::GPUSeries precedent, src/cudf/series.h:10-101); the default index is an implicit 0..n-1 range instead of a materialised
+// uint64 array (src/ndframe.cpp:100-107); only int64 / double / bool / timestamp[ns] columns exist on this path.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "pdx/abi.h"
+
+namespace pd {
+
+inline void ThrowOnFailure(int status) {
+  if (status != PDX_OK) throw std::runtime_error(pdx_last_error());
+}
+
+// ---------------------------------------------------------------- device buffer / column (shared ownership, like arrow::Buffer)
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  explicit DeviceBuffer(size_t n) : bytes(n) { ThrowOnFailure(pdx_malloc(&ptr, n ? n : 1)); }
+  ~DeviceBuffer() { pdx_free(ptr); }
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+};
+using BufferPtr = std::shared_ptr<DeviceBuffer>;
+
+inline size_t bitmap_bytes(int64_t n) { return (size_t)((n + 7) / 8 + 16); }
+
+struct Array {  // arrow::ArrayData analogue in HBM
+  int dtype = PDX_INT64;
+  int64_t length = 0, offset = 0, null_count = 0;
+  BufferPtr values, validity;
+
+  pdx_column c() const {
+    pdx_column col{};
+    col.dtype = dtype;
+    col.length = length;
+    col.offset = offset;
+    col.null_count = validity ? null_count : 0;
+    col.validity = validity ? validity->ptr : nullptr;
+    col.values = values ? values->ptr : nullptr;
+    return col;
+  }
+  pdx_mut_column mut() {
+    pdx_mut_column m{};
+    m.dtype = dtype;
+    m.length = length;
+    m.null_count = -1;
+    m.validity = validity ? validity->ptr : nullptr;
+    m.values = values ? values->ptr : nullptr;
+    return m;
+  }
+  bool has_nulls() const { return validity && null_count != 0; }
+
+  static Array Empty(int dtype, int64_t n, bool with_validity) {
+    Array a;
+    a.dtype = dtype;
+    a.length = n;
+    a.values = std::make_shared<DeviceBuffer>(dtype == PDX_BOOL ? bitmap_bytes(n) : (size_t)(n > 0 ? n : 1) * 8);
+    if (with_validity) {
+      a.validity = std::make_shared<DeviceBuffer>(bitmap_bytes(n));
+      a.null_count = -1;
+    }
+    return a;
+  }
+  static std::vector<uint8_t> PackBits(const std::vector<bool>& b) {
+    std::vector<uint8_t> out(bitmap_bytes((int64_t)b.size()), 0);
+    for (size_t i = 0; i < b.size(); ++i)
+      if (b[i]) out[i >> 3] |= (uint8_t)(1u << (i & 7));
+    return out;
+  }
+  template <typename T>
+  static Array Make(const std::vector<T>& v, const std::vector<bool>* valid = nullptr) {
+    Array a;
+    const int64_t n = (int64_t)v.size();
+    a.length = n;
+    std::vector<bool> nan_valid;
+    if constexpr (std::is_same_v<T, bool>) {
+      a.dtype = PDX_BOOL;
+      auto bits = PackBits(v);
+      a.values = std::make_shared<DeviceBuffer>(bits.size());
+      ThrowOnFailure(pdx_to_device(a.values->ptr, bits.data(), bits.size(), nullptr));
+    } else {
+      a.dtype = std::is_floating_point_v<T> ? PDX_FLOAT64 : PDX_INT64;
+      using W = std::conditional_t<std::is_floating_point_v<T>, double, int64_t>;
+      std::vector<W> wide(v.begin(), v.end());
+      if constexpr (std::is_floating_point_v<T>) {
+        // ArrayT<T>::Make: NaN becomes an Arrow null on construction (src/core.h:404-436)
+        if (!valid) {
+          bool any = false;
+          nan_valid.resize(v.size(), true);
+          for (size_t i = 0; i < v.size(); ++i)
+            if (std::isnan(v[i])) { nan_valid[i] = false; any = true; }
+          if (any) valid = &nan_valid;
+        }
+      }
+      a.values = std::make_shared<DeviceBuffer>((size_t)(n > 0 ? n : 1) * 8);
+      if (n) ThrowOnFailure(pdx_to_device(a.values->ptr, wide.data(), (size_t)n * 8, nullptr));
+    }
+    if (valid) {
+      if ((int64_t)valid->size() != n) throw std::runtime_error("validity length differs from values length");
+      auto bits = PackBits(*valid);
+      a.validity = std::make_shared<DeviceBuffer>(bits.size());
+      ThrowOnFailure(pdx_to_device(a.validity->ptr, bits.data(), bits.size(), nullptr));
+      a.null_count = 0;
+      for (bool b : *valid) a.null_count += !b;
+    }
+    return a;
+  }
+  template <typename T>
+  std::vector<T> values_as() const {
+    std::vector<T> out((size_t)length);
+    if (dtype == PDX_BOOL) {
+      std::vector<uint8_t> bits(bitmap_bytes(length + offset));
+      ThrowOnFailure(pdx_to_host(bits.data(), values->ptr, (size_t)((length + offset + 7) / 8), nullptr));
+      for (int64_t i = 0; i < length; ++i) out[(size_t)i] = (T)((bits[(size_t)((i + offset) >> 3)] >> ((i + offset) & 7)) & 1);
+      return out;
+    }
+    if (dtype == PDX_FLOAT64) {
+      std::vector<double> raw((size_t)length);
+      if (length) ThrowOnFailure(pdx_to_host(raw.data(), static_cast<const double*>(values->ptr) + offset, (size_t)length * 8, nullptr));
+      for (int64_t i = 0; i < length; ++i) out[(size_t)i] = (T)raw[(size_t)i];
+    } else {
+      std::vector<int64_t> raw((size_t)length);
+      if (length) ThrowOnFailure(pdx_to_host(raw.data(), static_cast<const int64_t*>(values->ptr) + offset, (size_t)length * 8, nullptr));
+      for (int64_t i = 0; i < length; ++i) out[(size_t)i] = (T)raw[(size_t)i];
+    }
+    return out;
+  }
+  std::vector<bool> valid_flags() const {
+    std::vector<bool> out((size_t)length, true);
+    if (!validity) return out;
+    std::vector<uint8_t> bits(bitmap_bytes(length + offset));
+    ThrowOnFailure(pdx_to_host(bits.data(), validity->ptr, (size_t)((length + offset + 7) / 8), nullptr));
+    for (int64_t i = 0; i < length; ++i) out[(size_t)i] = (bits[(size_t)((i + offset) >> 3)] >> ((i + offset) & 7)) & 1;
+    return out;
+  }
+};
+
+// ---------------------------------------------------------------- pd::Scalar (src/scalar.h:62-241)
+struct Scalar {
+  pdx_scalar s{};
+  Scalar() = default;
+  explicit Scalar(pdx_scalar v) : s(v) {}
+  Scalar(int64_t v) { s.dtype = PDX_INT64; s.is_valid = 1; s.v.i64 = v; }
+  Scalar(int v) : Scalar((int64_t)v) {}
+  Scalar(double v) { s.dtype = PDX_FLOAT64; s.is_valid = 1; s.v.f64 = v; }
+  bool isValid() const { return s.is_valid != 0; }
+  template <typename T>
+  T as() const {
+    if (!s.is_valid) {
+      if constexpr (std::is_floating_point_v<T>) return std::nan("");  // null -> NaN for floats (src/scalar.h:105-150)
+      throw std::runtime_error("scalar is null");
+    }
+    return s.dtype == PDX_FLOAT64 ? (T)s.v.f64 : (T)s.v.i64;
+  }
+  bool operator==(double x) const { return s.is_valid && (s.dtype == PDX_FLOAT64 ? s.v.f64 == x : (double)s.v.i64 == x); }
+  Array to_array() const {
+    std::vector<bool> valid{isValid()};
+    return s.dtype == PDX_FLOAT64 ? Array::Make(std::vector<double>{s.v.f64}, &valid) : Array::Make(std::vector<int64_t>{s.v.i64}, &valid);
+  }
+};
+
+class DataFrame;
+struct GroupBy;
+struct Resampler;
+
+// ---------------------------------------------------------------- pd::Series
+class Series {
+ public:
+  Array m_array;
+  std::optional<Array> m_index;  // nullopt = implicit 0..n-1 range
+  std::string m_name;
+  bool m_is_index = false;
+
+  Series() = default;
+  Series(Array a, std::optional<Array> index = std::nullopt, std::string name = "", bool is_index = false)
+      : m_array(std::move(a)), m_index(std::move(index)), m_name(std::move(name)), m_is_index(is_index) {}
+  template <typename T>
+  explicit Series(const std::vector<T>& v, std::string name = "") : m_array(Array::Make(v)), m_name(std::move(name)) {}
+  template <typename T>
+  Series(const std::vector<T>& v, const std::vector<bool>& valid, std::string name = "") : m_array(Array::Make(v, &valid)), m_name(std::move(name)) {}
+
+  int64_t size() const { return m_array.length; }
+  int dtype() const { return m_array.dtype; }
+  const std::string& name() const { return m_name; }
+  template <typename T>
+  std::vector<T> values() const { return m_array.values_as<T>(); }
+  Scalar at(int64_t i) const {
+    if (i < 0 || i >= size()) throw std::runtime_error("index out of range");
+    Array one = m_array;
+    one.offset += i;
+    one.length = 1;
+    pdx_scalar s{};
+    auto c = one.c();
+    // a length-1 min is the element itself (null-aware)
+    ThrowOnFailure(pdx_aggregate(m_array.dtype == PDX_BOOL ? PDX_AGG_COUNT : PDX_AGG_MIN, &c, &s, nullptr));
+    return Scalar(s);
+  }
+
+  // ---- BINARY_OPERATOR (src/series.cpp:19-33): Series rhs needs equal length (equal-index fast path of broadcast(), 212-216)
+  Series binary(int op, const Series& o) const {
+    if (o.size() != size()) throw std::runtime_error("Array arguments must all be the same length");
+    return wrap(run_binary(op, m_array, o.m_array, false));
+  }
+  Series binary(int op, const Scalar& o) const { return wrap(run_binary(op, m_array, o.to_array(), true)); }
+  Series operator+(const Series& o) const { return binary(PDX_ADD, o); }
+  Series operator-(const Series& o) const { return binary(PDX_SUB, o); }
+  Series operator*(const Series& o) const { return binary(PDX_MUL, o); }
+  Series operator/(const Series& o) const { return binary(PDX_DIV, o); }
+  Series operator+(const Scalar& o) const { return binary(PDX_ADD, o); }
+  Series operator-(const Scalar& o) const { return binary(PDX_SUB, o); }
+  Series operator*(const Scalar& o) const { return binary(PDX_MUL, o); }
+  Series operator/(const Scalar& o) const { return binary(PDX_DIV, o); }
+  Series operator-() const { return m_array.dtype == PDX_FLOAT64 ? binary(PDX_MUL, Scalar(-1.0)) : binary(PDX_MUL, Scalar((int64_t)-1)); }
+
+  // ---- comparisons (src/series.cpp:247-257) and logical (259-261, 319)
+  Series compare(int op, const Series& o) const {
+    if (o.size() != size()) throw std::runtime_error("Array arguments must all be the same length");
+    return wrap(run_compare(op, m_array, o.m_array, false));
+  }
+  Series compare(int op, const Scalar& o) const { return wrap(run_compare(op, m_array, o.to_array(), true)); }
+  Series operator<(const Series& o) const { return compare(PDX_LT, o); }
+  Series operator<=(const Series& o) const { return compare(PDX_LE, o); }
+  Series operator>(const Series& o) const { return compare(PDX_GT, o); }
+  Series operator>=(const Series& o) const { return compare(PDX_GE, o); }
+  Series operator==(const Series& o) const { return compare(PDX_EQ, o); }
+  Series operator!=(const Series& o) const { return compare(PDX_NE, o); }
+  Series operator<(const Scalar& o) const { return compare(PDX_LT, o); }
+  Series operator<=(const Scalar& o) const { return compare(PDX_LE, o); }
+  Series operator>(const Scalar& o) const { return compare(PDX_GT, o); }
+  Series operator>=(const Scalar& o) const { return compare(PDX_GE, o); }
+  Series operator==(const Scalar& o) const { return compare(PDX_EQ, o); }
+  Series operator!=(const Scalar& o) const { return compare(PDX_NE, o); }
+  Series operator&&(const Series& o) const { return wrap(run_logical(PDX_AND, m_array, o.m_array)); }
+  Series operator||(const Series& o) const { return wrap(run_logical(PDX_OR, m_array, o.m_array)); }
+  Series operator!() const {
+    Array out = Array::Empty(PDX_BOOL, size(), m_array.has_nulls());
+    auto a = m_array.c();
+    auto m = out.mut();
+    ThrowOnFailure(pdx_invert(&a, &m, nullptr));
+    out.null_count = m.null_count;
+    return wrap(std::move(out));
+  }
+
+  // ---- NDFrame aggregations (src/ndframe.cpp:119-220)
+  Scalar agg(int kind) const {
+    pdx_scalar s{};
+    auto c = m_array.c();
+    ThrowOnFailure(pdx_aggregate(kind, &c, &s, nullptr));
+    return Scalar(s);
+  }
+  Scalar sum() const { return agg(PDX_AGG_SUM); }
+  Scalar mean() const { return agg(PDX_AGG_MEAN); }
+  Scalar min() const { return agg(PDX_AGG_MIN); }
+  Scalar max() const { return agg(PDX_AGG_MAX); }
+  Scalar count() const { return agg(PDX_AGG_COUNT); }
+
+  // ---- where / take / operator[] (src/series.cpp:130-159, src/ndframe.cpp:347-350)
+  Series where(const Series& mask) const {
+    if (m_is_index) throw std::runtime_error("where() is not supported on an index Series");
+    if (mask.dtype() != PDX_BOOL) throw std::runtime_error("filter mask must be boolean");
+    auto outs = run_filter(columns_with_index(), mask.m_array);
+    return Series(outs[0], m_index ? std::optional<Array>(outs[1]) : std::nullopt, m_name);
+  }
+  Series take(const Series& idx) const {
+    if (idx.dtype() == PDX_BOOL) throw std::runtime_error("take indices must be integers, not boolean");
+    auto outs = run_take(columns_with_index(), idx.m_array);
+    return Series(outs[0], m_index ? std::optional<Array>(outs[1]) : std::nullopt, m_name);
+  }
+  Series operator[](const Series& s) const { return s.dtype() == PDX_BOOL ? where(s) : take(s); }
+
+  inline Resampler resample(const std::string& rule, bool closed_right = false, bool label_right = false) const;
+
+  // ---- shared kernels-through-ABI helpers (also used by DataFrame)
+  static Array run_binary(int op, const Array& a, const Array& b, bool scalar) {
+    const bool is_f = a.dtype == PDX_FLOAT64 || b.dtype == PDX_FLOAT64;
+    Array out = Array::Empty(is_f ? PDX_FLOAT64 : PDX_INT64, a.length, a.has_nulls() || b.has_nulls());
+    auto ca = a.c(), cb = b.c();
+    auto m = out.mut();
+    ThrowOnFailure(pdx_binary(op, &ca, &cb, scalar, &m, nullptr));
+    out.null_count = m.null_count;
+    return out;
+  }
+  static Array run_compare(int op, const Array& a, const Array& b, bool scalar) {
+    Array out = Array::Empty(PDX_BOOL, a.length, a.has_nulls() || b.has_nulls());
+    auto ca = a.c(), cb = b.c();
+    auto m = out.mut();
+    ThrowOnFailure(pdx_compare(op, &ca, &cb, scalar, &m, nullptr));
+    out.null_count = m.null_count;
+    return out;
+  }
+  static Array run_logical(int op, const Array& a, const Array& b) {
+    Array out = Array::Empty(PDX_BOOL, a.length, a.has_nulls() || b.has_nulls());
+    auto ca = a.c(), cb = b.c();
+    auto m = out.mut();
+    ThrowOnFailure(pdx_logical(op, &ca, &cb, &m, nullptr));
+    out.null_count = m.null_count;
+    return out;
+  }
+  static std::vector<Array> run_filter(const std::vector<Array>& cols, const Array& mask) {
+    std::vector<pdx_column> in;
+    for (auto& c : cols) in.push_back(c.c());
+    auto cm = mask.c();
+    int64_t m = 0;
+    if (!cols.empty() && cols[0].length != mask.length)
+      throw std::runtime_error("Filter inputs must all be the same length");
+    ThrowOnFailure(pdx_filter_count(&cm, /*emit_null=*/1, &m, nullptr));
+    std::vector<Array> outs;
+    std::vector<pdx_mut_column> mo;
+    for (auto& c : cols) {
+      outs.push_back(Array::Empty(c.dtype, m, c.has_nulls() || mask.has_nulls()));
+      mo.push_back(outs.back().mut());
+    }
+    ThrowOnFailure(pdx_filter(in.data(), (int)in.size(), &cm, 1, mo.data(), nullptr));
+    for (size_t i = 0; i < outs.size(); ++i) outs[i].null_count = mo[i].null_count;
+    return outs;
+  }
+  static std::vector<Array> run_take(const std::vector<Array>& cols, const Array& idx) {
+    std::vector<pdx_column> in;
+    for (auto& c : cols) in.push_back(c.c());
+    auto ci = idx.c();
+    std::vector<Array> outs;
+    std::vector<pdx_mut_column> mo;
+    for (auto& c : cols) {
+      outs.push_back(Array::Empty(c.dtype, idx.length, c.has_nulls() || idx.has_nulls()));
+      mo.push_back(outs.back().mut());
+    }
+    ThrowOnFailure(pdx_take(in.data(), (int)in.size(), &ci, mo.data(), nullptr));
+    for (size_t i = 0; i < outs.size(); ++i) outs[i].null_count = mo[i].null_count;
+    return outs;
+  }
+
+ private:
+  // ReturnSeriesOrThrowOnError (src/series.cpp:1364-1384): equal length -> same index; the result name is reset to ""
+  Series wrap(Array a) const { return Series(std::move(a), m_index, ""); }
+  std::vector<Array> columns_with_index() const {
+    std::vector<Array> cols{m_array};
+    if (m_index) cols.push_back(*m_index);
+    return cols;
+  }
+};
+inline Series operator+(const Scalar& a, const Series& b) { return b + a; }
+inline Series operator*(const Scalar& a, const Series& b) { return b * a; }
+
+// ---------------------------------------------------------------- handle shared by GroupBy / Resampler
+struct GroupHandle {
+  pdx_groupby* h = nullptr;
+  explicit GroupHandle(pdx_groupby* p) : h(p) {}
+  ~GroupHandle() { pdx_groupby_destroy(h); }
+  GroupHandle(const GroupHandle&) = delete;
+  GroupHandle& operator=(const GroupHandle&) = delete;
+};
+
+// ---------------------------------------------------------------- pd::DataFrame
+class DataFrame {
+ public:
+  std::vector<std::string> m_names;
+  std::vector<Array> m_columns;
+  std::optional<Array> m_index;
+
+  DataFrame() = default;
+  template <typename T>
+  explicit DataFrame(const std::map<std::string, std::vector<T>>& cols) {
+    for (auto& kv : cols) {
+      m_names.push_back(kv.first);
+      m_columns.push_back(Array::Make(kv.second));
+    }
+    check();
+  }
+  DataFrame(std::vector<std::string> names, std::vector<Array> cols, std::optional<Array> index = std::nullopt)
+      : m_names(std::move(names)), m_columns(std::move(cols)), m_index(std::move(index)) { check(); }
+
+  int64_t num_rows() const { return m_columns.empty() ? 0 : m_columns[0].length; }
+  int64_t num_columns() const { return (int64_t)m_columns.size(); }
+  int column_index(const std::string& name) const {
+    for (size_t i = 0; i < m_names.size(); ++i)
+      if (m_names[i] == name) return (int)i;
+    throw std::runtime_error("no column named " + name);
+  }
+  Series operator[](const std::string& name) const { return Series(m_columns[(size_t)column_index(name)], m_index, name); }
+  DataFrame operator[](const Series& s) const { return s.dtype() == PDX_BOOL ? where(s) : take(s); }
+
+  // BinaryFunction (src/dataframe.cpp:233-275): the same kernel over every column
+  DataFrame binary(int op, const DataFrame& o) const {
+    if (o.num_rows() != num_rows() || o.num_columns() != num_columns()) throw std::runtime_error("DataFrame shapes differ");
+    std::vector<Array> out;
+    for (size_t i = 0; i < m_columns.size(); ++i) out.push_back(Series::run_binary(op, m_columns[i], o.m_columns[i], false));
+    return DataFrame(m_names, out, m_index);
+  }
+  DataFrame binary(int op, const Series& o) const {
+    if (o.size() != num_rows()) throw std::runtime_error("Array arguments must all be the same length");
+    std::vector<Array> out;
+    for (auto& c : m_columns) out.push_back(Series::run_binary(op, c, o.m_array, false));
+    return DataFrame(m_names, out, m_index);
+  }
+  DataFrame binary(int op, const Scalar& o) const {
+    std::vector<Array> out;
+    Array s = o.to_array();
+    for (auto& c : m_columns) out.push_back(Series::run_binary(op, c, s, true));
+    return DataFrame(m_names, out, m_index);
+  }
+  template <typename R> DataFrame operator+(const R& o) const { return binary(PDX_ADD, o); }
+  template <typename R> DataFrame operator-(const R& o) const { return binary(PDX_SUB, o); }
+  template <typename R> DataFrame operator*(const R& o) const { return binary(PDX_MUL, o); }
+  template <typename R> DataFrame operator/(const R& o) const { return binary(PDX_DIV, o); }
+
+  // NDFrame::sum on a frame (src/ndframe.h:329-335): every column (chunk) summed, totals added in column order
+  Scalar sum() const {
+    bool first = true, is_f = false;
+    double f = 0;
+    int64_t i = 0;
+    for (auto& c : m_columns) {
+      Scalar s = Series(c).sum();
+      if (!s.isValid()) continue;
+      if (s.s.dtype == PDX_FLOAT64) { f = first ? s.s.v.f64 : f + s.s.v.f64; is_f = true; }
+      else i = first ? s.s.v.i64 : (int64_t)((uint64_t)i + (uint64_t)s.s.v.i64);
+      first = false;
+    }
+    if (first) return Scalar();
+    return is_f ? Scalar(f) : Scalar(i);
+  }
+
+  DataFrame where(const Series& mask) const {
+    if (mask.dtype() != PDX_BOOL) throw std::runtime_error("filter mask must be boolean");
+    auto outs = Series::run_filter(columns_with_index(), mask.m_array);
+    return rebuild(outs);
+  }
+  DataFrame take(const Series& idx) const {
+    if (idx.dtype() == PDX_BOOL) throw std::runtime_error("take indices must be integers, not boolean");
+    auto outs = Series::run_take(columns_with_index(), idx.m_array);
+    return rebuild(outs);
+  }
+
+  inline GroupBy group_by(const std::string& key) const;
+  inline Resampler resample(const std::string& rule, bool closed_right = false, bool label_right = false) const;
+
+ private:
+  void check() const {
+    for (auto& c : m_columns)
+      if (c.length != num_rows()) throw std::runtime_error("all columns must have the same length");
+  }
+  std::vector<Array> columns_with_index() const {
+    std::vector<Array> cols = m_columns;
+    if (m_index) cols.push_back(*m_index);
+    return cols;
+  }
+  DataFrame rebuild(std::vector<Array>& outs) const {
+    std::optional<Array> idx;
+    if (m_index) {
+      idx = outs.back();
+      outs.pop_back();
+    }
+    return DataFrame(m_names, outs, idx);
+  }
+};
+
+// ---------------------------------------------------------------- pd::GroupBy (src/group_by.h:22-299)
+struct GroupBy {
+  DataFrame df;
+  std::shared_ptr<GroupHandle> handle;
+  int key_dtype = PDX_INT64;
+
+  GroupBy(const std::string& key, DataFrame frame) : df(std::move(frame)) {  // the ctor runs makeGroups(key) (group_by.h:24-31)
+    const Array& k = df.m_columns[(size_t)df.column_index(key)];
+    key_dtype = k.dtype;
+    auto c = k.c();
+    pdx_groupby* h = nullptr;
+    ThrowOnFailure(pdx_groupby_create(&c, nullptr, &h));
+    handle = std::make_shared<GroupHandle>(h);
+  }
+  GroupBy(DataFrame frame, std::shared_ptr<GroupHandle> h, int kd) : df(std::move(frame)), handle(std::move(h)), key_dtype(kd) {}
+
+  size_t groupSize() const { return (size_t)pdx_groupby_num_groups(handle->h); }
+  Array unique() const {  // uniqueKeys (group_by.h:52-55)
+    Array out = Array::Empty(key_dtype, (int64_t)groupSize(), true);
+    auto m = out.mut();
+    ThrowOnFailure(pdx_groupby_unique_keys(handle->h, &m, nullptr));
+    return out;
+  }
+  Array agg_array(const std::string& arg, int kind) const {
+    const Array& v = df.m_columns[(size_t)df.column_index(arg)];
+    int out_dt = kind == PDX_AGG_MEAN ? PDX_FLOAT64 : kind == PDX_AGG_COUNT ? PDX_INT64 : v.dtype;
+    Array out = Array::Empty(out_dt, (int64_t)groupSize(), v.has_nulls() && kind != PDX_AGG_COUNT);
+    auto c = v.c();
+    auto m = out.mut();
+    ThrowOnFailure(pdx_groupby_agg(handle->h, &c, &kind, 1, &m, nullptr));
+    out.null_count = m.null_count;
+    return out;
+  }
+  // GROUPBY_AGG / GROUPBY_NUMERIC_AGG overloads (src/pd_core_macros.h:5-147): one column -> Series, several -> DataFrame,
+  // both indexed by uniqueKeys
+  Series agg(const std::string& arg, int kind) const { return Series(agg_array(arg, kind), unique(), arg); }
+  DataFrame agg(const std::vector<std::string>& args, int kind) const {
+    std::vector<Array> cols;
+    for (auto& a : args) cols.push_back(agg_array(a, kind));
+    return DataFrame(args, cols, unique());
+  }
+  Series sum(const std::string& a) const { return agg(a, PDX_AGG_SUM); }
+  Series mean(const std::string& a) const { return agg(a, PDX_AGG_MEAN); }
+  Series min(const std::string& a) const { return agg(a, PDX_AGG_MIN); }
+  Series max(const std::string& a) const { return agg(a, PDX_AGG_MAX); }
+  Series count(const std::string& a) const { return agg(a, PDX_AGG_COUNT); }
+  DataFrame sum(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_SUM); }
+  DataFrame mean(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_MEAN); }
+  DataFrame min(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_MIN); }
+  DataFrame max(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_MAX); }
+  DataFrame count(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_COUNT); }
+};
+
+// ---------------------------------------------------------------- pd::Resampler (src/group_by.h:255-299)
+struct Resampler : GroupBy {
+  using GroupBy::GroupBy;
+  Array index() const { return unique(); }
+  // RESAMPLE_GROUP_BY_FUNCTION (group_by.h:249-253): aggregate ALL columns, index = labels of the non-empty bins
+  DataFrame sum() const { return agg(df.m_names, PDX_AGG_SUM); }
+  DataFrame mean() const { return agg(df.m_names, PDX_AGG_MEAN); }
+  DataFrame min() const { return agg(df.m_names, PDX_AGG_MIN); }
+  DataFrame max() const { return agg(df.m_names, PDX_AGG_MAX); }
+  DataFrame count() const { return agg(df.m_names, PDX_AGG_COUNT); }
+};
+
+// rule string -> nanoseconds: splitTimeSpan + the unit table of pd::resample (src/resample.h:51-89); fixed durations only
+inline int64_t rule_to_ns(const std::string& rule) {
+  size_t p = 0;
+  while (p < rule.size() && std::isdigit((unsigned char)rule[p])) ++p;
+  int64_t mult = p ? std::stoll(rule.substr(0, p)) : 1;
+  std::string u = rule.substr(p);
+  if (u == "T" || u == "min") return mult * 60000000000LL;
+  if (u == "S") return mult * 1000000000LL;
+  if (u == "L" || u == "ms") return mult * 1000000LL;
+  if (u == "U" || u == "us") return mult * 1000LL;
+  if (u == "N" || u == "ns") return mult;
+  throw std::runtime_error("resample rule '" + rule + "': only [T/min S L/ms U/us N/ns] are supported on this path");
+}
+
+inline Resampler resample(const DataFrame& df, int64_t freq_ns, bool closed_right = false, bool label_right = false,
+                          int origin = PDX_ORIGIN_START_DAY, int64_t origin_custom_ns = 0, int64_t offset_ns = 0) {
+  if (!df.m_index) throw std::runtime_error("axis must be a TimestampArray but got the implicit range index");
+  auto c = df.m_index->c();
+  pdx_groupby* h = nullptr;
+  ThrowOnFailure(pdx_resample_create(&c, freq_ns, closed_right, label_right, origin, origin_custom_ns, offset_ns, nullptr, &h));
+  return Resampler(df, std::make_shared<GroupHandle>(h), PDX_TIMESTAMP_NS);
+}
+inline Resampler resample(const DataFrame& df, const std::string& rule, bool closed_right = false, bool label_right = false) {
+  return resample(df, rule_to_ns(rule), closed_right, label_right);
+}
+inline Resampler resample(const Series& s, int64_t freq_ns, bool closed_right = false, bool label_right = false) {
+  return resample(DataFrame({s.name().empty() ? "0" : s.name()}, {s.m_array}, s.m_index), freq_ns, closed_right, label_right);
+}
+inline GroupBy DataFrame::group_by(const std::string& key) const { return GroupBy(key, *this); }
+inline Resampler DataFrame::resample(const std::string& rule, bool cr, bool lr) const { return pd::resample(*this, rule, cr, lr); }
+inline Resampler Series::resample(const std::string& rule, bool cr, bool lr) const { return pd::resample(*this, rule_to_ns(rule), cr, lr); }
+
+// date_range(start, periods, freq) for the tests (src/core.cpp:333-360 shape): timestamp[ns] index
+inline Array date_range(int64_t start_ns, int periods, int64_t freq_ns = 60000000000LL) {
+  std::vector<int64_t> t((size_t)periods);
+  for (int i = 0; i < periods; ++i) t[(size_t)i] = start_ns + (int64_t)i * freq_ns;
+  Array a = Array::Make(t);
+  a.dtype = PDX_TIMESTAMP_NS;
+  return a;
+}
+
+// ---------------------------------------------------------------- pd::concat rows (src/concat.h:56-64, src/concat.cpp:116-190)
+inline Array concat_arrays(const std::vector<Array>& parts) {
+  std::vector<pdx_column> in;
+  int64_t total = 0;
+  bool nulls = false;
+  for (auto& p : parts) {
+    in.push_back(p.c());
+    total += p.length;
+    nulls = nulls || p.has_nulls();
+  }
+  Array out = Array::Empty(parts[0].dtype, total, nulls);
+  auto m = out.mut();
+  ThrowOnFailure(pdx_concat(in.data(), (int)in.size(), &m, nullptr));
+  out.null_count = m.null_count;
+  return out;
+}
+inline DataFrame concat(const std::vector<DataFrame>& dfs, bool ignore_index = false) {
+  if (dfs.empty()) throw std::runtime_error("concat of zero frames");
+  for (auto& d : dfs)
+    if (d.m_names != dfs[0].m_names) throw std::runtime_error("concat of frames with different schemas is not on the hot path");
+  std::vector<Array> cols;
+  for (size_t c = 0; c < dfs[0].m_columns.size(); ++c) {
+    std::vector<Array> parts;
+    for (auto& d : dfs) parts.push_back(d.m_columns[c]);
+    cols.push_back(concat_arrays(parts));
+  }
+  std::optional<Array> index;
+  if (!ignore_index) {  // each frame's index is carried along: [0,1,0,1] (tests/concat_test.cpp:40-50)
+    std::vector<Array> parts;
+    for (auto& d : dfs) {
+      if (d.m_index) parts.push_back(*d.m_index);
+      else {
+        std::vector<int64_t> r((size_t)d.num_rows());
+        for (size_t i = 0; i < r.size(); ++i) r[i] = (int64_t)i;
+        parts.push_back(Array::Make(r));
+      }
+    }
+    index = concat_arrays(parts);
+  }
+  return DataFrame(dfs[0].m_names, cols, index);
+}
+
+}  // namespace pd

@@ -330,6 +330,12 @@ int minmax_i64_host(const long long* v, int64_t n, long long* mn, long long* mx,
   return PDX_OK;
 }
 
+int minmax_keys_host(const long long* v, const uint8_t* valid, int64_t off, int64_t n, MinMaxPartial<long long>* out, Scratch& s,
+                     hipStream_t st) {
+  PDX_PROFILE("key_minmax", st);
+  return minmax_impl<long long>(v, valid, off, n, out, s, st);
+}
+
 // count of valid rows (host result)
 int count_valid_host(const pdx_column* a, int64_t* out, Scratch& s, hipStream_t st) {
   const uint8_t* valid = validity_or_null(a);

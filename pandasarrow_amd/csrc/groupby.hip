@@ -17,8 +17,9 @@
 //   4. k_seg_reduce: one wave per group: coalesced loads staged through LDS, 16-value sequential leaves per lane,
 //      shuffle tree + binary counter == Arrow's pairwise sum bit-for-bit; min/max/count/int-sum from the same pass.
 // Algorithmic bytes: 16 B/row (8 key + 8 value).  Actual traffic is higher (sort passes); see DESIGN.md.
-#include <vector>
+#include <stdlib.h>
 #include <algorithm>
+#include <vector>
 #include "compact.hpp"
 #include "minmax.hpp"
 #include "pairwise.hpp"
@@ -94,51 +95,75 @@ __global__ void __launch_bounds__(256) k_hash_insert(const long long* __restrict
   }
 }
 
+// Dense-domain fast path: when the valid keys span a small integer range the slot is key - min (no table, no probing):
+// the only per-row memory access besides the streams is first[slot] (4 B, range-sized table that stays cache resident).
+__global__ void __launch_bounds__(256) k_dense_slots(const long long* __restrict__ keys, const uint8_t* __restrict__ valid, int64_t off,
+                                                     int64_t n, long long mn, unsigned int range, unsigned int* first,
+                                                     uint32_t* __restrict__ slot_of_row) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    unsigned int s = range;  // the null key's slot
+    if (!valid || bit_get(valid, off + i)) s = (unsigned int)((unsigned long long)keys[i] - (unsigned long long)mn);
+    if ((unsigned int)i < first[s]) atomicMin(&first[s], (unsigned int)i);
+    slot_of_row[i] = s;
+  }
+}
+
+// first-row of every slot: from the hash table (table != nullptr) or the dense first[] array
 struct OccPred {
   const Slot* table;
-  __device__ bool operator()(int64_t i) const { return table[i].first != kNoRow; }
+  const unsigned int* first;
+  __device__ bool operator()(int64_t i) const { return (table ? table[i].first : first[i]) != kNoRow; }
 };
 struct OccEmit {
   const Slot* table;
+  const unsigned int* first;
   uint32_t* occ_slot;
   uint32_t* occ_first;
   __device__ void operator()(int64_t pos, int64_t i) const {
     occ_slot[pos] = (uint32_t)i;
-    occ_first[pos] = table[i].first;
+    occ_first[pos] = table ? table[i].first : first[i];
   }
 };
 
 // sorted_slot[r] = slot of the r-th group in first-occurrence order
-__global__ void k_assign_gids(Slot* table, const uint32_t* __restrict__ sorted_first, const uint32_t* __restrict__ sorted_slot, int64_t G,
-                              unsigned int cap, int64_t* __restrict__ uniques, uint8_t* __restrict__ unique_ok,
+// null_slot: the slot of the null key; table == nullptr => dense mode (key = dense_min + slot)
+__global__ void k_assign_gids(const Slot* __restrict__ table, long long dense_min, uint32_t* __restrict__ gid_of_slot,
+                              const uint32_t* __restrict__ sorted_first, const uint32_t* __restrict__ sorted_slot, int64_t G,
+                              unsigned int null_slot, int64_t* __restrict__ uniques, uint8_t* __restrict__ unique_ok,
                               int64_t* __restrict__ first_rows) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < G; r += stride) {
     unsigned int s = sorted_slot[r];
-    table[s].gid = (unsigned int)r;
-    long long k = table[s].key;
-    if (s == cap) k = 0;
-    if (s == cap + 1) k = kEmptyKey;
+    gid_of_slot[s] = (unsigned int)r;
+    long long k;
+    if (table) {
+      k = table[s].key;
+      if (s == null_slot + 1) k = kEmptyKey;
+    } else {
+      k = (long long)((unsigned long long)dense_min + (unsigned long long)s);
+    }
+    if (s == null_slot) k = 0;
     uniques[r] = k;
-    unique_ok[r] = s != cap;
+    unique_ok[r] = s != null_slot;
     first_rows[r] = (int64_t)sorted_first[r];
   }
 }
-__global__ void k_gid_of_occ(const Slot* __restrict__ table, const uint32_t* __restrict__ occ_slot, int64_t G, uint32_t* __restrict__ out) {
+__global__ void k_gid_of_occ(const uint32_t* __restrict__ gid_of_slot, const uint32_t* __restrict__ occ_slot, int64_t G, uint32_t* __restrict__ out) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < G; k += stride) out[k] = table[occ_slot[k]].gid;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < G; k += stride) out[k] = gid_of_slot[occ_slot[k]];
 }
-__global__ void k_row_gids(const Slot* __restrict__ table, const uint32_t* __restrict__ slot_of_row, int64_t n, uint32_t* __restrict__ out) {
+__global__ void k_row_gids(const uint32_t* __restrict__ gid_of_slot, const uint32_t* __restrict__ slot_of_row, int64_t n, uint32_t* __restrict__ out) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = table[slot_of_row[i]].gid;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = gid_of_slot[slot_of_row[i]];
 }
 
-__global__ void k_map_ids(const Slot* __restrict__ table, const uint32_t* __restrict__ slot_of_row, const uint32_t* __restrict__ seg_start,
+__global__ void k_map_ids(const uint32_t* __restrict__ gid_of_slot, const uint32_t* __restrict__ slot_of_row, const uint32_t* __restrict__ seg_start,
                           int64_t G, int64_t n, const int64_t* __restrict__ map, int64_t* __restrict__ out) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     uint32_t g;
-    if (table) g = table[slot_of_row[i]].gid;
+    if (gid_of_slot) g = gid_of_slot[slot_of_row[i]];
     else {
       int64_t lo = 0, hi = G;
       while (hi - lo > 1) {
@@ -435,9 +460,10 @@ struct pdx_groupby {
   int64_t n = 0, G = 0;
   int key_dtype = PDX_INT64;
   // hash mode
-  Slot* table = nullptr;
-  unsigned int cap = 0;
+  uint32_t* gid_of_slot = nullptr;  // nslots entries
+  int64_t nslots = 0;
   int slot_bits = 0;
+  int dense = 0;                    // 1: slots are key - min (dense integer key domain), 0: open-addressing hash table
   uint32_t* slot_of_row = nullptr;  // n
   uint32_t* occ_slot = nullptr;     // G, slot order
   uint32_t* gid_of_occ = nullptr;   // G
@@ -464,6 +490,8 @@ struct pdx_groupby {
 namespace pdx {
 
 int minmax_i64_host(const long long* v, int64_t n, long long* mn, long long* mx, Scratch& s, hipStream_t st);  // aggregate.hip
+int minmax_keys_host(const long long* v, const uint8_t* valid, int64_t off, int64_t n, MinMaxPartial<long long>* out, Scratch& s,
+                     hipStream_t st);  // aggregate.hip
 
 static unsigned int next_pow2(uint64_t x) {
   uint64_t p = 16;
@@ -521,10 +549,52 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     delete gb;
     return PDX_OOM;
   }
+  // ---- dense-domain fast path: valid keys span a small integer range -> slot = key - min, no table
+  Slot* table = nullptr;
+  unsigned int* dense_first = nullptr;
+  long long dense_min = 0;
+  unsigned int null_slot = 0;
+  int64_t nslots = 0;
+  {
+    MinMaxPartial<long long> mm;
+    int rc0 = minmax_keys_host(keys, valid, key->offset, n, &mm, s, st);
+    if (rc0 != PDX_OK) {
+      delete gb;
+      return rc0;
+    }
+    const char* env = getenv("PDX_GROUPBY_DENSE");
+    bool allow = !(env && env[0] == '0');
+    if (allow && mm.rmin >= 0) {
+      unsigned long long span = (unsigned long long)mm.vmax - (unsigned long long)mm.vmin;  // range - 1
+      unsigned long long lim = std::min<unsigned long long>(1ull << 26, (unsigned long long)n * 4 + 1024);
+      if (span < lim) {
+        gb->dense = 1;
+        dense_min = mm.vmin;
+        null_slot = (unsigned int)span + 1;
+        nslots = (int64_t)null_slot + 1;
+      }
+    } else if (allow && mm.rmin < 0) {  // every key is null: one group
+      gb->dense = 1;
+      null_slot = 0;
+      nslots = 1;
+    }
+  }
+  if (gb->dense) {
+    dense_first = s.get<unsigned int>((size_t)nslots);
+    if (s.failed) {
+      delete gb;
+      return PDX_OOM;
+    }
+    hipMemsetAsync(dense_first, 0xFF, (size_t)nslots * sizeof(unsigned int), st);
+    {
+      PDX_PROFILE("dense_slots", st);
+      hipLaunchKernelGGL(k_dense_slots, dim3(grid_for(n, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, n, dense_min, null_slot,
+                         dense_first, gb->slot_of_row);
+    }
+  } else {
   // table capacity: start at min(2^21, pow2 >= 2n) and grow x8 whenever more than 70 % of the slots fill up
   uint64_t want = next_pow2((uint64_t)n * 2);
   unsigned int cap = (unsigned int)std::min<uint64_t>(want, 1u << 21);
-  Slot* table = nullptr;
   for (;;) {
     table = static_cast<Slot*>(pool_alloc(((size_t)cap + 2) * sizeof(Slot)));
     if (!table) {
@@ -556,20 +626,22 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     }
     cap = (unsigned int)std::min<uint64_t>((uint64_t)cap * 8, want);
   }
-  gb->table = table;
   gb->owned.push_back(table);
-  gb->cap = cap;
-  gb->slot_bits = ilog2((uint64_t)cap + 2);
+  null_slot = cap;
+  nslots = (int64_t)cap + 2;
+  }
+  gb->nslots = nslots;
+  gb->slot_bits = ilog2((uint64_t)nslots);
+  gb->gid_of_slot = gb->own<uint32_t>((size_t)nslots);
   // occupied slots in slot order
-  const int64_t nslots = (int64_t)cap + 2;
   uint32_t* occ_slot_tmp = s.get<uint32_t>((size_t)std::min<int64_t>(nslots, n + 2));
   uint32_t* occ_first_tmp = s.get<uint32_t>((size_t)std::min<int64_t>(nslots, n + 2));
-  if (s.failed) {
+  if (s.failed || !gb->gid_of_slot) {
     delete gb;
     return PDX_OOM;
   }
   int64_t G = 0;
-  int rc = compact_indices(nslots, OccPred{table}, OccEmit{table, occ_slot_tmp, occ_first_tmp}, &G, s, st);
+  int rc = compact_indices(nslots, OccPred{table, dense_first}, OccEmit{table, dense_first, occ_slot_tmp, occ_first_tmp}, &G, s, st);
   if (rc != PDX_OK) {
     delete gb;
     return rc;
@@ -598,8 +670,9 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     return rc;
   }
   int g = grid_for(G, 256);
-  hipLaunchKernelGGL(k_assign_gids, dim3(g), dim3(256), 0, st, table, ks, vs, G, cap, gb->uniques, gb->unique_ok, gb->first_rows);
-  hipLaunchKernelGGL(k_gid_of_occ, dim3(g), dim3(256), 0, st, table, gb->occ_slot, G, gb->gid_of_occ);
+  hipLaunchKernelGGL(k_assign_gids, dim3(g), dim3(256), 0, st, table, dense_min, gb->gid_of_slot, ks, vs, G, null_slot, gb->uniques,
+                     gb->unique_ok, gb->first_rows);
+  hipLaunchKernelGGL(k_gid_of_occ, dim3(g), dim3(256), 0, st, gb->gid_of_slot, gb->occ_slot, G, gb->gid_of_occ);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) {
@@ -647,7 +720,7 @@ int pdx_groupby_group_ids(pdx_groupby* gb, uint32_t* out_ids, void* stream) {
   hipStream_t st = as_stream(stream);
   if (gb->n == 0) return PDX_OK;
   if (gb->mode == 0)
-    hipLaunchKernelGGL(k_row_gids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->table, gb->slot_of_row, gb->n, out_ids);
+    hipLaunchKernelGGL(k_row_gids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->gid_of_slot, gb->slot_of_row, gb->n, out_ids);
   else
     hipLaunchKernelGGL(k_seg_row_ids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->seg_start, gb->G, gb->n, out_ids);
   PDX_LAUNCH_CHECK();
@@ -659,7 +732,7 @@ int pdx_groupby_map_ids(pdx_groupby* gb, const int64_t* map, int64_t* out, void*
   if (!gb || !map || !out) return fail(PDX_INVALID, "pdx_groupby_map_ids: null argument");
   hipStream_t st = as_stream(stream);
   if (gb->n == 0) return PDX_OK;
-  hipLaunchKernelGGL(k_map_ids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->mode == 0 ? gb->table : nullptr, gb->slot_of_row,
+  hipLaunchKernelGGL(k_map_ids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->mode == 0 ? gb->gid_of_slot : nullptr, gb->slot_of_row,
                      gb->seg_start, gb->G, gb->n, map, out);
   PDX_LAUNCH_CHECK();
   PDX_HIP(hipStreamSynchronize(st));

@@ -1,0 +1,179 @@
+// test_facade.cpp -- the reference's own Catch2 cases for the hot path, replayed against the C++ facade (pandasarrow_amd/cpp/
+// pdx.hpp -> C ABI -> HIP kernels).  Each block cites the reference test it mirrors (file:line under the reference repository).
+// Built with g++ (host code only) and run on the GPU box by tests/test_gpu_cpp_facade.py.
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+
+#include "pdx.hpp"
+
+static int g_checks = 0, g_failed = 0;
+#define REQUIRE(cond)                                                              \
+  do {                                                                             \
+    ++g_checks;                                                                    \
+    if (!(cond)) {                                                                 \
+      ++g_failed;                                                                  \
+      std::printf("FAILED %s:%d  %s\n", __FILE__, __LINE__, #cond);                \
+    }                                                                              \
+  } while (0)
+#define REQUIRE_THROWS(expr)                                                       \
+  do {                                                                             \
+    ++g_checks;                                                                    \
+    bool threw = false;                                                            \
+    try { (void)(expr); } catch (const std::runtime_error&) { threw = true; }      \
+    if (!threw) {                                                                  \
+      ++g_failed;                                                                  \
+      std::printf("FAILED %s:%d  expected std::runtime_error: %s\n", __FILE__, __LINE__, #expr); \
+    }                                                                              \
+  } while (0)
+static bool approx(double a, double b) { return std::fabs(a - b) <= 1e-9 * (1 + std::fabs(b)); }
+using namespace pd;
+
+// tests/series_arithmetric_test.cpp:12-118
+static void test_series_math() {
+  std::vector<long> int_vec = {1, 2, 3, 4, 5};
+  Series int_series(int_vec);
+  REQUIRE((int_series + 2).at(0).as<long>() == 3);
+  REQUIRE((int_series - 2).at(0).as<long>() == -1);
+  REQUIRE((int_series * 2).at(0).as<long>() == 2);
+  REQUIRE((int_series / 2).at(0).as<long>() == 0);
+  REQUIRE((-int_series).at(0).as<long>() == -1);
+  std::vector<double> double_vec = {1.1, 2.2, 3.3, 4.4, 5.5};
+  Series double_series(double_vec);
+  REQUIRE(approx((double_series + 2).at(0).as<double>(), 3.1));
+  REQUIRE(approx((double_series - 2).at(0).as<double>(), -0.9));
+  REQUIRE(approx((double_series * 2).at(0).as<double>(), 2.2));
+  REQUIRE(approx((double_series / 2).at(0).as<double>(), 0.55));
+  REQUIRE(approx((-double_series).at(0).as<double>(), -1.1));
+  std::vector<long> int_vec2 = {2, 4, 6, 8, 10};
+  Series int_series2(int_vec2);
+  REQUIRE((int_series + int_series2).at(0).as<long>() == 3);
+  REQUIRE((int_series / int_series2).at(0).as<long>() == 0);
+  auto diff = double_series - int_series2;  // mixed double (-) int64 -> float64
+  REQUIRE(diff.dtype() == PDX_FLOAT64);
+  REQUIRE(diff.name() == "");
+  auto dv = diff.values<double>();
+  const double exp[] = {-0.9, -1.8, -2.7, -3.6, -4.5};
+  for (int i = 0; i < 5; ++i) REQUIRE(approx(dv[i], exp[i]));
+  Series named(int_vec, "int_series2");
+  auto add = int_series + named;
+  REQUIRE(add.size() == 5 && add.dtype() == PDX_INT64 && add.name() == "");
+  REQUIRE((add.values<long>() == std::vector<long>{2, 4, 6, 8, 10}));
+  REQUIRE(((int_series * named).values<long>() == std::vector<long>{1, 4, 9, 16, 25}));
+  REQUIRE(((int_series / named).values<long>() == std::vector<long>{1, 1, 1, 1, 1}));
+  REQUIRE_THROWS(int_series / Series(std::vector<long>{1, 0, 1, 1, 1}));  // ArrowInvalid: divide by zero
+  REQUIRE_THROWS(int_series + Series(std::vector<long>{1, 2, 3}));        // length mismatch
+}
+
+// tests/series_indexing_test.cpp:12-74
+static void test_series_where_take() {
+  Series s1(std::vector<int>{1, 2, 3, 4, 5});
+  REQUIRE_THROWS(Series(Array::Make(std::vector<int>{1, 2, 3, 4, 5}), std::nullopt, "", /*is_index=*/true)
+                     .where(Series(std::vector<bool>{true, false, true, false, true})));
+  REQUIRE_THROWS(s1.where(Series(std::vector<bool>{false, true, true})));  // mask of a different size
+  REQUIRE_THROWS(s1.take(Series(std::vector<bool>{false, true, true, true, false})));
+  Series result = s1.take(Series(std::vector<int32_t>{1, 3, 4}));
+  REQUIRE(result.size() == 3);
+  REQUIRE((result.values<int>() == std::vector<int>{2, 4, 5}));
+  REQUIRE_THROWS(s1.take(Series(std::vector<int>{0, 7})));  // ArrowIndexError
+  auto picked = s1[s1 > Scalar(2)];                         // operator[](bool Series) == where
+  REQUIRE((picked.values<int>() == std::vector<int>{3, 4, 5}));
+}
+
+// tests/series_aggregation_test.cpp:122-196 ; NaN -> null on construction tests/series_test.cpp:127-186
+static void test_series_aggregations() {
+  Series s(std::vector<int>{1, 2, 3, 4, 5});
+  REQUIRE(s.min().as<int>() == 1 && s.max().as<int>() == 5);
+  Series sn(std::vector<int>{1, 2, 3, 4, 5}, std::vector<bool>{true, true, true, true, false});
+  REQUIRE(sn.min().as<int>() == 1 && sn.max().as<int>() == 4);
+  REQUIRE(s.mean() == 3.0);
+  REQUIRE(sn.mean() == 2.5);
+  REQUIRE(Series(std::vector<int>{1, 2, 3, 4, 5}, std::vector<bool>{false, true, true, true, true}).mean() == 3.5);
+  Series nan_series(std::vector<double>{1.0, std::nan(""), 3.0});
+  REQUIRE(nan_series.count().as<long>() == 2);
+  REQUIRE(nan_series.sum() == 4.0);
+  REQUIRE(!Series(std::vector<double>{}).sum().isValid());  // min_count = 1
+}
+
+// tests/dataframe_iterator_test.cpp:11-77
+static void test_groupby() {
+  DataFrame df(std::map<std::string, std::vector<int32_t>>{{"a", {1, 1, 3, 1, 1, 1, 3, 8, 2, 2}}, {"b", {10, 9, 8, 7, 6, 5, 4, 3, 2, 1}}});
+  auto groupby = df.group_by("a");
+  REQUIRE(groupby.groupSize() == 4);
+  REQUIRE((groupby.unique().values_as<long>() == std::vector<long>{1, 3, 8, 2}));  // first-occurrence order
+  auto result = groupby.sum(std::vector<std::string>{"a", "b"});
+  REQUIRE(result.num_rows() == 4 && result.num_columns() == 2);
+  REQUIRE((result["a"].values<int64_t>() == std::vector<int64_t>{5, 6, 8, 4}));
+  REQUIRE((result["b"].values<int64_t>() == std::vector<int64_t>{37, 12, 3, 3}));
+  // tests/cudf_examples/dataframe_resample_test.cpp:71-248 (gender male=0 female=1)
+  DataFrame people({"gender", "age", "height"},
+                   {Array::Make(std::vector<long>{0, 1, 0, 0, 1, 0, 0, 1, 0, 0}), Array::Make(std::vector<int>{16, 10, 10, 20, 30, 40, 15, 25, 35, 45}),
+                    Array::Make(std::vector<int>{9, 9, 9, 9, 9, 8, 8, 8, 8, 8})});
+  GroupBy g("gender", people);
+  REQUIRE(g.groupSize() == 2);
+  auto mean = g.mean(std::vector<std::string>{"age", "height"});
+  REQUIRE(mean["age"].values<double>()[0] == 25.857142857142858);
+  REQUIRE(mean["age"].values<double>()[1] == 21.666666666666668);
+  REQUIRE(mean["height"].values<double>()[0] == 8.428571428571429);
+  REQUIRE(mean["height"].values<double>()[1] == 8.666666666666666);
+  REQUIRE((g.max("age").values<int>() == std::vector<int>{45, 30}));
+  REQUIRE((g.min("age").values<int>() == std::vector<int>{10, 10}));
+  REQUIRE((g.sum("age").values<int64_t>() == std::vector<int64_t>{181, 65}));
+  REQUIRE((g.count("age").values<int64_t>() == std::vector<int64_t>{7, 3}));
+}
+
+// tests/series_resample_test.cpp:12-85
+static void test_resample() {
+  const int64_t t0 = 946684800000000000LL;  // 2000-01-01
+  auto index = date_range(t0, 9);
+  Series series(Array::Make(std::vector<long>{0, 1, 2, 3, 4, 5, 6, 7, 8}), index, "v");
+  const int64_t min3 = 3 * 60000000000LL;
+  {
+    auto r = resample(series, min3);
+    REQUIRE((r.index().values_as<int64_t>() == std::vector<int64_t>{t0, t0 + min3, t0 + 2 * min3}));
+    REQUIRE((r.sum()["v"].values<long>() == std::vector<long>{3, 12, 21}));
+  }
+  {
+    auto r = resample(series, min3, false, true);
+    REQUIRE((r.index().values_as<int64_t>() == std::vector<int64_t>{t0 + min3, t0 + 2 * min3, t0 + 3 * min3}));
+    REQUIRE((r.sum()["v"].values<long>() == std::vector<long>{3, 12, 21}));
+  }
+  {
+    auto r = resample(series, min3, true, true);
+    REQUIRE(r.index().length == 4);
+    REQUIRE((r.index().values_as<int64_t>() == std::vector<int64_t>{t0, t0 + min3, t0 + 2 * min3, t0 + 3 * min3}));
+    REQUIRE((r.sum()["v"].values<long>() == std::vector<long>{0, 6, 15, 15}));
+  }
+  REQUIRE((series.resample("3T").sum()["v"].values<long>() == std::vector<long>{3, 12, 21}));
+}
+
+// tests/concat_test.cpp:10-50 ; DataFrame element-wise tests/dataframe_arithmetric_test.cpp:49-195
+static void test_concat_and_frame_ops() {
+  DataFrame df1({"number"}, {Array::Make(std::vector<long>{1, 2})});
+  DataFrame df3({"number"}, {Array::Make(std::vector<long>{3, 4})});
+  auto r = concat({df1, df3});
+  REQUIRE((r["number"].values<long>() == std::vector<long>{1, 2, 3, 4}));
+  REQUIRE((r.m_index->values_as<long>() == std::vector<long>{0, 1, 0, 1}));
+  DataFrame a(std::map<std::string, std::vector<int32_t>>{{"x", {1, 2, 3}}, {"y", {4, 5, 6}}});
+  DataFrame b({"x", "y"}, {Array::Make(std::vector<double>{0.5, 0.5, 0.5}), Array::Make(std::vector<double>{1.5, 1.5, 1.5})});
+  auto c = a + b;  // int32 frame (+) double frame -> double
+  REQUIRE(c["x"].dtype() == PDX_FLOAT64);
+  REQUIRE((c["y"].values<double>() == std::vector<double>{5.5, 6.5, 7.5}));
+  REQUIRE(((a * Scalar(2))["x"].values<long>() == std::vector<long>{2, 4, 6}));
+  REQUIRE(a.sum().as<long>() == 21);
+  REQUIRE_THROWS(a + DataFrame(std::map<std::string, std::vector<int32_t>>{{"x", {1, 2}}, {"y", {4, 5}}}));
+  auto f = a[a["x"] > Scalar(1)];  // DataFrame::where through operator[]
+  REQUIRE((f["y"].values<long>() == std::vector<long>{5, 6}));
+}
+
+int main() {
+  ThrowOnFailure(pdx_init(0));
+  test_series_math();
+  test_series_where_take();
+  test_series_aggregations();
+  test_groupby();
+  test_resample();
+  test_concat_and_frame_ops();
+  std::printf("%d checks, %d failed\n", g_checks, g_failed);
+  return g_failed ? 1 : 0;
+}

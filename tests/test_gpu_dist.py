@@ -1,0 +1,92 @@
+"""GPU: the sharded group-by (pandasarrow_amd/dist.py) with the product engine (HipEngine -> C ABI).  One process exercises
+the W=1 degenerate exchange; two processes share the single GPU of the test box over `gloo` (RCCL refuses two ranks on one
+device; the 8-GPU RCCL run is the driver's) -- the result must be bit-identical to the single-process oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+KINDS = [0, 1, 4, 2, 3]
+
+
+def _expected(keys, vals):
+    ids, uniq, isnull, first = orc.group_ids(keys)
+    return uniq, first, [orc.groupby_agg(k, ids, len(uniq), vals, nthreads=4)[0] for k in KINDS]
+
+
+def _compare(res, keys, vals):
+    uniq, first, outs = _expected(keys, vals)
+    assert res["G"] == len(uniq)
+    assert np.array_equal(res["keys"], uniq) and np.array_equal(res["first"], first)
+    for got, exp in zip(res["outs"], outs):
+        if exp.dtype == np.float64:
+            assert np.array_equal(got.view(np.uint64), exp.view(np.uint64))
+        else:
+            assert np.array_equal(got, exp)
+
+
+def _data(n, nk):
+    return orc.synth_keys(0, n, nk) * 7919 - 12345, orc.synth_vals(0, n) - 0.5
+
+
+def test_sharded_single_rank():
+    import torch
+    from pandasarrow_amd import _lib as L
+    from pandasarrow_amd import dist as pdist
+    from pandasarrow_amd.column import Column
+
+    L.check(L.load().pdx_init(0))
+    keys, vals = _data(400_003, 5000)
+    res = pdist.groupby_agg_sharded(pdist.HipEngine(), Column.from_numpy(keys), Column.from_numpy(vals), KINDS)
+    out = {"G": res["G"], "keys": res["keys"].cpu().numpy(), "first": res["first_rows"].cpu().numpy(),
+           "outs": [v.cpu().numpy() for v, _ in res["outs"]]}
+    _compare(out, keys, vals)
+    assert all(v for v in pdist.check_result(res, len(keys)).values() if isinstance(v, bool))
+    torch.cuda.synchronize()
+
+
+def _worker(rank, world, port, n, nk, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pandasarrow_amd import _lib as L
+        from pandasarrow_amd import dist as pdist
+        from pandasarrow_amd.column import Column
+
+        torch.cuda.set_device(0)
+        L.check(L.load().pdx_init(0))
+        keys, vals = _data(n, nk)
+        lo, hi = n * rank // world, n * (rank + 1) // world
+        res = pdist.groupby_agg_sharded(pdist.HipEngine(), Column.from_numpy(keys[lo:hi]), Column.from_numpy(vals[lo:hi]), KINDS, row_offset=lo)
+        if rank == 0:
+            q.put({"G": res["G"], "keys": res["keys"].cpu().numpy(), "first": res["first_rows"].cpu().numpy(),
+                   "outs": [v.cpu().numpy() for v, _ in res["outs"]]})
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_two_ranks_one_gpu():
+    import torch.multiprocessing as mp
+
+    n, nk, world = 300_007, 3000, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, nk, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    _compare(got, *_data(n, nk))

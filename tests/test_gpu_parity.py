@@ -360,9 +360,12 @@ def test_groupby_kat(px, kat):
             assert list(tot) == k["frame_sum"]
 
 
-@pytest.mark.parametrize("n,nk", [(1, 1), (70_001, 1), (1_000_003, 100_003), (2_500_000, 7), (5_000_000, 1_000_000)])
-def test_groupby_sizes_vs_oracle(px, n, nk):
-    """group sizes from 1 row to millions of rows (multi-chunk counter path) and table growth (nk > initial capacity / 2)."""
+@pytest.mark.parametrize("dense", ["1", "0"])
+@pytest.mark.parametrize("n,nk", [(1, 1), (70_001, 1), (1_000_003, 100_003), (2_500_000, 7), (5_000_000, 1_000_000), (6_000_000, 2_500_000)])
+def test_groupby_sizes_vs_oracle(px, monkeypatch, n, nk, dense):
+    """group sizes from 1 row to millions of rows (multi-chunk counter path); both key->slot paths: the dense-domain fast
+    path (slot = key - min) and the open-addressing hash table incl. table growth (nk > 70 % of the initial 2^21 slots)."""
+    monkeypatch.setenv("PDX_GROUPBY_DENSE", dense)
     keys, vals = orc.synth_keys(0, n, nk), orc.synth_vals(0, n) - 0.5
     gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys))
     s, m, cnt, lo, hi = gb.agg(px.Column.from_numpy(vals), [0, 1, 4, 2, 3])
@@ -375,6 +378,23 @@ def test_groupby_sizes_vs_oracle(px, n, nk):
     assert np.array_equal(gb.first_rows().cpu().numpy(), first)
     assert_f64_bits(lo.to_numpy()[0], orc.groupby_agg(orc.AGG_MIN, ids, len(uniq), vals, nthreads=8)[0], what="min")
     assert_f64_bits(hi.to_numpy()[0], orc.groupby_agg(orc.AGG_MAX, ids, len(uniq), vals, nthreads=8)[0], what="max")
+
+
+@pytest.mark.parametrize("dense", ["1", "0"])
+def test_groupby_dense_with_nulls_and_negative_keys(px, monkeypatch, dense):
+    monkeypatch.setenv("PDX_GROUPBY_DENSE", dense)
+    n = 300_001
+    keys = orc.synth_keys(0, n, 5000) - 2500
+    valid = orc.synth_keys(3, n, 17) != 0
+    vals = orc.synth_vals(0, n)
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys, valid, offset=3))
+    ids, uniq, isnull, first = orc.group_ids(keys, valid)
+    assert np.array_equal(gb.group_ids().cpu().numpy().astype(np.uint32), ids)
+    uk, uok = gb.unique_keys().to_numpy()
+    assert np.array_equal(uok, ~isnull) and np.array_equal(uk[uok], uniq[~isnull])
+    assert np.array_equal(gb.first_rows().cpu().numpy(), first)
+    s = gb.agg(px.Column.from_numpy(vals), [0])[0].to_numpy()[0]
+    assert_f64_bits(s, orc.groupby_agg(orc.AGG_SUM, ids, len(uniq), vals)[0])
 
 
 def test_groupby_special_keys(px):
