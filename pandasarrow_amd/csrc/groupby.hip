@@ -404,10 +404,51 @@ __global__ void __launch_bounds__(256) k_seg_reduce_nullable(const T* __restrict
 struct BinParams {
   const long long* ts;
   long long first, freq;
+  double inv_freq;  // 1.0 / freq: quotient estimate, corrected exactly below (int64 division is ~100 instructions on CDNA)
   int closed_right;
   __device__ long long bin(int64_t i) const {
-    long long v = ts[i];
-    return closed_right ? (v - first - 1) / freq : (v - first) / freq;
+    long long x = ts[i] - first - (closed_right ? 1 : 0);  // >= 0: every timestamp is >= first (checked on the host)
+    long long q = (long long)((double)x * inv_freq);
+    long long r = x - q * freq;
+    while (r < 0) { --q; r += freq; }
+    while (r >= freq) { ++q; r -= freq; }
+    return q;
+  }
+};
+// sparse bins (many rows per bin): bin b starts at the first row whose timestamp is >= (closed-left) / > (closed-right) edge b
+__global__ void k_bin_lower_bounds(BinParams p, int64_t n, int64_t nbins, uint32_t* __restrict__ lb /* nbins + 1 */) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b <= nbins; b += stride) {
+    if (b == nbins) {
+      lb[b] = (uint32_t)n;
+      continue;
+    }
+    long long edge = p.first + b * p.freq;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      int64_t mid = (lo + hi) >> 1;
+      long long v = p.ts[mid];
+      bool before = p.closed_right ? (v <= edge) : (v < edge);
+      if (before) lo = mid + 1;
+      else hi = mid;
+    }
+    lb[b] = (uint32_t)lo;
+  }
+}
+struct NonEmptyBinPred {
+  const uint32_t* lb;
+  __device__ bool operator()(int64_t b) const { return lb[b] < lb[b + 1]; }
+};
+struct NonEmptyBinEmit {
+  const uint32_t* lb;
+  long long label_base, freq;
+  uint32_t* seg_start;
+  int64_t* labels;
+  int64_t* first_rows;
+  __device__ void operator()(int64_t pos, int64_t b) const {
+    seg_start[pos] = lb[b];
+    labels[pos] = label_base + b * freq;
+    first_rows[pos] = (int64_t)lb[b];
   }
 };
 struct BinStartPred {
@@ -864,12 +905,18 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
   unsigned int* bad = s.get<unsigned int>(1);
   if (s.failed) { delete gb; return PDX_OOM; }
   hipMemsetAsync(bad, 0, sizeof(unsigned int), st);
-  hipLaunchKernelGGL(k_check_sorted, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, t, n, bad);
+  {
+    PDX_PROFILE("resample_check_sorted", st);
+    hipLaunchKernelGGL(k_check_sorted, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, t, n, bad);
+  }
+  // sorted input: MinMax (src/resample.cpp:223) is the first and the last timestamp
   long long mn = 0, mx = 0;
-  int rc = minmax_i64_host(t, n, &mn, &mx, s, st);
   unsigned int hbad = 0;
-  if (rc == PDX_OK) {
+  int rc = PDX_OK;
+  {
     hipError_t e = hipMemcpyAsync(&hbad, bad, sizeof(hbad), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&mn, t, sizeof(mn), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&mx, t + (n - 1), sizeof(mx), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) rc = hip_fail(e, "pdx_resample_create");
   }
@@ -903,7 +950,7 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
   if (mx > last_edge) { delete gb; return fail(PDX_INVALID, "Values falls after last bin"); }
   long long nbins = nedges - 1;
   if (n < nbins) { delete gb; return fail(PDX_INVALID, "upSampling is not implemented."); }  // GroupInfo::upsampling, src/resample.h:14-17
-  gb->bin = BinParams{t, first, freq_ns, closed_right};
+  gb->bin = BinParams{t, first, freq_ns, 1.0 / (double)freq_ns, closed_right};
   gb->label_base = first + (label_right ? freq_ns : 0);
   // non-empty bins: boundaries where the bin index changes (timestamps are sorted)
   int64_t maxg = std::min<int64_t>(n, nbins);
@@ -913,7 +960,19 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
   gb->unique_ok = gb->own<uint8_t>((size_t)maxg);
   if (!gb->seg_start || !gb->uniques || !gb->first_rows || !gb->unique_ok) { delete gb; return PDX_OOM; }
   int64_t G = 0;
-  rc = compact_indices(n, BinStartPred{gb->bin}, BinStartEmit{gb->bin, gb->label_base, gb->seg_start, gb->uniques, gb->first_rows}, &G, s, st);
+  {
+    PDX_PROFILE("resample_bins", st);
+    if (nbins * 16 <= n) {
+      // many rows per bin: binary-search every edge (nbins * log n reads) instead of evaluating the bin of every row
+      uint32_t* lb = s.get<uint32_t>((size_t)nbins + 1);
+      if (s.failed) { delete gb; return PDX_OOM; }
+      hipLaunchKernelGGL(k_bin_lower_bounds, dim3(grid_for(nbins + 1, 256)), dim3(256), 0, st, gb->bin, n, (int64_t)nbins, lb);
+      rc = compact_indices((int64_t)nbins, NonEmptyBinPred{lb}, NonEmptyBinEmit{lb, gb->label_base, freq_ns, gb->seg_start, gb->uniques, gb->first_rows},
+                           &G, s, st);
+    } else {
+      rc = compact_indices(n, BinStartPred{gb->bin}, BinStartEmit{gb->bin, gb->label_base, gb->seg_start, gb->uniques, gb->first_rows}, &G, s, st);
+    }
+  }
   if (rc != PDX_OK) { delete gb; return rc; }
   gb->G = G;
   hipLaunchKernelGGL(k_set_last, dim3(1), dim3(64), 0, st, gb->seg_start, G, (uint32_t)n);

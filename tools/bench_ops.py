@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the other rows of SURVEY.md section 8 (not the contract bench): achieved GB/s against each op's
+ALGORITHMIC bytes on BASELINE.json's configs C1 / C2 / C5 and a 1e9-row element-wise / whole-array pass.
+Usage: python tools/bench_ops.py [--scale 1.0]   (prints one JSON line per op)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from pandasarrow_amd import _lib as L  # noqa: E402
+from pandasarrow_amd import api  # noqa: E402
+from pandasarrow_amd import column as K  # noqa: E402
+
+PEAK = 8000.0
+
+
+def timeit(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def report(name, rows, algo_bytes, dt, extra=None):
+    gbs = algo_bytes / dt / 1e9
+    line = {"op": name, "rows": rows, "ms": dt * 1e3, "Grows/s": rows / dt / 1e9, "algo_GB/s": gbs, "frac_of_8TB/s": gbs / PEAK}
+    if extra:
+        line.update(extra)
+    print(json.dumps(line), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=1.0)
+    a = ap.parse_args()
+    L.check(L.load().pdx_init(0))
+    sc = a.scale
+    # C1: Series<double> add + sum, 1e6 rows (plumbing) and the same at 1e9 rows
+    for n in (int(1e6), int(1e9 * sc)):
+        x, y = K.synth_vals(0, n, 1), K.synth_vals(0, n, 2)
+        report(f"add_f64[{n:.0e}]", n, 24.0 * n, timeit(lambda: K.binary(L.ADD, x, y)))
+        report(f"sum_f64[{n:.0e}]", n, 8.0 * n, timeit(lambda: K.aggregate(L.AGG_SUM, x)))
+        report(f"minmax_f64[{n:.0e}]", n, 8.0 * n, timeit(lambda: K.aggregate(L.AGG_MIN, x)))
+        report(f"greater_f64[{n:.0e}]", n, (16.0 + 0.125) * n, timeit(lambda: K.compare(L.GT, x, y)))
+        del x, y
+    # C2: boolean-mask filter + take, 1e8 rows x 8 fp64 columns (+ uint64 index)
+    n = int(1e8 * sc)
+    cols = {f"c{j}": K.synth_vals(0, n, 20 + j) for j in range(8)}
+    idx = K.synth_keys(0, n, 1 << 62)  # stands in for an explicit index column
+    df = api.DataFrame(cols, index=idx)
+    mask = df["c0"] > 0.5
+    sel = K.filter_count(mask.col)
+    s = sel / n
+    report("filter_8cols+index[1e8]", n, (0.125 + 8 * 9 * (1 + s)) * n, timeit(lambda: df.where(mask)), {"selectivity": s})
+    m = n // 2
+    take_idx = api.Series(K.synth_keys(7, m, n))
+    report("take_8cols+index[5e7 of 1e8]", m, (8 + 16 * 9) * m, timeit(lambda: df.take(take_idx)))
+    del df, cols, idx, mask, take_idx
+    # C5: resample('1min').mean() on a 1e9-row timestamp + fp64 Series (100 ms spacing -> 600 rows per bin)
+    n = int(1e9 * sc)
+    ts = K.synth_ts(0, n, 946_684_800 * 10**9, 100_000_000)
+    ser = api.Series(K.synth_vals(0, n), index=ts, name="v")
+    report("resample_1min_mean[1e9]", n, 16.0 * n, timeit(lambda: ser.resample("1min").mean()))
+    # concat of 8 shards (the all-gatherv merge)
+    parts = [K.synth_vals(i, n // 8, 0) for i in range(8)]
+    report("concat_8parts[1e9]", n // 8 * 8, 16.0 * (n // 8 * 8), timeit(lambda: K.concat(parts)))
+
+
+if __name__ == "__main__":
+    main()
