@@ -109,6 +109,60 @@ __global__ void __launch_bounds__(256) k_dense_slots(const long long* __restrict
   }
 }
 
+// Rows [row0, n) of the dense path once a prefix has been processed by k_dense_slots: `seen` has one bit per slot that already
+// has a first row in the prefix.  Every row here is later than every prefix row, so a set bit means "not a first occurrence":
+// the common case touches only the (cache-resident) bitmap instead of first[].
+__global__ void k_seen_bitmap(const unsigned int* __restrict__ first, int64_t nslots, uint32_t* __restrict__ seen) {
+  int64_t nwords = (nslots + 31) >> 5;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += stride) {
+    uint32_t bits = 0;
+    for (int k = 0; k < 32; ++k) {
+      int64_t sl = (w << 5) + k;
+      if (sl < nslots && first[sl] != kNoRow) bits |= 1u << k;
+    }
+    seen[w] = bits;
+  }
+}
+__global__ void __launch_bounds__(256) k_dense_slots_tail(const long long* __restrict__ keys, const uint8_t* __restrict__ valid, int64_t off,
+                                                          int64_t row0, int64_t n, long long mn, unsigned int range,
+                                                          const uint32_t* __restrict__ seen, unsigned int* first,
+                                                          uint32_t* __restrict__ slot_of_row) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = row0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // 8 independent key loads in flight per thread: the loop is otherwise latency bound (one 8-byte load per iteration)
+  for (; i + 7 * stride < n; i += 8 * stride) {
+    long long k[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) k[u] = keys[i + u * stride];
+    unsigned int sl[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      sl[u] = range;
+      if (!valid || bit_get(valid, off + i + u * stride)) sl[u] = (unsigned int)((unsigned long long)k[u] - (unsigned long long)mn);
+    }
+    uint32_t w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = seen[sl[u] >> 5];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      slot_of_row[i + u * stride] = sl[u];
+      if (!((w[u] >> (sl[u] & 31)) & 1u)) {
+        unsigned int r = (unsigned int)(i + u * stride);
+        if (r < first[sl[u]]) atomicMin(&first[sl[u]], r);
+      }
+    }
+  }
+  for (; i < n; i += stride) {
+    unsigned int s = range;
+    if (!valid || bit_get(valid, off + i)) s = (unsigned int)((unsigned long long)keys[i] - (unsigned long long)mn);
+    slot_of_row[i] = s;
+    if (!((seen[s >> 5] >> (s & 31)) & 1u)) {
+      if ((unsigned int)i < first[s]) atomicMin(&first[s], (unsigned int)i);
+    }
+  }
+}
+
 // first-row of every slot: from the hash table (table != nullptr) or the dense first[] array
 struct OccPred {
   const Slot* table;
@@ -216,7 +270,6 @@ struct SegOut {
 };
 
 constexpr int kSegWaves = 4;
-constexpr int kSegChunk = 1024;  // values per wave-chunk = 64 leaves
 
 template <typename T>
 __device__ __forceinline__ double seg_to_f64(T x) { return (double)x; }
@@ -238,10 +291,14 @@ __device__ __forceinline__ void lds_counter_push(double* csum, uint64_t& mask, i
   if (cur > root) root = cur;
 }
 
-template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM>
+// LEAF = 16: `vals` are raw rows (sequential 16-value leaves are formed here).  LEAF = 1: `vals` are leaf sums produced by
+// k_bucket_accumulate in leaf order; only the merge tree is replayed and `counts` (rows per group) feeds the mean.
+template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM, int LEAF = 16>
 __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restrict__ vals, const uint32_t* __restrict__ seg_start,
-                                                               int64_t nseg, const uint32_t* __restrict__ out_index, SegOut out) {
-  __shared__ double stage[kSegWaves][64 * 17];
+                                                               int64_t nseg, const uint32_t* __restrict__ out_index, SegOut out,
+                                                               const long long* __restrict__ counts = nullptr) {
+  constexpr int kSegChunk = 64 * LEAF;  // values per wave-chunk = 64 leaves
+  __shared__ double stage[kSegWaves][LEAF == 16 ? 64 * 17 : 64];
   __shared__ double csum_all[kSegWaves][48];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* lds = stage[wave];
@@ -264,13 +321,13 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
     }
     for (int64_t c0 = 0; c0 < len; c0 += kSegChunk) {
       const int cl = (int)((len - c0) < kSegChunk ? (len - c0) : kSegChunk);
-      // coalesced loads: 16 wave-instructions of 64 consecutive values
+      // coalesced loads: LEAF wave-instructions of 64 consecutive values
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
+      for (int q = 0; q < LEAF; ++q) {
         int idx = q * 64 + lane;
         if (idx < cl) {
           T x = vals[s + c0 + idx];
-          if (WANT_PAIRWISE) lds[idx + (idx >> 4)] = seg_to_f64(x);
+          if (WANT_PAIRWISE) lds[LEAF == 16 ? idx + (idx >> 4) : idx] = seg_to_f64(x);
           if (WANT_MINMAX) {
             if (x == x) ext.add(x, (long long)(c0 + idx));
           }
@@ -279,12 +336,16 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
       }
       __builtin_amdgcn_wave_barrier();  // the LDS image is wave-private: in-order LDS issue makes it visible to all lanes
       if (WANT_PAIRWISE) {
-        const int m = (cl + 15) >> 4;  // leaves in this chunk (wave-uniform)
+        const int m = (cl + LEAF - 1) / LEAF;  // leaves in this chunk (wave-uniform)
         double x = 0.0;
-        const int first = lane * 16;
+        const int first = lane * LEAF;
         if (first < cl) {
-          int cnt = cl - first < 16 ? cl - first : 16;
-          x = leaf_sum(&lds[lane * 17], cnt);
+          if constexpr (LEAF == 16) {
+            int cnt = cl - first < 16 ? cl - first : 16;
+            x = leaf_sum(&lds[lane * 17], cnt);
+          } else {
+            x = lds[lane];
+          }
         }
         // butterfly; pick the perfect subtrees that tile [0, m)
         double node[7];
@@ -334,7 +395,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
     if (lane == 0) {
       if (WANT_PAIRWISE) {
         if (out.sum_f) out.sum_f[oi] = total;
-        if (out.mean) out.mean[oi] = total / (double)len;
+        if (out.mean) out.mean[oi] = total / (double)(LEAF == 16 ? len : counts[oi]);
       }
       if (WANT_ISUM && out.sum_i) out.sum_i[oi] = (long long)isum;
       if (WANT_MINMAX) {
@@ -343,7 +404,205 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
         if (out.vmin) static_cast<T*>(out.vmin)[oi] = ext.rmin < 0 ? nanv : ext.vmin;
         if (out.vmax) static_cast<T*>(out.vmax)[oi] = ext.rmax < 0 ? nanv : ext.vmax;
       }
-      if (out.count) out.count[oi] = (long long)len;
+      if (LEAF == 16 && out.count) out.count[oi] = (long long)len;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- bucket accumulate (fast path: dense slot space, no value nulls)
+// After ONE stable MSD partition by the top slot bits every bucket holds <= 2^LB groups and its rows are in row order.
+// One workgroup streams one bucket in 4096-row tiles: a stable in-LDS multisplit by the local group id (same match-any
+// ranking as the radix scatter) makes every group's rows of the tile contiguous in row order; the thread that owns a
+// group then extends that group's running 16-value leaf sequentially (state in registers across tiles) and emits each
+// completed leaf sum as a (slot, leaf) record.  Records of one group are emitted in leaf order, so a stable sort of the
+// records (1/16 of the rows) + the merge tree (k_seg_reduce<LEAF=1>) reproduces Arrow's pairwise sum bit-for-bit while the
+// rows themselves cross HBM once after the partition instead of three sort passes.
+constexpr int kAccBlock = 256;
+constexpr int kAccItems = 16;
+constexpr int kAccTile = kAccBlock * kAccItems;  // 4096 rows
+constexpr int kAccWaves = kAccBlock / 64;
+
+struct AccOut {
+  uint32_t* leaf_slot;                 // leaf records
+  double* leaf_val;
+  unsigned long long* leaf_cursor;     // global append cursor
+  const uint32_t* gid_of_slot;
+  long long* count;                    // by gid (always written)
+  long long* sum_i;                    // by gid or nullptr
+  void* vmin;                          // T* by gid or nullptr
+  void* vmax;
+};
+
+template <typename T, int LB, bool WANT_PW, bool WANT_MM, bool WANT_IS>
+__global__ void __launch_bounds__(kAccBlock) k_bucket_accumulate(const uint32_t* __restrict__ keys, const T* __restrict__ vals,
+                                                                 const uint32_t* __restrict__ bucket_off /* [tile0 offsets row: R entries] */,
+                                                                 int nbuckets, int64_t n, AccOut out) {
+  constexpr int NG = 1 << LB;            // local groups per bucket
+  constexpr int GPT = NG / kAccBlock;    // groups owned by one thread: g = j * 256 + tid
+  static_assert(GPT >= 1, "bucket must hold at least 256 groups");
+  __shared__ unsigned short cnt[kAccWaves][NG];  // per-wave multisplit counters -> per-(wave, group) base
+  __shared__ double svals[kAccTile];
+  __shared__ uint32_t scan_smem[8];
+  __shared__ unsigned long long tile_base_pos;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const int64_t bstart = bucket_off[b];
+  const int64_t bend = (b + 1 < nbuckets) ? (int64_t)bucket_off[b + 1] : n;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+
+  double acc[GPT];       // running leaf sum of each owned group
+  uint32_t gcnt[GPT];    // rows seen so far
+  unsigned long long isum[GPT];
+  T vmn[GPT], vmx[GPT];
+  bool has[GPT];
+#pragma unroll
+  for (int j = 0; j < GPT; ++j) {
+    acc[j] = 0.0;
+    gcnt[j] = 0;
+    isum[j] = 0;
+    vmn[j] = vmx[j] = T(0);
+    has[j] = false;
+  }
+
+  for (int64_t tb = bstart; tb < bend; tb += kAccTile) {
+    const int tile_rows = (int)((bend - tb) < kAccTile ? (bend - tb) : kAccTile);
+    for (int d = tid; d < kAccWaves * NG / 2; d += kAccBlock) reinterpret_cast<uint32_t*>(&cnt[0][0])[d] = 0;
+    uint32_t key[kAccItems];
+    T val[kAccItems];
+    uint32_t rank[kAccItems];
+#pragma unroll
+    for (int s = 0; s < kAccItems; ++s) {
+      int r = wave * (64 * kAccItems) + s * 64 + lane;
+      bool active = r < tile_rows;
+      key[s] = active ? (keys[tb + r] & (NG - 1)) : 0u;
+      if (active) val[s] = vals[tb + r];
+    }
+    __syncthreads();
+    // stable rank of every row among the rows of its group (wave-step order == row order)
+#pragma unroll
+    for (int s = 0; s < kAccItems; ++s) {
+      int r = wave * (64 * kAccItems) + s * 64 + lane;
+      bool active = r < tile_rows;
+      uint32_t d = key[s];
+      uint64_t peers = __ballot(active);
+#pragma unroll
+      for (int bit = 0; bit < LB; ++bit) {
+        bool bb = (d >> bit) & 1;
+        uint64_t m = __ballot(bb);
+        peers &= bb ? m : ~m;
+      }
+      int leader = active ? (__ffsll((unsigned long long)peers) - 1) : lane;
+      uint32_t base = 0;
+      if (active && lane == leader) {
+        base = cnt[wave][d];
+        cnt[wave][d] = (unsigned short)(base + (uint32_t)__popcll(peers));
+      }
+      base = __shfl(base, leader, 64);
+      rank[s] = base + (uint32_t)__popcll(peers & lt_mask);
+    }
+    __syncthreads();
+    // rows of this tile per owned group, placement (thread-major order) and per-(wave, group) bases
+    uint32_t c[GPT], gstart[GPT];
+    uint32_t tot = 0, newleaves = 0;
+#pragma unroll
+    for (int j = 0; j < GPT; ++j) {
+      int g = j * kAccBlock + tid;
+      uint32_t a = 0;
+#pragma unroll
+      for (int w = 0; w < kAccWaves; ++w) a += cnt[w][g];
+      c[j] = a;
+      tot += a;
+      newleaves += ((gcnt[j] + a) >> 4) - (gcnt[j] >> 4);
+    }
+    uint32_t total;
+    uint32_t pre = block_exclusive_scan(tot, SumOp(), &total, scan_smem);
+#pragma unroll
+    for (int j = 0; j < GPT; ++j) {
+      int g = j * kAccBlock + tid;
+      gstart[j] = pre;
+      uint32_t run = pre;
+#pragma unroll
+      for (int w = 0; w < kAccWaves; ++w) {
+        uint32_t x = cnt[w][g];
+        cnt[w][g] = (unsigned short)run;
+        run += x;
+      }
+      pre += c[j];
+    }
+    // reserve room for the leaves this tile completes: one global atomic per tile keeps a group's records in leaf order
+    uint32_t leaf_total;
+    uint32_t leaf_pre = block_exclusive_scan(newleaves, SumOp(), &leaf_total, scan_smem);
+    if (WANT_PW && tid == 0) tile_base_pos = leaf_total ? atomicAdd(out.leaf_cursor, (unsigned long long)leaf_total) : 0ull;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kAccItems; ++s) {
+      int r = wave * (64 * kAccItems) + s * 64 + lane;
+      if (r < tile_rows) {
+        uint32_t p = (uint32_t)cnt[wave][key[s]] + rank[s];
+        if constexpr (__is_same(T, double)) svals[p] = val[s];
+        else reinterpret_cast<long long*>(svals)[p] = (long long)val[s];
+      }
+    }
+    __syncthreads();
+    unsigned long long pos = WANT_PW ? tile_base_pos + leaf_pre : 0ull;
+#pragma unroll
+    for (int j = 0; j < GPT; ++j) {
+      const uint32_t slot = ((uint32_t)b << LB) | (uint32_t)(j * kAccBlock + tid);
+      for (uint32_t q = 0; q < c[j]; ++q) {
+        T x;
+        if constexpr (__is_same(T, double)) x = svals[gstart[j] + q];
+        else x = (T) reinterpret_cast<const long long*>(svals)[gstart[j] + q];
+        if (WANT_PW) {
+          acc[j] += (double)x;  // first add of a leaf is 0.0 + x, like Arrow's block_sum = 0
+          if (((gcnt[j] + q + 1) & 15) == 0) {
+            out.leaf_slot[pos] = slot;
+            out.leaf_val[pos] = acc[j];
+            ++pos;
+            acc[j] = 0.0;
+          }
+        }
+        if (WANT_IS) isum[j] += (unsigned long long)x;
+        if (WANT_MM) {
+          if (x == x) {
+            if (!has[j]) { vmn[j] = vmx[j] = x; has[j] = true; }
+            else {
+              if (x < vmn[j]) vmn[j] = x;  // strict: the first of tied values wins
+              if (x > vmx[j]) vmx[j] = x;
+            }
+          }
+        }
+      }
+      gcnt[j] += c[j];
+    }
+    __syncthreads();
+  }
+  // flush: partial last leaves and the order-insensitive aggregates
+  uint32_t nflush = 0;
+#pragma unroll
+  for (int j = 0; j < GPT; ++j) nflush += (gcnt[j] & 15) ? 1u : 0u;
+  uint32_t ftotal;
+  uint32_t fpre = block_exclusive_scan(nflush, SumOp(), &ftotal, scan_smem);
+  if (WANT_PW && tid == 0) tile_base_pos = ftotal ? atomicAdd(out.leaf_cursor, (unsigned long long)ftotal) : 0ull;
+  __syncthreads();
+  unsigned long long pos = WANT_PW ? tile_base_pos + fpre : 0ull;
+#pragma unroll
+  for (int j = 0; j < GPT; ++j) {
+    if (gcnt[j] == 0) continue;
+    const uint32_t slot = ((uint32_t)b << LB) | (uint32_t)(j * kAccBlock + tid);
+    if (WANT_PW && (gcnt[j] & 15)) {
+      out.leaf_slot[pos] = slot;
+      out.leaf_val[pos] = acc[j];
+      ++pos;
+    }
+    const uint32_t gid = out.gid_of_slot[slot];
+    out.count[gid] = (long long)gcnt[j];
+    if (WANT_IS && out.sum_i) out.sum_i[gid] = (long long)isum[j];
+    if (WANT_MM) {
+      T nanv = T(0);
+      if constexpr (__is_same(T, double)) nanv = __builtin_nan("");
+      if (out.vmin) static_cast<T*>(out.vmin)[gid] = has[j] ? vmn[j] : nanv;
+      if (out.vmax) static_cast<T*>(out.vmax)[gid] = has[j] ? vmx[j] : nanv;
     }
   }
 }
@@ -562,6 +821,12 @@ static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int
   return PDX_OK;
 }
 
+// Fast path of pdx_groupby_agg (hash / dense mode, values without nulls): ONE MSD partition pass + bucket accumulate.
+// Returns PDX_OK with *done = false when the shape does not qualify (caller continues with the full sort).
+template <typename T>
+static int agg_bucket_path(pdx_groupby* gb, const T* vals, SegOut o, bool want_pw, bool want_mm, bool want_is, Scratch& s, hipStream_t st,
+                           bool* done);
+
 }  // namespace pdx
 
 extern "C" {
@@ -629,8 +894,20 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     hipMemsetAsync(dense_first, 0xFF, (size_t)nslots * sizeof(unsigned int), st);
     {
       PDX_PROFILE("dense_slots", st);
-      hipLaunchKernelGGL(k_dense_slots, dim3(grid_for(n, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, n, dense_min, null_slot,
+      // prefix with the full first-row protocol, then the bitmap-filtered tail
+      const int64_t prefix = std::min<int64_t>(n, std::max<int64_t>((int64_t)1 << 22, 16 * nslots));
+      hipLaunchKernelGGL(k_dense_slots, dim3(grid_for(prefix, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, prefix, dense_min, null_slot,
                          dense_first, gb->slot_of_row);
+      if (prefix < n) {
+        uint32_t* seen = s.get<uint32_t>((size_t)((nslots + 31) >> 5));
+        if (s.failed) {
+          delete gb;
+          return PDX_OOM;
+        }
+        hipLaunchKernelGGL(k_seen_bitmap, dim3(grid_for((nslots + 31) >> 5, 256)), dim3(256), 0, st, dense_first, nslots, seen);
+        hipLaunchKernelGGL(k_dense_slots_tail, dim3(grid_for(n - prefix, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, prefix, n, dense_min,
+                           null_slot, seen, dense_first, gb->slot_of_row);
+      }
     }
   } else {
   // table capacity: start at min(2^21, pow2 >= 2n) and grow x8 whenever more than 70 % of the slots fill up
@@ -821,6 +1098,20 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   const uint32_t* seg_start = nullptr;
   const uint32_t* out_index = nullptr;
   const uint8_t* row_valid = nullptr;  // segments mode reads validity in place
+  if (gb->mode == 0 && !vvalid) {
+    bool done = false;
+    const char* env = getenv("PDX_GROUPBY_BUCKET");  // experimental (slower than the swizzled sort today): opt-in with 1, tests force 2
+    if (env && (env[0] == '1' || env[0] == '2')) {
+      if (is_f) PDX_TRY(agg_bucket_path<double>(gb, static_cast<const double*>(values->values) + values->offset, o, want_pw, want_mm, want_is, s, st, &done));
+      else PDX_TRY(agg_bucket_path<long long>(gb, static_cast<const long long*>(values->values) + values->offset, o, want_pw, want_mm, want_is, s, st, &done));
+    }
+    if (done) {
+      for (int k = 0; k < nk; ++k)
+        if (outs[k].validity) PDX_HIP(hipMemsetAsync(outs[k].validity, 0xFF, (size_t)((G + 7) / 8), st));
+      PDX_HIP(hipStreamSynchronize(st));
+      return PDX_OK;
+    }
+  }
   if (gb->mode == 0) {
     // stable sort of (slot, value) by slot: each group's values become contiguous in row order
     const uint32_t* kin = gb->slot_of_row;
@@ -995,3 +1286,107 @@ int pdx_resample_row_labels(pdx_groupby* gb, int64_t* out_labels, void* stream) 
 }
 
 }  // extern "C"
+
+namespace pdx {
+
+template <typename T, int LB>
+static void launch_bucket_accumulate(const uint32_t* keys, const T* vals, const uint32_t* bucket_off, int nbuckets, int64_t n, const AccOut& ao,
+                                     bool want_pw, bool want_mm, bool want_is, hipStream_t st) {
+  dim3 g(nbuckets), b(kAccBlock);
+#define ACC_LAUNCH(PW, MM, IS) hipLaunchKernelGGL((k_bucket_accumulate<T, LB, PW, MM, IS>), g, b, 0, st, keys, vals, bucket_off, nbuckets, n, ao)
+  if (want_pw && !want_mm && !want_is) ACC_LAUNCH(true, false, false);
+  else if (!want_pw && want_mm && !want_is) ACC_LAUNCH(false, true, false);
+  else if (!want_pw && !want_mm && want_is) ACC_LAUNCH(false, false, true);
+  else if (!want_pw && !want_mm && !want_is) ACC_LAUNCH(false, false, false);
+  else ACC_LAUNCH(true, true, true);
+#undef ACC_LAUNCH
+}
+
+template <typename T>
+static int agg_bucket_path(pdx_groupby* gb, const T* vals, SegOut o, bool want_pw, bool want_mm, bool want_is, Scratch& s, hipStream_t st,
+                           bool* done) {
+  *done = false;
+  const int64_t n = gb->n, G = gb->G;
+  int LB, bits1;
+  if (gb->slot_bits >= 20 && gb->slot_bits <= 22) { LB = 12; bits1 = gb->slot_bits - 12; }
+  else if (gb->slot_bits >= 16 && gb->slot_bits < 20) { LB = 8; bits1 = gb->slot_bits - 8; }
+  else return PDX_OK;
+  const char* env = getenv("PDX_GROUPBY_BUCKET");
+  const bool forced = env && env[0] == '2';  // tests: take this path at any size
+  if (!forced && n < (int64_t)1 << 22) return PDX_OK;  // small inputs: the plain sort is already launch-latency bound
+  const int nbuckets = 1 << bits1;
+  // ---- one stable MSD partition pass by the top `bits1` slot bits
+  const int64_t ntiles = ceil_div(n, kSortTile), nchunks = ceil_div(ntiles, kColChunk);
+  uint32_t* hist = s.get<uint32_t>((size_t)ntiles * nbuckets);
+  uint32_t* chunk_sum = s.get<uint32_t>((size_t)nchunks * nbuckets);
+  uint32_t* k0 = s.get<uint32_t>((size_t)n);
+  uint64_t* v0 = s.get<uint64_t>((size_t)n);
+  PDX_SCRATCH_CHECK(s);
+  PDX_TRY(radix_pass_dispatch<uint64_t>(bits1, gb->slot_of_row, reinterpret_cast<const uint64_t*>(vals), k0, v0, n, LB, true, hist, chunk_sum, st));
+  // bucket starts = the offsets row of tile 0; balance check on the host (one WG streams one bucket)
+  std::vector<uint32_t> hoff((size_t)nbuckets);
+  PDX_HIP(hipMemcpyAsync(hoff.data(), hist, sizeof(uint32_t) * (size_t)nbuckets, hipMemcpyDeviceToHost, st));
+  PDX_HIP(hipStreamSynchronize(st));
+  int64_t max_rows = 0;
+  for (int b = 0; b < nbuckets; ++b) {
+    int64_t e = b + 1 < nbuckets ? (int64_t)hoff[(size_t)b + 1] : n;
+    max_rows = std::max<int64_t>(max_rows, e - (int64_t)hoff[(size_t)b]);
+  }
+  if (!forced && max_rows > 8 * (n / nbuckets) + (1 << 16)) return PDX_OK;  // skewed key space: a few buckets would serialise the pass
+  // ---- bucket accumulate
+  const int64_t leaf_cap = n / 16 + G + 64;
+  AccOut ao{};
+  ao.leaf_slot = s.get<uint32_t>((size_t)(want_pw ? leaf_cap : 1));
+  ao.leaf_val = s.get<double>((size_t)(want_pw ? leaf_cap : 1));
+  ao.leaf_cursor = s.get<unsigned long long>(1);
+  long long* counts = o.count ? o.count : s.get<long long>((size_t)G);
+  PDX_SCRATCH_CHECK(s);
+  ao.gid_of_slot = gb->gid_of_slot;
+  ao.count = counts;
+  ao.sum_i = o.sum_i;
+  ao.vmin = o.vmin;
+  ao.vmax = o.vmax;
+  PDX_HIP(hipMemsetAsync(ao.leaf_cursor, 0, sizeof(unsigned long long), st));
+  {
+    PDX_PROFILE("bucket_accumulate", st);
+    const T* pv = reinterpret_cast<const T*>(v0);
+    if (LB == 12) launch_bucket_accumulate<T, 12>(k0, pv, hist, nbuckets, n, ao, want_pw, want_mm, want_is, st);
+    else launch_bucket_accumulate<T, 8>(k0, pv, hist, nbuckets, n, ao, want_pw, want_mm, want_is, st);
+  }
+  PDX_LAUNCH_CHECK();
+  if (want_pw) {
+    unsigned long long L = 0;
+    PDX_HIP(hipMemcpyAsync(&L, ao.leaf_cursor, sizeof(L), hipMemcpyDeviceToHost, st));
+    PDX_HIP(hipStreamSynchronize(st));
+    if ((int64_t)L > leaf_cap) return fail(PDX_DEVICE, "bucket accumulate: leaf buffer overflow");
+    // ---- merge tree over the leaf records: stable sort by slot (1/16 of the rows), then the counter replay
+    uint32_t* lk0 = s.get<uint32_t>((size_t)L);
+    uint32_t* lk1 = s.get<uint32_t>((size_t)L);
+    uint64_t* lv0 = s.get<uint64_t>((size_t)L);
+    uint64_t* lv1 = s.get<uint64_t>((size_t)L);
+    uint32_t* ss = s.get<uint32_t>((size_t)G + 1);
+    PDX_SCRATCH_CHECK(s);
+    const uint32_t* ks = nullptr;
+    const uint64_t* vs = nullptr;
+    {
+      PDX_PROFILE("leaf_sort", st);
+      PDX_TRY(radix_sort_pairs<uint64_t>(ao.leaf_slot, reinterpret_cast<const uint64_t*>(ao.leaf_val), lk0, lv0, lk1, lv1, (int64_t)L, gb->slot_bits,
+                                         &ks, &vs, true, s, st));
+      hipLaunchKernelGGL(k_seg_starts, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, ks, (int64_t)L, gb->occ_slot, G, ss);
+    }
+    {
+      PDX_PROFILE("leaf_tree", st);
+      int grid = (int)std::min<int64_t>(ceil_div(G, kSegWaves), (int64_t)kCUs * 8);
+      SegOut so{};
+      so.sum_f = o.sum_f;
+      so.mean = o.mean;
+      hipLaunchKernelGGL((k_seg_reduce<double, true, false, false, 1>), dim3(grid), dim3(kSegWaves * 64), 0, st, reinterpret_cast<const double*>(vs), ss, G,
+                         gb->gid_of_occ, so, counts);
+    }
+    PDX_LAUNCH_CHECK();
+  }
+  *done = true;
+  return PDX_OK;
+}
+
+}  // namespace pdx

@@ -103,7 +103,8 @@ __global__ void __launch_bounds__(256) k_col_apply(uint32_t* __restrict__ hist, 
 template <int BITS, typename V, bool WRITE_KEYS>
 __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals_in,
                                                               uint32_t* __restrict__ keys_out, V* __restrict__ vals_out, int64_t n,
-                                                              int shift, const uint32_t* __restrict__ offsets /* [tiles][R] */) {
+                                                              int shift, const uint32_t* __restrict__ offsets /* [tiles][R] */,
+                                                              int xcd_swizzle) {
   constexpr int R = 1 << BITS;
   constexpr int DPT = (R + kSortBlock - 1) / kSortBlock;
   __shared__ uint32_t cnt[kSortWaves][R];   // per-wave digit counters, later per-(wave,digit) local base
@@ -113,7 +114,16 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const uint32_t* __
   __shared__ uint32_t scan_smem[8];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t tile_base = (int64_t)blockIdx.x * kSortTile;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give every XCD a CONTIGUOUS range of tiles.
+  // Neighbouring tiles append to neighbouring addresses of every bucket; written through the same L2 their partial cache
+  // lines merge before they leave the XCD (placement only changes speed, never the result).
+  const int64_t ntiles_all = (int64_t)gridDim.x;
+  int64_t tile = blockIdx.x;
+  if (xcd_swizzle) {
+    const int64_t per = ntiles_all >> 3;  // tiles per XCD (the remainder keeps its natural index)
+    if (tile < per * 8) tile = (tile & 7) * per + (tile >> 3);
+  }
+  const int64_t tile_base = tile * kSortTile;
   const int tile_rows = (int)((n - tile_base) < kSortTile ? (n - tile_base) : kSortTile);
 
   for (int d = tid; d < kSortWaves * R; d += kSortBlock) (&cnt[0][0])[d] = 0;
@@ -181,7 +191,7 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const uint32_t* __
     if (d < R) {
 #pragma unroll
       for (int w = 0; w < kSortWaves; ++w) cnt[w][d] += pre;
-      gbase[d] = offsets[(int64_t)blockIdx.x * R + d] - pre;
+      gbase[d] = offsets[tile * R + d] - pre;
     }
     pre += dsum[j];
   }
@@ -242,10 +252,11 @@ int radix_pass(const uint32_t* kin, const V* vin, uint32_t* kout, V* vout, int64
   hipLaunchKernelGGL((k_col_chunk_scan<BITS>), dim3(1), dim3(256), 0, st, chunk_sum, nchunks);
   hipLaunchKernelGGL((k_col_apply<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum);
   PDX_PROFILE(sizeof(V) == 8 ? "radix_scatter" : "radix_scatter_small", st);
+  static const int swz = [] { const char* e = getenv("PDX_SORT_XCD_SWIZZLE"); return (e && e[0] == '0') ? 0 : 1; }();
   if (write_keys)
-    hipLaunchKernelGGL((k_radix_scatter<BITS, V, true>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, vin, kout, vout, n, shift, hist);
+    hipLaunchKernelGGL((k_radix_scatter<BITS, V, true>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, vin, kout, vout, n, shift, hist, swz);
   else
-    hipLaunchKernelGGL((k_radix_scatter<BITS, V, false>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, vin, kout, vout, n, shift, hist);
+    hipLaunchKernelGGL((k_radix_scatter<BITS, V, false>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, vin, kout, vout, n, shift, hist, swz);
   PDX_LAUNCH_CHECK();
   return PDX_OK;
 }

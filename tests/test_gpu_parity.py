@@ -381,6 +381,35 @@ def test_groupby_sizes_vs_oracle(px, monkeypatch, n, nk, dense):
 
 
 @pytest.mark.parametrize("dense", ["1", "0"])
+@pytest.mark.parametrize("n,nk,dtype", [(300_007, 100_000, "f"), (300_007, 100_000, "i"), (1_200_011, 900_000, "f"), (70_001, 40_000, "f"),
+                                        (2_000_003, 50_000, "f")])
+def test_groupby_bucket_path_vs_oracle(px, monkeypatch, n, nk, dtype, dense):
+    """the MSD-partition + bucket-accumulate path (forced at small sizes), both slot spaces, LB = 8 and 12, all five aggregates;
+    with skewed (2 hot keys) group sizes so single groups span many tiles and many leaves."""
+    monkeypatch.setenv("PDX_GROUPBY_DENSE", dense)
+    monkeypatch.setenv("PDX_GROUPBY_BUCKET", "2")
+    keys = orc.synth_keys(0, n, nk)
+    keys[::7] = 5
+    keys[1::11] = nk - 1
+    vals = (orc.synth_vals(0, n) - 0.5) * 1e6 if dtype == "f" else orc.synth_keys(9, n, 1 << 40) - (1 << 39)
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys))
+    ids, uniq, _, _ = orc.group_ids(keys)
+    outs = gb.agg(px.Column.from_numpy(vals), [0, 1, 4, 2, 3])
+    assert np.array_equal(gb.unique_keys().to_numpy()[0], uniq)
+    for out, kind in zip(outs, (orc.AGG_SUM, orc.AGG_MEAN, orc.AGG_COUNT, orc.AGG_MIN, orc.AGG_MAX)):
+        got = out.to_numpy()[0]
+        exp = orc.groupby_agg(kind, ids, len(uniq), vals, nthreads=8)[0]
+        if exp.dtype == np.float64:
+            assert_f64_bits(got, exp, what=f"kind={kind}")
+        else:
+            assert np.array_equal(got, exp), f"kind={kind}"
+    for kind in (orc.AGG_SUM, orc.AGG_COUNT, orc.AGG_MAX):  # single-kind specialisations
+        got = gb.agg(px.Column.from_numpy(vals), [kind])[0].to_numpy()[0]
+        exp = orc.groupby_agg(kind, ids, len(uniq), vals, nthreads=8)[0]
+        assert (np.array_equal(got.view(np.uint64), exp.view(np.uint64)) if exp.dtype == np.float64 else np.array_equal(got, exp)), f"single kind={kind}"
+
+
+@pytest.mark.parametrize("dense", ["1", "0"])
 def test_groupby_dense_with_nulls_and_negative_keys(px, monkeypatch, dense):
     monkeypatch.setenv("PDX_GROUPBY_DENSE", dense)
     n = 300_001
