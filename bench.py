@@ -106,7 +106,8 @@ def main():
         engine = pdist.HipEngine()
 
         def step():
-            return pdist.groupby_agg_sharded(engine, keys, vals, kinds, row_offset=lo)
+            # sum/mean/count with the exact partial-tree exchange (fragments + aligned subtree nodes, no rows shipped)
+            return pdist.groupby_sum_mean_count_sharded(engine, keys, vals, row_offset=lo)
 
     def barrier():
         torch.cuda.synchronize()

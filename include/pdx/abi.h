@@ -186,6 +186,29 @@ int pdx_groupby_first_rows(const pdx_groupby* gb, int64_t* out_rows, void* strea
  * (validity required in that case) except COUNT. */
 int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds, int nk, pdx_mut_column* outs, void* stream);
 
+/* ---------------------------------------------------------------- exact multi-GPU fp64 sum (partial-tree exchange)
+ * The reference's per-group sum is Arrow's pairwise tree over the group's rows in GLOBAL row order; with row-range shards a
+ * rank holds the global ranks [P, P+c) of a group.  Instead of shipping its rows to the group's owner, a rank ships
+ *   - the raw values of the (at most two) 16-value leaves it shares with its neighbours ("fragments"), and
+ *   - one node per maximal ALIGNED power-of-two block of the leaves that lie completely inside its range,
+ * as records (key = global_gid * 64 + level + 1; level + 1 == 0 marks a fragment value).  The owner replays the records of a
+ * group in (rank, emission) order through Arrow's binary counter: bit-identical to the single-process result, with
+ * O(32 + 2 log c) instead of c values per group and rank.
+ *
+ * pdx_groupby_group_values : stable sort of a non-null float64 column by group; the handle caches the grouped values.
+ * pdx_grouped_counts       : rows per group (G int64, group-id order).
+ * pdx_grouped_partial_plan : number of records given prefix[g] = rows of group g held by lower ranks (G int64, group-id order).
+ * pdx_grouped_partial_fill : writes the records; gid_map[g] = global group id of local group g.
+ * pdx_replay_partials      : owner side: records for global ids [gid_lo, gid_lo + n_own) in (source rank, emission) order ->
+ *                            out_sum[gid - gid_lo].  Every owned id must have at least one record. */
+typedef struct pdx_grouped pdx_grouped;
+int pdx_groupby_group_values(pdx_groupby* gb, const pdx_column* values, void* stream, pdx_grouped** out);
+int pdx_grouped_destroy(pdx_grouped* g);
+int pdx_grouped_counts(pdx_grouped* g, int64_t* out_counts, void* stream);
+int pdx_grouped_partial_plan(pdx_grouped* g, const int64_t* prefix, int64_t* out_total, void* stream);
+int pdx_grouped_partial_fill(pdx_grouped* g, const int64_t* gid_map, int64_t* rec_key, double* rec_val, void* stream);
+int pdx_replay_partials(const int64_t* rec_key, const double* rec_val, int64_t m, int64_t gid_lo, int64_t n_own, double* out_sum, void* stream);
+
 /* ---------------------------------------------------------------- resample
  * Replaces pd::resample<> / makeGroupInfo / generate_bins_dt64 / GroupInfo::downsample + the Resampler's GroupBy on
  * the per-row labels (src/resample.h:19-43,91-122; src/resample.cpp:11-83,85-178,202-295; src/core.cpp:308-331;

@@ -345,6 +345,56 @@ class GroupByHandle:
         return [o._adopt(marr[i]) for i, o in enumerate(outs)]
 
 
+class GroupedValues:
+    """Owner of a pdx_grouped*: one float64 column stably sorted by group (for the multi-GPU partial-tree exchange)."""
+
+    def __init__(self, gb: GroupByHandle, values: Column):
+        self._gb = gb  # keep the group-by handle alive
+        self._h = C.c_void_p()
+        cv = values.c()
+        L.check(L.load().pdx_groupby_group_values(gb._h, C.byref(cv), _stream(), C.byref(self._h)))
+        self.total = None
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            L.load().pdx_grouped_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def counts(self) -> torch.Tensor:
+        out = torch.empty(max(self._gb.num_groups, 1), dtype=torch.int64, device=_device())
+        L.check(L.load().pdx_grouped_counts(self._h, out.data_ptr(), _stream()))
+        return out[: self._gb.num_groups]
+
+    def partial_plan(self, prefix: torch.Tensor) -> int:
+        self._prefix = prefix.contiguous()  # read again by partial_fill
+        total = C.c_int64(0)
+        L.check(L.load().pdx_grouped_partial_plan(self._h, self._prefix.data_ptr(), C.byref(total), _stream()))
+        self.total = int(total.value)
+        return self.total
+
+    def partial_fill(self, gid_map: torch.Tensor):
+        """-> (rec_key int64[total], rec_val float64[total]) device tensors."""
+        dev = _device()
+        key = torch.empty(max(self.total, 1), dtype=torch.int64, device=dev)
+        val = torch.empty(max(self.total, 1), dtype=torch.float64, device=dev)
+        gm = gid_map.contiguous()
+        L.check(L.load().pdx_grouped_partial_fill(self._h, gm.data_ptr(), key.data_ptr(), val.data_ptr(), _stream()))
+        return key[: self.total], val[: self.total]
+
+
+def replay_partials(rec_key: torch.Tensor, rec_val: torch.Tensor, gid_lo: int, n_own: int) -> torch.Tensor:
+    out = torch.empty(max(n_own, 1), dtype=torch.float64, device=_device())
+    rk, rv = rec_key.contiguous(), rec_val.contiguous()
+    L.check(L.load().pdx_replay_partials(rk.data_ptr(), rv.data_ptr(), int(rk.numel()), int(gid_lo), int(n_own), out.data_ptr(), _stream()))
+    return out[:n_own]
+
+
 # ---------------------------------------------------------------- synthetic inputs (bench / tests)
 def synth_keys(start, n, num_keys) -> Column:
     out = Column.empty(L.INT64, n)

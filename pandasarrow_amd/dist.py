@@ -24,6 +24,31 @@ import torch.distributed as dist
 from . import _lib as L
 
 
+# ---------------------------------------------------------------- optional stage timing (PDX_DIST_TIMING=1): syncs per stage
+import os as _os
+import time as _time
+
+TIMING = {}
+
+
+class _Stage:
+    def __init__(self, name):
+        self.name = name
+        self.on = _os.environ.get("PDX_DIST_TIMING") == "1"
+
+    def __enter__(self):
+        if self.on:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            self.t0 = _time.perf_counter()
+
+    def __exit__(self, *a):
+        if self.on:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            TIMING[self.name] = TIMING.get(self.name, 0.0) + (_time.perf_counter() - self.t0) * 1e3
+
+
 # ---------------------------------------------------------------- collectives (variable-length helpers)
 def _world():
     return (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
@@ -144,6 +169,26 @@ class HipEngine:
             return None
         return torch.from_numpy(col.to_numpy()[1]).to(self.device)
 
+    # ---- partial-tree exchange primitives (exact fp64 sum without shipping rows)
+    def group_values(self, gb, values_col):
+        return self.K.GroupedValues(gb, values_col)
+
+    def grouped_counts(self, gv):
+        return gv.counts()
+
+    def partial_records(self, gv, prefix: torch.Tensor, gid_map: torch.Tensor):
+        gv.partial_plan(prefix)
+        return gv.partial_fill(gid_map)
+
+    def replay(self, rec_key, rec_val, gid_lo, n_own):
+        return self.K.replay_partials(rec_key, rec_val, gid_lo, n_own)
+
+    def select_tensor_eq(self, tensors, by: torch.Tensor, value):
+        """stable selection of rows of 1-D int64/float64 tensors where by == value (through the filter kernels)."""
+        by_col = self.col(by, L.INT64)
+        cols = [self.col(t, L.FLOAT64 if t.dtype == torch.float64 else L.INT64) for t in tensors]
+        return [self.values(c) for c in self.select_eq(cols, by_col, value)]
+
 
 # ---------------------------------------------------------------- sharded group-by
 def groupby_agg_sharded(engine, keys, vals, kinds, row_offset=0):
@@ -207,6 +252,76 @@ def groupby_agg_sharded(engine, keys, vals, kinds, row_offset=0):
             ok = all_gather_v(okb.to(torch.uint8), own_sizes).to(torch.bool)
         outs.append((v, ok))
     return {"G": G, "keys": glob_keys, "keys_ok": glob_ok, "first_rows": glob_first, "outs": outs, "kinds": list(kinds)}
+
+
+def groupby_sum_mean_count_sharded(engine, keys, vals, row_offset=0):
+    """Headline query (sum, mean, count of a non-null float64 column) with the PARTIAL-TREE exchange: instead of routing every
+    row to its group's owner, each rank ships the boundary-leaf fragments and the aligned subtree nodes of its share of every
+    group (include/pdx/abi.h, "exact multi-GPU fp64 sum").  Same result dict as groupby_agg_sharded with kinds [SUM, MEAN, COUNT]."""
+    W, r = _world()
+    dev = engine.device
+    with _Stage("1_local_group"):
+        gb = engine.group(keys)
+        uk, uok = engine.unique_keys(gb)
+        fr = engine.first_rows(gb) + int(row_offset)
+        Gl = int(uk.numel())
+    with _Stage("2_dictionary"):
+        sizes = all_gather_sizes(Gl, dev)
+        cat_keys = all_gather_v(uk, sizes)
+        cat_ok = all_gather_v(uok.to(torch.uint8), sizes).to(torch.bool)
+        cat_first = all_gather_v(fr, sizes)
+        if W == 1:
+            glob_keys, glob_ok, glob_first, G = uk, uok, fr, Gl
+            my_map = torch.arange(Gl, dtype=torch.int64, device=dev)
+        else:
+            gb_cat = engine.group(engine.col(cat_keys, L.INT64, cat_ok))
+            glob_keys, glob_ok = engine.unique_keys(gb_cat)
+            G = int(glob_keys.numel())
+            gid_cat = engine.group_ids(gb_cat)
+            glob_first = cat_first[engine.first_rows(gb_cat)] if G else cat_first[:0]
+            off = sum(sizes[:r])
+            my_map = gid_cat[off:off + Gl].contiguous()
+    # rows per (global group, rank): dense count vectors, all-gathered; prefix over lower ranks
+    with _Stage("3_group_values"):
+        gv = engine.group_values(gb, vals)
+        cnt_local = engine.grouped_counts(gv)
+    with _Stage("4_counts_exchange"):
+        dense = torch.zeros(max(G, 1), dtype=torch.int64, device=dev)
+        dense[my_map] = cnt_local
+        if W > 1:
+            allc = [torch.empty_like(dense) for _ in range(W)]
+            dist.all_gather(allc, dense)
+            allc = torch.stack(allc)  # [W, G]
+            prefix_g = allc[:r].sum(dim=0) if r > 0 else torch.zeros_like(dense)
+            count_g = allc.sum(dim=0)
+        else:
+            prefix_g, count_g = torch.zeros_like(dense), dense
+    with _Stage("5_partial_records"):
+        rec_key, rec_val = engine.partial_records(gv, prefix_g[my_map].contiguous(), my_map)
+    # route records to the owners of contiguous global-id ranges
+    bounds = [G * d // W for d in range(W + 1)]
+    with _Stage("6_route_all_to_all"):
+        if W > 1:
+            owner = torch.bucketize(rec_key >> 6, torch.tensor(bounds[1:], dtype=torch.int64, device=dev), right=True)
+            send_k, send_v = [], []
+            for d in range(W):
+                k_d, v_d = engine.select_tensor_eq([rec_key, rec_val], owner, d)
+                send_k.append(k_d)
+                send_v.append(v_d)
+            rk = torch.cat(all_to_all_v(send_k))
+            rv = torch.cat(all_to_all_v(send_v))
+        else:
+            rk, rv = rec_key, rec_val
+    with _Stage("7_replay"):
+        n_own = bounds[r + 1] - bounds[r]
+        sums_own = engine.replay(rk, rv, bounds[r], n_own)
+    with _Stage("8_gather_results"):
+        own_sizes = [bounds[d + 1] - bounds[d] for d in range(W)]
+        sums = all_gather_v(sums_own, own_sizes)
+        counts = count_g[:G]
+        means = sums / counts.to(torch.float64)
+    return {"G": G, "keys": glob_keys, "keys_ok": glob_ok, "first_rows": glob_first, "kinds": [L.AGG_SUM, L.AGG_MEAN, L.AGG_COUNT],
+            "outs": [(sums, None), (means, None), (counts, None)], "records": int(rec_key.numel())}
 
 
 def check_result(res, n_total):

@@ -75,3 +75,107 @@ class OracleEngine:
 
     def valid_bools(self, col):
         return None if col.valid is None else torch.from_numpy(col.valid)
+
+
+    # ---- partial-tree exchange primitives: independent Python restatement of include/pdx/abi.h "exact multi-GPU fp64 sum"
+    def group_values(self, gb, values_col):
+        offsets, rows = orc.groupings(gb.ids, gb.G)
+        return {"gb": gb, "vals": [values_col.values[rows[offsets[g]:offsets[g + 1]]] for g in range(gb.G)]}
+
+    def grouped_counts(self, gv):
+        return torch.tensor([len(v) for v in gv["vals"]], dtype=torch.int64)
+
+    @staticmethod
+    def _blocks(kf, kl):
+        s = kf
+        while s < kl:
+            j = 62 if s == 0 else (s & -s).bit_length() - 1
+            j = min(j, (kl - s).bit_length() - 1)
+            yield s, j
+            s += 1 << j
+
+    def partial_records(self, gv, prefix, gid_map):
+        keys, vals = [], []
+        P, gm = prefix.numpy(), gid_map.numpy()
+        for lg, v in enumerate(gv["vals"]):
+            a, c = int(P[lg]), len(v)
+            if c == 0:
+                continue
+            b, gkey = a + c, int(gm[lg]) * 64
+            kf, kl = (a + 15) // 16, b // 16
+            if kf > kl:
+                keys += [gkey] * c
+                vals += list(v)
+                continue
+            h = 16 * kf - a
+            keys += [gkey] * h
+            vals += list(v[:h])
+            for s0, j in self._blocks(kf, kl):
+                cn = _Counter()
+                for q in range(1 << j):
+                    base = 16 * (s0 + q) - a
+                    acc = 0.0
+                    for e in range(16):
+                        acc = acc + float(v[base + e])
+                    cn.push(acc, 0)
+                keys.append(gkey + j + 1)
+                vals.append(cn.sum[j])
+            t0 = 16 * kl - a
+            keys += [gkey] * (c - t0)
+            vals += list(v[t0:])
+        return torch.tensor(keys, dtype=torch.int64), torch.tensor(vals, dtype=torch.float64)
+
+    def replay(self, rec_key, rec_val, gid_lo, n_own):
+        k, v = rec_key.numpy(), rec_val.numpy()
+        per = [[] for _ in range(n_own)]
+        for key, val in zip(k, v):  # arrival order == (source rank, emission) order
+            per[(int(key) >> 6) - gid_lo].append((int(key) & 63, float(val)))
+        out = np.zeros(n_own)
+        for g, recs in enumerate(per):
+            assert recs, "an owned group received no record"
+            cn, acc, fill = _Counter(), 0.0, 0
+            for lvl, val in recs:
+                if lvl == 0:
+                    acc = acc + val
+                    fill += 1
+                    if fill == 16:
+                        cn.push(acc, 0)
+                        acc, fill = 0.0, 0
+                else:
+                    assert fill == 0
+                    cn.push(val, lvl - 1)
+            if fill:
+                cn.push(acc, 0)
+            out[g] = cn.finish()
+        return torch.from_numpy(out)
+
+    def select_tensor_eq(self, tensors, by, value):
+        m = by == value
+        return [t[m] for t in tensors]
+
+
+class _Counter:
+    """Arrow's binary counter with pushes at arbitrary levels."""
+
+    def __init__(self):
+        self.sum = [0.0] * 64
+        self.mask = 0
+        self.root = 0
+
+    def push(self, x, level):
+        cur, m = level, 1 << level
+        self.sum[cur] += x
+        self.mask ^= m
+        while (self.mask & m) == 0:
+            x = self.sum[cur]
+            self.sum[cur] = 0.0
+            cur += 1
+            m <<= 1
+            self.sum[cur] += x
+            self.mask ^= m
+        self.root = max(self.root, cur)
+
+    def finish(self):
+        for i in range(1, self.root + 1):
+            self.sum[i] += self.sum[i - 1]
+        return self.sum[self.root]

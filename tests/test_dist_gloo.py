@@ -35,6 +35,14 @@ def _worker(rank, world, port, case, q):
         eng = OracleEngine()
         res = pdist.groupby_agg_sharded(eng, OCol(keys[lo:hi], None if kvalid is None else kvalid[lo:hi]),
                                         OCol(vals[lo:hi], None if vvalid is None else vvalid[lo:hi]), KINDS, row_offset=lo)
+        if keys is not None and kvalid is None and vvalid is None and vals.dtype == np.float64:
+            # the partial-tree exchange (no rows shipped) must give the same three columns bit-for-bit
+            fast = pdist.groupby_sum_mean_count_sharded(eng, OCol(keys[lo:hi]), OCol(vals[lo:hi]), row_offset=lo)
+            for kind in (0, 1, 4):
+                a = fast["outs"][fast["kinds"].index(kind)][0].numpy()
+                b = res["outs"][KINDS.index(kind)][0].numpy()
+                assert a.dtype == b.dtype and np.array_equal(a.view(np.uint64), b.view(np.uint64)), f"partial-tree exchange differs for kind {kind}"
+            assert np.array_equal(fast["keys"].numpy(), res["keys"].numpy()) and np.array_equal(fast["first_rows"].numpy(), res["first_rows"].numpy())
         if rank == world - 1:  # any rank holds the full result
             q.put({"G": res["G"], "keys": res["keys"].numpy(), "keys_ok": res["keys_ok"].numpy(), "first": res["first_rows"].numpy(),
                    "outs": [(v.numpy(), None if ok is None else ok.numpy()) for v, ok in res["outs"]],
@@ -71,10 +79,14 @@ def _cases():
     yield "nulls_i64", (rng.integers(-5, 40, n).astype(np.int64), rng.integers(-10**6, 10**6, n).astype(np.int64), rng.random(n) > 0.05,
                         rng.random(n) > 0.2)
     yield "tiny", (np.array([3, 3, 1], np.int64), np.array([0.5, 0.25, 4.0]), None, None)
+    # group sizes straddling every leaf / block alignment: 3 keys with ~6000 rows each + tiny groups, cancellation-heavy values
+    k = np.concatenate([rng.integers(0, 3, 18000), np.arange(100, 140).repeat(rng.integers(1, 40, 40))]).astype(np.int64)
+    rng.shuffle(k)
+    yield "aligned_blocks", (k, rng.standard_normal(len(k)) * 10.0 ** rng.integers(-3, 12, len(k)), None, None)
 
 
-@pytest.mark.parametrize("world,name,case", [(2, n, c) for n, c in _cases()] + [(3, n, c) for n, c in _cases() if n in ("tiny", "nulls_i64")],
-                         ids=[f"w2-{n}" for n, _ in _cases()] + ["w3-nulls_i64", "w3-tiny"])
+@pytest.mark.parametrize("world,name,case", [(2, n, c) for n, c in _cases()] + [(3, n, c) for n, c in _cases() if n in ("tiny", "nulls_i64", "aligned_blocks")],
+                         ids=[f"w2-{n}" for n, _ in _cases()] + ["w3-nulls_i64", "w3-tiny", "w3-aligned_blocks"])
 def test_sharded_groupby_matches_single_process(world, name, case):
     got = _run(world, case)
     uniq, isnull, first, outs = _expected(*case)

@@ -29,6 +29,15 @@ def _compare(res, keys, vals):
             assert np.array_equal(got, exp)
 
 
+def _compare_fast(fast, keys, vals):
+    uniq, first, outs = _expected(keys, vals)
+    assert fast["G"] == len(uniq) and np.array_equal(fast["keys"].cpu().numpy(), uniq) and np.array_equal(fast["first_rows"].cpu().numpy(), first)
+    for j, kind in enumerate((0, 1, 4)):  # sum, mean, count
+        got = fast["outs"][j][0].cpu().numpy()
+        exp = outs[KINDS.index(kind)]
+        assert (np.array_equal(got.view(np.uint64), exp.view(np.uint64)) if exp.dtype == np.float64 else np.array_equal(got, exp)), kind
+
+
 def _data(n, nk):
     return orc.synth_keys(0, n, nk) * 7919 - 12345, orc.synth_vals(0, n) - 0.5
 
@@ -46,6 +55,8 @@ def test_sharded_single_rank():
            "outs": [v.cpu().numpy() for v, _ in res["outs"]]}
     _compare(out, keys, vals)
     assert all(v for v in pdist.check_result(res, len(keys)).values() if isinstance(v, bool))
+    fast = pdist.groupby_sum_mean_count_sharded(pdist.HipEngine(), Column.from_numpy(keys), Column.from_numpy(vals))
+    _compare_fast(fast, keys, vals)
     torch.cuda.synchronize()
 
 
@@ -65,18 +76,20 @@ def _worker(rank, world, port, n, nk, q):
         keys, vals = _data(n, nk)
         lo, hi = n * rank // world, n * (rank + 1) // world
         res = pdist.groupby_agg_sharded(pdist.HipEngine(), Column.from_numpy(keys[lo:hi]), Column.from_numpy(vals[lo:hi]), KINDS, row_offset=lo)
+        fast = pdist.groupby_sum_mean_count_sharded(pdist.HipEngine(), Column.from_numpy(keys[lo:hi]), Column.from_numpy(vals[lo:hi]), row_offset=lo)
         if rank == 0:
             q.put({"G": res["G"], "keys": res["keys"].cpu().numpy(), "first": res["first_rows"].cpu().numpy(),
-                   "outs": [v.cpu().numpy() for v, _ in res["outs"]]})
+                   "outs": [v.cpu().numpy() for v, _ in res["outs"]],
+                   "fast": {"G": fast["G"], "keys": fast["keys"].cpu(), "first_rows": fast["first_rows"].cpu(), "outs": [(v.cpu(), None) for v, _ in fast["outs"]]}})
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_two_ranks_one_gpu():
+def test_sharded_three_ranks_one_gpu():
     import torch.multiprocessing as mp
 
-    n, nk, world = 300_007, 3000, 2
+    n, nk, world = 300_007, 3000, 3
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -90,3 +103,4 @@ def test_sharded_two_ranks_one_gpu():
         p.join(timeout=120)
         assert p.exitcode == 0
     _compare(got, *_data(n, nk))
+    _compare_fast(got["fast"], *_data(n, nk))
