@@ -32,7 +32,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=float, default=1e9, help="total rows (strong scaling: split by row range over the ranks)")
     ap.add_argument("--keys", type=float, default=1e6)
-    ap.add_argument("--cpu-sample-rows", type=float, default=3e7, help="rows of the same workload timed on the host cores (rank 0, N=1)")
+    ap.add_argument("--cpu-sample-rows", type=float, default=2.5e8, help="rows of the same workload timed on the host cores (rank 0, N=1), ~10-20 s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the size-independent result checks after the timed region")
     return ap.parse_args()
@@ -148,6 +148,18 @@ def main():
                 "traffic": None, "launches_per_step": cnt / args.steps, "avg_launch_ms": avg_ms,
                 "whole_step_frac": ALGO_BYTES_PER_ROW * n_local / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items())}}
+
+    # HBM traffic of the dominant kernel: PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate passes) collected on the same
+    # build by tools/collect_profiles.sh and committed under profiles/ -- only valid for the configuration it was measured on
+    if roof is not None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if pmc.get("rows") == n_total and pmc.get("n_gpus") == world:
+                roof["traffic"] = pmc["by_bench_tag_hbm_bytes_per_launch"].get(roof["kernel"])
+                roof["traffic_source"] = "profiles/r01_pmc_traffic.json"
+        except (OSError, ValueError, KeyError):
+            pass
 
     # size-independent checks on the last result (outside the timed region)
     check = None

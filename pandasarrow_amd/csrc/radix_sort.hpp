@@ -247,10 +247,12 @@ int radix_pass(const uint32_t* kin, const V* vin, uint32_t* kout, V* vout, int64
     PDX_PROFILE(sizeof(V) == 8 ? "radix_hist" : "radix_hist_small", st);
     hipLaunchKernelGGL((k_radix_hist<BITS>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, n, shift, hist);
   }
-  PDX_PROFILE(sizeof(V) == 8 ? "radix_scan_scatter" : "radix_scan_scatter_small", st);
-  hipLaunchKernelGGL((k_col_chunk_sums<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum);
-  hipLaunchKernelGGL((k_col_chunk_scan<BITS>), dim3(1), dim3(256), 0, st, chunk_sum, nchunks);
-  hipLaunchKernelGGL((k_col_apply<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum);
+  {
+    PDX_PROFILE(sizeof(V) == 8 ? "radix_scan" : "radix_scan_small", st);
+    hipLaunchKernelGGL((k_col_chunk_sums<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum);
+    hipLaunchKernelGGL((k_col_chunk_scan<BITS>), dim3(1), dim3(256), 0, st, chunk_sum, nchunks);
+    hipLaunchKernelGGL((k_col_apply<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum);
+  }
   PDX_PROFILE(sizeof(V) == 8 ? "radix_scatter" : "radix_scatter_small", st);
   static const int swz = [] { const char* e = getenv("PDX_SORT_XCD_SWIZZLE"); return (e && e[0] == '0') ? 0 : 1; }();
   if (write_keys)

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/prof_<tag>/ (written by tools/collect_profiles.sh on the GPU box) into tracked files under profiles/:
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `bench.py`
+  profiles/<tag>_pmc_traffic.json   per-kernel HBM bytes per launch from FETCH_SIZE / WRITE_SIZE (KiB units; FETCH_SIZE doubled:
+                                    on gfx950 it reports half of a wide coalesced read stream -- MI355X_MICROARCH.md, HBM section)
+  profiles/<tag>_bench.json         the bench line of the same build
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+stats = glob.glob(os.path.join(src, "kt", "*", "*kernel_stats.csv"))
+shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
+
+
+def short(name):
+    m = re.search(r"pdx::(k_[a-z_0-9]+(<[^>]*>)?)", name)
+    return m.group(1) if m else name[:40]
+
+
+traffic = collections.defaultdict(lambda: {"launches": 0, "fetch_kib": 0.0, "write_kib": 0.0})
+for counter, field in (("FETCH_SIZE", "fetch_kib"), ("WRITE_SIZE", "write_kib")):
+    f = glob.glob(os.path.join(src, f"pmc_{counter}", "*", "*counter_collection.csv"))[0]
+    seen = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = short(r["Kernel_Name"])
+        traffic[k][field] += float(r["Counter_Value"])
+        seen[k] += 1
+    for k, n in seen.items():
+        traffic[k]["launches"] = max(traffic[k]["launches"], n)
+out = {}
+for k, t in traffic.items():
+    n = max(t["launches"], 1)
+    rd, wr = 2.0 * t["fetch_kib"] * 1024 / n, t["write_kib"] * 1024 / n
+    if rd + wr < 1e8:
+        continue
+    out[k] = {"launches_in_profiled_run": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
+# bench.py tags -> kernels (large-payload instantiations only)
+TAGS = {"radix_scatter": r"k_radix_scatter<\d+, unsigned long", "radix_hist": r"k_radix_hist<", "dense_slots": r"k_dense_slots_tail", "hash_insert": r"k_hash_insert",
+        "seg_reduce": r"k_seg_reduce<", "key_minmax": r"k_minmax_partial<long long>"}
+by_tag = {}
+for tg, pat in TAGS.items():
+    ks = [(k, v) for k, v in out.items() if re.search(pat, k)]
+    if ks:
+        n = sum(v["launches_in_profiled_run"] for _, v in ks)
+        by_tag[tg] = sum(v["hbm_bytes_per_launch"] * v["launches_in_profiled_run"] for _, v in ks) / n
+json.dump({"by_bench_tag_hbm_bytes_per_launch": by_tag, "rows": 1000000000, "n_gpus": 1, "note": "bytes per launch at 1e9 rows / 1e6 keys, 1 GPU; read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB",
+           "kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]))},
+          open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+print(open(os.path.join(dst, f"{tag}_bench.json")).read()[:600])
+print(json.dumps(out, indent=1)[:1500])
