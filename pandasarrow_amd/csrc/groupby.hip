@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) k_hash_insert(const long long* __restrict
   const unsigned int mask = cap - 1;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    if (__hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    // (the overflow flag is polled only on the insert / long-probe path: a per-row poll of one address serialises on one L2 channel)
     unsigned int s;
     long long key = keys[i];
     if (valid && !bit_get(valid, off + i)) {
@@ -72,6 +72,7 @@ __global__ void __launch_bounds__(256) k_hash_insert(const long long* __restrict
         long long cur = table[h].key;
         if (cur == key) { s = h; break; }
         if (cur == kEmptyKey) {
+          if (__hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
           unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[h].key), (unsigned long long)kEmptyKey,
                                              (unsigned long long)key);
           if (old == (unsigned long long)kEmptyKey) {
@@ -83,7 +84,9 @@ __global__ void __launch_bounds__(256) k_hash_insert(const long long* __restrict
           if (old == (unsigned long long)key) { s = h; break; }
         }
         h = (h + 1) & mask;
-        if (++probes > cap) {
+        ++probes;
+        if ((probes & 63) == 0 && __hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        if (probes > cap) {
           atomicExch(&ctl->overflow, 1u);
           s = cap;
           break;
@@ -93,6 +96,210 @@ __global__ void __launch_bounds__(256) k_hash_insert(const long long* __restrict
     if ((unsigned int)i < table[s].first) atomicMin(&table[s].first, (unsigned int)i);
     slot_of_row[i] = s;
   }
+}
+
+// ---- partitioned hash build (general keys).  Rows are first partitioned (stably) by the low kPartBits of a 32-bit key hash:
+// that pass IS the first LSD pass of the later sort by slot, because the logical slot id is (index inside the bucket's table
+// region << kPartBits) | bucket.  All rows of a bucket probe one contiguous 1/256 region of the table, and tiles are processed in
+// bucket order, so the active part of the table (a few hundred KB) stays in every XCD's L2 instead of costing one random
+// 128-byte line from the Infinity Cache per row.
+constexpr int kPartBits = 8;
+__global__ void __launch_bounds__(256) k_hash32(const long long* __restrict__ keys, const uint8_t* __restrict__ valid, int64_t off, int64_t n,
+                                                uint32_t* __restrict__ h32) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    long long k[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) k[u] = keys[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      uint32_t h = (uint32_t)(splitmix64((uint64_t)k[u]) >> 32);
+      if (k[u] == kEmptyKey) h = 1;                                  // its dedicated slot cap + 1 has low bits 1
+      if (valid && !bit_get(valid, off + i + u * stride)) h = 0;     // the null slot `cap` has low bits 0
+      h32[i + u * stride] = h;
+    }
+  }
+  for (; i < n; i += stride) {
+    long long k = keys[i];
+    uint32_t h = (uint32_t)(splitmix64((uint64_t)k) >> 32);
+    if (k == kEmptyKey) h = 1;
+    if (valid && !bit_get(valid, off + i)) h = 0;
+    h32[i] = h;
+  }
+}
+// inputs in partitioned order; rows carry the null flag in bit 31.  U rows per thread are kept in flight: the stream loads and
+// the first table probe of all U rows are issued before any of them is consumed.
+template <int U>
+__global__ void __launch_bounds__(256) k_hash_probe_part(const long long* __restrict__ keys_part, const uint32_t* __restrict__ rows_part,
+                                                         const uint32_t* __restrict__ h32_part, int64_t n, Slot* table, unsigned int cap,
+                                                         unsigned int region, unsigned int limit, uint32_t* __restrict__ slot_part,
+                                                         HashCtl* ctl) {
+  const unsigned int rmask = region - 1;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < n; p0 += (int64_t)U * stride) {
+    unsigned int row[U], h[U], phys[U], idx[U];
+    long long key[U], cur[U];
+    bool act[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t p = p0 + u * stride;
+      act[u] = p < n;
+      row[u] = act[u] ? rows_part[p] : 0u;
+      key[u] = act[u] ? keys_part[p] : 0;
+      h[u] = act[u] ? h32_part[p] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned int b = h[u] & ((1u << kPartBits) - 1);
+      idx[u] = (h[u] >> kPartBits) & rmask;
+      phys[u] = b * region + idx[u];
+      if (row[u] >> 31) phys[u] = cap;
+      else if (key[u] == kEmptyKey) phys[u] = cap + 1;
+      cur[u] = act[u] ? table[phys[u]].key : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!act[u]) continue;
+      const bool special = (row[u] >> 31) || key[u] == kEmptyKey;
+      const unsigned int r = row[u] & 0x7FFFFFFFu;
+      unsigned int logical;
+      if (special) {
+        logical = phys[u];
+      } else {
+        const unsigned int b = h[u] & ((1u << kPartBits) - 1), base = b * region;
+        unsigned int probes = 0;
+        long long c = cur[u];
+        for (;;) {
+          if (c == key[u]) break;
+          if (c == kEmptyKey) {
+            if (__hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+            unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[base + idx[u]].key), (unsigned long long)kEmptyKey,
+                                               (unsigned long long)key[u]);
+            if (old == (unsigned long long)kEmptyKey) {
+              unsigned int cc = atomicAdd(&ctl->inserted, 1u);
+              if (cc >= limit) atomicExch(&ctl->overflow, 1u);
+              break;
+            }
+            if (old == (unsigned long long)key[u]) break;
+          }
+          idx[u] = (idx[u] + 1) & rmask;
+          if (++probes > region) {  // this bucket's region is full: grow the table
+            atomicExch(&ctl->overflow, 1u);
+            break;
+          }
+          c = table[base + idx[u]].key;
+        }
+        phys[u] = base + idx[u];
+        logical = (idx[u] << kPartBits) | b;
+      }
+      if (r < table[phys[u]].first) atomicMin(&table[phys[u]].first, r);
+      slot_part[p0 + u * stride] = logical;
+    }
+  }
+}
+// LDS-resident build: one workgroup per bucket keeps the bucket's whole table region (<= 8192 keys + first rows = 96 KB) in LDS,
+// streams the bucket's rows once and writes the region back.  Random probes hit LDS banks instead of the L2/TA path, which
+// tops out near 70 G random accesses/s chip-wide however local the table is (measured: profiles/ notes in DESIGN.md).
+constexpr int kLdsRegionMax = 8192;
+constexpr int kProbeBlock = 1024;
+__global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long* __restrict__ keys_part, const uint32_t* __restrict__ rows_part,
+                                                                const uint32_t* __restrict__ h32_part, const uint32_t* __restrict__ bucket_off,
+                                                                int64_t n, Slot* table, unsigned int cap, unsigned int region,
+                                                                uint32_t* __restrict__ slot_part, HashCtl* ctl) {
+  __shared__ unsigned long long lkeys[kLdsRegionMax];
+  __shared__ unsigned int lfirst[kLdsRegionMax];
+  __shared__ unsigned int linserted;
+  const int tid = threadIdx.x;
+  const unsigned int b = blockIdx.x;
+  const unsigned int rmask = region - 1;
+  const int64_t start = bucket_off[b];
+  const int64_t end = (b + 1 < (1u << kPartBits)) ? (int64_t)bucket_off[b + 1] : n;
+  for (int i = tid; i < (int)region; i += kProbeBlock) {
+    lkeys[i] = (unsigned long long)kEmptyKey;
+    lfirst[i] = kNoRow;
+  }
+  if (tid == 0) linserted = 0;
+  __syncthreads();
+  constexpr int U = 4;
+  for (int64_t p0 = start + tid; p0 < end; p0 += (int64_t)U * kProbeBlock) {
+    unsigned int row[U], h[U];
+    long long key[U];
+    bool act[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t p = p0 + (int64_t)u * kProbeBlock;
+      act[u] = p < end;
+      row[u] = act[u] ? rows_part[p] : 0u;
+      key[u] = act[u] ? keys_part[p] : 0;
+      h[u] = act[u] ? h32_part[p] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!act[u]) continue;
+      const unsigned int r = row[u] & 0x7FFFFFFFu;
+      unsigned int logical;
+      if ((row[u] >> 31) || key[u] == kEmptyKey) {  // null key / INT64_MIN key: dedicated global slots (rare)
+        const unsigned int sp = (row[u] >> 31) ? cap : cap + 1;
+        atomicMin(&table[sp].first, r);
+        logical = sp;
+      } else {
+        unsigned int idx = (h[u] >> kPartBits) & rmask, probes = 0;
+        for (;;) {
+          unsigned long long cur = lkeys[idx];
+          if (cur == (unsigned long long)key[u]) break;
+          if (cur == (unsigned long long)kEmptyKey) {
+            unsigned long long old = atomicCAS(&lkeys[idx], (unsigned long long)kEmptyKey, (unsigned long long)key[u]);
+            if (old == (unsigned long long)kEmptyKey) {
+              atomicAdd(&linserted, 1u);
+              break;
+            }
+            if (old == (unsigned long long)key[u]) break;
+          }
+          idx = (idx + 1) & rmask;
+          if (++probes > region) {  // region full: the host retries with a larger table (L2 path)
+            atomicExch(&ctl->overflow, 1u);
+            break;
+          }
+        }
+        if (r < lfirst[idx]) atomicMin(&lfirst[idx], r);
+        logical = (idx << kPartBits) | b;
+      }
+      slot_part[p0 + (int64_t)u * kProbeBlock] = logical;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < (int)region; i += kProbeBlock) {
+    Slot sl;
+    sl.key = (long long)lkeys[i];
+    sl.first = lfirst[i];
+    sl.gid = kNoRow;
+    table[(int64_t)b * region + i] = sl;
+  }
+  if (tid == 0 && linserted) atomicAdd(&ctl->inserted, linserted);
+}
+
+__device__ __forceinline__ int64_t phys_slot(int64_t logical, unsigned int region, unsigned int cap) {
+  if (region == 0 || logical >= (int64_t)cap) return logical;
+  return (logical & ((1 << kPartBits) - 1)) * (int64_t)region + (logical >> kPartBits);
+}
+// row-order views from the partitioned arrays (on demand: group ids / mapped ids)
+__global__ void k_part_row_gids(const uint32_t* __restrict__ gid_of_slot, const uint32_t* __restrict__ slot_part,
+                                const uint32_t* __restrict__ rows_part, int64_t n, const int64_t* __restrict__ map, uint32_t* __restrict__ out32,
+                                int64_t* __restrict__ out64) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+    uint32_t g = gid_of_slot[slot_part[p]];
+    uint32_t row = rows_part[p] & 0x7FFFFFFFu;
+    if (out32) out32[row] = g;
+    if (out64) out64[row] = map[g];
+  }
+}
+__global__ void k_flag_keys_part(const uint32_t* __restrict__ slot_part, const uint32_t* __restrict__ rows_part, const uint8_t* __restrict__ valid,
+                                 int64_t off, int64_t n, uint32_t* __restrict__ out) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride)
+    out[p] = slot_part[p] | (bit_get(valid, off + (int64_t)(rows_part[p] & 0x7FFFFFFFu)) ? 0u : 0x80000000u);
 }
 
 // Dense-domain fast path: when the valid keys span a small integer range the slot is key - min (no table, no probing):
@@ -167,16 +374,18 @@ __global__ void __launch_bounds__(256) k_dense_slots_tail(const long long* __res
 struct OccPred {
   const Slot* table;
   const unsigned int* first;
-  __device__ bool operator()(int64_t i) const { return (table ? table[i].first : first[i]) != kNoRow; }
+  unsigned int region, cap;  // region != 0: i is a LOGICAL slot of the partitioned table
+  __device__ bool operator()(int64_t i) const { return (table ? table[phys_slot(i, region, cap)].first : first[i]) != kNoRow; }
 };
 struct OccEmit {
   const Slot* table;
   const unsigned int* first;
+  unsigned int region, cap;
   uint32_t* occ_slot;
   uint32_t* occ_first;
   __device__ void operator()(int64_t pos, int64_t i) const {
     occ_slot[pos] = (uint32_t)i;
-    occ_first[pos] = table ? table[i].first : first[i];
+    occ_first[pos] = table ? table[phys_slot(i, region, cap)].first : first[i];
   }
 };
 
@@ -185,14 +394,14 @@ struct OccEmit {
 __global__ void k_assign_gids(const Slot* __restrict__ table, long long dense_min, uint32_t* __restrict__ gid_of_slot,
                               const uint32_t* __restrict__ sorted_first, const uint32_t* __restrict__ sorted_slot, int64_t G,
                               unsigned int null_slot, int64_t* __restrict__ uniques, uint8_t* __restrict__ unique_ok,
-                              int64_t* __restrict__ first_rows) {
+                              int64_t* __restrict__ first_rows, unsigned int region) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < G; r += stride) {
     unsigned int s = sorted_slot[r];
     gid_of_slot[s] = (unsigned int)r;
     long long k;
     if (table) {
-      k = table[s].key;
+      k = table[phys_slot(s, region, null_slot)].key;
       if (s == null_slot + 1) k = kEmptyKey;
     } else {
       k = (long long)((unsigned long long)dense_min + (unsigned long long)s);
@@ -764,6 +973,11 @@ struct pdx_groupby {
   int64_t nslots = 0;
   int slot_bits = 0;
   int dense = 0;                    // 1: slots are key - min (dense integer key domain), 0: open-addressing hash table
+  // partitioned hash build (slot_of_row == nullptr): rows live in hash-partition order
+  uint32_t* h32 = nullptr;          // n, row order: low kPartBits = partition
+  uint32_t* part_off = nullptr;     // [tiles][256] scatter offsets of the partition pass
+  uint32_t* slot_part = nullptr;    // n, logical slot per partitioned position
+  uint32_t* rows_part = nullptr;    // n, original row (bit 31: key is null)
   uint32_t* slot_of_row = nullptr;  // n
   uint32_t* occ_slot = nullptr;     // G, slot order
   uint32_t* gid_of_occ = nullptr;   // G
@@ -802,6 +1016,41 @@ static int ilog2(uint64_t x) {
   int b = 0;
   while ((1ull << b) < x) ++b;
   return b;
+}
+
+// Values (8-byte payload in ROW order, optional validity) stably sorted by logical slot.  `alloc` provides the buffers
+// (scratch for pdx_groupby_agg, handle-owned for pdx_groupby_group_values).  In the partitioned layout the values are first
+// scattered with the stored partition offsets (the first LSD pass) and only the remaining slot bits are sorted.
+template <typename Alloc>
+static int sort_values_by_slot(pdx_groupby* gb, const uint64_t* vals, const uint8_t* vvalid, int64_t voff, Alloc&& alloc, Scratch& s, hipStream_t st,
+                               const uint32_t** keys_sorted, const uint64_t** vals_sorted) {
+  const int64_t n = gb->n;
+  uint32_t* k0 = static_cast<uint32_t*>(alloc((size_t)n * 4));
+  uint32_t* k1 = static_cast<uint32_t*>(alloc((size_t)n * 4));
+  uint64_t* v0 = static_cast<uint64_t*>(alloc((size_t)n * 8));
+  uint64_t* v1 = static_cast<uint64_t*>(alloc((size_t)n * 8));
+  if (!k0 || !k1 || !v0 || !v1) return PDX_OOM;
+  if (gb->slot_part) {
+    uint64_t* vals_part = static_cast<uint64_t*>(alloc((size_t)n * 8));
+    if (!vals_part) return PDX_OOM;
+    PDX_TRY((radix_scatter_only<kPartBits, uint64_t>(gb->h32, vals, nullptr, vals_part, n, 0, false, gb->part_off, st)));
+    const uint32_t* kin = gb->slot_part;
+    if (vvalid) {
+      uint32_t* fk = static_cast<uint32_t*>(alloc((size_t)n * 4));
+      if (!fk) return PDX_OOM;
+      hipLaunchKernelGGL(k_flag_keys_part, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, gb->slot_part, gb->rows_part, vvalid, voff, n, fk);
+      kin = fk;
+    }
+    return radix_sort_pairs<uint64_t>(kin, vals_part, k0, v0, k1, v1, n, gb->slot_bits - kPartBits, keys_sorted, vals_sorted, true, s, st, kPartBits);
+  }
+  const uint32_t* kin = gb->slot_of_row;
+  if (vvalid) {
+    uint32_t* fk = static_cast<uint32_t*>(alloc((size_t)n * 4));
+    if (!fk) return PDX_OOM;
+    hipLaunchKernelGGL(k_flag_keys, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, gb->slot_of_row, vvalid, voff, n, fk);
+    kin = fk;
+  }
+  return radix_sort_pairs<uint64_t>(kin, vals, k0, v0, k1, v1, n, gb->slot_bits, keys_sorted, vals_sorted, true, s, st);
 }
 
 template <typename T>
@@ -849,9 +1098,8 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   Scratch s;
   const long long* keys = static_cast<const long long*>(key->values) + key->offset;
   const uint8_t* valid = validity_or_null(key);
-  gb->slot_of_row = gb->own<uint32_t>((size_t)n);
   HashCtl* ctl = s.get<HashCtl>(1);
-  if (!gb->slot_of_row || s.failed) {
+  if (s.failed) {
     delete gb;
     return PDX_OOM;
   }
@@ -885,6 +1133,16 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
       nslots = 1;
     }
   }
+  unsigned int region = 0;  // != 0: partitioned hash table (logical slot = (index in region << kPartBits) | bucket)
+  const char* penv = getenv("PDX_HASH_PARTITION");
+  const bool use_partition = !gb->dense && !(penv && penv[0] == '0') && (n >= ((int64_t)1 << 18) || (penv && penv[0] == '2'));
+  if (!use_partition) {
+    gb->slot_of_row = gb->own<uint32_t>((size_t)n);
+    if (!gb->slot_of_row) {
+      delete gb;
+      return PDX_OOM;
+    }
+  }
   if (gb->dense) {
     dense_first = s.get<unsigned int>((size_t)nslots);
     if (s.failed) {
@@ -909,6 +1167,75 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
                            null_slot, seen, dense_first, gb->slot_of_row);
       }
     }
+  } else if (use_partition) {
+    // ---- general keys, partitioned build: hash -> stable partition by the low 8 hash bits (== first LSD pass of the sort by slot)
+    const int64_t ntiles = ceil_div(n, kSortTile), nchunks = ceil_div(ntiles, kColChunk);
+    gb->h32 = gb->own<uint32_t>((size_t)n);
+    gb->part_off = gb->own<uint32_t>((size_t)ntiles << kPartBits);
+    gb->slot_part = gb->own<uint32_t>((size_t)n);
+    gb->rows_part = gb->own<uint32_t>((size_t)n);
+    uint32_t* chunk_sum = s.get<uint32_t>((size_t)nchunks << kPartBits);
+    uint32_t* h32_part = s.get<uint32_t>((size_t)n);
+    long long* keys_part = s.get<long long>((size_t)n);
+    if (s.failed || !gb->h32 || !gb->part_off || !gb->slot_part || !gb->rows_part) {
+      delete gb;
+      return PDX_OOM;
+    }
+    {
+      PDX_PROFILE("hash32", st);
+      hipLaunchKernelGGL(k_hash32, dim3(grid_for(n, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, n, gb->h32);
+    }
+    int rcp = radix_offsets<kPartBits>(gb->h32, n, 0, gb->part_off, chunk_sum, true, st);
+    if (rcp == PDX_OK)
+      rcp = radix_scatter_only<kPartBits, uint64_t>(gb->h32, reinterpret_cast<const uint64_t*>(keys), h32_part, reinterpret_cast<uint64_t*>(keys_part), n, 0,
+                                                    true, gb->part_off, st);
+    if (rcp == PDX_OK) rcp = radix_scatter_iota<kPartBits>(gb->h32, nullptr, gb->rows_part, n, 0, false, gb->part_off, valid, key->offset, st);
+    if (rcp != PDX_OK) {
+      delete gb;
+      return rcp;
+    }
+    uint64_t want = std::max<uint64_t>(next_pow2((uint64_t)n * 2), 1u << 16);
+    unsigned int cap = (unsigned int)std::min<uint64_t>(want, 1u << 21);
+    for (;;) {
+      table = static_cast<Slot*>(pool_alloc(((size_t)cap + 2) * sizeof(Slot)));
+      if (!table) {
+        delete gb;
+        return PDX_OOM;
+      }
+      region = cap >> kPartBits;
+      hipLaunchKernelGGL(k_table_init, dim3(grid_for((int64_t)cap + 2, 256, 4)), dim3(256), 0, st, table, (int64_t)cap + 2);
+      hipMemsetAsync(ctl, 0, sizeof(HashCtl), st);
+      unsigned int limit = (unsigned int)((uint64_t)cap * 7 / 10);
+      const char* lenv = getenv("PDX_HASH_LDS");
+      if (region <= (unsigned)kLdsRegionMax && !(lenv && lenv[0] == '0')) {
+        PDX_PROFILE("hash_probe_lds", st);
+        // bucket starts = offsets row of tile 0 of the partition pass
+        hipLaunchKernelGGL(k_hash_probe_lds, dim3(1 << kPartBits), dim3(kProbeBlock), 0, st, keys_part, gb->rows_part, h32_part, gb->part_off, n, table, cap,
+                           region, gb->slot_part, ctl);
+      } else {
+        PDX_PROFILE("hash_probe_part", st);
+        hipLaunchKernelGGL((k_hash_probe_part<4>), dim3(grid_for(n, 256, 8)), dim3(256), 0, st, keys_part, gb->rows_part, h32_part, n, table, cap, region,
+                           limit, gb->slot_part, ctl);
+      }
+      HashCtl h;
+      hipError_t e = hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) {
+        pool_free(table);
+        delete gb;
+        return hip_fail(e, "k_hash_probe_part");
+      }
+      if (!h.overflow && h.inserted <= limit) break;  // (the LDS build only flags a completely full region: keep the load factor sane)
+      pool_free(table);
+      if (cap >= want * 4 || cap >= (1u << 30)) {
+        delete gb;
+        return fail(PDX_DEVICE, "pdx_groupby_create: hash table overflow at maximum capacity");
+      }
+      cap = (unsigned int)std::min<uint64_t>((uint64_t)cap * 8, std::max<uint64_t>(want * 4, 1u << 16));
+    }
+    gb->owned.push_back(table);
+    null_slot = cap;
+    nslots = (int64_t)cap + 2;
   } else {
   // table capacity: start at min(2^21, pow2 >= 2n) and grow x8 whenever more than 70 % of the slots fill up
   uint64_t want = next_pow2((uint64_t)n * 2);
@@ -959,7 +1286,8 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     return PDX_OOM;
   }
   int64_t G = 0;
-  int rc = compact_indices(nslots, OccPred{table, dense_first}, OccEmit{table, dense_first, occ_slot_tmp, occ_first_tmp}, &G, s, st);
+  int rc = compact_indices(nslots, OccPred{table, dense_first, region, null_slot}, OccEmit{table, dense_first, region, null_slot, occ_slot_tmp, occ_first_tmp},
+                           &G, s, st);
   if (rc != PDX_OK) {
     delete gb;
     return rc;
@@ -989,7 +1317,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   }
   int g = grid_for(G, 256);
   hipLaunchKernelGGL(k_assign_gids, dim3(g), dim3(256), 0, st, table, dense_min, gb->gid_of_slot, ks, vs, G, null_slot, gb->uniques,
-                     gb->unique_ok, gb->first_rows);
+                     gb->unique_ok, gb->first_rows, region);
   hipLaunchKernelGGL(k_gid_of_occ, dim3(g), dim3(256), 0, st, gb->gid_of_slot, gb->occ_slot, G, gb->gid_of_occ);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1037,7 +1365,10 @@ int pdx_groupby_group_ids(pdx_groupby* gb, uint32_t* out_ids, void* stream) {
   if (!gb || !out_ids) return fail(PDX_INVALID, "pdx_groupby_group_ids: null argument");
   hipStream_t st = as_stream(stream);
   if (gb->n == 0) return PDX_OK;
-  if (gb->mode == 0)
+  if (gb->mode == 0 && gb->slot_part)
+    hipLaunchKernelGGL(k_part_row_gids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->gid_of_slot, gb->slot_part, gb->rows_part, gb->n,
+                       (const int64_t*)nullptr, out_ids, (int64_t*)nullptr);
+  else if (gb->mode == 0)
     hipLaunchKernelGGL(k_row_gids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->gid_of_slot, gb->slot_of_row, gb->n, out_ids);
   else
     hipLaunchKernelGGL(k_seg_row_ids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->seg_start, gb->G, gb->n, out_ids);
@@ -1050,8 +1381,12 @@ int pdx_groupby_map_ids(pdx_groupby* gb, const int64_t* map, int64_t* out, void*
   if (!gb || !map || !out) return fail(PDX_INVALID, "pdx_groupby_map_ids: null argument");
   hipStream_t st = as_stream(stream);
   if (gb->n == 0) return PDX_OK;
-  hipLaunchKernelGGL(k_map_ids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->mode == 0 ? gb->gid_of_slot : nullptr, gb->slot_of_row,
-                     gb->seg_start, gb->G, gb->n, map, out);
+  if (gb->mode == 0 && gb->slot_part)
+    hipLaunchKernelGGL(k_part_row_gids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->gid_of_slot, gb->slot_part, gb->rows_part, gb->n, map,
+                       (uint32_t*)nullptr, out);
+  else
+    hipLaunchKernelGGL(k_map_ids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->mode == 0 ? gb->gid_of_slot : nullptr, gb->slot_of_row,
+                       gb->seg_start, gb->G, gb->n, map, out);
   PDX_LAUNCH_CHECK();
   PDX_HIP(hipStreamSynchronize(st));
   return PDX_OK;
@@ -1098,7 +1433,7 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   const uint32_t* seg_start = nullptr;
   const uint32_t* out_index = nullptr;
   const uint8_t* row_valid = nullptr;  // segments mode reads validity in place
-  if (gb->mode == 0 && !vvalid) {
+  if (gb->mode == 0 && !vvalid && gb->slot_of_row) {
     bool done = false;
     const char* env = getenv("PDX_GROUPBY_BUCKET");  // experimental (slower than the swizzled sort today): opt-in with 1, tests force 2
     if (env && (env[0] == '1' || env[0] == '2')) {
@@ -1114,22 +1449,11 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   }
   if (gb->mode == 0) {
     // stable sort of (slot, value) by slot: each group's values become contiguous in row order
-    const uint32_t* kin = gb->slot_of_row;
-    if (vvalid) {
-      uint32_t* fk = s.get<uint32_t>((size_t)n);
-      PDX_SCRATCH_CHECK(s);
-      hipLaunchKernelGGL(k_flag_keys, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, gb->slot_of_row, vvalid, values->offset, n, fk);
-      kin = fk;
-    }
-    uint32_t* k0 = s.get<uint32_t>((size_t)n);
-    uint32_t* k1 = s.get<uint32_t>((size_t)n);
-    uint64_t* v0 = s.get<uint64_t>((size_t)n);
-    uint64_t* v1 = s.get<uint64_t>((size_t)n);
     uint32_t* ss = s.get<uint32_t>((size_t)G + 1);
     PDX_SCRATCH_CHECK(s);
     const uint64_t* vin = static_cast<const uint64_t*>(values->values) + values->offset;
     const uint64_t* vs = nullptr;
-    PDX_TRY(radix_sort_pairs<uint64_t>(kin, vin, k0, v0, k1, v1, n, gb->slot_bits, &keys_sorted, &vs, true, s, st));
+    PDX_TRY(sort_values_by_slot(gb, vin, vvalid, values->offset, [&](size_t bytes) { return (void*)s.get<uint8_t>(bytes); }, s, st, &keys_sorted, &vs));
     vals_sorted = vs;
     {
       PDX_PROFILE("seg_starts", st);
@@ -1556,17 +1880,13 @@ int pdx_groupby_group_values(pdx_groupby* gb, const pdx_column* values, void* st
   *out = nullptr;
   const int64_t n = gb->n, G = gb->G;
   g->seg_start = g->own<uint32_t>((size_t)G + 1);
-  uint32_t* k0 = g->own<uint32_t>((size_t)n);
-  uint64_t* v0 = g->own<uint64_t>((size_t)n);
-  uint32_t* k1 = g->own<uint32_t>((size_t)n);
-  uint64_t* v1 = g->own<uint64_t>((size_t)n);
-  if (!g->seg_start || !k0 || !v0 || !k1 || !v1) { delete g; return PDX_OOM; }
+  if (!g->seg_start) { delete g; return PDX_OOM; }
   if (n > 0) {
     Scratch s;
     const uint32_t* ks = nullptr;
     const uint64_t* vs = nullptr;
-    int rc = radix_sort_pairs<uint64_t>(gb->slot_of_row, static_cast<const uint64_t*>(values->values) + values->offset, k0, v0, k1, v1, n, gb->slot_bits,
-                                        &ks, &vs, true, s, st);
+    int rc = sort_values_by_slot(gb, static_cast<const uint64_t*>(values->values) + values->offset, nullptr, 0,
+                                 [&](size_t bytes) { return (void*)g->own<uint8_t>(bytes); }, s, st, &ks, &vs);
     if (rc != PDX_OK) { delete g; return rc; }
     g->vals_sorted = reinterpret_cast<const double*>(vs);
     hipLaunchKernelGGL(k_seg_starts, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, ks, n, gb->occ_slot, G, g->seg_start);

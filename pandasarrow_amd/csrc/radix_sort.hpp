@@ -100,11 +100,16 @@ __global__ void __launch_bounds__(256) k_col_apply(uint32_t* __restrict__ hist, 
 }
 
 // ---- scatter
-template <int BITS, typename V, bool WRITE_KEYS>
+// IOTA: the payload is not read from memory: it is the row index (with bit 31 set when the row's validity bit is clear)
+struct IotaSrc {
+  const uint8_t* valid;
+  int64_t off;
+};
+template <int BITS, typename V, bool WRITE_KEYS, bool IOTA = false>
 __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const uint32_t* __restrict__ keys_in, const V* __restrict__ vals_in,
                                                               uint32_t* __restrict__ keys_out, V* __restrict__ vals_out, int64_t n,
                                                               int shift, const uint32_t* __restrict__ offsets /* [tiles][R] */,
-                                                              int xcd_swizzle) {
+                                                              int xcd_swizzle, IotaSrc iota = IotaSrc{nullptr, 0}) {
   constexpr int R = 1 << BITS;
   constexpr int DPT = (R + kSortBlock - 1) / kSortBlock;
   __shared__ uint32_t cnt[kSortWaves][R];   // per-wave digit counters, later per-(wave,digit) local base
@@ -139,7 +144,14 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const uint32_t* __
     int r = wave * (64 * kSortItems) + s * 64 + lane;
     bool active = r < tile_rows;
     key[s] = active ? keys_in[tile_base + r] : 0u;
-    if (active) val[s] = vals_in[tile_base + r];
+    if (active) {
+      if constexpr (IOTA) {
+        int64_t row = tile_base + r;
+        val[s] = (V)row | ((iota.valid && !bit_get(iota.valid, iota.off + row)) ? (V)0x80000000u : (V)0);
+      } else {
+        val[s] = vals_in[tile_base + r];
+      }
+    }
   }
 #pragma unroll
   for (int s = 0; s < kSortItems; ++s) {
@@ -238,29 +250,66 @@ inline SortPlan make_sort_plan(int total_bits, int max_bits_per_pass = 8) {
   return p;
 }
 
-template <int BITS, typename V>
-int radix_pass(const uint32_t* kin, const V* vin, uint32_t* kout, V* vout, int64_t n, int shift, bool write_keys, uint32_t* hist,
-               uint32_t* chunk_sum, hipStream_t st) {
+// per-tile digit histogram + column scan: afterwards hist[tile][digit] = output offset of the tile's first row with that digit
+template <int BITS>
+int radix_offsets(const uint32_t* kin, int64_t n, int shift, uint32_t* hist, uint32_t* chunk_sum, bool big, hipStream_t st) {
   int64_t ntiles = ceil_div(n, kSortTile);
   int64_t nchunks = ceil_div(ntiles, kColChunk);
   {
-    PDX_PROFILE(sizeof(V) == 8 ? "radix_hist" : "radix_hist_small", st);
+    PDX_PROFILE(big ? "radix_hist" : "radix_hist_small", st);
     hipLaunchKernelGGL((k_radix_hist<BITS>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, n, shift, hist);
   }
   {
-    PDX_PROFILE(sizeof(V) == 8 ? "radix_scan" : "radix_scan_small", st);
+    PDX_PROFILE(big ? "radix_scan" : "radix_scan_small", st);
     hipLaunchKernelGGL((k_col_chunk_sums<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum);
     hipLaunchKernelGGL((k_col_chunk_scan<BITS>), dim3(1), dim3(256), 0, st, chunk_sum, nchunks);
     hipLaunchKernelGGL((k_col_apply<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum);
   }
-  PDX_PROFILE(sizeof(V) == 8 ? "radix_scatter" : "radix_scatter_small", st);
-  static const int swz = [] { const char* e = getenv("PDX_SORT_XCD_SWIZZLE"); return (e && e[0] == '0') ? 0 : 1; }();
-  if (write_keys)
-    hipLaunchKernelGGL((k_radix_scatter<BITS, V, true>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, vin, kout, vout, n, shift, hist, swz);
-  else
-    hipLaunchKernelGGL((k_radix_scatter<BITS, V, false>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, vin, kout, vout, n, shift, hist, swz);
   PDX_LAUNCH_CHECK();
   return PDX_OK;
+}
+inline int sort_xcd_swizzle() {
+  static const int swz = [] { const char* e = getenv("PDX_SORT_XCD_SWIZZLE"); return (e && e[0] == '0') ? 0 : 1; }();
+  return swz;
+}
+// stable scatter of one payload column by the digit, using offsets from radix_offsets (reusable for several payloads)
+template <int BITS, typename V>
+int radix_scatter_only(const uint32_t* kin, const V* vin, uint32_t* kout, V* vout, int64_t n, int shift, bool write_keys, const uint32_t* hist,
+                       hipStream_t st) {
+  int64_t ntiles = ceil_div(n, kSortTile);
+  PDX_PROFILE(sizeof(V) == 8 ? "radix_scatter" : "radix_scatter_small", st);
+  const int swz = sort_xcd_swizzle();
+  if (write_keys)
+    hipLaunchKernelGGL((k_radix_scatter<BITS, V, true>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, vin, kout, vout, n, shift, hist, swz,
+                       IotaSrc{nullptr, 0});
+  else
+    hipLaunchKernelGGL((k_radix_scatter<BITS, V, false>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, vin, kout, vout, n, shift, hist, swz,
+                       IotaSrc{nullptr, 0});
+  PDX_LAUNCH_CHECK();
+  return PDX_OK;
+}
+// payload = row index (| null flag): no payload input stream
+template <int BITS>
+int radix_scatter_iota(const uint32_t* kin, uint32_t* kout, uint32_t* rows_out, int64_t n, int shift, bool write_keys, const uint32_t* hist,
+                       const uint8_t* valid, int64_t valid_off, hipStream_t st) {
+  int64_t ntiles = ceil_div(n, kSortTile);
+  PDX_PROFILE("radix_scatter_rows", st);
+  const int swz = sort_xcd_swizzle();
+  if (write_keys)
+    hipLaunchKernelGGL((k_radix_scatter<BITS, uint32_t, true, true>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, (const uint32_t*)nullptr, kout,
+                       rows_out, n, shift, hist, swz, IotaSrc{valid, valid_off});
+  else
+    hipLaunchKernelGGL((k_radix_scatter<BITS, uint32_t, false, true>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, (const uint32_t*)nullptr, kout,
+                       rows_out, n, shift, hist, swz, IotaSrc{valid, valid_off});
+  PDX_LAUNCH_CHECK();
+  return PDX_OK;
+}
+
+template <int BITS, typename V>
+int radix_pass(const uint32_t* kin, const V* vin, uint32_t* kout, V* vout, int64_t n, int shift, bool write_keys, uint32_t* hist,
+               uint32_t* chunk_sum, hipStream_t st) {
+  PDX_TRY((radix_offsets<BITS>(kin, n, shift, hist, chunk_sum, sizeof(V) == 8, st)));
+  return radix_scatter_only<BITS, V>(kin, vin, kout, vout, n, shift, write_keys, hist, st);
 }
 
 template <typename V>
@@ -283,7 +332,8 @@ int radix_pass_dispatch(int bits, const uint32_t* kin, const V* vin, uint32_t* k
 // caller's ping-pong buffers (k0,v0)/(k1,v1).  Inputs are never written.  n must be < 2^32.
 template <typename V>
 int radix_sort_pairs(const uint32_t* keys_in, const V* vals_in, uint32_t* k0, V* v0, uint32_t* k1, V* v1, int64_t n, int total_bits,
-                     const uint32_t** keys_sorted, const V** vals_sorted, bool need_sorted_keys, Scratch& s, hipStream_t st) {
+                     const uint32_t** keys_sorted, const V** vals_sorted, bool need_sorted_keys, Scratch& s, hipStream_t st,
+                     int first_shift = 0) {
   int max_bits = 8;
   if (const char* e = getenv("PDX_SORT_MAX_BITS")) max_bits = atoi(e) >= 4 && atoi(e) <= 11 ? atoi(e) : 8;
   SortPlan plan = make_sort_plan(total_bits, max_bits);
@@ -294,7 +344,7 @@ int radix_sort_pairs(const uint32_t* keys_in, const V* vals_in, uint32_t* k0, V*
   PDX_SCRATCH_CHECK(s);
   const uint32_t* kin = keys_in;
   const V* vin = vals_in;
-  int shift = 0;
+  int shift = first_shift;
   for (int p = 0; p < plan.npasses; ++p) {
     uint32_t* kout = (p & 1) ? k1 : k0;
     V* vout = (p & 1) ? v1 : v0;

@@ -283,8 +283,12 @@ def test_concat(px, kat):
 GB = {"sum": 0, "mean": 1, "min": 2, "max": 3, "count": 4}
 
 
+@pytest.mark.parametrize("hashmode", ["default", "partitioned", "global"])
 @pytest.mark.parametrize("name", [c for c in G.cases("groupby") if "synth" not in c])
-def test_groupby_golden(px, name):
+def test_groupby_golden(px, monkeypatch, name, hashmode):
+    if hashmode != "default":  # force the open-addressing table (no dense-domain shortcut), partitioned (2) or global (0) build
+        monkeypatch.setenv("PDX_GROUPBY_DENSE", "0")
+        monkeypatch.setenv("PDX_HASH_PARTITION", "2" if hashmode == "partitioned" else "0")
     c = G.case(name)
     kvalid = _valid_or_none(c["kvalid"]) if "kvalid" in c else None
     key = px.Column.from_numpy(c["keys"], kvalid, offset=1)
@@ -360,9 +364,12 @@ def test_groupby_kat(px, kat):
             assert list(tot) == k["frame_sum"]
 
 
-@pytest.mark.parametrize("dense", ["1", "0"])
+@pytest.mark.parametrize("dense", ["1", "0", "0-global"])
 @pytest.mark.parametrize("n,nk", [(1, 1), (70_001, 1), (1_000_003, 100_003), (2_500_000, 7), (5_000_000, 1_000_000), (6_000_000, 2_500_000)])
 def test_groupby_sizes_vs_oracle(px, monkeypatch, n, nk, dense):
+    if dense == "0-global":
+        dense = "0"
+        monkeypatch.setenv("PDX_HASH_PARTITION", "0")
     """group sizes from 1 row to millions of rows (multi-chunk counter path); both key->slot paths: the dense-domain fast
     path (slot = key - min) and the open-addressing hash table incl. table growth (nk > 70 % of the initial 2^21 slots)."""
     monkeypatch.setenv("PDX_GROUPBY_DENSE", dense)
@@ -409,8 +416,11 @@ def test_groupby_bucket_path_vs_oracle(px, monkeypatch, n, nk, dtype, dense):
         assert (np.array_equal(got.view(np.uint64), exp.view(np.uint64)) if exp.dtype == np.float64 else np.array_equal(got, exp)), f"single kind={kind}"
 
 
-@pytest.mark.parametrize("dense", ["1", "0"])
+@pytest.mark.parametrize("dense", ["1", "0", "0-global"])
 def test_groupby_dense_with_nulls_and_negative_keys(px, monkeypatch, dense):
+    if dense == "0-global":
+        dense = "0"
+        monkeypatch.setenv("PDX_HASH_PARTITION", "0")
     monkeypatch.setenv("PDX_GROUPBY_DENSE", dense)
     n = 300_001
     keys = orc.synth_keys(0, n, 5000) - 2500
@@ -426,7 +436,9 @@ def test_groupby_dense_with_nulls_and_negative_keys(px, monkeypatch, dense):
     assert_f64_bits(s, orc.groupby_agg(orc.AGG_SUM, ids, len(uniq), vals)[0])
 
 
-def test_groupby_special_keys(px):
+@pytest.mark.parametrize("part", ["2", "0"])
+def test_groupby_special_keys(px, monkeypatch, part):
+    monkeypatch.setenv("PDX_HASH_PARTITION", part)
     keys = np.array([np.iinfo(np.int64).min, 5, np.iinfo(np.int64).min, 0, 5, np.iinfo(np.int64).max, 0], np.int64)
     valid = np.array([1, 1, 1, 0, 1, 1, 1], bool)
     gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys, valid))
