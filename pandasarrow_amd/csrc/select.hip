@@ -26,6 +26,9 @@ struct GatherCols {
 };
 
 // idx[j] < 0  => emit a null row.  idx_valid (bitmap, optional) marks null indices.  Bounds are checked against n_src.
+// A wave owns kGatherU consecutive 64-row output words per iteration and issues the index loads of all of them, then per
+// column the kGatherU gathers, before anything is consumed (memory-level parallelism; the loop is latency bound otherwise).
+constexpr int kGatherU = 4;
 template <typename IDX>
 __global__ void __launch_bounds__(256) k_gather(GatherCols c, const IDX* __restrict__ idx, const uint8_t* __restrict__ idx_valid,
                                                 int64_t idx_off, int64_t m, int64_t n_src, int check_bounds, ErrFlag* err,
@@ -34,36 +37,51 @@ __global__ void __launch_bounds__(256) k_gather(GatherCols c, const IDX* __restr
   int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   int64_t nwords = (m + 63) >> 6;
-  for (int64_t w = wave; w < nwords; w += nwaves) {
-    int64_t j = (w << 6) + lane;
-    bool in = j < m;
-    long long k = -1;
-    if (in) {
-      bool iv = !idx_valid || bit_get(idx_valid, idx_off + j);
-      if (iv) {
-        k = (long long)idx[j];
-        if (check_bounds && (k < 0 || k >= n_src)) {
+  int64_t ngroups = (nwords + kGatherU - 1) / kGatherU;
+  for (int64_t g = wave; g < ngroups; g += nwaves) {
+    long long k[kGatherU];
+    bool in[kGatherU], have[kGatherU];
+#pragma unroll
+    for (int u = 0; u < kGatherU; ++u) {
+      int64_t j = ((g * kGatherU + u) << 6) + lane;
+      in[u] = j < m;
+      have[u] = in[u] && (!idx_valid || bit_get(idx_valid, idx_off + j));
+      k[u] = have[u] ? (long long)idx[j] : -1;
+    }
+    if (check_bounds) {
+#pragma unroll
+      for (int u = 0; u < kGatherU; ++u)
+        if (have[u] && (k[u] < 0 || k[u] >= n_src)) {
           atomicMax(&err->code, 1ull);
-          err->payload = k;
-          k = -1;
+          err->payload = k[u];
+          k[u] = -1;
         }
-      }
     }
     for (int col = 0; col < c.ncols; ++col) {
-      bool ok = k >= 0 && (!c.src_valid[col] || bit_get(c.src_valid[col], c.src_off[col] + k));
-      if (in) c.dst[col][j] = ok ? c.src[col][k] : 0ull;
-      if (c.dst_valid[col]) {
-        uint64_t bal = __ballot(ok);
-        if (lane == 0) {
-          int64_t remain = m - (w << 6);
-          if (remain >= 64) reinterpret_cast<uint64_t*>(c.dst_valid[col])[w] = bal;
-          else {
-            int nbytes = (int)((remain + 7) >> 3);
-            for (int q = 0; q < nbytes; ++q) c.dst_valid[col][(w << 3) + q] = (uint8_t)(bal >> (8 * q));
+      uint64_t v[kGatherU];
+      bool ok[kGatherU];
+#pragma unroll
+      for (int u = 0; u < kGatherU; ++u) {
+        ok[u] = k[u] >= 0 && (!c.src_valid[col] || bit_get(c.src_valid[col], c.src_off[col] + k[u]));
+        v[u] = ok[u] ? c.src[col][k[u]] : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < kGatherU; ++u) {
+        const int64_t w = g * kGatherU + u;
+        if (in[u]) c.dst[col][(w << 6) + lane] = v[u];
+        if (c.dst_valid[col]) {
+          uint64_t bal = __ballot(ok[u]);
+          if (lane == 0 && w < nwords) {
+            int64_t remain = m - (w << 6);
+            if (remain >= 64) reinterpret_cast<uint64_t*>(c.dst_valid[col])[w] = bal;
+            else {
+              int nbytes = (int)((remain + 7) >> 3);
+              for (int q = 0; q < nbytes; ++q) c.dst_valid[col][(w << 3) + q] = (uint8_t)(bal >> (8 * q));
+            }
+            int valid_rows = (int)(remain >= 64 ? 64 : remain);
+            unsigned long long nulls = (unsigned long long)(valid_rows - __popcll(bal));
+            if (nulls) atomicAdd(&null_counts[col], nulls);
           }
-          int valid_rows = (int)(remain >= 64 ? 64 : remain);
-          unsigned long long nulls = (unsigned long long)(valid_rows - __popcll(bal));
-          if (nulls) atomicAdd(&null_counts[col], nulls);
         }
       }
     }
@@ -145,7 +163,8 @@ static int run_gather(GatherCols& g, const IDX* idx, const uint8_t* idx_valid, i
   PDX_HIP(hipMemsetAsync(nulls, 0, sizeof(unsigned long long) * kMaxCols, st));
   if (m > 0) {
     int64_t nwords = (m + 63) >> 6;
-    hipLaunchKernelGGL((k_gather<IDX>), dim3(grid_for(nwords * 64, 256)), dim3(256), 0, st, g, idx, idx_valid, idx_off, m, n_src, check, err, nulls);
+    hipLaunchKernelGGL((k_gather<IDX>), dim3(grid_for(ceil_div(nwords, kGatherU) * 64, 256)), dim3(256), 0, st, g, idx, idx_valid, idx_off, m, n_src, check, err,
+                       nulls);
     PDX_LAUNCH_CHECK();
   }
   ErrFlag h;
