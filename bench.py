@@ -50,19 +50,26 @@ def profile_report(lib):
     return out
 
 
-def cpu_baseline(sample_rows, nkeys):
-    """The oracle's restatement of the reference's Arrow-CPU call sequence, timed on this host ("port")."""
+def cpu_baseline(sample_rows, nkeys, gpu_check=None):
+    """The oracle's restatement of the reference's Arrow-CPU call sequence, timed on this host ("port").  The same sample is
+    also pushed through the HIP path and compared bit-for-bit (the oracle as checker, outside every timed region)."""
+    import numpy as np
     import oracle as orc
 
     threads = max(1, min(16, os.cpu_count() or 1))
     keys = orc.synth_keys(0, sample_rows, nkeys)
     vals = orc.synth_vals(0, sample_rows)
     t0 = time.perf_counter()
-    uk, *_ = orc.groupby_sum_mean_count(keys, vals, nthreads=threads)
+    uk, s, m, c = orc.groupby_sum_mean_count(keys, vals, nthreads=threads)
     dt = time.perf_counter() - t0
-    return {"value": sample_rows / dt / 1e9, "unit": "Grows/s", "cores": threads, "kind": "port",
-            "sample": f"first {sample_rows:.3g} rows of the same synthetic workload ({len(uk)} groups), "
-                      f"oracle/pdx_oracle.c orc_groupby_sum_mean_count, {dt:.1f} s"}
+    out = {"value": sample_rows / dt / 1e9, "unit": "Grows/s", "cores": threads, "kind": "port",
+           "sample": f"first {sample_rows:.3g} rows of the same synthetic workload ({len(uk)} groups), "
+                     f"oracle/pdx_oracle.c orc_groupby_sum_mean_count, {dt:.1f} s"}
+    if gpu_check is not None:
+        gk, gs, gm, gc = gpu_check(sample_rows)
+        out["gpu_matches_oracle_bit_exact"] = bool(np.array_equal(gk, uk) and np.array_equal(gs.view(np.uint64), s.view(np.uint64))
+                                                   and np.array_equal(gm.view(np.uint64), m.view(np.uint64)) and np.array_equal(gc, c))
+    return out
 
 
 def main():
@@ -188,7 +195,14 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(int(min(args.cpu_sample_rows, n_total)), nkeys)
+        def gpu_on_sample(m):
+            gb = K.GroupByHandle.create(keys.slice(0, m))
+            o = gb.agg(vals.slice(0, m), kinds)
+            return (gb.unique_keys().to_numpy()[0], o[0].to_numpy()[0], o[1].to_numpy()[0], o[2].to_numpy()[0])
+
+        cpu = cpu_baseline(int(min(args.cpu_sample_rows, n_total)), nkeys, gpu_on_sample)
+        if cpu.get("gpu_matches_oracle_bit_exact") is False:
+            raise SystemExit("HIP result differs from the oracle on the cpu_baseline sample")
 
     if rank == 0:
         line = {
