@@ -19,6 +19,7 @@
 // Algorithmic bytes: 16 B/row (8 key + 8 value).  Actual traffic is higher (sort passes); see DESIGN.md.
 #include <stdlib.h>
 #include <algorithm>
+#include <memory>
 #include <vector>
 #include "compact.hpp"
 #include "minmax.hpp"
@@ -500,14 +501,12 @@ __device__ __forceinline__ void lds_counter_push(double* csum, uint64_t& mask, i
   if (cur > root) root = cur;
 }
 
-// LEAF = 16: `vals` are raw rows (sequential 16-value leaves are formed here).  LEAF = 1: `vals` are leaf sums produced by
-// k_bucket_accumulate in leaf order; only the merge tree is replayed and `counts` (rows per group) feeds the mean.
-template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM, int LEAF = 16>
+template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM>
 __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restrict__ vals, const uint32_t* __restrict__ seg_start,
-                                                               int64_t nseg, const uint32_t* __restrict__ out_index, SegOut out,
-                                                               const long long* __restrict__ counts = nullptr) {
+                                                               int64_t nseg, const uint32_t* __restrict__ out_index, SegOut out) {
+  constexpr int LEAF = 16;              // Arrow's kBlockSize
   constexpr int kSegChunk = 64 * LEAF;  // values per wave-chunk = 64 leaves
-  __shared__ double stage[kSegWaves][LEAF == 16 ? 64 * 17 : 64];
+  __shared__ double stage[kSegWaves][64 * 17];
   __shared__ double csum_all[kSegWaves][48];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* lds = stage[wave];
@@ -536,7 +535,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
         int idx = q * 64 + lane;
         if (idx < cl) {
           T x = vals[s + c0 + idx];
-          if (WANT_PAIRWISE) lds[LEAF == 16 ? idx + (idx >> 4) : idx] = seg_to_f64(x);
+          if (WANT_PAIRWISE) lds[idx + (idx >> 4)] = seg_to_f64(x);
           if (WANT_MINMAX) {
             if (x == x) ext.add(x, (long long)(c0 + idx));
           }
@@ -549,12 +548,8 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
         double x = 0.0;
         const int first = lane * LEAF;
         if (first < cl) {
-          if constexpr (LEAF == 16) {
-            int cnt = cl - first < 16 ? cl - first : 16;
-            x = leaf_sum(&lds[lane * 17], cnt);
-          } else {
-            x = lds[lane];
-          }
+          int cnt = cl - first < 16 ? cl - first : 16;
+          x = leaf_sum(&lds[lane * 17], cnt);
         }
         // butterfly; pick the perfect subtrees that tile [0, m)
         double node[7];
@@ -604,7 +599,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
     if (lane == 0) {
       if (WANT_PAIRWISE) {
         if (out.sum_f) out.sum_f[oi] = total;
-        if (out.mean) out.mean[oi] = total / (double)(LEAF == 16 ? len : counts[oi]);
+        if (out.mean) out.mean[oi] = total / (double)len;
       }
       if (WANT_ISUM && out.sum_i) out.sum_i[oi] = (long long)isum;
       if (WANT_MINMAX) {
@@ -613,205 +608,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
         if (out.vmin) static_cast<T*>(out.vmin)[oi] = ext.rmin < 0 ? nanv : ext.vmin;
         if (out.vmax) static_cast<T*>(out.vmax)[oi] = ext.rmax < 0 ? nanv : ext.vmax;
       }
-      if (LEAF == 16 && out.count) out.count[oi] = (long long)len;
-    }
-  }
-}
-
-// ---------------------------------------------------------------- bucket accumulate (fast path: dense slot space, no value nulls)
-// After ONE stable MSD partition by the top slot bits every bucket holds <= 2^LB groups and its rows are in row order.
-// One workgroup streams one bucket in 4096-row tiles: a stable in-LDS multisplit by the local group id (same match-any
-// ranking as the radix scatter) makes every group's rows of the tile contiguous in row order; the thread that owns a
-// group then extends that group's running 16-value leaf sequentially (state in registers across tiles) and emits each
-// completed leaf sum as a (slot, leaf) record.  Records of one group are emitted in leaf order, so a stable sort of the
-// records (1/16 of the rows) + the merge tree (k_seg_reduce<LEAF=1>) reproduces Arrow's pairwise sum bit-for-bit while the
-// rows themselves cross HBM once after the partition instead of three sort passes.
-constexpr int kAccBlock = 256;
-constexpr int kAccItems = 16;
-constexpr int kAccTile = kAccBlock * kAccItems;  // 4096 rows
-constexpr int kAccWaves = kAccBlock / 64;
-
-struct AccOut {
-  uint32_t* leaf_slot;                 // leaf records
-  double* leaf_val;
-  unsigned long long* leaf_cursor;     // global append cursor
-  const uint32_t* gid_of_slot;
-  long long* count;                    // by gid (always written)
-  long long* sum_i;                    // by gid or nullptr
-  void* vmin;                          // T* by gid or nullptr
-  void* vmax;
-};
-
-template <typename T, int LB, bool WANT_PW, bool WANT_MM, bool WANT_IS>
-__global__ void __launch_bounds__(kAccBlock) k_bucket_accumulate(const uint32_t* __restrict__ keys, const T* __restrict__ vals,
-                                                                 const uint32_t* __restrict__ bucket_off /* [tile0 offsets row: R entries] */,
-                                                                 int nbuckets, int64_t n, AccOut out) {
-  constexpr int NG = 1 << LB;            // local groups per bucket
-  constexpr int GPT = NG / kAccBlock;    // groups owned by one thread: g = j * 256 + tid
-  static_assert(GPT >= 1, "bucket must hold at least 256 groups");
-  __shared__ unsigned short cnt[kAccWaves][NG];  // per-wave multisplit counters -> per-(wave, group) base
-  __shared__ double svals[kAccTile];
-  __shared__ uint32_t scan_smem[8];
-  __shared__ unsigned long long tile_base_pos;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x;
-  const int64_t bstart = bucket_off[b];
-  const int64_t bend = (b + 1 < nbuckets) ? (int64_t)bucket_off[b + 1] : n;
-  const uint64_t lt_mask = (1ull << lane) - 1ull;
-
-  double acc[GPT];       // running leaf sum of each owned group
-  uint32_t gcnt[GPT];    // rows seen so far
-  unsigned long long isum[GPT];
-  T vmn[GPT], vmx[GPT];
-  bool has[GPT];
-#pragma unroll
-  for (int j = 0; j < GPT; ++j) {
-    acc[j] = 0.0;
-    gcnt[j] = 0;
-    isum[j] = 0;
-    vmn[j] = vmx[j] = T(0);
-    has[j] = false;
-  }
-
-  for (int64_t tb = bstart; tb < bend; tb += kAccTile) {
-    const int tile_rows = (int)((bend - tb) < kAccTile ? (bend - tb) : kAccTile);
-    for (int d = tid; d < kAccWaves * NG / 2; d += kAccBlock) reinterpret_cast<uint32_t*>(&cnt[0][0])[d] = 0;
-    uint32_t key[kAccItems];
-    T val[kAccItems];
-    uint32_t rank[kAccItems];
-#pragma unroll
-    for (int s = 0; s < kAccItems; ++s) {
-      int r = wave * (64 * kAccItems) + s * 64 + lane;
-      bool active = r < tile_rows;
-      key[s] = active ? (keys[tb + r] & (NG - 1)) : 0u;
-      if (active) val[s] = vals[tb + r];
-    }
-    __syncthreads();
-    // stable rank of every row among the rows of its group (wave-step order == row order)
-#pragma unroll
-    for (int s = 0; s < kAccItems; ++s) {
-      int r = wave * (64 * kAccItems) + s * 64 + lane;
-      bool active = r < tile_rows;
-      uint32_t d = key[s];
-      uint64_t peers = __ballot(active);
-#pragma unroll
-      for (int bit = 0; bit < LB; ++bit) {
-        bool bb = (d >> bit) & 1;
-        uint64_t m = __ballot(bb);
-        peers &= bb ? m : ~m;
-      }
-      int leader = active ? (__ffsll((unsigned long long)peers) - 1) : lane;
-      uint32_t base = 0;
-      if (active && lane == leader) {
-        base = cnt[wave][d];
-        cnt[wave][d] = (unsigned short)(base + (uint32_t)__popcll(peers));
-      }
-      base = __shfl(base, leader, 64);
-      rank[s] = base + (uint32_t)__popcll(peers & lt_mask);
-    }
-    __syncthreads();
-    // rows of this tile per owned group, placement (thread-major order) and per-(wave, group) bases
-    uint32_t c[GPT], gstart[GPT];
-    uint32_t tot = 0, newleaves = 0;
-#pragma unroll
-    for (int j = 0; j < GPT; ++j) {
-      int g = j * kAccBlock + tid;
-      uint32_t a = 0;
-#pragma unroll
-      for (int w = 0; w < kAccWaves; ++w) a += cnt[w][g];
-      c[j] = a;
-      tot += a;
-      newleaves += ((gcnt[j] + a) >> 4) - (gcnt[j] >> 4);
-    }
-    uint32_t total;
-    uint32_t pre = block_exclusive_scan(tot, SumOp(), &total, scan_smem);
-#pragma unroll
-    for (int j = 0; j < GPT; ++j) {
-      int g = j * kAccBlock + tid;
-      gstart[j] = pre;
-      uint32_t run = pre;
-#pragma unroll
-      for (int w = 0; w < kAccWaves; ++w) {
-        uint32_t x = cnt[w][g];
-        cnt[w][g] = (unsigned short)run;
-        run += x;
-      }
-      pre += c[j];
-    }
-    // reserve room for the leaves this tile completes: one global atomic per tile keeps a group's records in leaf order
-    uint32_t leaf_total;
-    uint32_t leaf_pre = block_exclusive_scan(newleaves, SumOp(), &leaf_total, scan_smem);
-    if (WANT_PW && tid == 0) tile_base_pos = leaf_total ? atomicAdd(out.leaf_cursor, (unsigned long long)leaf_total) : 0ull;
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < kAccItems; ++s) {
-      int r = wave * (64 * kAccItems) + s * 64 + lane;
-      if (r < tile_rows) {
-        uint32_t p = (uint32_t)cnt[wave][key[s]] + rank[s];
-        if constexpr (__is_same(T, double)) svals[p] = val[s];
-        else reinterpret_cast<long long*>(svals)[p] = (long long)val[s];
-      }
-    }
-    __syncthreads();
-    unsigned long long pos = WANT_PW ? tile_base_pos + leaf_pre : 0ull;
-#pragma unroll
-    for (int j = 0; j < GPT; ++j) {
-      const uint32_t slot = ((uint32_t)b << LB) | (uint32_t)(j * kAccBlock + tid);
-      for (uint32_t q = 0; q < c[j]; ++q) {
-        T x;
-        if constexpr (__is_same(T, double)) x = svals[gstart[j] + q];
-        else x = (T) reinterpret_cast<const long long*>(svals)[gstart[j] + q];
-        if (WANT_PW) {
-          acc[j] += (double)x;  // first add of a leaf is 0.0 + x, like Arrow's block_sum = 0
-          if (((gcnt[j] + q + 1) & 15) == 0) {
-            out.leaf_slot[pos] = slot;
-            out.leaf_val[pos] = acc[j];
-            ++pos;
-            acc[j] = 0.0;
-          }
-        }
-        if (WANT_IS) isum[j] += (unsigned long long)x;
-        if (WANT_MM) {
-          if (x == x) {
-            if (!has[j]) { vmn[j] = vmx[j] = x; has[j] = true; }
-            else {
-              if (x < vmn[j]) vmn[j] = x;  // strict: the first of tied values wins
-              if (x > vmx[j]) vmx[j] = x;
-            }
-          }
-        }
-      }
-      gcnt[j] += c[j];
-    }
-    __syncthreads();
-  }
-  // flush: partial last leaves and the order-insensitive aggregates
-  uint32_t nflush = 0;
-#pragma unroll
-  for (int j = 0; j < GPT; ++j) nflush += (gcnt[j] & 15) ? 1u : 0u;
-  uint32_t ftotal;
-  uint32_t fpre = block_exclusive_scan(nflush, SumOp(), &ftotal, scan_smem);
-  if (WANT_PW && tid == 0) tile_base_pos = ftotal ? atomicAdd(out.leaf_cursor, (unsigned long long)ftotal) : 0ull;
-  __syncthreads();
-  unsigned long long pos = WANT_PW ? tile_base_pos + fpre : 0ull;
-#pragma unroll
-  for (int j = 0; j < GPT; ++j) {
-    if (gcnt[j] == 0) continue;
-    const uint32_t slot = ((uint32_t)b << LB) | (uint32_t)(j * kAccBlock + tid);
-    if (WANT_PW && (gcnt[j] & 15)) {
-      out.leaf_slot[pos] = slot;
-      out.leaf_val[pos] = acc[j];
-      ++pos;
-    }
-    const uint32_t gid = out.gid_of_slot[slot];
-    out.count[gid] = (long long)gcnt[j];
-    if (WANT_IS && out.sum_i) out.sum_i[gid] = (long long)isum[j];
-    if (WANT_MM) {
-      T nanv = T(0);
-      if constexpr (__is_same(T, double)) nanv = __builtin_nan("");
-      if (out.vmin) static_cast<T*>(out.vmin)[gid] = has[j] ? vmn[j] : nanv;
-      if (out.vmax) static_cast<T*>(out.vmax)[gid] = has[j] ? vmx[j] : nanv;
+      if (out.count) out.count[oi] = (long long)len;
     }
   }
 }
@@ -1070,12 +867,6 @@ static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int
   return PDX_OK;
 }
 
-// Fast path of pdx_groupby_agg (hash / dense mode, values without nulls): ONE MSD partition pass + bucket accumulate.
-// Returns PDX_OK with *done = false when the shape does not qualify (caller continues with the full sort).
-template <typename T>
-static int agg_bucket_path(pdx_groupby* gb, const T* vals, SegOut o, bool want_pw, bool want_mm, bool want_is, Scratch& s, hipStream_t st,
-                           bool* done);
-
 }  // namespace pdx
 
 extern "C" {
@@ -1087,22 +878,20 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   const int64_t n = key->length;
   if (n > 0x7FFFFFFFll) return fail(PDX_NOT_IMPLEMENTED, "pdx_groupby_create: more than 2^31-1 rows per call is not supported yet");
   hipStream_t st = as_stream(stream);
-  pdx_groupby* gb = new pdx_groupby();
+  std::unique_ptr<pdx_groupby> owner(new pdx_groupby());  // released into *out on success
+  pdx_groupby* gb = owner.get();
   gb->n = n;
   gb->key_dtype = key->dtype;
   *out = nullptr;
   if (n == 0) {
-    *out = gb;
+    *out = owner.release();
     return PDX_OK;
   }
   Scratch s;
   const long long* keys = static_cast<const long long*>(key->values) + key->offset;
   const uint8_t* valid = validity_or_null(key);
   HashCtl* ctl = s.get<HashCtl>(1);
-  if (s.failed) {
-    delete gb;
-    return PDX_OOM;
-  }
+  if (s.failed) return PDX_OOM;
   // ---- dense-domain fast path: valid keys span a small integer range -> slot = key - min, no table
   Slot* table = nullptr;
   unsigned int* dense_first = nullptr;
@@ -1112,10 +901,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   {
     MinMaxPartial<long long> mm;
     int rc0 = minmax_keys_host(keys, valid, key->offset, n, &mm, s, st);
-    if (rc0 != PDX_OK) {
-      delete gb;
-      return rc0;
-    }
+    if (rc0 != PDX_OK) return rc0;
     const char* env = getenv("PDX_GROUPBY_DENSE");
     bool allow = !(env && env[0] == '0');
     if (allow && mm.rmin >= 0) {
@@ -1138,17 +924,11 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   const bool use_partition = !gb->dense && !(penv && penv[0] == '0') && (n >= ((int64_t)1 << 18) || (penv && penv[0] == '2'));
   if (!use_partition) {
     gb->slot_of_row = gb->own<uint32_t>((size_t)n);
-    if (!gb->slot_of_row) {
-      delete gb;
-      return PDX_OOM;
-    }
+    if (!gb->slot_of_row) return PDX_OOM;
   }
   if (gb->dense) {
     dense_first = s.get<unsigned int>((size_t)nslots);
-    if (s.failed) {
-      delete gb;
-      return PDX_OOM;
-    }
+    if (s.failed) return PDX_OOM;
     hipMemsetAsync(dense_first, 0xFF, (size_t)nslots * sizeof(unsigned int), st);
     {
       PDX_PROFILE("dense_slots", st);
@@ -1158,10 +938,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
                          dense_first, gb->slot_of_row);
       if (prefix < n) {
         uint32_t* seen = s.get<uint32_t>((size_t)((nslots + 31) >> 5));
-        if (s.failed) {
-          delete gb;
-          return PDX_OOM;
-        }
+        if (s.failed) return PDX_OOM;
         hipLaunchKernelGGL(k_seen_bitmap, dim3(grid_for((nslots + 31) >> 5, 256)), dim3(256), 0, st, dense_first, nslots, seen);
         hipLaunchKernelGGL(k_dense_slots_tail, dim3(grid_for(n - prefix, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, prefix, n, dense_min,
                            null_slot, seen, dense_first, gb->slot_of_row);
@@ -1177,10 +954,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     uint32_t* chunk_sum = s.get<uint32_t>((size_t)nchunks << kPartBits);
     uint32_t* h32_part = s.get<uint32_t>((size_t)n);
     long long* keys_part = s.get<long long>((size_t)n);
-    if (s.failed || !gb->h32 || !gb->part_off || !gb->slot_part || !gb->rows_part) {
-      delete gb;
-      return PDX_OOM;
-    }
+    if (s.failed || !gb->h32 || !gb->part_off || !gb->slot_part || !gb->rows_part) return PDX_OOM;
     {
       PDX_PROFILE("hash32", st);
       hipLaunchKernelGGL(k_hash32, dim3(grid_for(n, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, n, gb->h32);
@@ -1190,18 +964,12 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
       rcp = radix_scatter_only<kPartBits, uint64_t>(gb->h32, reinterpret_cast<const uint64_t*>(keys), h32_part, reinterpret_cast<uint64_t*>(keys_part), n, 0,
                                                     true, gb->part_off, st);
     if (rcp == PDX_OK) rcp = radix_scatter_iota<kPartBits>(gb->h32, nullptr, gb->rows_part, n, 0, false, gb->part_off, valid, key->offset, st);
-    if (rcp != PDX_OK) {
-      delete gb;
-      return rcp;
-    }
+    if (rcp != PDX_OK) return rcp;
     uint64_t want = std::max<uint64_t>(next_pow2((uint64_t)n * 2), 1u << 16);
     unsigned int cap = (unsigned int)std::min<uint64_t>(want, 1u << 21);
     for (;;) {
       table = static_cast<Slot*>(pool_alloc(((size_t)cap + 2) * sizeof(Slot)));
-      if (!table) {
-        delete gb;
-        return PDX_OOM;
-      }
+      if (!table) return PDX_OOM;
       region = cap >> kPartBits;
       hipLaunchKernelGGL(k_table_init, dim3(grid_for((int64_t)cap + 2, 256, 4)), dim3(256), 0, st, table, (int64_t)cap + 2);
       hipMemsetAsync(ctl, 0, sizeof(HashCtl), st);
@@ -1222,15 +990,11 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
       if (e == hipSuccess) e = hipStreamSynchronize(st);
       if (e != hipSuccess) {
         pool_free(table);
-        delete gb;
         return hip_fail(e, "k_hash_probe_part");
       }
       if (!h.overflow && h.inserted <= limit) break;  // (the LDS build only flags a completely full region: keep the load factor sane)
       pool_free(table);
-      if (cap >= want * 4 || cap >= (1u << 30)) {
-        delete gb;
-        return fail(PDX_DEVICE, "pdx_groupby_create: hash table overflow at maximum capacity");
-      }
+      if (cap >= want * 4 || cap >= (1u << 30)) return fail(PDX_DEVICE, "pdx_groupby_create: hash table overflow at maximum capacity");
       cap = (unsigned int)std::min<uint64_t>((uint64_t)cap * 8, std::max<uint64_t>(want * 4, 1u << 16));
     }
     gb->owned.push_back(table);
@@ -1242,10 +1006,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   unsigned int cap = (unsigned int)std::min<uint64_t>(want, 1u << 21);
   for (;;) {
     table = static_cast<Slot*>(pool_alloc(((size_t)cap + 2) * sizeof(Slot)));
-    if (!table) {
-      delete gb;
-      return PDX_OOM;
-    }
+    if (!table) return PDX_OOM;
     hipLaunchKernelGGL(k_table_init, dim3(grid_for((int64_t)cap + 2, 256, 4)), dim3(256), 0, st, table, (int64_t)cap + 2);
     hipMemsetAsync(ctl, 0, sizeof(HashCtl), st);
     unsigned int limit = (unsigned int)((uint64_t)cap * 7 / 10);
@@ -1259,16 +1020,12 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     hipError_t e = hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
-      pool_free(table);
-      delete gb;
-      return hip_fail(e, "k_hash_insert");
-    }
+        pool_free(table);
+        return hip_fail(e, "k_hash_insert");
+      }
     if (!h.overflow) break;
     pool_free(table);
-    if (cap >= want) {
-      delete gb;
-      return fail(PDX_DEVICE, "pdx_groupby_create: hash table overflow at maximum capacity");
-    }
+    if (cap >= want) return fail(PDX_DEVICE, "pdx_groupby_create: hash table overflow at maximum capacity");
     cap = (unsigned int)std::min<uint64_t>((uint64_t)cap * 8, want);
   }
   gb->owned.push_back(table);
@@ -1281,17 +1038,11 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   // occupied slots in slot order
   uint32_t* occ_slot_tmp = s.get<uint32_t>((size_t)std::min<int64_t>(nslots, n + 2));
   uint32_t* occ_first_tmp = s.get<uint32_t>((size_t)std::min<int64_t>(nslots, n + 2));
-  if (s.failed || !gb->gid_of_slot) {
-    delete gb;
-    return PDX_OOM;
-  }
+  if (s.failed || !gb->gid_of_slot) return PDX_OOM;
   int64_t G = 0;
   int rc = compact_indices(nslots, OccPred{table, dense_first, region, null_slot}, OccEmit{table, dense_first, region, null_slot, occ_slot_tmp, occ_first_tmp},
                            &G, s, st);
-  if (rc != PDX_OK) {
-    delete gb;
-    return rc;
-  }
+  if (rc != PDX_OK) return rc;
   gb->G = G;
   gb->occ_slot = gb->own<uint32_t>((size_t)G);
   gb->gid_of_occ = gb->own<uint32_t>((size_t)G);
@@ -1302,30 +1053,21 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   uint32_t* v0 = s.get<uint32_t>((size_t)G);
   uint32_t* k1 = s.get<uint32_t>((size_t)G);
   uint32_t* v1 = s.get<uint32_t>((size_t)G);
-  if (s.failed || !gb->occ_slot || !gb->gid_of_occ || !gb->uniques || !gb->unique_ok || !gb->first_rows) {
-    delete gb;
-    return PDX_OOM;
-  }
+  if (s.failed || !gb->occ_slot || !gb->gid_of_occ || !gb->uniques || !gb->unique_ok || !gb->first_rows) return PDX_OOM;
   hipMemcpyAsync(gb->occ_slot, occ_slot_tmp, (size_t)G * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
   // order groups by first occurrence: sort (first_row -> slot); first rows are distinct so any order of ties is moot
   const uint32_t *ks = nullptr, *vs = nullptr;
   rc = radix_sort_pairs<uint32_t>(occ_first_tmp, occ_slot_tmp, k0, v0, k1, v1, G, ilog2((uint64_t)n + 1) < 31 ? ilog2((uint64_t)n + 1) : 31,
                                   &ks, &vs, true, s, st);
-  if (rc != PDX_OK) {
-    delete gb;
-    return rc;
-  }
+  if (rc != PDX_OK) return rc;
   int g = grid_for(G, 256);
   hipLaunchKernelGGL(k_assign_gids, dim3(g), dim3(256), 0, st, table, dense_min, gb->gid_of_slot, ks, vs, G, null_slot, gb->uniques,
                      gb->unique_ok, gb->first_rows, region);
   hipLaunchKernelGGL(k_gid_of_occ, dim3(g), dim3(256), 0, st, gb->gid_of_slot, gb->occ_slot, G, gb->gid_of_occ);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  if (e != hipSuccess) {
-    delete gb;
-    return hip_fail(e, "pdx_groupby_create");
-  }
-  *out = gb;
+  if (e != hipSuccess) return hip_fail(e, "pdx_groupby_create");
+  *out = owner.release();
   return PDX_OK;
 }
 
@@ -1433,20 +1175,6 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   const uint32_t* seg_start = nullptr;
   const uint32_t* out_index = nullptr;
   const uint8_t* row_valid = nullptr;  // segments mode reads validity in place
-  if (gb->mode == 0 && !vvalid && gb->slot_of_row) {
-    bool done = false;
-    const char* env = getenv("PDX_GROUPBY_BUCKET");  // experimental (slower than the swizzled sort today): opt-in with 1, tests force 2
-    if (env && (env[0] == '1' || env[0] == '2')) {
-      if (is_f) PDX_TRY(agg_bucket_path<double>(gb, static_cast<const double*>(values->values) + values->offset, o, want_pw, want_mm, want_is, s, st, &done));
-      else PDX_TRY(agg_bucket_path<long long>(gb, static_cast<const long long*>(values->values) + values->offset, o, want_pw, want_mm, want_is, s, st, &done));
-    }
-    if (done) {
-      for (int k = 0; k < nk; ++k)
-        if (outs[k].validity) PDX_HIP(hipMemsetAsync(outs[k].validity, 0xFF, (size_t)((G + 7) / 8), st));
-      PDX_HIP(hipStreamSynchronize(st));
-      return PDX_OK;
-    }
-  }
   if (gb->mode == 0) {
     // stable sort of (slot, value) by slot: each group's values become contiguous in row order
     uint32_t* ss = s.get<uint32_t>((size_t)G + 1);
@@ -1506,19 +1234,20 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
   const int64_t n = ts->length;
   if (n > 0x7FFFFFFFll) return fail(PDX_NOT_IMPLEMENTED, "pdx_resample_create: more than 2^31-1 rows per call is not supported yet");
   hipStream_t st = as_stream(stream);
-  pdx_groupby* gb = new pdx_groupby();
+  std::unique_ptr<pdx_groupby> owner(new pdx_groupby());  // released into *out on success
+  pdx_groupby* gb = owner.get();
   gb->mode = 1;
   gb->n = n;
   gb->key_dtype = PDX_TIMESTAMP_NS;
   *out = nullptr;
   if (n == 0) {
-    *out = gb;
+    *out = owner.release();
     return PDX_OK;
   }
   Scratch s;
   const long long* t = static_cast<const long long*>(ts->values) + ts->offset;
   unsigned int* bad = s.get<unsigned int>(1);
-  if (s.failed) { delete gb; return PDX_OOM; }
+  if (s.failed) return PDX_OOM;
   hipMemsetAsync(bad, 0, sizeof(unsigned int), st);
   {
     PDX_PROFILE("resample_check_sorted", st);
@@ -1535,8 +1264,8 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) rc = hip_fail(e, "pdx_resample_create");
   }
-  if (rc != PDX_OK) { delete gb; return rc; }
-  if (hbad) { delete gb; return fail(PDX_INVALID, "pdx_resample_create: timestamps must be sorted ascending"); }
+  if (rc != PDX_OK) return rc;
+  if (hbad) return fail(PDX_INVALID, "pdx_resample_create: timestamps must be sorted ascending");
   // adjustDatesAnchored (src/resample.cpp:85-178), tz == ""
   auto floor_div = [](long long a, long long b) { long long q = a / b, r = a % b; return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q; };
   const long long day = 86400000000000LL;
@@ -1558,13 +1287,13 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
     if (foffset > 0) first -= foffset;
     if (loffset > 0) last += freq_ns - loffset; else last += freq_ns;
   }
-  if (first >= last) { delete gb; return fail(PDX_INVALID, "start date has to be less than end date"); }
+  if (first >= last) return fail(PDX_INVALID, "start date has to be less than end date");
   long long nedges = (last - first) / freq_ns + 1;  // date_range: first + k*freq <= last (src/core.cpp:308-331)
   long long last_edge = first + (nedges - 1) * freq_ns;
-  if (mn < first) { delete gb; return fail(PDX_INVALID, "Values falls before first bin"); }
-  if (mx > last_edge) { delete gb; return fail(PDX_INVALID, "Values falls after last bin"); }
+  if (mn < first) return fail(PDX_INVALID, "Values falls before first bin");
+  if (mx > last_edge) return fail(PDX_INVALID, "Values falls after last bin");
   long long nbins = nedges - 1;
-  if (n < nbins) { delete gb; return fail(PDX_INVALID, "upSampling is not implemented."); }  // GroupInfo::upsampling, src/resample.h:14-17
+  if (n < nbins) return fail(PDX_INVALID, "upSampling is not implemented.");  // GroupInfo::upsampling, src/resample.h:14-17
   gb->bin = BinParams{t, first, freq_ns, 1.0 / (double)freq_ns, closed_right};
   gb->label_base = first + (label_right ? freq_ns : 0);
   // non-empty bins: boundaries where the bin index changes (timestamps are sorted)
@@ -1573,14 +1302,14 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
   gb->uniques = gb->own<int64_t>((size_t)maxg);
   gb->first_rows = gb->own<int64_t>((size_t)maxg);
   gb->unique_ok = gb->own<uint8_t>((size_t)maxg);
-  if (!gb->seg_start || !gb->uniques || !gb->first_rows || !gb->unique_ok) { delete gb; return PDX_OOM; }
+  if (!gb->seg_start || !gb->uniques || !gb->first_rows || !gb->unique_ok) return PDX_OOM;
   int64_t G = 0;
   {
     PDX_PROFILE("resample_bins", st);
     if (nbins * 16 <= n) {
       // many rows per bin: binary-search every edge (nbins * log n reads) instead of evaluating the bin of every row
       uint32_t* lb = s.get<uint32_t>((size_t)nbins + 1);
-      if (s.failed) { delete gb; return PDX_OOM; }
+      if (s.failed) return PDX_OOM;
       hipLaunchKernelGGL(k_bin_lower_bounds, dim3(grid_for(nbins + 1, 256)), dim3(256), 0, st, gb->bin, n, (int64_t)nbins, lb);
       rc = compact_indices((int64_t)nbins, NonEmptyBinPred{lb}, NonEmptyBinEmit{lb, gb->label_base, freq_ns, gb->seg_start, gb->uniques, gb->first_rows},
                            &G, s, st);
@@ -1588,14 +1317,14 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
       rc = compact_indices(n, BinStartPred{gb->bin}, BinStartEmit{gb->bin, gb->label_base, gb->seg_start, gb->uniques, gb->first_rows}, &G, s, st);
     }
   }
-  if (rc != PDX_OK) { delete gb; return rc; }
+  if (rc != PDX_OK) return rc;
   gb->G = G;
   hipLaunchKernelGGL(k_set_last, dim3(1), dim3(64), 0, st, gb->seg_start, G, (uint32_t)n);
   hipMemsetAsync(gb->unique_ok, 1, (size_t)G, st);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  if (e != hipSuccess) { delete gb; return hip_fail(e, "pdx_resample_create"); }
-  *out = gb;
+  if (e != hipSuccess) return hip_fail(e, "pdx_resample_create");
+  *out = owner.release();
   return PDX_OK;
 }
 
@@ -1610,110 +1339,6 @@ int pdx_resample_row_labels(pdx_groupby* gb, int64_t* out_labels, void* stream) 
 }
 
 }  // extern "C"
-
-namespace pdx {
-
-template <typename T, int LB>
-static void launch_bucket_accumulate(const uint32_t* keys, const T* vals, const uint32_t* bucket_off, int nbuckets, int64_t n, const AccOut& ao,
-                                     bool want_pw, bool want_mm, bool want_is, hipStream_t st) {
-  dim3 g(nbuckets), b(kAccBlock);
-#define ACC_LAUNCH(PW, MM, IS) hipLaunchKernelGGL((k_bucket_accumulate<T, LB, PW, MM, IS>), g, b, 0, st, keys, vals, bucket_off, nbuckets, n, ao)
-  if (want_pw && !want_mm && !want_is) ACC_LAUNCH(true, false, false);
-  else if (!want_pw && want_mm && !want_is) ACC_LAUNCH(false, true, false);
-  else if (!want_pw && !want_mm && want_is) ACC_LAUNCH(false, false, true);
-  else if (!want_pw && !want_mm && !want_is) ACC_LAUNCH(false, false, false);
-  else ACC_LAUNCH(true, true, true);
-#undef ACC_LAUNCH
-}
-
-template <typename T>
-static int agg_bucket_path(pdx_groupby* gb, const T* vals, SegOut o, bool want_pw, bool want_mm, bool want_is, Scratch& s, hipStream_t st,
-                           bool* done) {
-  *done = false;
-  const int64_t n = gb->n, G = gb->G;
-  int LB, bits1;
-  if (gb->slot_bits >= 20 && gb->slot_bits <= 22) { LB = 12; bits1 = gb->slot_bits - 12; }
-  else if (gb->slot_bits >= 16 && gb->slot_bits < 20) { LB = 8; bits1 = gb->slot_bits - 8; }
-  else return PDX_OK;
-  const char* env = getenv("PDX_GROUPBY_BUCKET");
-  const bool forced = env && env[0] == '2';  // tests: take this path at any size
-  if (!forced && n < (int64_t)1 << 22) return PDX_OK;  // small inputs: the plain sort is already launch-latency bound
-  const int nbuckets = 1 << bits1;
-  // ---- one stable MSD partition pass by the top `bits1` slot bits
-  const int64_t ntiles = ceil_div(n, kSortTile), nchunks = ceil_div(ntiles, kColChunk);
-  uint32_t* hist = s.get<uint32_t>((size_t)ntiles * nbuckets);
-  uint32_t* chunk_sum = s.get<uint32_t>((size_t)nchunks * nbuckets);
-  uint32_t* k0 = s.get<uint32_t>((size_t)n);
-  uint64_t* v0 = s.get<uint64_t>((size_t)n);
-  PDX_SCRATCH_CHECK(s);
-  PDX_TRY(radix_pass_dispatch<uint64_t>(bits1, gb->slot_of_row, reinterpret_cast<const uint64_t*>(vals), k0, v0, n, LB, true, hist, chunk_sum, st));
-  // bucket starts = the offsets row of tile 0; balance check on the host (one WG streams one bucket)
-  std::vector<uint32_t> hoff((size_t)nbuckets);
-  PDX_HIP(hipMemcpyAsync(hoff.data(), hist, sizeof(uint32_t) * (size_t)nbuckets, hipMemcpyDeviceToHost, st));
-  PDX_HIP(hipStreamSynchronize(st));
-  int64_t max_rows = 0;
-  for (int b = 0; b < nbuckets; ++b) {
-    int64_t e = b + 1 < nbuckets ? (int64_t)hoff[(size_t)b + 1] : n;
-    max_rows = std::max<int64_t>(max_rows, e - (int64_t)hoff[(size_t)b]);
-  }
-  if (!forced && max_rows > 8 * (n / nbuckets) + (1 << 16)) return PDX_OK;  // skewed key space: a few buckets would serialise the pass
-  // ---- bucket accumulate
-  const int64_t leaf_cap = n / 16 + G + 64;
-  AccOut ao{};
-  ao.leaf_slot = s.get<uint32_t>((size_t)(want_pw ? leaf_cap : 1));
-  ao.leaf_val = s.get<double>((size_t)(want_pw ? leaf_cap : 1));
-  ao.leaf_cursor = s.get<unsigned long long>(1);
-  long long* counts = o.count ? o.count : s.get<long long>((size_t)G);
-  PDX_SCRATCH_CHECK(s);
-  ao.gid_of_slot = gb->gid_of_slot;
-  ao.count = counts;
-  ao.sum_i = o.sum_i;
-  ao.vmin = o.vmin;
-  ao.vmax = o.vmax;
-  PDX_HIP(hipMemsetAsync(ao.leaf_cursor, 0, sizeof(unsigned long long), st));
-  {
-    PDX_PROFILE("bucket_accumulate", st);
-    const T* pv = reinterpret_cast<const T*>(v0);
-    if (LB == 12) launch_bucket_accumulate<T, 12>(k0, pv, hist, nbuckets, n, ao, want_pw, want_mm, want_is, st);
-    else launch_bucket_accumulate<T, 8>(k0, pv, hist, nbuckets, n, ao, want_pw, want_mm, want_is, st);
-  }
-  PDX_LAUNCH_CHECK();
-  if (want_pw) {
-    unsigned long long L = 0;
-    PDX_HIP(hipMemcpyAsync(&L, ao.leaf_cursor, sizeof(L), hipMemcpyDeviceToHost, st));
-    PDX_HIP(hipStreamSynchronize(st));
-    if ((int64_t)L > leaf_cap) return fail(PDX_DEVICE, "bucket accumulate: leaf buffer overflow");
-    // ---- merge tree over the leaf records: stable sort by slot (1/16 of the rows), then the counter replay
-    uint32_t* lk0 = s.get<uint32_t>((size_t)L);
-    uint32_t* lk1 = s.get<uint32_t>((size_t)L);
-    uint64_t* lv0 = s.get<uint64_t>((size_t)L);
-    uint64_t* lv1 = s.get<uint64_t>((size_t)L);
-    uint32_t* ss = s.get<uint32_t>((size_t)G + 1);
-    PDX_SCRATCH_CHECK(s);
-    const uint32_t* ks = nullptr;
-    const uint64_t* vs = nullptr;
-    {
-      PDX_PROFILE("leaf_sort", st);
-      PDX_TRY(radix_sort_pairs<uint64_t>(ao.leaf_slot, reinterpret_cast<const uint64_t*>(ao.leaf_val), lk0, lv0, lk1, lv1, (int64_t)L, gb->slot_bits,
-                                         &ks, &vs, true, s, st));
-      hipLaunchKernelGGL(k_seg_starts, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, ks, (int64_t)L, gb->occ_slot, G, ss);
-    }
-    {
-      PDX_PROFILE("leaf_tree", st);
-      int grid = (int)std::min<int64_t>(ceil_div(G, kSegWaves), (int64_t)kCUs * 8);
-      SegOut so{};
-      so.sum_f = o.sum_f;
-      so.mean = o.mean;
-      hipLaunchKernelGGL((k_seg_reduce<double, true, false, false, 1>), dim3(grid), dim3(kSegWaves * 64), 0, st, reinterpret_cast<const double*>(vs), ss, G,
-                         gb->gid_of_occ, so, counts);
-    }
-    PDX_LAUNCH_CHECK();
-  }
-  *done = true;
-  return PDX_OK;
-}
-
-}  // namespace pdx
 
 // =====================================================================================================================
 // Exact multi-GPU fp64 sum: partial-tree exchange (see include/pdx/abi.h).  Thread-per-group kernels: every group's values
@@ -1873,28 +1498,29 @@ int pdx_groupby_group_values(pdx_groupby* gb, const pdx_column* values, void* st
   if (values->dtype != PDX_FLOAT64 || validity_or_null(values)) return fail(PDX_NOT_IMPLEMENTED, "pdx_groupby_group_values: float64 values without nulls only");
   if (values->length != gb->n) return fail(PDX_INVALID, "pdx_groupby_group_values: values length differs from the grouped key length");
   hipStream_t st = as_stream(stream);
-  pdx_grouped* g = new pdx_grouped();
+  std::unique_ptr<pdx_grouped> gowner(new pdx_grouped());
+  pdx_grouped* g = gowner.get();
   g->gb = gb;
   g->n = gb->n;
   g->G = gb->G;
   *out = nullptr;
   const int64_t n = gb->n, G = gb->G;
   g->seg_start = g->own<uint32_t>((size_t)G + 1);
-  if (!g->seg_start) { delete g; return PDX_OOM; }
+  if (!g->seg_start) return PDX_OOM;
   if (n > 0) {
     Scratch s;
     const uint32_t* ks = nullptr;
     const uint64_t* vs = nullptr;
     int rc = sort_values_by_slot(gb, static_cast<const uint64_t*>(values->values) + values->offset, nullptr, 0,
                                  [&](size_t bytes) { return (void*)g->own<uint8_t>(bytes); }, s, st, &ks, &vs);
-    if (rc != PDX_OK) { delete g; return rc; }
+    if (rc != PDX_OK) return rc;
     g->vals_sorted = reinterpret_cast<const double*>(vs);
     hipLaunchKernelGGL(k_seg_starts, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, ks, n, gb->occ_slot, G, g->seg_start);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { delete g; return hip_fail(e, "pdx_groupby_group_values"); }
+    if (e != hipSuccess) return hip_fail(e, "pdx_groupby_group_values");
   }
-  *out = g;
+  *out = gowner.release();
   return PDX_OK;
 }
 int pdx_grouped_destroy(pdx_grouped* g) {

@@ -390,11 +390,11 @@ def test_groupby_sizes_vs_oracle(px, monkeypatch, n, nk, dense):
 @pytest.mark.parametrize("dense", ["1", "0"])
 @pytest.mark.parametrize("n,nk,dtype", [(300_007, 100_000, "f"), (300_007, 100_000, "i"), (1_200_011, 900_000, "f"), (70_001, 40_000, "f"),
                                         (2_000_003, 50_000, "f")])
-def test_groupby_bucket_path_vs_oracle(px, monkeypatch, n, nk, dtype, dense):
-    """the MSD-partition + bucket-accumulate path (forced at small sizes), both slot spaces, LB = 8 and 12, all five aggregates;
-    with skewed (2 hot keys) group sizes so single groups span many tiles and many leaves."""
+def test_groupby_skewed_vs_oracle(px, monkeypatch, n, nk, dtype, dense):
+    """both key->slot paths, float64 and int64 values, all five aggregates; skewed group sizes (2 hot keys holding ~1/7 and
+    ~1/11 of the rows) so single groups span many sort tiles, many leaves and the multi-chunk counter path."""
     monkeypatch.setenv("PDX_GROUPBY_DENSE", dense)
-    monkeypatch.setenv("PDX_GROUPBY_BUCKET", "2")
+    monkeypatch.setenv("PDX_HASH_PARTITION", "2")
     keys = orc.synth_keys(0, n, nk)
     keys[::7] = 5
     keys[1::11] = nk - 1
