@@ -371,6 +371,48 @@ __global__ void __launch_bounds__(256) k_dense_slots_tail(const long long* __res
   }
 }
 
+// Tile-shaped variant of the tail (one block = one 4096-row sort tile) that also produces the tile's pass-0 digit histogram, so
+// the first pass of every later sort by slot needs no histogram read of slot_of_row.
+template <int BITS>
+__global__ void __launch_bounds__(kSortBlock) k_dense_slots_tail_hist(const long long* __restrict__ keys, const uint8_t* __restrict__ valid,
+                                                                      int64_t off, int64_t tile0, int64_t n, long long mn, unsigned int range,
+                                                                      const uint32_t* __restrict__ seen, unsigned int* first,
+                                                                      uint32_t* __restrict__ slot_of_row, uint32_t* __restrict__ hist) {
+  constexpr int R = 1 << BITS;
+  __shared__ uint32_t h[R];
+  for (int d = threadIdx.x; d < R; d += kSortBlock) h[d] = 0;
+  __syncthreads();
+  const int64_t tile = tile0 + blockIdx.x;
+  const int64_t base = tile * kSortTile;
+  long long k[kSortItems];
+#pragma unroll
+  for (int u = 0; u < kSortItems; ++u) {
+    int64_t i = base + u * kSortBlock + threadIdx.x;
+    k[u] = i < n ? keys[i] : 0;
+  }
+  unsigned int sl[kSortItems];
+  uint32_t w[kSortItems];
+#pragma unroll
+  for (int u = 0; u < kSortItems; ++u) {
+    int64_t i = base + u * kSortBlock + threadIdx.x;
+    sl[u] = range;
+    if (i < n && (!valid || bit_get(valid, off + i))) sl[u] = (unsigned int)((unsigned long long)k[u] - (unsigned long long)mn);
+    w[u] = i < n ? seen[sl[u] >> 5] : ~0u;
+  }
+#pragma unroll
+  for (int u = 0; u < kSortItems; ++u) {
+    int64_t i = base + u * kSortBlock + threadIdx.x;
+    if (i >= n) continue;
+    slot_of_row[i] = sl[u];
+    atomicAdd(&h[sl[u] & (R - 1)], 1u);
+    if (!((w[u] >> (sl[u] & 31)) & 1u)) {
+      if ((unsigned int)i < first[sl[u]]) atomicMin(&first[sl[u]], (unsigned int)i);
+    }
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < R; d += kSortBlock) hist[tile * R + d] = h[d];
+}
+
 // first-row of every slot: from the hash table (table != nullptr) or the dense first[] array
 struct OccPred {
   const Slot* table;
@@ -775,6 +817,7 @@ struct pdx_groupby {
   uint32_t* part_off = nullptr;     // [tiles][256] scatter offsets of the partition pass
   uint32_t* slot_part = nullptr;    // n, logical slot per partitioned position
   uint32_t* rows_part = nullptr;    // n, original row (bit 31: key is null)
+  uint32_t* pass0_off = nullptr;    // row-order slots: scanned offsets of the first sort pass (fused into the slot kernel)
   uint32_t* slot_of_row = nullptr;  // n
   uint32_t* occ_slot = nullptr;     // G, slot order
   uint32_t* gid_of_occ = nullptr;   // G
@@ -847,7 +890,8 @@ static int sort_values_by_slot(pdx_groupby* gb, const uint64_t* vals, const uint
     hipLaunchKernelGGL(k_flag_keys, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, gb->slot_of_row, vvalid, voff, n, fk);
     kin = fk;
   }
-  return radix_sort_pairs<uint64_t>(kin, vals, k0, v0, k1, v1, n, gb->slot_bits, keys_sorted, vals_sorted, true, s, st);
+  // (pass0_off describes the unflagged slots; the digit of a flagged key is the same: the flag lives in bit 31)
+  return radix_sort_pairs<uint64_t>(kin, vals, k0, v0, k1, v1, n, gb->slot_bits, keys_sorted, vals_sorted, true, s, st, 0, gb->pass0_off);
 }
 
 template <typename T>
@@ -931,17 +975,54 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     if (s.failed) return PDX_OOM;
     hipMemsetAsync(dense_first, 0xFF, (size_t)nslots * sizeof(unsigned int), st);
     {
-      PDX_PROFILE("dense_slots", st);
-      // prefix with the full first-row protocol, then the bitmap-filtered tail
-      const int64_t prefix = std::min<int64_t>(n, std::max<int64_t>((int64_t)1 << 22, 16 * nslots));
-      hipLaunchKernelGGL(k_dense_slots, dim3(grid_for(prefix, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, prefix, dense_min, null_slot,
-                         dense_first, gb->slot_of_row);
-      if (prefix < n) {
-        uint32_t* seen = s.get<uint32_t>((size_t)((nslots + 31) >> 5));
-        if (s.failed) return PDX_OOM;
-        hipLaunchKernelGGL(k_seen_bitmap, dim3(grid_for((nslots + 31) >> 5, 256)), dim3(256), 0, st, dense_first, nslots, seen);
-        hipLaunchKernelGGL(k_dense_slots_tail, dim3(grid_for(n - prefix, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, prefix, n, dense_min,
-                           null_slot, seen, dense_first, gb->slot_of_row);
+      // prefix with the full first-row protocol, then the bitmap-filtered tail; the tail kernel is tile shaped and also emits the
+      // per-tile histogram of the first sort digit (prefix tiles get theirs from the plain histogram kernel)
+      const int64_t ntiles = ceil_div(n, kSortTile), nchunks = ceil_div(ntiles, kColChunk);
+      const int bits0 = make_sort_plan(ilog2((uint64_t)nslots), sort_max_bits()).bits[0];
+      int64_t prefix = std::min<int64_t>(n, std::max<int64_t>((int64_t)1 << 22, 16 * nslots));
+      prefix = std::min<int64_t>(n, round_up(prefix, kSortTile));
+      const bool fuse = bits0 >= 4 && bits0 <= 8;
+      uint32_t* chunk_sum = nullptr;
+      if (fuse) {
+        gb->pass0_off = gb->own<uint32_t>((size_t)ntiles << bits0);
+        chunk_sum = s.get<uint32_t>((size_t)nchunks << bits0);
+        if (!gb->pass0_off || s.failed) return PDX_OOM;
+      }
+      {
+        PDX_PROFILE("dense_slots", st);
+        hipLaunchKernelGGL(k_dense_slots, dim3(grid_for(prefix, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, prefix, dense_min, null_slot,
+                           dense_first, gb->slot_of_row);
+        if (prefix < n) {
+          uint32_t* seen = s.get<uint32_t>((size_t)((nslots + 31) >> 5));
+          if (s.failed) return PDX_OOM;
+          hipLaunchKernelGGL(k_seen_bitmap, dim3(grid_for((nslots + 31) >> 5, 256)), dim3(256), 0, st, dense_first, nslots, seen);
+          const int64_t tile0 = prefix / kSortTile;
+          const unsigned tail_tiles = (unsigned)(ntiles - tile0);
+#define TAIL_HIST(B) hipLaunchKernelGGL((k_dense_slots_tail_hist<B>), dim3(tail_tiles), dim3(kSortBlock), 0, st, keys, valid, key->offset, tile0, n, \
+                                        dense_min, null_slot, seen, dense_first, gb->slot_of_row, gb->pass0_off)
+          if (!fuse)
+            hipLaunchKernelGGL(k_dense_slots_tail, dim3(grid_for(n - prefix, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, prefix, n, dense_min,
+                               null_slot, seen, dense_first, gb->slot_of_row);
+          else if (bits0 == 4) TAIL_HIST(4);
+          else if (bits0 == 5) TAIL_HIST(5);
+          else if (bits0 == 6) TAIL_HIST(6);
+          else if (bits0 == 7) TAIL_HIST(7);
+          else TAIL_HIST(8);
+#undef TAIL_HIST
+        }
+      }
+      if (fuse) {
+        // histogram of the prefix tiles (the prefix is a whole number of tiles unless it is the whole input), then the column scan
+#define PREFIX_HIST(B) hipLaunchKernelGGL((k_radix_hist<B>), dim3((unsigned)ceil_div(prefix, kSortTile)), dim3(kSortBlock), 0, st, gb->slot_of_row, prefix, 0, \
+                                          gb->pass0_off)
+        if (bits0 == 4) PREFIX_HIST(4);
+        else if (bits0 == 5) PREFIX_HIST(5);
+        else if (bits0 == 6) PREFIX_HIST(6);
+        else if (bits0 == 7) PREFIX_HIST(7);
+        else PREFIX_HIST(8);
+#undef PREFIX_HIST
+        int rcs = radix_scan_dispatch(bits0, gb->pass0_off, ntiles, chunk_sum, true, st);
+        if (rcs != PDX_OK) return rcs;
       }
     }
   } else if (use_partition) {

@@ -250,23 +250,36 @@ inline SortPlan make_sort_plan(int total_bits, int max_bits_per_pass = 8) {
   return p;
 }
 
-// per-tile digit histogram + column scan: afterwards hist[tile][digit] = output offset of the tile's first row with that digit
+// column scan of raw per-tile histograms: afterwards hist[tile][digit] = output offset of the tile's first row with that digit
+template <int BITS>
+int radix_scan_only(uint32_t* hist, int64_t ntiles, uint32_t* chunk_sum, bool big, hipStream_t st) {
+  int64_t nchunks = ceil_div(ntiles, kColChunk);
+  PDX_PROFILE(big ? "radix_scan" : "radix_scan_small", st);
+  hipLaunchKernelGGL((k_col_chunk_sums<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum);
+  hipLaunchKernelGGL((k_col_chunk_scan<BITS>), dim3(1), dim3(256), 0, st, chunk_sum, nchunks);
+  hipLaunchKernelGGL((k_col_apply<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum);
+  PDX_LAUNCH_CHECK();
+  return PDX_OK;
+}
+inline int radix_scan_dispatch(int bits, uint32_t* hist, int64_t ntiles, uint32_t* chunk_sum, bool big, hipStream_t st) {
+  switch (bits) {
+    case 4: return radix_scan_only<4>(hist, ntiles, chunk_sum, big, st);
+    case 5: return radix_scan_only<5>(hist, ntiles, chunk_sum, big, st);
+    case 6: return radix_scan_only<6>(hist, ntiles, chunk_sum, big, st);
+    case 7: return radix_scan_only<7>(hist, ntiles, chunk_sum, big, st);
+    case 8: return radix_scan_only<8>(hist, ntiles, chunk_sum, big, st);
+    default: return fail(PDX_INVALID, "radix sort: unsupported digit width");
+  }
+}
+// per-tile digit histogram + column scan
 template <int BITS>
 int radix_offsets(const uint32_t* kin, int64_t n, int shift, uint32_t* hist, uint32_t* chunk_sum, bool big, hipStream_t st) {
   int64_t ntiles = ceil_div(n, kSortTile);
-  int64_t nchunks = ceil_div(ntiles, kColChunk);
   {
     PDX_PROFILE(big ? "radix_hist" : "radix_hist_small", st);
     hipLaunchKernelGGL((k_radix_hist<BITS>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, n, shift, hist);
   }
-  {
-    PDX_PROFILE(big ? "radix_scan" : "radix_scan_small", st);
-    hipLaunchKernelGGL((k_col_chunk_sums<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum);
-    hipLaunchKernelGGL((k_col_chunk_scan<BITS>), dim3(1), dim3(256), 0, st, chunk_sum, nchunks);
-    hipLaunchKernelGGL((k_col_apply<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum);
-  }
-  PDX_LAUNCH_CHECK();
-  return PDX_OK;
+  return radix_scan_only<BITS>(hist, ntiles, chunk_sum, big, st);
 }
 inline int sort_xcd_swizzle() {
   static const int swz = [] { const char* e = getenv("PDX_SORT_XCD_SWIZZLE"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -328,14 +341,33 @@ int radix_pass_dispatch(int bits, const uint32_t* kin, const V* vin, uint32_t* k
   }
 }
 
+template <typename V>
+int radix_scatter_dispatch(int bits, const uint32_t* kin, const V* vin, uint32_t* kout, V* vout, int64_t n, int shift, bool write_keys,
+                           const uint32_t* offsets, hipStream_t st) {
+  switch (bits) {
+    case 4: return radix_scatter_only<4, V>(kin, vin, kout, vout, n, shift, write_keys, offsets, st);
+    case 5: return radix_scatter_only<5, V>(kin, vin, kout, vout, n, shift, write_keys, offsets, st);
+    case 6: return radix_scatter_only<6, V>(kin, vin, kout, vout, n, shift, write_keys, offsets, st);
+    case 7: return radix_scatter_only<7, V>(kin, vin, kout, vout, n, shift, write_keys, offsets, st);
+    case 8: return radix_scatter_only<8, V>(kin, vin, kout, vout, n, shift, write_keys, offsets, st);
+    default: return fail(PDX_INVALID, "radix sort: unsupported digit width");
+  }
+}
+inline int sort_max_bits() {
+  int max_bits = 8;
+  if (const char* e = getenv("PDX_SORT_MAX_BITS")) max_bits = atoi(e) >= 4 && atoi(e) <= 11 ? atoi(e) : 8;
+  return max_bits;
+}
+
 // Sorts (keys_in, vals_in) by key bits [0, total_bits) into (*keys_sorted, *vals_sorted), which point into the
 // caller's ping-pong buffers (k0,v0)/(k1,v1).  Inputs are never written.  n must be < 2^32.
 template <typename V>
 int radix_sort_pairs(const uint32_t* keys_in, const V* vals_in, uint32_t* k0, V* v0, uint32_t* k1, V* v1, int64_t n, int total_bits,
                      const uint32_t** keys_sorted, const V** vals_sorted, bool need_sorted_keys, Scratch& s, hipStream_t st,
-                     int first_shift = 0) {
-  int max_bits = 8;
-  if (const char* e = getenv("PDX_SORT_MAX_BITS")) max_bits = atoi(e) >= 4 && atoi(e) <= 11 ? atoi(e) : 8;
+                     int first_shift = 0, const uint32_t* first_pass_offsets = nullptr) {
+  // first_pass_offsets: scanned offsets of pass 0 (digit width = make_sort_plan(total_bits, sort_max_bits()).bits[0]) computed by the
+  // caller, e.g. fused into the kernel that produced keys_in; pass 0 then needs neither the histogram nor the scan
+  int max_bits = sort_max_bits();
   SortPlan plan = make_sort_plan(total_bits, max_bits);
   int64_t ntiles = ceil_div(n, kSortTile);
   int64_t nchunks = ceil_div(ntiles, kColChunk);
@@ -349,7 +381,10 @@ int radix_sort_pairs(const uint32_t* keys_in, const V* vals_in, uint32_t* k0, V*
     uint32_t* kout = (p & 1) ? k1 : k0;
     V* vout = (p & 1) ? v1 : v0;
     bool last = p == plan.npasses - 1;
-    PDX_TRY(radix_pass_dispatch<V>(plan.bits[p], kin, vin, kout, vout, n, shift, !last || need_sorted_keys, hist, chunk_sum, st));
+    if (p == 0 && first_pass_offsets)
+      PDX_TRY(radix_scatter_dispatch<V>(plan.bits[p], kin, vin, kout, vout, n, shift, !last || need_sorted_keys, first_pass_offsets, st));
+    else
+      PDX_TRY(radix_pass_dispatch<V>(plan.bits[p], kin, vin, kout, vout, n, shift, !last || need_sorted_keys, hist, chunk_sum, st));
     shift += plan.bits[p];
     kin = kout;
     vin = vout;
