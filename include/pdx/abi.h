@@ -197,7 +197,9 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
  *
  * pdx_groupby_group_values : stable sort of a non-null float64 column by group; the handle caches the grouped values.
  * pdx_grouped_counts       : rows per group (G int64, group-id order).
- * pdx_grouped_partial_plan : number of records given prefix[g] = rows of group g held by lower ranks (G int64, group-id order).
+ * pdx_grouped_partial_plan : number of records given prefix[g] = rows of group g held by lower ranks (G int64, group-id order);
+ *                            order (optional, G int64) = local group ids in record EMISSION order -- pass the ids sorted by global
+ *                            group id and the records come out already partitioned by owner rank (no routing pass).
  * pdx_grouped_partial_fill : writes the records; gid_map[g] = global group id of local group g.
  * pdx_replay_partials      : owner side: records for global ids [gid_lo, gid_lo + n_own) in (source rank, emission) order ->
  *                            out_sum[gid - gid_lo].  Every owned id must have at least one record. */
@@ -205,7 +207,7 @@ typedef struct pdx_grouped pdx_grouped;
 int pdx_groupby_group_values(pdx_groupby* gb, const pdx_column* values, void* stream, pdx_grouped** out);
 int pdx_grouped_destroy(pdx_grouped* g);
 int pdx_grouped_counts(pdx_grouped* g, int64_t* out_counts, void* stream);
-int pdx_grouped_partial_plan(pdx_grouped* g, const int64_t* prefix, int64_t* out_total, void* stream);
+int pdx_grouped_partial_plan(pdx_grouped* g, const int64_t* prefix, const int64_t* order, int64_t* out_total, void* stream);
 int pdx_grouped_partial_fill(pdx_grouped* g, const int64_t* gid_map, int64_t* rec_key, double* rec_val, void* stream);
 int pdx_replay_partials(const int64_t* rec_key, const double* rec_val, int64_t m, int64_t gid_lo, int64_t n_own, double* out_sum, void* stream);
 

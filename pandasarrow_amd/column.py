@@ -371,10 +371,12 @@ class GroupedValues:
         L.check(L.load().pdx_grouped_counts(self._h, out.data_ptr(), _stream()))
         return out[: self._gb.num_groups]
 
-    def partial_plan(self, prefix: torch.Tensor) -> int:
+    def partial_plan(self, prefix: torch.Tensor, order: torch.Tensor | None = None) -> int:
         self._prefix = prefix.contiguous()  # read again by partial_fill
+        self._order = None if order is None else order.contiguous()
         total = C.c_int64(0)
-        L.check(L.load().pdx_grouped_partial_plan(self._h, self._prefix.data_ptr(), C.byref(total), _stream()))
+        L.check(L.load().pdx_grouped_partial_plan(self._h, self._prefix.data_ptr(), None if self._order is None else self._order.data_ptr(),
+                                                  C.byref(total), _stream()))
         self.total = int(total.value)
         return self.total
 

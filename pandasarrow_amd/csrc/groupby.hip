@@ -1452,26 +1452,37 @@ __global__ void k_grouped_counts(const uint32_t* __restrict__ seg_start, const u
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < G; k += stride)
     out[gid_of_occ[k]] = (int64_t)seg_start[k + 1] - (int64_t)seg_start[k];
 }
-__global__ void k_partial_plan(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ gid_of_occ, int64_t G,
-                               const int64_t* __restrict__ prefix, int64_t* __restrict__ rec_cnt) {
+// emission order: record block j belongs to local group order[j] (order == nullptr: group j); occ_of_gid maps a local group id to
+// its position in slot order (where its values live)
+__global__ void k_occ_of_gid(const uint32_t* __restrict__ gid_of_occ, int64_t G, uint32_t* __restrict__ occ_of_gid) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < G; k += stride)
-    rec_cnt[k] = partial_record_count(prefix[gid_of_occ[k]], (int64_t)seg_start[k + 1] - (int64_t)seg_start[k]);
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < G; k += stride) occ_of_gid[gid_of_occ[k]] = (uint32_t)k;
+}
+__global__ void k_partial_plan(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ occ_of_gid, const int64_t* __restrict__ order,
+                               int64_t G, const int64_t* __restrict__ prefix, int64_t* __restrict__ rec_cnt) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < G; j += stride) {
+    const int64_t lg = order ? order[j] : j;
+    const uint32_t k = occ_of_gid[lg];
+    rec_cnt[j] = partial_record_count(prefix[lg], (int64_t)seg_start[k + 1] - (int64_t)seg_start[k]);
+  }
 }
 __global__ void __launch_bounds__(256) k_partial_fill(const double* __restrict__ vals, const uint32_t* __restrict__ seg_start,
-                                                      const uint32_t* __restrict__ gid_of_occ, int64_t G, const int64_t* __restrict__ prefix,
-                                                      const int64_t* __restrict__ gid_map, const int64_t* __restrict__ rec_off,
-                                                      int64_t* __restrict__ rec_key, double* __restrict__ rec_val) {
+                                                      const uint32_t* __restrict__ occ_of_gid, const int64_t* __restrict__ order, int64_t G,
+                                                      const int64_t* __restrict__ prefix, const int64_t* __restrict__ gid_map,
+                                                      const int64_t* __restrict__ rec_off, int64_t* __restrict__ rec_key,
+                                                      double* __restrict__ rec_val) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < G; k += stride) {
-    const uint32_t lg = gid_of_occ[k];
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < G; j += stride) {
+    const int64_t lg = order ? order[j] : j;
+    const uint32_t k = occ_of_gid[lg];
     const double* v = vals + seg_start[k];
     const int64_t c = (int64_t)seg_start[k + 1] - (int64_t)seg_start[k];
     if (c <= 0) continue;
     const int64_t a = prefix[lg], b = a + c;
     const int64_t kf = (a + 15) >> 4, kl = b >> 4;
     const int64_t gkey = gid_map[lg] * 64;
-    int64_t pos = rec_off[k];
+    int64_t pos = rec_off[j];
     if (kf > kl) {
       for (int64_t i = 0; i < c; ++i) { rec_key[pos] = gkey; rec_val[pos] = v[i]; ++pos; }
       continue;
@@ -1555,8 +1566,10 @@ struct pdx_grouped {
   int64_t n = 0, G = 0;
   const double* vals_sorted = nullptr;
   uint32_t* seg_start = nullptr;  // G + 1, slot (occ) order
-  int64_t* rec_off = nullptr;     // G + 1 after plan
+  uint32_t* occ_of_gid = nullptr; // G: local group id -> position in slot order
+  int64_t* rec_off = nullptr;     // G + 1 after plan (emission order)
   const int64_t* prefix = nullptr;
+  const int64_t* order = nullptr;
   int64_t total = -1;
   std::vector<void*> owned;
   template <typename T>
@@ -1587,7 +1600,8 @@ int pdx_groupby_group_values(pdx_groupby* gb, const pdx_column* values, void* st
   *out = nullptr;
   const int64_t n = gb->n, G = gb->G;
   g->seg_start = g->own<uint32_t>((size_t)G + 1);
-  if (!g->seg_start) return PDX_OOM;
+  g->occ_of_gid = g->own<uint32_t>((size_t)G);
+  if (!g->seg_start || !g->occ_of_gid) return PDX_OOM;
   if (n > 0) {
     Scratch s;
     const uint32_t* ks = nullptr;
@@ -1597,6 +1611,7 @@ int pdx_groupby_group_values(pdx_groupby* gb, const pdx_column* values, void* st
     if (rc != PDX_OK) return rc;
     g->vals_sorted = reinterpret_cast<const double*>(vs);
     hipLaunchKernelGGL(k_seg_starts, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, ks, n, gb->occ_slot, G, g->seg_start);
+    hipLaunchKernelGGL(k_occ_of_gid, dim3(grid_for(G, 256)), dim3(256), 0, st, gb->gid_of_occ, G, g->occ_of_gid);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return hip_fail(e, "pdx_groupby_group_values");
@@ -1616,11 +1631,12 @@ int pdx_grouped_counts(pdx_grouped* g, int64_t* out_counts, void* stream) {
   PDX_HIP(hipStreamSynchronize(st));
   return PDX_OK;
 }
-int pdx_grouped_partial_plan(pdx_grouped* g, const int64_t* prefix, int64_t* out_total, void* stream) {
+int pdx_grouped_partial_plan(pdx_grouped* g, const int64_t* prefix, const int64_t* order, int64_t* out_total, void* stream) {
   if (!g || !prefix || !out_total) return fail(PDX_INVALID, "pdx_grouped_partial_plan: null argument");
   hipStream_t st = as_stream(stream);
   *out_total = 0;
   g->prefix = prefix;
+  g->order = order;
   g->total = 0;
   if (g->G == 0) return PDX_OK;
   if (!g->rec_off) g->rec_off = g->own<int64_t>((size_t)g->G + 1);
@@ -1628,7 +1644,7 @@ int pdx_grouped_partial_plan(pdx_grouped* g, const int64_t* prefix, int64_t* out
   Scratch s;
   int64_t* total = s.get<int64_t>(1);
   PDX_SCRATCH_CHECK(s);
-  hipLaunchKernelGGL(k_partial_plan, dim3(grid_for(g->G, 256)), dim3(256), 0, st, g->seg_start, g->gb->gid_of_occ, g->G, prefix, g->rec_off);
+  hipLaunchKernelGGL(k_partial_plan, dim3(grid_for(g->G, 256)), dim3(256), 0, st, g->seg_start, g->occ_of_gid, order, g->G, prefix, g->rec_off);
   PDX_TRY((device_exclusive_scan<int64_t, SumOp>(g->rec_off, g->rec_off, g->G, total, s, st)));
   PDX_HIP(hipMemcpyAsync(&g->total, total, sizeof(int64_t), hipMemcpyDeviceToHost, st));
   PDX_HIP(hipStreamSynchronize(st));
@@ -1641,7 +1657,7 @@ int pdx_grouped_partial_fill(pdx_grouped* g, const int64_t* gid_map, int64_t* re
   hipStream_t st = as_stream(stream);
   if (g->G) {
     PDX_PROFILE("partial_fill", st);
-    hipLaunchKernelGGL(k_partial_fill, dim3(grid_for(g->G, 256)), dim3(256), 0, st, g->vals_sorted, g->seg_start, g->gb->gid_of_occ, g->G, g->prefix,
+    hipLaunchKernelGGL(k_partial_fill, dim3(grid_for(g->G, 256)), dim3(256), 0, st, g->vals_sorted, g->seg_start, g->occ_of_gid, g->order, g->G, g->prefix,
                        gid_map, g->rec_off, rec_key, rec_val);
   }
   PDX_LAUNCH_CHECK();

@@ -176,8 +176,8 @@ class HipEngine:
     def grouped_counts(self, gv):
         return gv.counts()
 
-    def partial_records(self, gv, prefix: torch.Tensor, gid_map: torch.Tensor):
-        gv.partial_plan(prefix)
+    def partial_records(self, gv, prefix: torch.Tensor, gid_map: torch.Tensor, order: torch.Tensor | None = None):
+        gv.partial_plan(prefix, order)
         return gv.partial_fill(gid_map)
 
     def replay(self, rec_key, rec_val, gid_lo, n_own):
@@ -297,19 +297,16 @@ def groupby_sum_mean_count_sharded(engine, keys, vals, row_offset=0):
         else:
             prefix_g, count_g = torch.zeros_like(dense), dense
     with _Stage("5_partial_records"):
-        rec_key, rec_val = engine.partial_records(gv, prefix_g[my_map].contiguous(), my_map)
-    # route records to the owners of contiguous global-id ranges
+        # records are emitted group by group in GLOBAL-id order, so they leave the kernel already partitioned by owner rank
+        order = torch.argsort(my_map) if W > 1 else None
+        rec_key, rec_val = engine.partial_records(gv, prefix_g[my_map].contiguous(), my_map, order)
+    # owners of contiguous global-id ranges: one all-to-all(v) of contiguous slices
     bounds = [G * d // W for d in range(W + 1)]
-    with _Stage("6_route_all_to_all"):
+    with _Stage("6_all_to_all"):
         if W > 1:
-            owner = torch.bucketize(rec_key >> 6, torch.tensor(bounds[1:], dtype=torch.int64, device=dev), right=True)
-            send_k, send_v = [], []
-            for d in range(W):
-                k_d, v_d = engine.select_tensor_eq([rec_key, rec_val], owner, d)
-                send_k.append(k_d)
-                send_v.append(v_d)
-            rk = torch.cat(all_to_all_v(send_k))
-            rv = torch.cat(all_to_all_v(send_v))
+            cuts = torch.searchsorted(rec_key, torch.tensor([b * 64 for b in bounds], dtype=torch.int64, device=dev)).tolist()
+            rk = torch.cat(all_to_all_v([rec_key[cuts[d]:cuts[d + 1]] for d in range(W)]))
+            rv = torch.cat(all_to_all_v([rec_val[cuts[d]:cuts[d + 1]] for d in range(W)]))
         else:
             rk, rv = rec_key, rec_val
     with _Stage("7_replay"):

@@ -94,10 +94,12 @@ class OracleEngine:
             yield s, j
             s += 1 << j
 
-    def partial_records(self, gv, prefix, gid_map):
+    def partial_records(self, gv, prefix, gid_map, order=None):
         keys, vals = [], []
         P, gm = prefix.numpy(), gid_map.numpy()
-        for lg, v in enumerate(gv["vals"]):
+        emission = range(len(gv["vals"])) if order is None else [int(x) for x in order.numpy()]
+        for lg in emission:
+            v = gv["vals"][lg]
             a, c = int(P[lg]), len(v)
             if c == 0:
                 continue
