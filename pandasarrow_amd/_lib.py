@@ -106,6 +106,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and owns the device memory this binding hands to the
+    # library, so torch must be loaded FIRST -- libpdx_hip.so's NEEDED libamdhip64.so.7 then resolves to the already-loaded copy.
+    # (Loaded the other way round, the ROCm and the torch runtimes both end up in the process and the second one to initialise
+    # reports "no ROCm-capable device".)  Pure C/C++ hosts link the system runtime as usual.
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise PdxError(DEVICE, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
