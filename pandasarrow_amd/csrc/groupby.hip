@@ -655,55 +655,163 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
   }
 }
 
-// ---------------------------------------------------------------- segmented reduce (nullable values): one thread per group,
-// literal replay of the per-group scalar kernels (runs of valid rows restart the 16-value leaves)
+// ---------------------------------------------------------------- segmented reduce (nullable values): one wave per group.
+// Arrow restarts the 16-value leaves at every run of valid rows, so leaf boundaries are data dependent.  Per 1024-row chunk a
+// lane owns a 16-row window: the number of rows already in the leaf that is open at the window start comes from a "latest"
+// scan across the lanes (a window is as long as a leaf, so a full window passes the count through unchanged), the open leaf's
+// partial sum is the sequential sum of the previous window's last rows (one shuffle), and each lane walks its 16 validity bits
+// emitting finished leaves in order.  The emitted leaf sums are merged with a butterfly whose lanes are aligned to the GLOBAL leaf
+// index, so every perfect subtree it extracts is exactly a run of carries of Arrow's binary counter.
+constexpr int kNullLeafCap = 64 * 9 + 8;  // a 16-row window emits at most 9 leaves (8 isolated values + the carried one)
+
 template <typename T>
-__global__ void __launch_bounds__(256) k_seg_reduce_nullable(const T* __restrict__ vals, const uint32_t* __restrict__ sorted_keys,
-                                                             const uint8_t* __restrict__ row_valid, int64_t valid_off,
-                                                             const uint32_t* __restrict__ seg_start, int64_t nseg,
-                                                             const uint32_t* __restrict__ out_index, SegOut out, uint8_t* __restrict__ ok) {
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += stride) {
+__global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_nullable(const T* __restrict__ vals, const uint32_t* __restrict__ sorted_keys,
+                                                                        const uint8_t* __restrict__ row_valid, int64_t valid_off,
+                                                                        const uint32_t* __restrict__ seg_start, int64_t nseg,
+                                                                        const uint32_t* __restrict__ out_index, SegOut out,
+                                                                        uint8_t* __restrict__ ok) {
+  __shared__ double stage[kSegWaves][64 * 17];
+  __shared__ double leafbuf[kSegWaves][kNullLeafCap];
+  __shared__ double csum_all[kSegWaves][48];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* lds = stage[wave];
+  double* leaves = leafbuf[wave];
+  double* csum = csum_all[wave];
+  int64_t gw = (int64_t)blockIdx.x * kSegWaves + wave;
+  int64_t nw = (int64_t)gridDim.x * kSegWaves;
+  for (int64_t k = gw; k < nseg; k += nw) {
     const int64_t s = seg_start[k], e = seg_start[k + 1];
+    const int64_t len = e - s;
     const uint32_t oi = out_index ? out_index[k] : (uint32_t)k;
-    PairwiseCounter c;
-    c.init();
-    int run = 0;
-    double acc = 0.0;
-    long long cnt = 0;
-    unsigned long long isum = 0;
     Extreme<T> ext;
     ext.init();
-    for (int64_t i = s; i < e; ++i) {
-      bool valid = sorted_keys ? !(sorted_keys[i] >> 31) : (!row_valid || bit_get(row_valid, valid_off + i));
-      if (valid) {
-        T x = vals[i];
-        acc += (double)x;
-        ++cnt;
-        isum += (unsigned long long)x;
-        if (x == x) ext.add(x, (long long)(i - s));
-        if (++run == 16) {
-          c.push(acc, 0);
-          acc = 0.0;
-          run = 0;
+    unsigned long long isum = 0;
+    long long nvalid = 0;
+    uint64_t cmask = 0;       // binary counter occupancy (wave-uniform)
+    int croot = 0;
+    long long nleaves = 0;    // leaves pushed so far (wave-uniform): lane alignment of the merge butterfly
+    int carry_pos = 0;        // rows already in the leaf that is open at the chunk start
+    double carry_acc = 0.0;   // ... and their sequential sum
+    if (lane < 48) csum[lane] = 0.0;
+    for (int64_t c0 = 0; c0 < len; c0 += 1024) {
+      const int cl = (int)((len - c0) < 1024 ? (len - c0) : 1024);
+      // coalesced loads + validity words; lane l keeps the word that holds its window [16l, 16l+16)
+      uint64_t myword = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int idx = q * 64 + lane;
+        bool v = false;
+        if (idx < cl) {
+          const int64_t i = s + c0 + idx;
+          v = sorted_keys ? !(sorted_keys[i] >> 31) : (!row_valid || bit_get(row_valid, valid_off + i));
+          T x = vals[i];
+          lds[idx + (idx >> 4)] = (double)x;
+          if (v) {
+            isum += (unsigned long long)x;
+            if (x == x) ext.add(x, (long long)(c0 + idx));
+          }
         }
-      } else if (run) {
-        c.push(acc, 0);
-        acc = 0.0;
-        run = 0;
+        const uint64_t bal = __ballot(v);
+        nvalid += __popcll(bal);
+        if ((lane >> 2) == q) myword = bal;
       }
+      __builtin_amdgcn_wave_barrier();
+      const unsigned m = (unsigned)(myword >> ((lane & 3) * 16)) & 0xFFFFu;
+      const bool full = m == 0xFFFFu;
+      const int t = full ? 16 : __builtin_clz(~(m << 16));  // valid rows at the END of the window (leading ones of m << 16)
+      // rows in the open leaf at the start of every window ("latest" scan; a full window passes its own start value on)
+      const int z = full ? -1 : t;
+      const int inc = wave_inclusive_scan(z, LatestOp());
+      const int exc = __shfl_up(inc, 1, 64);
+      const int pos = (lane != 0 && exc >= 0) ? exc : carry_pos;  // exc < 0: every earlier window of this chunk is full
+      // sequential sum of this window's last rows that stay in an open leaf (handed to the next window)
+      const int cnt_tail = full ? pos : t;
+      double tail = 0.0;
+      for (int q = 16 - cnt_tail; q < 16; ++q) tail += lds[lane * 17 + q];
+      double acc = __shfl_up(tail, 1, 64);
+      if (lane == 0) acc = carry_acc;
+      // pass 1: number of leaves this window finishes
+      int nfin = 0;
+      {
+        int p = pos;
+        for (int q = 0; q < 16; ++q) {
+          if ((m >> q) & 1u) {
+            if (++p == 16) { ++nfin; p = 0; }
+          } else if (p > 0) { ++nfin; p = 0; }
+        }
+      }
+      int inc_n = wave_inclusive_scan(nfin, SumOp());
+      const int base = inc_n - nfin;
+      const int total_new = __shfl(inc_n, 63, 64);
+      // pass 2: emit the finished leaves in order
+      {
+        int p = pos, w = base;
+        double a = pos > 0 ? acc : 0.0;
+        for (int q = 0; q < 16; ++q) {
+          if ((m >> q) & 1u) {
+            a = (p == 0 ? 0.0 : a) + lds[lane * 17 + q];
+            if (++p == 16) { leaves[w++] = a; p = 0; }
+          } else if (p > 0) { leaves[w++] = a; p = 0; }
+        }
+      }
+      // state handed to the next chunk
+      const int last_inc = __shfl(inc, 63, 64);
+      const double last_tail = __shfl(tail, 63, 64);
+      carry_pos = last_inc < 0 ? carry_pos : last_inc;
+      carry_acc = last_tail;
+      __builtin_amdgcn_wave_barrier();
+      // merge the new leaves: batches of lanes aligned to the global leaf index
+      int consumed = 0;
+      while (consumed < total_new) {
+        const int lo = (int)(nleaves & 63);
+        const int take = (64 - lo) < (total_new - consumed) ? (64 - lo) : (total_new - consumed);
+        const int hi = lo + take;
+        double x0 = (lane >= lo && lane < hi) ? leaves[consumed + lane - lo] : 0.0;
+        double x1 = x0 + __shfl_down(x0, 1, 64);
+        double x2 = x1 + __shfl_down(x1, 2, 64);
+        double x3 = x2 + __shfl_down(x2, 4, 64);
+        double x4 = x3 + __shfl_down(x3, 8, 64);
+        double x5 = x4 + __shfl_down(x4, 16, 64);
+        double x6 = x5 + __shfl_down(x5, 32, 64);
+        for (int sidx = lo; sidx < hi;) {
+          int tz = sidx == 0 ? 6 : __builtin_ctz((unsigned)sidx);
+          int lg = 31 - __builtin_clz((unsigned)(hi - sidx));
+          const int j = tz < lg ? tz : lg;
+          double xs = j == 0 ? x0 : j == 1 ? x1 : j == 2 ? x2 : j == 3 ? x3 : j == 4 ? x4 : j == 5 ? x5 : x6;
+          lds_counter_push(csum, cmask, croot, __shfl(xs, sidx, 64), j, lane);
+          sidx += 1 << j;
+        }
+        nleaves += take;
+        consumed += take;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    if (run) c.push(acc, 0);
-    double total = cnt ? c.finish() : 0.0;
-    if (out.sum_f) out.sum_f[oi] = total;
-    if (out.mean) out.mean[oi] = cnt ? total / (double)cnt : 0.0;
-    if (out.sum_i) out.sum_i[oi] = (long long)isum;
-    T nanv = T(0);
-    if constexpr (__is_same(T, double)) nanv = __builtin_nan("");
-    if (out.vmin) static_cast<T*>(out.vmin)[oi] = ext.rmin < 0 ? nanv : ext.vmin;
-    if (out.vmax) static_cast<T*>(out.vmax)[oi] = ext.rmax < 0 ? nanv : ext.vmax;
-    if (out.count) out.count[oi] = cnt;
-    ok[oi] = cnt > 0;
+    // the leaf still open at the end of the group
+    if (carry_pos > 0) lds_counter_push(csum, cmask, croot, carry_acc, 0, lane);
+    double total = 0.0;
+    if (nvalid > 0) {
+      double a = csum[0];
+      for (int i = 1; i <= croot; ++i) a = csum[i] + a;
+      total = a;
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+      T omin = __shfl_down(ext.vmin, d, 64), omax = __shfl_down(ext.vmax, d, 64);
+      long long ormin = __shfl_down(ext.rmin, d, 64), ormax = __shfl_down(ext.rmax, d, 64);
+      ext.merge(omin, ormin, omax, ormax);
+      isum += __shfl_down(isum, d, 64);
+    }
+    if (lane == 0) {
+      if (out.sum_f) out.sum_f[oi] = total;
+      if (out.mean) out.mean[oi] = nvalid ? total / (double)nvalid : 0.0;
+      if (out.sum_i) out.sum_i[oi] = (long long)isum;
+      T nanv = T(0);
+      if constexpr (__is_same(T, double)) nanv = __builtin_nan("");
+      if (out.vmin) static_cast<T*>(out.vmin)[oi] = ext.rmin < 0 ? nanv : ext.vmin;
+      if (out.vmax) static_cast<T*>(out.vmax)[oi] = ext.rmax < 0 ? nanv : ext.vmax;
+      if (out.count) out.count[oi] = nvalid;
+      ok[oi] = nvalid > 0;
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -1285,13 +1393,13 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   } else {
     uint8_t* ok = s.get<uint8_t>((size_t)G);
     PDX_SCRATCH_CHECK(s);
-    int grid = grid_for(G, 256);
+    int grid = (int)std::min<int64_t>(ceil_div(G, kSegWaves), (int64_t)kCUs * 8);
     const uint32_t* fk = gb->mode == 0 ? keys_sorted : nullptr;
     if (is_f)
-      hipLaunchKernelGGL((k_seg_reduce_nullable<double>), dim3(grid), dim3(256), 0, st, static_cast<const double*>(vals_sorted), fk, row_valid,
+      hipLaunchKernelGGL((k_seg_reduce_nullable<double>), dim3(grid), dim3(kSegWaves * 64), 0, st, static_cast<const double*>(vals_sorted), fk, row_valid,
                          values->offset, seg_start, G, out_index, o, ok);
     else
-      hipLaunchKernelGGL((k_seg_reduce_nullable<long long>), dim3(grid), dim3(256), 0, st, static_cast<const long long*>(vals_sorted), fk,
+      hipLaunchKernelGGL((k_seg_reduce_nullable<long long>), dim3(grid), dim3(kSegWaves * 64), 0, st, static_cast<const long long*>(vals_sorted), fk,
                          row_valid, values->offset, seg_start, G, out_index, o, ok);
     PDX_LAUNCH_CHECK();
     for (int k = 0; k < nk; ++k) {

@@ -480,6 +480,43 @@ def test_resample_kat_and_errors(px, kat):
         S(np.arange(4.0), index=px.Column.from_numpy(np.array([5, 4, 7, 8]) * 10**9, dtype=px.L.TIMESTAMP_NS)).resample("1S")
 
 
+@pytest.mark.parametrize("density", [0.03, 0.5, 0.97])
+def test_resample_and_groupby_null_values_vs_oracle(px, density):
+    """null VALUES restart Arrow's 16-row leaves at every run of valid rows: long runs, alternating rows and mostly-null columns,
+    through both layouts of the nullable segmented reduce (contiguous resample bins and sorted hash groups)."""
+    n = 400_003
+    t0, step = 946_684_800 * 10**9, 100_000_000
+    ts, v = orc.synth_ts(0, n, t0, step), (orc.synth_vals(0, n) - 0.5) * 1e3
+    valid = orc.synth_vals(0, n, 77) >= density
+    valid[1000:9000] = True       # a run of 8000 valid rows spanning many windows and chunks
+    valid[20000:20040:2] = False  # alternating
+    r = px.api.Series(px.Column.from_numpy(v, valid, offset=5), index=px.Column.from_numpy(ts, dtype=px.L.TIMESTAMP_NS), name="v").resample("1min")
+    for agg, kind in (("sum", orc.AGG_SUM), ("mean", orc.AGG_MEAN), ("min", orc.AGG_MIN), ("max", orc.AGG_MAX), ("count", orc.AGG_COUNT)):
+        labels, exp, eok = orc.resample_agg(kind, ts, v, 60 * 10**9, valid)
+        got, gok = getattr(r, agg)()["v"].to_numpy()
+        if gok is not None:
+            assert np.array_equal(gok, eok), agg
+        else:
+            assert eok.all()
+        if exp.dtype == np.float64:
+            assert_f64_bits(got, exp, valid=eok, what=agg)
+        else:
+            assert np.array_equal(got[eok], exp[eok]), agg
+    keys = orc.synth_keys(0, n, 300)
+    keys[::3] = 7  # one group with > 130 000 rows (many chunks)
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys))
+    ids, uniq, _, _ = orc.group_ids(keys)
+    for kind in (orc.AGG_SUM, orc.AGG_MEAN, orc.AGG_COUNT, orc.AGG_MAX):
+        got, gok = gb.agg(px.Column.from_numpy(v, valid), [kind])[0].to_numpy()
+        exp, eok = orc.groupby_agg(kind, ids, len(uniq), v, valid)
+        if gok is not None:
+            assert np.array_equal(gok, eok)
+        if exp.dtype == np.float64:
+            assert_f64_bits(got, exp, valid=eok, what=f"gb kind={kind}")
+        else:
+            assert np.array_equal(got[eok], exp[eok])
+
+
 def test_resample_large_vs_oracle(px):
     n = 2_000_000  # C5 shape: 100 ms spacing, 1-minute bins -> 600 rows per bin
     t0, step = 946_684_800 * 10**9, 100_000_000
