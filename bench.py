@@ -65,6 +65,19 @@ def cpu_baseline(sample_rows, nkeys, gpu_check=None):
     out = {"value": sample_rows / dt / 1e9, "unit": "Grows/s", "cores": threads, "kind": "port",
            "sample": f"first {sample_rows:.3g} rows of the same synthetic workload ({len(uk)} groups), "
                      f"oracle/pdx_oracle.c orc_groupby_sum_mean_count, {dt:.1f} s"}
+    # context only: Arrow's own multi-threaded hash aggregate on a 1e8-row slice (strongest readily available CPU number; its
+    # fp64 sums use a different summation order than the reference's per-group scalar sum, so it is not the parity target)
+    try:
+        import pyarrow as pa
+
+        rows_pa = min(sample_rows, 100_000_000)
+        tbl = pa.table({"k": keys[:rows_pa], "v": vals[:rows_pa]})
+        t1 = time.perf_counter()
+        tbl.group_by("k").aggregate([("v", "sum"), ("v", "mean"), ("v", "count")])
+        out["arrow_hash_aggregate_Grows_per_s"] = rows_pa / (time.perf_counter() - t1) / 1e9
+        out["arrow_version"] = pa.__version__
+    except Exception:  # pyarrow missing on the box: the port above is the baseline
+        pass
     if gpu_check is not None:
         gk, gs, gm, gc = gpu_check(sample_rows)
         out["gpu_matches_oracle_bit_exact"] = bool(np.array_equal(gk, uk) and np.array_equal(gs.view(np.uint64), s.view(np.uint64))
