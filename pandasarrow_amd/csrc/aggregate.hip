@@ -147,100 +147,116 @@ static int sum_dense(const T* v, int64_t n, double* result_dev, Scratch& s, hipS
 }
 
 // ---------------------------------------------------------------- nullable path
-// One thread per logical 64-row word.  Because 64 % 16 == 0, the run position (mod 16) at the start of a word is the
-// value produced by the nearest earlier word that contains an invalid bit ("latest" scan), or 0 at the array start.
-__global__ void k_null_word_state(const uint8_t* __restrict__ valid, int64_t off, int64_t n, int32_t* __restrict__ z) {
-  int64_t nwords = (n + 63) >> 6;
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += stride) {
-    int64_t base = w << 6;
-    int cnt = (int)((n - base) < 64 ? (n - base) : 64);
-    uint64_t bits = load_bits64(valid, off + base, off + n);
-    uint64_t inv = ~bits & (cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull));
-    int32_t r = -1;
-    if (inv) {
-      int last_zero = 63 - __clzll(inv);
-      r = (cnt - 1 - last_zero) & 15;  // valid rows after the last invalid one, mod 16
-    }
-    z[w] = r;
-  }
+// Arrow restarts its 16-value leaves at every run of valid rows.  One thread owns a 16-row window (= one leaf length):
+//   k_null_window_state : rows at the END of the window that stay in an open leaf if the window has an invalid row, else "pass"
+//   "latest" device scan: rows already in the open leaf at every window START (a full window passes the value through: 16 | 16)
+//   k_null_window_count : leaves FINISHED inside the window (+ the leaf still open at the end of the array)  -> device sum scan
+//   k_null_window_emit  : 4096 rows per block staged through LDS (coalesced loads); the open leaf's partial sum at a window
+//                         start is the sequential sum of the previous window's last rows; every window walks its 16 bits once
+//                         and writes the leaves it finishes, in order, into the compact leaf array
+// then the ordinary merge tree (run_tree) over the leaf array.
+__device__ __forceinline__ unsigned window_bits(const uint8_t* valid, int64_t off, int64_t n, int64_t w) {
+  // 16 validity bits of window w (rows [16w, 16w+16)), zero beyond n
+  const int64_t row = w << 4;
+  if (row >= n) return 0u;
+  const int64_t bit0 = off + row;
+  const int64_t byte0 = bit0 >> 3;
+  const int sh = (int)(bit0 & 7);
+  const int64_t last_byte = (off + n + 7) >> 3;
+  unsigned v = (unsigned)valid[byte0];
+  if (byte0 + 1 < last_byte) v |= (unsigned)valid[byte0 + 1] << 8;
+  if (sh && byte0 + 2 < last_byte) v |= (unsigned)valid[byte0 + 2] << 16;
+  v = (v >> sh) & 0xFFFFu;
+  const int64_t remain = n - row;
+  if (remain < 16) v &= (1u << remain) - 1u;
+  return v;
 }
-__global__ void k_null_leaf_count(const uint8_t* __restrict__ valid, int64_t off, int64_t n, const int32_t* __restrict__ state,
-                                  int64_t* __restrict__ leaf_count, unsigned long long* __restrict__ valid_total) {
-  int64_t nwords = (n + 63) >> 6;
+__global__ void k_null_window_state(const uint8_t* __restrict__ valid, int64_t off, int64_t n, int64_t nwin, int32_t* __restrict__ z,
+                                    unsigned long long* __restrict__ valid_total) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   unsigned long long vc = 0;
-  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += stride) {
-    int64_t base = w << 6;
-    int cnt = (int)((n - base) < 64 ? (n - base) : 64);
-    uint64_t bits = load_bits64(valid, off + base, off + n);
-    int pos = state[w] < 0 ? 0 : state[w];
-    int leaves = 0;
-    for (int k = 0; k < cnt; ++k) {
-      if ((bits >> k) & 1) {
-        leaves += (pos == 0);
-        pos = (pos + 1) & 15;
-      } else {
-        pos = 0;
-      }
-    }
-    leaf_count[w] = leaves;
-    vc += __popcll(bits);
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwin; w += stride) {
+    const unsigned m = window_bits(valid, off, n, w);
+    z[w] = m == 0xFFFFu ? -1 : (int32_t)__builtin_clz(~(m << 16));  // valid rows at the end of the window
+    vc += __popc(m);
   }
-  // wave-reduce the valid count, one atomic per wave
   for (int d = 32; d > 0; d >>= 1) vc += __shfl_down(vc, d, 64);
   if ((threadIdx.x & 63) == 0 && vc) atomicAdd(valid_total, vc);
 }
-template <typename T>
-__global__ void k_null_leaf_sums(const T* __restrict__ v, const uint8_t* __restrict__ valid, int64_t off, int64_t n,
-                                 const int32_t* __restrict__ state, const int64_t* __restrict__ leaf_base, double* __restrict__ leaves) {
-  int64_t nwords = (n + 63) >> 6;
+__global__ void k_null_window_count(const uint8_t* __restrict__ valid, int64_t off, int64_t n, int64_t nwin, const int32_t* __restrict__ pos_in,
+                                    int64_t* __restrict__ count) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += stride) {
-    int64_t base = w << 6;
-    int cnt = (int)((n - base) < 64 ? (n - base) : 64);
-    uint64_t bits = load_bits64(valid, off + base, off + n);
-    int pos = state[w] < 0 ? 0 : state[w];
-    int64_t li = leaf_base[w];
-    for (int k = 0; k < cnt; ++k) {
-      if ((bits >> k) & 1) {
-        if (pos == 0) {
-          // a leaf starts here: up to 16 consecutive valid rows (may run into the following words)
-          double acc = 0.0;
-          int64_t i = base + k;
-          for (int q = 0; q < 16 && i < n; ++q, ++i) {
-            if (q > 0 && !bit_get(valid, off + i)) break;
-            acc += to_f64(v[i]);
-          }
-          leaves[li++] = acc;
-        }
-        pos = (pos + 1) & 15;
-      } else {
-        pos = 0;
-      }
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwin; w += stride) {
+    const unsigned m = window_bits(valid, off, n, w);
+    int p = pos_in[w] < 0 ? 0 : pos_in[w];
+    int fin = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      if ((m >> q) & 1u) {
+        if (++p == 16) { ++fin; p = 0; }
+      } else if (p > 0) { ++fin; p = 0; }
+    }
+    if (w == nwin - 1 && p > 0) ++fin;  // the leaf still open at the end of the array
+    count[w] = fin;
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(kLeafBlock) k_null_window_emit(const T* __restrict__ v, const uint8_t* __restrict__ valid, int64_t off, int64_t n,
+                                                                 int64_t nwin, const int32_t* __restrict__ pos_in,
+                                                                 const int64_t* __restrict__ leaf_base, double* __restrict__ leaves) {
+  __shared__ double lds[kLeafBlock * kLeafPad];
+  const int tid = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * kLeafElems;
+  const int rows = (int)((n - base) < kLeafElems ? (n - base) : kLeafElems);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    int idx = k * kLeafBlock + tid;
+    if (idx < rows) lds[idx + (idx >> 4)] = to_f64(v[base + idx]);
+  }
+  __syncthreads();
+  const int64_t w = (int64_t)blockIdx.x * kLeafBlock + tid;
+  if (w >= nwin) return;
+  const unsigned m = window_bits(valid, off, n, w);
+  int p = pos_in[w] < 0 ? 0 : pos_in[w];
+  // partial sum of the leaf that is open at the window start: its p rows are the LAST p rows of the previous window (all valid)
+  double acc = 0.0;
+  if (p > 0) {
+    if (tid > 0) {
+      for (int q = 16 - p; q < 16; ++q) acc += lds[(tid - 1) * kLeafPad + q];
+    } else {
+      for (int q = 16 - p; q < 16; ++q) acc += to_f64(v[base - 16 + q]);  // first window of the block: the rows live in the previous block
     }
   }
+  int64_t li = leaf_base[w];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    if ((m >> q) & 1u) {
+      acc = (p == 0 ? 0.0 : acc) + lds[tid * kLeafPad + q];
+      if (++p == 16) { leaves[li++] = acc; p = 0; }
+    } else if (p > 0) { leaves[li++] = acc; p = 0; }
+  }
+  if (w == nwin - 1 && p > 0) leaves[li++] = acc;
 }
 
 template <typename T>
 static int sum_nullable(const T* v, const uint8_t* valid, int64_t off, int64_t n, double* result_dev, unsigned long long* valid_total,
                         Scratch& s, hipStream_t st) {
-  int64_t nwords = (n + 63) >> 6;
-  int32_t* z = s.get<int32_t>((size_t)nwords);
-  int64_t* lc = s.get<int64_t>((size_t)nwords);
+  const int64_t nwin = (n + 15) >> 4;
+  int32_t* z = s.get<int32_t>((size_t)nwin);
+  int64_t* lc = s.get<int64_t>((size_t)nwin);
   int64_t* total = s.get<int64_t>(1);
   PDX_SCRATCH_CHECK(s);
-  int grid = grid_for(nwords, 256);
-  hipLaunchKernelGGL(k_null_word_state, dim3(grid), dim3(256), 0, st, valid, off, n, z);
-  PDX_TRY((device_exclusive_scan<int32_t, LatestOp>(z, z, nwords, nullptr, s, st)));
-  hipLaunchKernelGGL(k_null_leaf_count, dim3(grid), dim3(256), 0, st, valid, off, n, z, lc, valid_total);
-  PDX_TRY((device_exclusive_scan<int64_t, SumOp>(lc, lc, nwords, total, s, st)));
+  int grid = grid_for(nwin, 256, 4);
+  hipLaunchKernelGGL(k_null_window_state, dim3(grid), dim3(256), 0, st, valid, off, n, nwin, z, valid_total);
+  PDX_TRY((device_exclusive_scan<int32_t, LatestOp>(z, z, nwin, nullptr, s, st)));
+  hipLaunchKernelGGL(k_null_window_count, dim3(grid), dim3(256), 0, st, valid, off, n, nwin, z, lc);
+  PDX_TRY((device_exclusive_scan<int64_t, SumOp>(lc, lc, nwin, total, s, st)));
   int64_t m = 0;
   PDX_HIP(hipMemcpyAsync(&m, total, sizeof(m), hipMemcpyDeviceToHost, st));
   PDX_HIP(hipStreamSynchronize(st));
   double* leaves = s.get<double>((size_t)(m ? m : 1));
   PDX_SCRATCH_CHECK(s);
-  hipLaunchKernelGGL((k_null_leaf_sums<T>), dim3(grid), dim3(256), 0, st, v, valid, off, n, z, lc, leaves);
+  hipLaunchKernelGGL((k_null_window_emit<T>), dim3((unsigned)ceil_div(n, kLeafElems)), dim3(kLeafBlock), 0, st, v, valid, off, n, nwin, z, lc, leaves);
   PDX_LAUNCH_CHECK();
   return run_tree(leaves, m, nullptr, 0, nullptr, 0, result_dev, s, st);
 }
