@@ -41,6 +41,7 @@ constexpr unsigned int kNoRow = 0xFFFFFFFFu;
 struct HashCtl {
   unsigned int inserted;
   unsigned int overflow;
+  unsigned long long rows_seen;  // LDS build only: rows consumed before the buckets finished / gave up (cardinality estimate)
 };
 
 __global__ void k_table_init(Slot* __restrict__ table, int64_t nslots) {
@@ -129,6 +130,7 @@ __global__ void __launch_bounds__(256) k_hash32(const long long* __restrict__ ke
     h32[i] = h;
   }
 }
+constexpr int kProbeTiles = 4;
 // inputs in partitioned order; rows carry the null flag in bit 31.  U rows per thread are kept in flight: the stream loads and
 // the first table probe of all U rows are issued before any of them is consumed.
 template <int U>
@@ -136,9 +138,17 @@ __global__ void __launch_bounds__(256) k_hash_probe_part(const long long* __rest
                                                          const uint32_t* __restrict__ h32_part, int64_t n, Slot* table, unsigned int cap,
                                                          unsigned int region, unsigned int limit, uint32_t* __restrict__ slot_part,
                                                          HashCtl* ctl) {
+  // One contiguous run of kProbeTiles*U*256 partition-ordered rows per workgroup, runs dispatched in order: the workgroups
+  // resident at any moment work on one or two neighbouring buckets, so a table far larger than the L2 is probed a few MB at a time.
+  // Insertions are counted per thread and flushed once per wave: with tens of millions of groups a per-insert atomic on the one
+  // counter word serialises the whole build (measured 0.9 s for 1e8 groups).
   const unsigned int rmask = region - 1;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < n; p0 += (int64_t)U * stride) {
+  const int64_t stride = blockDim.x;
+  unsigned int my_inserts = 0;
+  bool dead = false;
+  for (int t = 0; t < kProbeTiles && !dead; ++t) {
+    const int64_t p0 = ((int64_t)blockIdx.x * kProbeTiles + t) * blockDim.x * U + threadIdx.x;
+    if (p0 - threadIdx.x >= n) break;
     unsigned int row[U], h[U], phys[U], idx[U];
     long long key[U], cur[U];
     bool act[U];
@@ -161,7 +171,7 @@ __global__ void __launch_bounds__(256) k_hash_probe_part(const long long* __rest
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (!act[u]) continue;
+      if (!act[u] || dead) continue;
       const bool special = (row[u] >> 31) || key[u] == kEmptyKey;
       const unsigned int r = row[u] & 0x7FFFFFFFu;
       unsigned int logical;
@@ -174,29 +184,38 @@ __global__ void __launch_bounds__(256) k_hash_probe_part(const long long* __rest
         for (;;) {
           if (c == key[u]) break;
           if (c == kEmptyKey) {
-            if (__hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
             unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[base + idx[u]].key), (unsigned long long)kEmptyKey,
                                                (unsigned long long)key[u]);
             if (old == (unsigned long long)kEmptyKey) {
-              unsigned int cc = atomicAdd(&ctl->inserted, 1u);
-              if (cc >= limit) atomicExch(&ctl->overflow, 1u);
+              ++my_inserts;
               break;
             }
             if (old == (unsigned long long)key[u]) break;
           }
           idx[u] = (idx[u] + 1) & rmask;
-          if (++probes > region) {  // this bucket's region is full: grow the table
-            atomicExch(&ctl->overflow, 1u);
-            break;
+          if ((++probes & 63) == 0) {  // long chain: this bucket's region is (nearly) full, or another wave already gave up
+            if (probes > region || probes >= 4096 || __hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+              atomicExch(&ctl->overflow, 1u);
+              dead = true;
+              break;
+            }
           }
           c = table[base + idx[u]].key;
         }
+        if (dead) continue;
         phys[u] = base + idx[u];
         logical = (idx[u] << kPartBits) | b;
       }
       if (r < table[phys[u]].first) atomicMin(&table[phys[u]].first, r);
       slot_part[p0 + u * stride] = logical;
     }
+  }
+  // one counter update per wave (divergent exits above are re-converged here)
+  unsigned int wave_inserts = my_inserts;
+  for (int d = 32; d >= 1; d >>= 1) wave_inserts += __shfl_xor(wave_inserts, d, 64);
+  if ((threadIdx.x & 63) == 0 && wave_inserts) {
+    unsigned int before = atomicAdd(&ctl->inserted, wave_inserts);
+    if (before + wave_inserts > limit) atomicExch(&ctl->overflow, 1u);
   }
 }
 // LDS-resident build: one workgroup per bucket keeps the bucket's whole table region (<= 8192 keys + first rows = 96 KB) in LDS,
@@ -223,7 +242,14 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
   if (tid == 0) linserted = 0;
   __syncthreads();
   constexpr int U = 4;
+  const unsigned int dense_limit = region - (region >> 3);  // 87.5 % full: give up early, the host retries with a larger table
+  int64_t rows_done = end - start;
   for (int64_t p0 = start + tid; p0 < end; p0 += (int64_t)U * kProbeBlock) {
+    if (linserted > dense_limit) {  // (LDS word, read by every thread each iteration: a handful of cycles)
+      if (tid == 0) atomicExch(&ctl->overflow, 1u);
+      rows_done = p0 - tid - start;
+      break;
+    }
     unsigned int row[U], h[U];
     long long key[U];
     bool act[U];
@@ -258,7 +284,7 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
             if (old == (unsigned long long)key[u]) break;
           }
           idx = (idx + 1) & rmask;
-          if (++probes > region) {  // region full: the host retries with a larger table (L2 path)
+          if (++probes > 512) {  // pathologically long probe chain: the host retries with a larger table (L2 path)
             atomicExch(&ctl->overflow, 1u);
             break;
           }
@@ -277,7 +303,10 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
     sl.gid = kNoRow;
     table[(int64_t)b * region + i] = sl;
   }
-  if (tid == 0 && linserted) atomicAdd(&ctl->inserted, linserted);
+  if (tid == 0) {
+    if (linserted) atomicAdd(&ctl->inserted, linserted);
+    atomicAdd(&ctl->rows_seen, (unsigned long long)(rows_done < end - start ? rows_done : end - start));
+  }
 }
 
 __device__ __forceinline__ int64_t phys_slot(int64_t logical, unsigned int region, unsigned int cap) {
@@ -655,6 +684,54 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
   }
 }
 
+// ---------------------------------------------------------------- segmented reduce, small groups: one thread per group.
+// With a few dozen rows per group a wave per group leaves most lanes idle; here neighbouring lanes read neighbouring (contiguous)
+// segments, so the loads still share cache lines.  Literal replay of leaves + binary counter.
+template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM>
+__global__ void __launch_bounds__(256) k_seg_reduce_small(const T* __restrict__ vals, const uint32_t* __restrict__ seg_start, int64_t nseg,
+                                                          const uint32_t* __restrict__ out_index, SegOut out) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += stride) {
+    const int64_t s = seg_start[k], e = seg_start[k + 1];
+    const uint32_t oi = out_index ? out_index[k] : (uint32_t)k;
+    PairwiseCounter c;
+    if (WANT_PAIRWISE) c.init();
+    unsigned long long isum = 0;
+    T vmn = T(0), vmx = T(0);
+    bool has = false;
+    for (int64_t i = s; i < e; i += 16) {
+      const int cnt = (int)((e - i) < 16 ? (e - i) : 16);
+      double acc = 0.0;
+      for (int q = 0; q < cnt; ++q) {
+        T x = vals[i + q];
+        if (WANT_PAIRWISE) acc += (double)x;
+        if (WANT_ISUM) isum += (unsigned long long)x;
+        if (WANT_MINMAX && x == x) {
+          if (!has) { vmn = vmx = x; has = true; }
+          else {
+            if (x < vmn) vmn = x;
+            if (x > vmx) vmx = x;
+          }
+        }
+      }
+      if (WANT_PAIRWISE) c.push(acc, 0);
+    }
+    if (WANT_PAIRWISE) {
+      double total = c.finish();
+      if (out.sum_f) out.sum_f[oi] = total;
+      if (out.mean) out.mean[oi] = total / (double)(e - s);
+    }
+    if (WANT_ISUM && out.sum_i) out.sum_i[oi] = (long long)isum;
+    if (WANT_MINMAX) {
+      T nanv = T(0);
+      if constexpr (__is_same(T, double)) nanv = __builtin_nan("");
+      if (out.vmin) static_cast<T*>(out.vmin)[oi] = has ? vmn : nanv;
+      if (out.vmax) static_cast<T*>(out.vmax)[oi] = has ? vmx : nanv;
+    }
+    if (out.count) out.count[oi] = (long long)(e - s);
+  }
+}
+
 // ---------------------------------------------------------------- segmented reduce (nullable values): one wave per group.
 // Arrow restarts the 16-value leaves at every run of valid rows, so leaf boundaries are data dependent.  Per 1024-row chunk a
 // lane owns a 16-row window: the number of rows already in the leaf that is open at the window start comes from a "latest"
@@ -1004,8 +1081,21 @@ static int sort_values_by_slot(pdx_groupby* gb, const uint64_t* vals, const uint
 
 template <typename T>
 static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int64_t nseg, const uint32_t* out_index, const SegOut& o,
-                                   bool want_pw, bool want_mm, bool want_is, hipStream_t st) {
+                                   bool want_pw, bool want_mm, bool want_is, int64_t nrows, hipStream_t st) {
   if (nseg == 0) return PDX_OK;
+  static const int64_t small_max = [] { const char* e = getenv("PDX_SEG_SMALL_MAX"); return e ? atoll(e) : 48ll; }();
+  if (nrows / nseg < small_max) {  // small groups on average: thread per group
+    dim3 g(grid_for(nseg, 256)), b(256);
+#define SEG_SMALL(PW, MM, IS) hipLaunchKernelGGL((k_seg_reduce_small<T, PW, MM, IS>), g, b, 0, st, vals, seg_start, nseg, out_index, o)
+    if (want_pw && !want_mm && !want_is) SEG_SMALL(true, false, false);
+    else if (!want_pw && want_mm && !want_is) SEG_SMALL(false, true, false);
+    else if (!want_pw && !want_mm && want_is) SEG_SMALL(false, false, true);
+    else if (!want_pw && !want_mm && !want_is) SEG_SMALL(false, false, false);
+    else SEG_SMALL(true, true, true);
+#undef SEG_SMALL
+    PDX_LAUNCH_CHECK();
+    return PDX_OK;
+  }
   int grid = (int)std::min<int64_t>(ceil_div(nseg, kSegWaves), (int64_t)kCUs * 8);
   dim3 g(grid), b(kSegWaves * 64);
 #define SEG_LAUNCH(PW, MM, IS) hipLaunchKernelGGL((k_seg_reduce<T, PW, MM, IS>), g, b, 0, st, vals, seg_start, nseg, out_index, o)
@@ -1171,7 +1261,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
                            region, gb->slot_part, ctl);
       } else {
         PDX_PROFILE("hash_probe_part", st);
-        hipLaunchKernelGGL((k_hash_probe_part<4>), dim3(grid_for(n, 256, 8)), dim3(256), 0, st, keys_part, gb->rows_part, h32_part, n, table, cap, region,
+        hipLaunchKernelGGL((k_hash_probe_part<4>), dim3((unsigned int)ceil_div(n, 1024 * kProbeTiles)), dim3(256), 0, st, keys_part, gb->rows_part, h32_part, n, table, cap, region,
                            limit, gb->slot_part, ctl);
       }
       HashCtl h;
@@ -1184,7 +1274,24 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
       if (!h.overflow && h.inserted <= limit) break;  // (the LDS build only flags a completely full region: keep the load factor sane)
       pool_free(table);
       if (cap >= want * 4 || cap >= (1u << 30)) return fail(PDX_DEVICE, "pdx_groupby_create: hash table overflow at maximum capacity");
-      cap = (unsigned int)std::min<uint64_t>((uint64_t)cap * 8, std::max<uint64_t>(want * 4, 1u << 16));
+      uint64_t next = (uint64_t)cap * 8;
+      if (h.rows_seen) {
+        // the LDS attempt saw d distinct keys in its first r rows: size the retry for the cardinality that predicts
+        // (d = K (1 - exp(-r / K)) for uniformly mixed keys; keys that are all new so far predict "every row its own group")
+        const double d = (double)h.inserted, r = (double)h.rows_seen;
+        double groups = (double)n;
+        if (d < 0.95 * r) {
+          double lo = d, hi = 1e18;  // bisection on K
+          for (int it = 0; it < 200; ++it) {
+            double mid = std::sqrt(lo * hi);
+            if (mid * -std::expm1(-r / mid) < d) lo = mid;
+            else hi = mid;
+          }
+          groups = std::min((double)n, hi * -std::expm1(-(double)n / hi));
+        }
+        next = std::max<uint64_t>(next, next_pow2((uint64_t)(groups / 0.55) + 1));
+      }
+      cap = (unsigned int)std::min<uint64_t>(next, std::max<uint64_t>(want * 4, 1u << 16));
     }
     gb->owned.push_back(table);
     null_slot = cap;
@@ -1386,8 +1493,8 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   }
   PDX_PROFILE("seg_reduce", st);
   if (!vvalid) {
-    if (is_f) PDX_TRY(launch_seg_reduce_dense<double>(static_cast<const double*>(vals_sorted), seg_start, G, out_index, o, want_pw, want_mm, want_is, st));
-    else PDX_TRY(launch_seg_reduce_dense<long long>(static_cast<const long long*>(vals_sorted), seg_start, G, out_index, o, want_pw, want_mm, want_is, st));
+    if (is_f) PDX_TRY(launch_seg_reduce_dense<double>(static_cast<const double*>(vals_sorted), seg_start, G, out_index, o, want_pw, want_mm, want_is, n, st));
+    else PDX_TRY(launch_seg_reduce_dense<long long>(static_cast<const long long*>(vals_sorted), seg_start, G, out_index, o, want_pw, want_mm, want_is, n, st));
     for (int k = 0; k < nk; ++k)
       if (outs[k].validity) PDX_HIP(hipMemsetAsync(outs[k].validity, 0xFF, (size_t)((G + 7) / 8), st));
   } else {
