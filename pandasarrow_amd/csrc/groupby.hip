@@ -442,6 +442,56 @@ __global__ void __launch_bounds__(kSortBlock) k_dense_slots_tail_hist(const long
   for (int d = threadIdx.x; d < R; d += kSortBlock) hist[tile * R + d] = h[d];
 }
 
+// Same, for domains of <= 2^20 slots: persistent workgroups (one per CU) keep the whole `seen` bitmap in LDS (128 KB), so the
+// per-row bitmap lookup is an LDS read instead of a random TA/L1 access; one wave owns one tile at a time (wave-private histogram).
+constexpr int kDenseLdsWords = 32768;
+constexpr int kDenseLdsBlock = 1024;
+template <int BITS>
+__global__ void __launch_bounds__(kDenseLdsBlock) k_dense_slots_tail_hist_lds(const long long* __restrict__ keys, const uint8_t* __restrict__ valid,
+                                                                              int64_t off, int64_t tile0, int64_t ntiles, int64_t n, long long mn,
+                                                                              unsigned int range, const uint32_t* __restrict__ seen, int nwords,
+                                                                              unsigned int* first, uint32_t* __restrict__ slot_of_row,
+                                                                              uint32_t* __restrict__ hist) {
+  constexpr int R = 1 << BITS;
+  constexpr int W = kDenseLdsBlock / 64;
+  __shared__ uint32_t lseen[kDenseLdsWords];
+  __shared__ uint32_t lh[W][R];
+  for (int i = threadIdx.x; i < nwords; i += kDenseLdsBlock) lseen[i] = seen[i];
+  for (int i = threadIdx.x; i < W * R; i += kDenseLdsBlock) (&lh[0][0])[i] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t nw = (int64_t)gridDim.x * W;
+  for (int64_t tile = tile0 + (int64_t)blockIdx.x * W + wave; tile < ntiles; tile += nw) {
+    const int64_t base = tile * kSortTile;
+#pragma unroll 1
+    for (int c = 0; c < kSortTile / 1024; ++c) {
+      long long k[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        int64_t i = base + c * 1024 + u * 64 + lane;
+        k[u] = i < n ? keys[i] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        int64_t i = base + c * 1024 + u * 64 + lane;
+        if (i >= n) continue;
+        unsigned int sl = range;
+        if (!valid || bit_get(valid, off + i)) sl = (unsigned int)((unsigned long long)k[u] - (unsigned long long)mn);
+        const uint32_t w = lseen[sl >> 5];
+        slot_of_row[i] = sl;
+        atomicAdd(&lh[wave][sl & (R - 1)], 1u);
+        if (!((w >> (sl & 31)) & 1u)) {
+          if ((unsigned int)i < first[sl]) atomicMin(&first[sl], (unsigned int)i);
+        }
+      }
+    }
+    for (int d = lane; d < R; d += 64) {
+      hist[tile * R + d] = lh[wave][d];
+      lh[wave][d] = 0;
+    }
+  }
+}
+
 // first-row of every slot: from the hash table (table != nullptr) or the dense first[] array
 struct OccPred {
   const Slot* table;
@@ -1183,7 +1233,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
       uint32_t* chunk_sum = nullptr;
       if (fuse) {
         gb->pass0_off = gb->own<uint32_t>((size_t)ntiles << bits0);
-        chunk_sum = s.get<uint32_t>((size_t)nchunks << bits0);
+        chunk_sum = s.get<uint32_t>((size_t)(nchunks + 1) << bits0);  // + digit totals row
         if (!gb->pass0_off || s.failed) return PDX_OOM;
       }
       {
@@ -1196,8 +1246,16 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
           hipLaunchKernelGGL(k_seen_bitmap, dim3(grid_for((nslots + 31) >> 5, 256)), dim3(256), 0, st, dense_first, nslots, seen);
           const int64_t tile0 = prefix / kSortTile;
           const unsigned tail_tiles = (unsigned)(ntiles - tile0);
-#define TAIL_HIST(B) hipLaunchKernelGGL((k_dense_slots_tail_hist<B>), dim3(tail_tiles), dim3(kSortBlock), 0, st, keys, valid, key->offset, tile0, n, \
-                                        dense_min, null_slot, seen, dense_first, gb->slot_of_row, gb->pass0_off)
+          const int64_t nwords = (nslots + 31) >> 5;
+          static const bool lds_ok = [] { const char* e = getenv("PDX_DENSE_LDS"); return !(e && e[0] == '0'); }();
+          const bool lds_bitmap = lds_ok && nwords <= kDenseLdsWords && tail_tiles >= 256;
+#define TAIL_HIST(B)                                                                                                                              \
+  if (lds_bitmap)                                                                                                                                 \
+    hipLaunchKernelGGL((k_dense_slots_tail_hist_lds<B>), dim3(kCUs), dim3(kDenseLdsBlock), 0, st, keys, valid, key->offset, tile0, ntiles, n,       \
+                       dense_min, null_slot, seen, (int)nwords, dense_first, gb->slot_of_row, gb->pass0_off);                                      \
+  else                                                                                                                                            \
+    hipLaunchKernelGGL((k_dense_slots_tail_hist<B>), dim3(tail_tiles), dim3(kSortBlock), 0, st, keys, valid, key->offset, tile0, n, dense_min,     \
+                       null_slot, seen, dense_first, gb->slot_of_row, gb->pass0_off)
           if (!fuse)
             hipLaunchKernelGGL(k_dense_slots_tail, dim3(grid_for(n - prefix, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, prefix, n, dense_min,
                                null_slot, seen, dense_first, gb->slot_of_row);
@@ -1230,7 +1288,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     gb->part_off = gb->own<uint32_t>((size_t)ntiles << kPartBits);
     gb->slot_part = gb->own<uint32_t>((size_t)n);
     gb->rows_part = gb->own<uint32_t>((size_t)n);
-    uint32_t* chunk_sum = s.get<uint32_t>((size_t)nchunks << kPartBits);
+    uint32_t* chunk_sum = s.get<uint32_t>((size_t)(nchunks + 1) << kPartBits);  // + digit totals row
     uint32_t* h32_part = s.get<uint32_t>((size_t)n);
     long long* keys_part = s.get<long long>((size_t)n);
     if (s.failed || !gb->h32 || !gb->part_off || !gb->slot_part || !gb->rows_part) return PDX_OOM;

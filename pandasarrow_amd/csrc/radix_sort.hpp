@@ -31,10 +31,25 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_hist(const uint32_t* __res
   for (int d = threadIdx.x; d < R; d += kSortBlock) h[d] = 0;
   __syncthreads();
   int64_t base = (int64_t)blockIdx.x * kSortTile;
+  if (base + kSortTile <= n && (reinterpret_cast<uintptr_t>(keys) & 15) == 0) {
+    // full tile: 16-byte loads, all four in flight before the LDS atomics
+    const uint4* k4 = reinterpret_cast<const uint4*>(keys + base);
+    uint4 v[kSortItems / 4];
 #pragma unroll
-  for (int k = 0; k < kSortItems; ++k) {
-    int64_t i = base + k * kSortBlock + threadIdx.x;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & (R - 1)], 1u);
+    for (int k = 0; k < kSortItems / 4; ++k) v[k] = k4[k * kSortBlock + threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < kSortItems / 4; ++k) {
+      atomicAdd(&h[(v[k].x >> shift) & (R - 1)], 1u);
+      atomicAdd(&h[(v[k].y >> shift) & (R - 1)], 1u);
+      atomicAdd(&h[(v[k].z >> shift) & (R - 1)], 1u);
+      atomicAdd(&h[(v[k].w >> shift) & (R - 1)], 1u);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+      int64_t i = base + k * kSortBlock + threadIdx.x;
+      if (i < n) atomicAdd(&h[(keys[i] >> shift) & (R - 1)], 1u);
+    }
   }
   __syncthreads();
   for (int d = threadIdx.x; d < R; d += kSortBlock) hist[(int64_t)blockIdx.x * R + d] = h[d];
@@ -54,43 +69,53 @@ __global__ void __launch_bounds__(256) k_col_chunk_sums(const uint32_t* __restri
     chunk_sum[(int64_t)blockIdx.x * R + d] = acc;
   }
 }
+// one workgroup per digit: exclusive scan of the digit's column of chunk sums; digit_total[d] = rows with that digit
 template <int BITS>
-__global__ void __launch_bounds__(256) k_col_chunk_scan(uint32_t* __restrict__ chunk_sum, int64_t nchunks) {
+__global__ void __launch_bounds__(256) k_col_chunk_scan(uint32_t* __restrict__ chunk_sum, int64_t nchunks, uint32_t* __restrict__ digit_total) {
   constexpr int R = 1 << BITS;
-  constexpr int DPT = (R + 255) / 256;  // digits per thread, contiguous
   __shared__ uint32_t smem[8];
-  uint32_t tot[DPT];
-  uint32_t tsum = 0;
-#pragma unroll
-  for (int j = 0; j < DPT; ++j) {
-    int d = threadIdx.x * DPT + j;
-    uint32_t acc = 0;
-    if (d < R)
-      for (int64_t c = 0; c < nchunks; ++c) {
-        uint32_t v = chunk_sum[c * R + d];
-        chunk_sum[c * R + d] = acc;  // exclusive over chunks (per digit)
-        acc += v;
-      }
-    tot[j] = acc;
-    tsum += acc;
+  const int d = blockIdx.x;
+  uint32_t carry = 0;
+  for (int64_t c0 = 0; c0 < nchunks; c0 += 256) {
+    int64_t c = c0 + threadIdx.x;
+    uint32_t v = c < nchunks ? chunk_sum[c * R + d] : 0u;
+    uint32_t total;
+    uint32_t pre = block_exclusive_scan(v, SumOp(), &total, smem);
+    if (c < nchunks) chunk_sum[c * R + d] = carry + pre;
+    carry += total;
+    __syncthreads();
   }
-  uint32_t total;
-  uint32_t pre = block_exclusive_scan(tsum, SumOp(), &total, smem);  // exclusive over digits
-#pragma unroll
-  for (int j = 0; j < DPT; ++j) {
-    int d = threadIdx.x * DPT + j;
-    if (d < R)
-      for (int64_t c = 0; c < nchunks; ++c) chunk_sum[c * R + d] += pre;
-    pre += tot[j];
-  }
+  if (threadIdx.x == 0) digit_total[d] = carry;
 }
 template <int BITS>
-__global__ void __launch_bounds__(256) k_col_apply(uint32_t* __restrict__ hist, int64_t ntiles, const uint32_t* __restrict__ chunk_off) {
+__global__ void __launch_bounds__(256) k_col_apply(uint32_t* __restrict__ hist, int64_t ntiles, const uint32_t* __restrict__ chunk_off,
+                                                   const uint32_t* __restrict__ digit_total) {
   constexpr int R = 1 << BITS;
+  constexpr int DPT = (R + 255) / 256;
+  __shared__ uint32_t smem[8];
+  __shared__ uint32_t dpre[R];
+  {  // exclusive prefix over digits of the digit totals (R <= 2048 words, recomputed per workgroup: cheaper than another launch)
+    uint32_t t[DPT], tsum = 0;
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {
+      int d = threadIdx.x * DPT + j;
+      t[j] = d < R ? digit_total[d] : 0u;
+      tsum += t[j];
+    }
+    uint32_t total;
+    uint32_t pre = block_exclusive_scan(tsum, SumOp(), &total, smem);
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {
+      int d = threadIdx.x * DPT + j;
+      if (d < R) dpre[d] = pre;
+      pre += t[j];
+    }
+    __syncthreads();
+  }
   int64_t t0 = (int64_t)blockIdx.x * kColChunk;
   int64_t t1 = t0 + kColChunk < ntiles ? t0 + kColChunk : ntiles;
   for (int d = threadIdx.x; d < R; d += 256) {
-    uint32_t off = chunk_off[(int64_t)blockIdx.x * R + d];
+    uint32_t off = chunk_off[(int64_t)blockIdx.x * R + d] + dpre[d];
     for (int64_t t = t0; t < t1; ++t) {
       uint32_t v = hist[t * R + d];
       hist[t * R + d] = off;
@@ -256,8 +281,9 @@ int radix_scan_only(uint32_t* hist, int64_t ntiles, uint32_t* chunk_sum, bool bi
   int64_t nchunks = ceil_div(ntiles, kColChunk);
   PDX_PROFILE(big ? "radix_scan" : "radix_scan_small", st);
   hipLaunchKernelGGL((k_col_chunk_sums<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum);
-  hipLaunchKernelGGL((k_col_chunk_scan<BITS>), dim3(1), dim3(256), 0, st, chunk_sum, nchunks);
-  hipLaunchKernelGGL((k_col_apply<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum);
+  uint32_t* digit_total = chunk_sum + nchunks * ((int64_t)1 << BITS);  // (callers size chunk_sum with one extra row)
+  hipLaunchKernelGGL((k_col_chunk_scan<BITS>), dim3(1 << BITS), dim3(256), 0, st, chunk_sum, nchunks, digit_total);
+  hipLaunchKernelGGL((k_col_apply<BITS>), dim3((unsigned)nchunks), dim3(256), 0, st, hist, ntiles, chunk_sum, digit_total);
   PDX_LAUNCH_CHECK();
   return PDX_OK;
 }
@@ -372,7 +398,7 @@ int radix_sort_pairs(const uint32_t* keys_in, const V* vals_in, uint32_t* k0, V*
   int64_t ntiles = ceil_div(n, kSortTile);
   int64_t nchunks = ceil_div(ntiles, kColChunk);
   uint32_t* hist = s.get<uint32_t>((size_t)ntiles * ((size_t)1 << max_bits));
-  uint32_t* chunk_sum = s.get<uint32_t>((size_t)nchunks * ((size_t)1 << max_bits));
+  uint32_t* chunk_sum = s.get<uint32_t>((size_t)(nchunks + 1) * ((size_t)1 << max_bits));  // + digit totals row
   PDX_SCRATCH_CHECK(s);
   const uint32_t* kin = keys_in;
   const V* vin = vals_in;

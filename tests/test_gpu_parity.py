@@ -366,7 +366,7 @@ def test_groupby_kat(px, kat):
 
 @pytest.mark.parametrize("dense", ["1", "0", "0-global"])
 @pytest.mark.parametrize("n,nk", [(1, 1), (70_001, 1), (1_000_003, 100_003), (2_500_000, 7), (5_000_000, 1_000_000), (6_000_000, 2_500_000),
-                                  (4_000_000, 400_000_000)])
+                                  (4_000_000, 400_000_000), (6_000_000, 5_000)])
 def test_groupby_sizes_vs_oracle(px, monkeypatch, n, nk, dense):
     if dense == "0-global":
         dense = "0"
