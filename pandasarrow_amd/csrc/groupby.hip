@@ -622,6 +622,9 @@ __device__ __forceinline__ void lds_counter_push(double* csum, uint64_t& mask, i
   if (cur > root) root = cur;
 }
 
+// The wave walks its (group, chunk) sequence with the NEXT chunk's 16 loads per lane already in flight while the current chunk
+// is staged and reduced, and the bounds of the next group loaded one group ahead: without this every group pays a full
+// dependent seg_start -> values memory round trip with nothing else to do (measured 3.0 -> see DESIGN.md).
 template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM>
 __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restrict__ vals, const uint32_t* __restrict__ seg_start,
                                                                int64_t nseg, const uint32_t* __restrict__ out_index, SegOut out) {
@@ -632,105 +635,161 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* lds = stage[wave];
   double* csum = csum_all[wave];
-  int64_t gw = (int64_t)blockIdx.x * kSegWaves + wave;
-  int64_t nw = (int64_t)gridDim.x * kSegWaves;
-  for (int64_t k = gw; k < nseg; k += nw) {
-    const int64_t s = seg_start[k], e = seg_start[k + 1];
-    const int64_t len = e - s;
-    const uint32_t oi = out_index ? out_index[k] : (uint32_t)k;
-    Extreme<T> ext;
-    ext.init();
-    unsigned long long isum = 0;
-    uint64_t mask = 0;
-    int root = 0;
-    double single = 0.0;  // result when the group fits one chunk
-    const bool multi = len > kSegChunk;
-    if (WANT_PAIRWISE && multi) {
-      if (lane < 48) csum[lane] = 0.0;
+  const int64_t nw = (int64_t)gridDim.x * kSegWaves;
+  int64_t k = (int64_t)blockIdx.x * kSegWaves + wave;
+  if (k >= nseg) return;
+  int64_t s = seg_start[k], e = seg_start[k + 1];
+  int64_t s_next = 0, e_next = 0;  // bounds of group k + nw
+  if (k + nw < nseg) {
+    s_next = seg_start[k + nw];
+    e_next = seg_start[k + nw + 1];
+  }
+  int64_t c0 = 0;
+  T cur[LEAF];
+  {
+    const int cl = (int)((e - s) < kSegChunk ? (e - s) : kSegChunk);
+#pragma unroll
+    for (int q = 0; q < LEAF; ++q) {
+      int idx = q * 64 + lane;
+      cur[q] = idx < cl ? vals[s + idx] : T(0);
     }
-    for (int64_t c0 = 0; c0 < len; c0 += kSegChunk) {
-      const int cl = (int)((len - c0) < kSegChunk ? (len - c0) : kSegChunk);
-      // coalesced loads: LEAF wave-instructions of 64 consecutive values
+  }
+  Extreme<T> ext;
+  ext.init();
+  unsigned long long isum = 0;
+  uint64_t mask = 0;
+  int root = 0;
+  double single = 0.0;  // result when the group fits one chunk
+  if (WANT_PAIRWISE && (e - s) > kSegChunk) {
+    if (lane < 48) csum[lane] = 0.0;
+  }
+  for (;;) {
+    const int64_t len = e - s;
+    const bool multi = len > kSegChunk;
+    const int cl = (int)((len - c0) < kSegChunk ? (len - c0) : kSegChunk);
+    const bool last_chunk = c0 + kSegChunk >= len;
+    // ---- issue the next chunk's loads
+    const int64_t nk = last_chunk ? k + nw : k;
+    const bool have_next = nk < nseg;
+    const int64_t ns = last_chunk ? s_next : s, ne = last_chunk ? e_next : e, nc0 = last_chunk ? 0 : c0 + kSegChunk;
+    T nxt[LEAF];
+    if (have_next) {
+      const int ncl = (int)((ne - ns - nc0) < kSegChunk ? (ne - ns - nc0) : kSegChunk);
 #pragma unroll
       for (int q = 0; q < LEAF; ++q) {
         int idx = q * 64 + lane;
-        if (idx < cl) {
-          T x = vals[s + c0 + idx];
-          if (WANT_PAIRWISE) lds[idx + (idx >> 4)] = seg_to_f64(x);
-          if (WANT_MINMAX) {
-            if (x == x) ext.add(x, (long long)(c0 + idx));
+        nxt[q] = idx < ncl ? vals[ns + nc0 + idx] : T(0);
+      }
+    }
+    int64_t s_nn = 0, e_nn = 0;
+    if (last_chunk && nk + nw < nseg) {  // bounds two groups ahead, consumed when the next group finishes
+      s_nn = seg_start[nk + nw];
+      e_nn = seg_start[nk + nw + 1];
+    }
+    // ---- current chunk
+#pragma unroll
+    for (int q = 0; q < LEAF; ++q) {
+      int idx = q * 64 + lane;
+      if (idx < cl) {
+        T x = cur[q];
+        if (WANT_PAIRWISE) lds[idx + (idx >> 4)] = seg_to_f64(x);
+        if (WANT_MINMAX) {
+          if (x == x) ext.add(x, (long long)(c0 + idx));
+        }
+        if (WANT_ISUM) isum += (unsigned long long)x;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the LDS image is wave-private: in-order LDS issue makes it visible to all lanes
+    if (WANT_PAIRWISE) {
+      const int m = (cl + LEAF - 1) / LEAF;  // leaves in this chunk (wave-uniform)
+      double x = 0.0;
+      const int first = lane * LEAF;
+      if (first < cl) {
+        int cnt = cl - first < 16 ? cl - first : 16;
+        x = leaf_sum(&lds[lane * 17], cnt);
+      }
+      // butterfly; pick the perfect subtrees that tile [0, m)
+      double node[7];
+#pragma unroll
+      for (int sft = 0; sft < 6; ++sft) {
+        node[sft] = 0.0;
+        if ((m >> sft) & 1) node[sft] = __shfl(x, m & ~((2 << sft) - 1), 64);
+        double y = __shfl_down(x, 1 << sft, 64);
+        x = x + y;
+      }
+      node[6] = __shfl(x, 0, 64);
+      if (!multi) {
+        // fold ascending: acc = lowest node; acc = higher + acc
+        bool have = false;
+        double acc = 0.0;
+#pragma unroll
+        for (int sft = 0; sft <= 6; ++sft) {
+          if ((m >> sft) & 1) {
+            acc = have ? node[sft] + acc : node[sft];
+            have = true;
           }
-          if (WANT_ISUM) isum += (unsigned long long)x;
         }
-      }
-      __builtin_amdgcn_wave_barrier();  // the LDS image is wave-private: in-order LDS issue makes it visible to all lanes
-      if (WANT_PAIRWISE) {
-        const int m = (cl + LEAF - 1) / LEAF;  // leaves in this chunk (wave-uniform)
-        double x = 0.0;
-        const int first = lane * LEAF;
-        if (first < cl) {
-          int cnt = cl - first < 16 ? cl - first : 16;
-          x = leaf_sum(&lds[lane * 17], cnt);
-        }
-        // butterfly; pick the perfect subtrees that tile [0, m)
-        double node[7];
+        single = acc;
+      } else {
 #pragma unroll
-        for (int sft = 0; sft < 6; ++sft) {
-          node[sft] = 0.0;
-          if ((m >> sft) & 1) node[sft] = __shfl(x, m & ~((2 << sft) - 1), 64);
-          double y = __shfl_down(x, 1 << sft, 64);
-          x = x + y;
-        }
-        node[6] = __shfl(x, 0, 64);
-        if (!multi) {
-          // fold ascending: acc = lowest node; acc = higher + acc
-          bool have = false;
-          double acc = 0.0;
-#pragma unroll
-          for (int sft = 0; sft <= 6; ++sft) {
-            if ((m >> sft) & 1) {
-              acc = have ? node[sft] + acc : node[sft];
-              have = true;
-            }
-          }
-          single = acc;
-        } else {
-#pragma unroll
-          for (int sft = 6; sft >= 0; --sft)
-            if ((m >> sft) & 1) lds_counter_push(csum, mask, root, node[sft], sft, lane);
-        }
+        for (int sft = 6; sft >= 0; --sft)
+          if ((m >> sft) & 1) lds_counter_push(csum, mask, root, node[sft], sft, lane);
       }
     }
-    double total = single;
-    if (WANT_PAIRWISE && multi) {
-      double acc = csum[0];
-      for (int i = 1; i <= root; ++i) acc = csum[i] + acc;
-      total = acc;
-    }
-    if (WANT_MINMAX) {
-      for (int d = 32; d > 0; d >>= 1) {
-        T omin = __shfl_down(ext.vmin, d, 64), omax = __shfl_down(ext.vmax, d, 64);
-        long long ormin = __shfl_down(ext.rmin, d, 64), ormax = __shfl_down(ext.rmax, d, 64);
-        ext.merge(omin, ormin, omax, ormax);
+    __builtin_amdgcn_wave_barrier();
+    if (last_chunk) {
+      // ---- group k is complete
+      const uint32_t oi = out_index ? out_index[k] : (uint32_t)k;
+      double total = single;
+      if (WANT_PAIRWISE && multi) {
+        double acc = csum[0];
+        for (int i = 1; i <= root; ++i) acc = csum[i] + acc;
+        total = acc;
       }
-    }
-    if (WANT_ISUM) {
-      for (int d = 32; d > 0; d >>= 1) isum += __shfl_down(isum, d, 64);
-    }
-    if (lane == 0) {
-      if (WANT_PAIRWISE) {
-        if (out.sum_f) out.sum_f[oi] = total;
-        if (out.mean) out.mean[oi] = total / (double)len;
-      }
-      if (WANT_ISUM && out.sum_i) out.sum_i[oi] = (long long)isum;
       if (WANT_MINMAX) {
-        T nanv = T(0);
-        if constexpr (__is_same(T, double)) nanv = __builtin_nan("");
-        if (out.vmin) static_cast<T*>(out.vmin)[oi] = ext.rmin < 0 ? nanv : ext.vmin;
-        if (out.vmax) static_cast<T*>(out.vmax)[oi] = ext.rmax < 0 ? nanv : ext.vmax;
+        for (int d = 32; d > 0; d >>= 1) {
+          T omin = __shfl_down(ext.vmin, d, 64), omax = __shfl_down(ext.vmax, d, 64);
+          long long ormin = __shfl_down(ext.rmin, d, 64), ormax = __shfl_down(ext.rmax, d, 64);
+          ext.merge(omin, ormin, omax, ormax);
+        }
       }
-      if (out.count) out.count[oi] = (long long)len;
+      if (WANT_ISUM) {
+        for (int d = 32; d > 0; d >>= 1) isum += __shfl_down(isum, d, 64);
+      }
+      if (lane == 0) {
+        if (WANT_PAIRWISE) {
+          if (out.sum_f) out.sum_f[oi] = total;
+          if (out.mean) out.mean[oi] = total / (double)len;
+        }
+        if (WANT_ISUM && out.sum_i) out.sum_i[oi] = (long long)isum;
+        if (WANT_MINMAX) {
+          T nanv = T(0);
+          if constexpr (__is_same(T, double)) nanv = __builtin_nan("");
+          if (out.vmin) static_cast<T*>(out.vmin)[oi] = ext.rmin < 0 ? nanv : ext.vmin;
+          if (out.vmax) static_cast<T*>(out.vmax)[oi] = ext.rmax < 0 ? nanv : ext.vmax;
+        }
+        if (out.count) out.count[oi] = (long long)len;
+      }
+      if (!have_next) break;
+      // ---- reset the per-group state
+      ext.init();
+      isum = 0;
+      mask = 0;
+      root = 0;
+      single = 0.0;
+      s_next = s_nn;
+      e_next = e_nn;
+      if (WANT_PAIRWISE && (ne - ns) > kSegChunk) {
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 48) csum[lane] = 0.0;
+      }
     }
+    k = nk;
+    s = ns;
+    e = ne;
+    c0 = nc0;
+#pragma unroll
+    for (int q = 0; q < LEAF; ++q) cur[q] = nxt[q];
   }
 }
 
