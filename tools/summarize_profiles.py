@@ -19,7 +19,12 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-stats = glob.glob(os.path.join(src, "kt", "*", "*kernel_stats.csv"))
+def newest(pattern):
+    """gpurun merges each call's files into gpurun_out/ without deleting older ones: take the latest run's file"""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+stats = [newest(os.path.join(src, "kt", "*", "*kernel_stats.csv"))]
 shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
 
@@ -31,7 +36,7 @@ def short(name):
 
 traffic = collections.defaultdict(lambda: {"launches": 0, "fetch_kib": 0.0, "write_kib": 0.0})
 for counter, field in (("FETCH_SIZE", "fetch_kib"), ("WRITE_SIZE", "write_kib")):
-    f = glob.glob(os.path.join(src, f"pmc_{counter}", "*", "*counter_collection.csv"))[0]
+    f = newest(os.path.join(src, f"pmc_{counter}", "*", "*counter_collection.csv"))
     seen = collections.Counter()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
