@@ -334,13 +334,66 @@ __global__ void k_flag_keys_part(const uint32_t* __restrict__ slot_part, const u
 
 // Dense-domain fast path: when the valid keys span a small integer range the slot is key - min (no table, no probing):
 // the only per-row memory access besides the streams is first[slot] (4 B, range-sized table that stays cache resident).
+// Residue form (mask != 0): slot = key & mask.  Any window of <= mask + 1 consecutive integers has distinct residues, so this
+// is the same perfect hash up to a rotation -- and it needs no minimum, which lets the build run in the SAME pass that
+// computes the exact min/max (speculating on the width of the window; verified afterwards).
+__device__ __forceinline__ unsigned int dense_slot_of(long long k, long long mn, unsigned int mask) {
+  return mask ? ((unsigned int)(unsigned long long)k & mask) : (unsigned int)((unsigned long long)k - (unsigned long long)mn);
+}
+struct KeyRange {
+  long long vmin, vmax;
+  int any, pad;
+};
+// min/max of <= 65536 evenly spaced valid keys (64 workgroups, one sample per thread, one KeyRange per workgroup): the guess for
+// the width of the key window
+__global__ void __launch_bounds__(1024) k_sample_key_range(const long long* __restrict__ keys, const uint8_t* __restrict__ valid, int64_t off,
+                                                           int64_t n, KeyRange* __restrict__ out) {
+  __shared__ long long smn[16], smx[16];
+  __shared__ int sany[16];
+  const int64_t nsamp = n < 65536 ? n : 65536;
+  long long mn = 0x7FFFFFFFFFFFFFFFll, mx = (long long)0x8000000000000000ull;
+  int any = 0;
+  {
+    const int64_t j = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    int64_t i = j < nsamp ? (int64_t)((unsigned __int128)j * (unsigned __int128)n / (unsigned __int128)nsamp) : n;
+    if (i < n && (!valid || bit_get(valid, off + i))) {
+      long long k = keys[i];
+      mn = k < mn ? k : mn;
+      mx = k > mx ? k : mx;
+      any = 1;
+    }
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    long long a = __shfl_xor(mn, d, 64), b = __shfl_xor(mx, d, 64);
+    int c = __shfl_xor(any, d, 64);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+    any |= c;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    smn[threadIdx.x >> 6] = mn;
+    smx[threadIdx.x >> 6] = mx;
+    sany[threadIdx.x >> 6] = any;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) {
+      mn = smn[w] < mn ? smn[w] : mn;
+      mx = smx[w] > mx ? smx[w] : mx;
+      any |= sany[w];
+    }
+    out[blockIdx.x].vmin = mn;
+    out[blockIdx.x].vmax = mx;
+    out[blockIdx.x].any = any;
+  }
+}
 __global__ void __launch_bounds__(256) k_dense_slots(const long long* __restrict__ keys, const uint8_t* __restrict__ valid, int64_t off,
-                                                     int64_t n, long long mn, unsigned int range, unsigned int* first,
+                                                     int64_t n, long long mn, unsigned int mask, unsigned int range, unsigned int* first,
                                                      uint32_t* __restrict__ slot_of_row) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     unsigned int s = range;  // the null key's slot
-    if (!valid || bit_get(valid, off + i)) s = (unsigned int)((unsigned long long)keys[i] - (unsigned long long)mn);
+    if (!valid || bit_get(valid, off + i)) s = dense_slot_of(keys[i], mn, mask);
     if ((unsigned int)i < first[s]) atomicMin(&first[s], (unsigned int)i);
     slot_of_row[i] = s;
   }
@@ -362,7 +415,7 @@ __global__ void k_seen_bitmap(const unsigned int* __restrict__ first, int64_t ns
   }
 }
 __global__ void __launch_bounds__(256) k_dense_slots_tail(const long long* __restrict__ keys, const uint8_t* __restrict__ valid, int64_t off,
-                                                          int64_t row0, int64_t n, long long mn, unsigned int range,
+                                                          int64_t row0, int64_t n, long long mn, unsigned int mask, unsigned int range,
                                                           const uint32_t* __restrict__ seen, unsigned int* first,
                                                           uint32_t* __restrict__ slot_of_row) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -376,7 +429,7 @@ __global__ void __launch_bounds__(256) k_dense_slots_tail(const long long* __res
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       sl[u] = range;
-      if (!valid || bit_get(valid, off + i + u * stride)) sl[u] = (unsigned int)((unsigned long long)k[u] - (unsigned long long)mn);
+      if (!valid || bit_get(valid, off + i + u * stride)) sl[u] = dense_slot_of(k[u], mn, mask);
     }
     uint32_t w[8];
 #pragma unroll
@@ -392,7 +445,7 @@ __global__ void __launch_bounds__(256) k_dense_slots_tail(const long long* __res
   }
   for (; i < n; i += stride) {
     unsigned int s = range;
-    if (!valid || bit_get(valid, off + i)) s = (unsigned int)((unsigned long long)keys[i] - (unsigned long long)mn);
+    if (!valid || bit_get(valid, off + i)) s = dense_slot_of(keys[i], mn, mask);
     slot_of_row[i] = s;
     if (!((seen[s >> 5] >> (s & 31)) & 1u)) {
       if ((unsigned int)i < first[s]) atomicMin(&first[s], (unsigned int)i);
@@ -404,8 +457,8 @@ __global__ void __launch_bounds__(256) k_dense_slots_tail(const long long* __res
 // the first pass of every later sort by slot needs no histogram read of slot_of_row.
 template <int BITS>
 __global__ void __launch_bounds__(kSortBlock) k_dense_slots_tail_hist(const long long* __restrict__ keys, const uint8_t* __restrict__ valid,
-                                                                      int64_t off, int64_t tile0, int64_t n, long long mn, unsigned int range,
-                                                                      const uint32_t* __restrict__ seen, unsigned int* first,
+                                                                      int64_t off, int64_t tile0, int64_t n, long long mn, unsigned int mask,
+                                                                      unsigned int range, const uint32_t* __restrict__ seen, unsigned int* first,
                                                                       uint32_t* __restrict__ slot_of_row, uint32_t* __restrict__ hist) {
   constexpr int R = 1 << BITS;
   __shared__ uint32_t h[R];
@@ -425,7 +478,7 @@ __global__ void __launch_bounds__(kSortBlock) k_dense_slots_tail_hist(const long
   for (int u = 0; u < kSortItems; ++u) {
     int64_t i = base + u * kSortBlock + threadIdx.x;
     sl[u] = range;
-    if (i < n && (!valid || bit_get(valid, off + i))) sl[u] = (unsigned int)((unsigned long long)k[u] - (unsigned long long)mn);
+    if (i < n && (!valid || bit_get(valid, off + i))) sl[u] = dense_slot_of(k[u], mn, mask);
     w[u] = i < n ? seen[sl[u] >> 5] : ~0u;
   }
 #pragma unroll
@@ -449,18 +502,25 @@ constexpr int kDenseLdsBlock = 1024;
 template <int BITS>
 __global__ void __launch_bounds__(kDenseLdsBlock) k_dense_slots_tail_hist_lds(const long long* __restrict__ keys, const uint8_t* __restrict__ valid,
                                                                               int64_t off, int64_t tile0, int64_t ntiles, int64_t n, long long mn,
-                                                                              unsigned int range, const uint32_t* __restrict__ seen, int nwords,
+                                                                              unsigned int mask, unsigned int range,
+                                                                              const uint32_t* __restrict__ seen, int nwords, int64_t track_from,
                                                                               unsigned int* first, uint32_t* __restrict__ slot_of_row,
-                                                                              uint32_t* __restrict__ hist) {
+                                                                              uint32_t* __restrict__ hist, KeyRange* __restrict__ range_out) {
+  // rows < track_from already went through the full first-row protocol (k_dense_slots): here they only get their slot, their
+  // histogram count and their share of the min/max.  range_out (optional): one exact KeyRange per workgroup.
   constexpr int R = 1 << BITS;
   constexpr int W = kDenseLdsBlock / 64;
   __shared__ uint32_t lseen[kDenseLdsWords];
   __shared__ uint32_t lh[W][R];
+  __shared__ long long smn[W], smx[W];
+  __shared__ int sany[W];
   for (int i = threadIdx.x; i < nwords; i += kDenseLdsBlock) lseen[i] = seen[i];
   for (int i = threadIdx.x; i < W * R; i += kDenseLdsBlock) (&lh[0][0])[i] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t nw = (int64_t)gridDim.x * W;
+  long long kmn = 0x7FFFFFFFFFFFFFFFll, kmx = (long long)0x8000000000000000ull;
+  int any = 0;
   for (int64_t tile = tile0 + (int64_t)blockIdx.x * W + wave; tile < ntiles; tile += nw) {
     const int64_t base = tile * kSortTile;
 #pragma unroll 1
@@ -476,11 +536,16 @@ __global__ void __launch_bounds__(kDenseLdsBlock) k_dense_slots_tail_hist_lds(co
         int64_t i = base + c * 1024 + u * 64 + lane;
         if (i >= n) continue;
         unsigned int sl = range;
-        if (!valid || bit_get(valid, off + i)) sl = (unsigned int)((unsigned long long)k[u] - (unsigned long long)mn);
+        if (!valid || bit_get(valid, off + i)) {
+          sl = dense_slot_of(k[u], mn, mask);
+          kmn = k[u] < kmn ? k[u] : kmn;
+          kmx = k[u] > kmx ? k[u] : kmx;
+          any = 1;
+        }
         const uint32_t w = lseen[sl >> 5];
         slot_of_row[i] = sl;
         atomicAdd(&lh[wave][sl & (R - 1)], 1u);
-        if (!((w >> (sl & 31)) & 1u)) {
+        if (!((w >> (sl & 31)) & 1u) && i >= track_from) {
           if ((unsigned int)i < first[sl]) atomicMin(&first[sl], (unsigned int)i);
         }
       }
@@ -488,6 +553,31 @@ __global__ void __launch_bounds__(kDenseLdsBlock) k_dense_slots_tail_hist_lds(co
     for (int d = lane; d < R; d += 64) {
       hist[tile * R + d] = lh[wave][d];
       lh[wave][d] = 0;
+    }
+  }
+  if (range_out) {
+    for (int d = 32; d >= 1; d >>= 1) {
+      long long a = __shfl_xor(kmn, d, 64), b = __shfl_xor(kmx, d, 64);
+      int c = __shfl_xor(any, d, 64);
+      kmn = a < kmn ? a : kmn;
+      kmx = b > kmx ? b : kmx;
+      any |= c;
+    }
+    if (lane == 0) {
+      smn[wave] = kmn;
+      smx[wave] = kmx;
+      sany[wave] = any;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < W; ++w) {
+        kmn = smn[w] < kmn ? smn[w] : kmn;
+        kmx = smx[w] > kmx ? smx[w] : kmx;
+        any |= sany[w];
+      }
+      range_out[blockIdx.x].vmin = kmn;
+      range_out[blockIdx.x].vmax = kmx;
+      range_out[blockIdx.x].any = any;
     }
   }
 }
@@ -513,7 +603,7 @@ struct OccEmit {
 
 // sorted_slot[r] = slot of the r-th group in first-occurrence order
 // null_slot: the slot of the null key; table == nullptr => dense mode (key = dense_min + slot)
-__global__ void k_assign_gids(const Slot* __restrict__ table, long long dense_min, uint32_t* __restrict__ gid_of_slot,
+__global__ void k_assign_gids(const Slot* __restrict__ table, long long dense_min, unsigned int dense_mask, uint32_t* __restrict__ gid_of_slot,
                               const uint32_t* __restrict__ sorted_first, const uint32_t* __restrict__ sorted_slot, int64_t G,
                               unsigned int null_slot, int64_t* __restrict__ uniques, uint8_t* __restrict__ unique_ok,
                               int64_t* __restrict__ first_rows, unsigned int region) {
@@ -526,7 +616,8 @@ __global__ void k_assign_gids(const Slot* __restrict__ table, long long dense_mi
       k = table[phys_slot(s, region, null_slot)].key;
       if (s == null_slot + 1) k = kEmptyKey;
     } else {
-      k = (long long)((unsigned long long)dense_min + (unsigned long long)s);
+      k = dense_mask ? (long long)((unsigned long long)dense_min + (((unsigned long long)s - (unsigned long long)dense_min) & dense_mask))
+                     : (long long)((unsigned long long)dense_min + (unsigned long long)s);
     }
     if (s == null_slot) k = 0;
     uniques[r] = k;
@@ -1243,91 +1334,78 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   const uint8_t* valid = validity_or_null(key);
   HashCtl* ctl = s.get<HashCtl>(1);
   if (s.failed) return PDX_OOM;
-  // ---- dense-domain fast path: valid keys span a small integer range -> slot = key - min, no table
+  // ---- dense-domain fast path: valid keys span a small integer range -> slot = key - min (or its residue form), no table
   Slot* table = nullptr;
   unsigned int* dense_first = nullptr;
   long long dense_min = 0;
+  unsigned int dense_mask = 0;
   unsigned int null_slot = 0;
   int64_t nslots = 0;
-  {
-    MinMaxPartial<long long> mm;
-    int rc0 = minmax_keys_host(keys, valid, key->offset, n, &mm, s, st);
-    if (rc0 != PDX_OK) return rc0;
-    const char* env = getenv("PDX_GROUPBY_DENSE");
-    bool allow = !(env && env[0] == '0');
-    if (allow && mm.rmin >= 0) {
-      unsigned long long span = (unsigned long long)mm.vmax - (unsigned long long)mm.vmin;  // range - 1
-      unsigned long long lim = std::min<unsigned long long>(1ull << 26, (unsigned long long)n * 4 + 1024);
-      if (span < lim) {
-        gb->dense = 1;
-        dense_min = mm.vmin;
-        null_slot = (unsigned int)span + 1;
-        nslots = (int64_t)null_slot + 1;
-      }
-    } else if (allow && mm.rmin < 0) {  // every key is null: one group
-      gb->dense = 1;
-      null_slot = 0;
-      nslots = 1;
-    }
-  }
-  unsigned int region = 0;  // != 0: partitioned hash table (logical slot = (index in region << kPartBits) | bucket)
-  const char* penv = getenv("PDX_HASH_PARTITION");
-  const bool use_partition = !gb->dense && !(penv && penv[0] == '0') && (n >= ((int64_t)1 << 18) || (penv && penv[0] == '2'));
-  if (!use_partition) {
-    gb->slot_of_row = gb->own<uint32_t>((size_t)n);
-    if (!gb->slot_of_row) return PDX_OOM;
-  }
-  if (gb->dense) {
+  const char* denv = getenv("PDX_GROUPBY_DENSE");
+  const bool allow_dense = !(denv && denv[0] == '0');
+  static const bool lds_ok = [] { const char* e = getenv("PDX_DENSE_LDS"); return !(e && e[0] == '0'); }();
+  const unsigned long long dense_lim = std::min<unsigned long long>(1ull << 26, (unsigned long long)n * 4 + 1024);
+
+  // Builds slot_of_row, first[] and (when the first sort digit is 4..8 bits wide) the scanned pass-0 offsets for the dense domain
+  // described by (mn, mask, null_slot, nslots).  range_out != nullptr: also the exact key range, computed by the same pass.
+  auto dense_build = [&](long long mn, unsigned int mask, KeyRange* range_out) -> int {
     dense_first = s.get<unsigned int>((size_t)nslots);
     if (s.failed) return PDX_OOM;
     hipMemsetAsync(dense_first, 0xFF, (size_t)nslots * sizeof(unsigned int), st);
+    // prefix with the full first-row protocol, then the bitmap-filtered tail; the tail kernel is tile shaped and also emits the
+    // per-tile histogram of the first sort digit
+    const int64_t ntiles = ceil_div(n, kSortTile), nchunks = ceil_div(ntiles, kColChunk);
+    const int bits0 = make_sort_plan(ilog2((uint64_t)nslots), sort_max_bits()).bits[0];
+    int64_t prefix = std::min<int64_t>(n, std::max<int64_t>((int64_t)1 << 22, 16 * nslots));
+    prefix = std::min<int64_t>(n, round_up(prefix, kSortTile));
+    const bool fuse = bits0 >= 4 && bits0 <= 8;
+    const int64_t nwords = (nslots + 31) >> 5;
+    const int64_t tile_first_tail = prefix / kSortTile;
+    const bool lds_bitmap = fuse && lds_ok && prefix < n && nwords <= kDenseLdsWords && ntiles - tile_first_tail >= 256;
+    if (range_out && !lds_bitmap) return fail(PDX_DEVICE, "dense_build: fused key range needs the LDS tail");
+    uint32_t* chunk_sum = nullptr;
+    if (fuse) {
+      gb->pass0_off = gb->own<uint32_t>((size_t)ntiles << bits0);
+      chunk_sum = s.get<uint32_t>((size_t)(nchunks + 1) << bits0);  // + digit totals row
+      if (!gb->pass0_off || s.failed) return PDX_OOM;
+    }
+    KeyRange* wg_range = nullptr;
+    if (range_out) {
+      wg_range = s.get<KeyRange>((size_t)kCUs);
+      if (s.failed) return PDX_OOM;
+    }
     {
-      // prefix with the full first-row protocol, then the bitmap-filtered tail; the tail kernel is tile shaped and also emits the
-      // per-tile histogram of the first sort digit (prefix tiles get theirs from the plain histogram kernel)
-      const int64_t ntiles = ceil_div(n, kSortTile), nchunks = ceil_div(ntiles, kColChunk);
-      const int bits0 = make_sort_plan(ilog2((uint64_t)nslots), sort_max_bits()).bits[0];
-      int64_t prefix = std::min<int64_t>(n, std::max<int64_t>((int64_t)1 << 22, 16 * nslots));
-      prefix = std::min<int64_t>(n, round_up(prefix, kSortTile));
-      const bool fuse = bits0 >= 4 && bits0 <= 8;
-      uint32_t* chunk_sum = nullptr;
-      if (fuse) {
-        gb->pass0_off = gb->own<uint32_t>((size_t)ntiles << bits0);
-        chunk_sum = s.get<uint32_t>((size_t)(nchunks + 1) << bits0);  // + digit totals row
-        if (!gb->pass0_off || s.failed) return PDX_OOM;
-      }
-      {
-        PDX_PROFILE("dense_slots", st);
-        hipLaunchKernelGGL(k_dense_slots, dim3(grid_for(prefix, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, prefix, dense_min, null_slot,
-                           dense_first, gb->slot_of_row);
-        if (prefix < n) {
-          uint32_t* seen = s.get<uint32_t>((size_t)((nslots + 31) >> 5));
-          if (s.failed) return PDX_OOM;
-          hipLaunchKernelGGL(k_seen_bitmap, dim3(grid_for((nslots + 31) >> 5, 256)), dim3(256), 0, st, dense_first, nslots, seen);
-          const int64_t tile0 = prefix / kSortTile;
-          const unsigned tail_tiles = (unsigned)(ntiles - tile0);
-          const int64_t nwords = (nslots + 31) >> 5;
-          static const bool lds_ok = [] { const char* e = getenv("PDX_DENSE_LDS"); return !(e && e[0] == '0'); }();
-          const bool lds_bitmap = lds_ok && nwords <= kDenseLdsWords && tail_tiles >= 256;
+      PDX_PROFILE("dense_slots", st);
+      hipLaunchKernelGGL(k_dense_slots, dim3(grid_for(prefix, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, prefix, mn, mask, null_slot,
+                         dense_first, gb->slot_of_row);
+      if (prefix < n) {
+        uint32_t* seen = s.get<uint32_t>((size_t)nwords);
+        if (s.failed) return PDX_OOM;
+        hipLaunchKernelGGL(k_seen_bitmap, dim3(grid_for(nwords, 256)), dim3(256), 0, st, dense_first, nslots, seen);
+        const unsigned tail_tiles = (unsigned)(ntiles - tile_first_tail);
+        // the LDS tail walks ALL tiles (slots, histogram and key range of the prefix rows too; first-row tracking from `prefix` on)
 #define TAIL_HIST(B)                                                                                                                              \
   if (lds_bitmap)                                                                                                                                 \
-    hipLaunchKernelGGL((k_dense_slots_tail_hist_lds<B>), dim3(kCUs), dim3(kDenseLdsBlock), 0, st, keys, valid, key->offset, tile0, ntiles, n,       \
-                       dense_min, null_slot, seen, (int)nwords, dense_first, gb->slot_of_row, gb->pass0_off);                                      \
+    hipLaunchKernelGGL((k_dense_slots_tail_hist_lds<B>), dim3(kCUs), dim3(kDenseLdsBlock), 0, st, keys, valid, key->offset, (int64_t)0, ntiles, n,  \
+                       mn, mask, null_slot, seen, (int)nwords, prefix, dense_first, gb->slot_of_row, gb->pass0_off, wg_range);                    \
   else                                                                                                                                            \
-    hipLaunchKernelGGL((k_dense_slots_tail_hist<B>), dim3(tail_tiles), dim3(kSortBlock), 0, st, keys, valid, key->offset, tile0, n, dense_min,     \
-                       null_slot, seen, dense_first, gb->slot_of_row, gb->pass0_off)
-          if (!fuse)
-            hipLaunchKernelGGL(k_dense_slots_tail, dim3(grid_for(n - prefix, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, prefix, n, dense_min,
-                               null_slot, seen, dense_first, gb->slot_of_row);
-          else if (bits0 == 4) TAIL_HIST(4);
-          else if (bits0 == 5) TAIL_HIST(5);
-          else if (bits0 == 6) TAIL_HIST(6);
-          else if (bits0 == 7) TAIL_HIST(7);
-          else TAIL_HIST(8);
+    hipLaunchKernelGGL((k_dense_slots_tail_hist<B>), dim3(tail_tiles), dim3(kSortBlock), 0, st, keys, valid, key->offset, tile_first_tail, n, mn,  \
+                       mask, null_slot, seen, dense_first, gb->slot_of_row, gb->pass0_off)
+        if (!fuse)
+          hipLaunchKernelGGL(k_dense_slots_tail, dim3(grid_for(n - prefix, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, prefix, n, mn, mask,
+                             null_slot, seen, dense_first, gb->slot_of_row);
+        else if (bits0 == 4) TAIL_HIST(4);
+        else if (bits0 == 5) TAIL_HIST(5);
+        else if (bits0 == 6) TAIL_HIST(6);
+        else if (bits0 == 7) TAIL_HIST(7);
+        else TAIL_HIST(8);
 #undef TAIL_HIST
-        }
       }
-      if (fuse) {
-        // histogram of the prefix tiles (the prefix is a whole number of tiles unless it is the whole input), then the column scan
+    }
+    PDX_LAUNCH_CHECK();
+    if (fuse) {
+      if (!lds_bitmap) {
+        // histogram of the prefix tiles (the prefix is a whole number of tiles unless it is the whole input)
 #define PREFIX_HIST(B) hipLaunchKernelGGL((k_radix_hist<B>), dim3((unsigned)ceil_div(prefix, kSortTile)), dim3(kSortBlock), 0, st, gb->slot_of_row, prefix, 0, \
                                           gb->pass0_off)
         if (bits0 == 4) PREFIX_HIST(4);
@@ -1336,10 +1414,112 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
         else if (bits0 == 7) PREFIX_HIST(7);
         else PREFIX_HIST(8);
 #undef PREFIX_HIST
-        int rcs = radix_scan_dispatch(bits0, gb->pass0_off, ntiles, chunk_sum, true, st);
-        if (rcs != PDX_OK) return rcs;
+      }
+      int rcs = radix_scan_dispatch(bits0, gb->pass0_off, ntiles, chunk_sum, true, st);
+      if (rcs != PDX_OK) return rcs;
+    }
+    if (range_out) {
+      std::vector<KeyRange> h((size_t)kCUs);
+      PDX_HIP(hipMemcpyAsync(h.data(), wg_range, sizeof(KeyRange) * kCUs, hipMemcpyDeviceToHost, st));
+      PDX_HIP(hipStreamSynchronize(st));
+      KeyRange r{0x7FFFFFFFFFFFFFFFll, (long long)0x8000000000000000ull, 0, 0};
+      for (const KeyRange& w : h)
+        if (w.any) {
+          r.vmin = std::min(r.vmin, w.vmin);
+          r.vmax = std::max(r.vmax, w.vmax);
+          r.any = 1;
+        }
+      *range_out = r;
+    }
+    return PDX_OK;
+  };
+
+  MinMaxPartial<long long> mm;
+  bool have_mm = false;
+  // ---- speculative single pass: guess the width of the key window from a sample, build the residue-form dense domain and the
+  // exact min/max together (saves the separate 8 B/row min/max pass), accept when the exact span fits the guessed width
+  static const bool spec_ok = [] { const char* e = getenv("PDX_DENSE_SPECULATE"); return !(e && e[0] == '0'); }();
+  if (allow_dense && spec_ok && lds_ok && n >= ((int64_t)1 << 23)) {
+    KeyRange* dsample = s.get<KeyRange>(64);
+    if (s.failed) return PDX_OOM;
+    hipLaunchKernelGGL(k_sample_key_range, dim3(64), dim3(1024), 0, st, keys, valid, key->offset, n, dsample);
+    KeyRange hsv[64];
+    PDX_HIP(hipMemcpyAsync(hsv, dsample, sizeof(hsv), hipMemcpyDeviceToHost, st));
+    PDX_HIP(hipStreamSynchronize(st));
+    KeyRange hs{0x7FFFFFFFFFFFFFFFll, (long long)0x8000000000000000ull, 0, 0};
+    for (const KeyRange& w : hsv)
+      if (w.any) {
+        hs.vmin = std::min(hs.vmin, w.vmin);
+        hs.vmax = std::max(hs.vmax, w.vmax);
+        hs.any = 1;
+      }
+    int b = 64;
+    if (hs.any) {
+      const unsigned long long span_s = (unsigned long long)hs.vmax - (unsigned long long)hs.vmin;
+      b = 4;
+      while (b < 64 && (span_s >> b)) ++b;  // smallest width (>= 4 bits) with sample span < 2^b
+    }
+    if (b <= 20 && (1ull << b) <= dense_lim) {
+      dense_mask = (1u << b) - 1;
+      null_slot = 1u << b;
+      nslots = (int64_t)null_slot + (valid ? 1 : 0);
+      gb->slot_of_row = gb->own<uint32_t>((size_t)n);
+      if (!gb->slot_of_row) return PDX_OOM;
+      KeyRange exact;
+      PDX_TRY(dense_build(0, dense_mask, &exact));
+      mm.vmin = exact.vmin;
+      mm.vmax = exact.vmax;
+      mm.rmin = mm.rmax = exact.any ? 0 : -1;
+      have_mm = true;
+      if (exact.any && (unsigned long long)exact.vmax - (unsigned long long)exact.vmin <= dense_mask) {
+        gb->dense = 1;
+        dense_min = exact.vmin;
+      } else {
+        // the window is wider than the sample suggested (or there is no valid key at all): redo on the exact range below
+        dense_mask = 0;
+        dense_first = nullptr;
+        while (!gb->owned.empty()) {
+          pool_free(gb->owned.back());
+          gb->owned.pop_back();
+        }
+        gb->slot_of_row = nullptr;
+        gb->pass0_off = nullptr;
       }
     }
+  }
+  if (!gb->dense) {
+    if (!have_mm) {
+      int rc0 = minmax_keys_host(keys, valid, key->offset, n, &mm, s, st);
+      if (rc0 != PDX_OK) return rc0;
+    }
+    if (allow_dense && mm.rmin >= 0) {
+      unsigned long long span = (unsigned long long)mm.vmax - (unsigned long long)mm.vmin;  // range - 1
+      if (span < dense_lim) {
+        gb->dense = 1;
+        dense_min = mm.vmin;
+        null_slot = (unsigned int)span + 1;
+        nslots = (int64_t)null_slot + 1;
+      }
+    } else if (allow_dense && mm.rmin < 0) {  // every key is null: one group
+      gb->dense = 1;
+      null_slot = 0;
+      nslots = 1;
+    }
+    if (gb->dense) {
+      gb->slot_of_row = gb->own<uint32_t>((size_t)n);
+      if (!gb->slot_of_row) return PDX_OOM;
+      PDX_TRY(dense_build(dense_min, 0, nullptr));
+    }
+  }
+  unsigned int region = 0;  // != 0: partitioned hash table (logical slot = (index in region << kPartBits) | bucket)
+  const char* penv = getenv("PDX_HASH_PARTITION");
+  const bool use_partition = !gb->dense && !(penv && penv[0] == '0') && (n >= ((int64_t)1 << 18) || (penv && penv[0] == '2'));
+  if (!use_partition && !gb->dense) {
+    gb->slot_of_row = gb->own<uint32_t>((size_t)n);
+    if (!gb->slot_of_row) return PDX_OOM;
+  }
+  if (gb->dense) {
+    // (built above)
   } else if (use_partition) {
     // ---- general keys, partitioned build: hash -> stable partition by the low 8 hash bits (== first LSD pass of the sort by slot)
     const int64_t ntiles = ceil_div(n, kSortTile), nchunks = ceil_div(ntiles, kColChunk);
@@ -1474,7 +1654,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
                                   &ks, &vs, true, s, st);
   if (rc != PDX_OK) return rc;
   int g = grid_for(G, 256);
-  hipLaunchKernelGGL(k_assign_gids, dim3(g), dim3(256), 0, st, table, dense_min, gb->gid_of_slot, ks, vs, G, null_slot, gb->uniques,
+  hipLaunchKernelGGL(k_assign_gids, dim3(g), dim3(256), 0, st, table, dense_min, dense_mask, gb->gid_of_slot, ks, vs, G, null_slot, gb->uniques,
                      gb->unique_ok, gb->first_rows, region);
   hipLaunchKernelGGL(k_gid_of_occ, dim3(g), dim3(256), 0, st, gb->gid_of_slot, gb->occ_slot, G, gb->gid_of_occ);
   hipError_t e = hipGetLastError();

@@ -526,3 +526,43 @@ def test_resample_large_vs_oracle(px):
     labels, means, _ = orc.resample_agg(orc.AGG_MEAN, ts, v, 60 * 10**9)
     assert np.array_equal(r.index().to_numpy()[0], labels)
     assert_f64_bits(r.mean()["v"].values(), means)
+
+
+@pytest.mark.parametrize("case", ["uniform", "outlier_small", "outlier_huge", "null_keys", "negative", "window_edge", "no_spec"])
+def test_groupby_dense_speculation(px, monkeypatch, case):
+    """>= 2^23 rows: the dense build speculates on the width of the key window from a 65536-key sample and computes the exact
+    min/max in the same pass (residue slots, key & mask).  Accepted guesses, rejected guesses (an unsampled outlier widens the
+    window -> exact dense domain, or far outlier -> hash table), null keys (extra slot), negative keys and windows that straddle a
+    multiple of 2^b must all give the oracle's groups in first-occurrence order with bit-equal sums."""
+    n = 9_000_011
+    keys = orc.synth_keys(0, n, 100_000)
+    kvalid = None
+    if case == "outlier_small":
+        keys = keys % 1000
+        keys[1] = 5000            # index 1 is not a sample point (stride ~137 rows): sample says 10 bits, exact span needs 13
+    elif case == "outlier_huge":
+        keys[12345] = 1 << 40
+    elif case == "null_keys":
+        kvalid = np.ones(n, bool)
+        kvalid[::9] = False
+    elif case == "negative":
+        keys = keys - 50_000
+    elif case == "window_edge":
+        keys = keys + (1 << 17) - 7    # [2^17 - 7, 2^17 - 7 + 1e5): residues wrap around
+    elif case == "no_spec":
+        monkeypatch.setenv("PDX_DENSE_SPECULATE", "0")
+    vals = orc.synth_vals(0, n) - 0.5
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys, kvalid))
+    s, m, cnt = gb.agg(px.Column.from_numpy(vals), [0, 1, 4])
+    ids, uniq, uniq_null, first = orc.group_ids(keys, kvalid)
+    uk, uk_valid = gb.unique_keys().to_numpy()
+    if kvalid is None:
+        assert np.array_equal(uk, uniq)
+    else:
+        assert np.array_equal(~np.asarray(uk_valid, bool), uniq_null) and np.array_equal(uk[~uniq_null], uniq[~uniq_null])
+    assert np.array_equal(gb.first_rows().cpu().numpy(), first)
+    G = len(uniq)
+    assert_f64_bits(s.to_numpy()[0], orc.groupby_agg(orc.AGG_SUM, ids, G, vals, nthreads=8)[0], what="sum")
+    assert_f64_bits(m.to_numpy()[0], orc.groupby_agg(orc.AGG_MEAN, ids, G, vals, nthreads=8)[0], what="mean")
+    assert np.array_equal(cnt.to_numpy()[0], np.bincount(ids, minlength=G))
+    assert np.array_equal(gb.group_ids().cpu().numpy(), ids)
