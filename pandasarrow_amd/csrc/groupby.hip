@@ -106,36 +106,45 @@ __global__ void __launch_bounds__(256) k_hash_insert(const long long* __restrict
 // bucket order, so the active part of the table (a few hundred KB) stays in every XCD's L2 instead of costing one random
 // 128-byte line from the Infinity Cache per row.
 constexpr int kPartBits = 8;
-__global__ void __launch_bounds__(256) k_hash32(const long long* __restrict__ keys, const uint8_t* __restrict__ valid, int64_t off, int64_t n,
-                                                uint32_t* __restrict__ h32) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n; i += 4 * stride) {
-    long long k[4];
+// 32-bit hash of a key as the partitioned build sees it; the two keys with dedicated slots get fixed hashes whose low bits
+// equal the low bits of those slots' logical ids (cap -> 0, cap + 1 -> 1)
+__device__ __forceinline__ uint32_t key_hash32(long long k, bool is_null) {
+  uint32_t h = (uint32_t)(splitmix64((uint64_t)k) >> 32);
+  if (k == kEmptyKey) h = 1;
+  if (is_null) h = 0;
+  return h;
+}
+// bucket (low kPartBits of the hash) of every row, one byte per row, + the per-tile bucket histogram of the partition pass
+__global__ void __launch_bounds__(kSortBlock) k_hash_bucket_hist(const long long* __restrict__ keys, const uint8_t* __restrict__ valid, int64_t off,
+                                                                 int64_t n, uint8_t* __restrict__ bucket, uint32_t* __restrict__ hist) {
+  constexpr int R = 1 << kPartBits;
+  __shared__ uint32_t h[R];
+  for (int d = threadIdx.x; d < R; d += kSortBlock) h[d] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kSortTile;
+  long long k[kSortItems];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) k[u] = keys[i + u * stride];
+  for (int u = 0; u < kSortItems; ++u) {
+    int64_t i = base + u * kSortBlock + threadIdx.x;
+    k[u] = i < n ? keys[i] : 0;
+  }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      uint32_t h = (uint32_t)(splitmix64((uint64_t)k[u]) >> 32);
-      if (k[u] == kEmptyKey) h = 1;                                  // its dedicated slot cap + 1 has low bits 1
-      if (valid && !bit_get(valid, off + i + u * stride)) h = 0;     // the null slot `cap` has low bits 0
-      h32[i + u * stride] = h;
-    }
+  for (int u = 0; u < kSortItems; ++u) {
+    int64_t i = base + u * kSortBlock + threadIdx.x;
+    if (i >= n) continue;
+    const uint32_t b = key_hash32(k[u], valid && !bit_get(valid, off + i)) & (R - 1);
+    bucket[i] = (uint8_t)b;
+    atomicAdd(&h[b], 1u);
   }
-  for (; i < n; i += stride) {
-    long long k = keys[i];
-    uint32_t h = (uint32_t)(splitmix64((uint64_t)k) >> 32);
-    if (k == kEmptyKey) h = 1;
-    if (valid && !bit_get(valid, off + i)) h = 0;
-    h32[i] = h;
-  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < R; d += kSortBlock) hist[(int64_t)blockIdx.x * R + d] = h[d];
 }
 constexpr int kProbeTiles = 4;
 // inputs in partitioned order; rows carry the null flag in bit 31.  U rows per thread are kept in flight: the stream loads and
 // the first table probe of all U rows are issued before any of them is consumed.
 template <int U>
 __global__ void __launch_bounds__(256) k_hash_probe_part(const long long* __restrict__ keys_part, const uint32_t* __restrict__ rows_part,
-                                                         const uint32_t* __restrict__ h32_part, int64_t n, Slot* table, unsigned int cap,
+                                                         int64_t n, Slot* table, unsigned int cap,
                                                          unsigned int region, unsigned int limit, uint32_t* __restrict__ slot_part,
                                                          HashCtl* ctl) {
   // One contiguous run of kProbeTiles*U*256 partition-ordered rows per workgroup, runs dispatched in order: the workgroups
@@ -158,10 +167,10 @@ __global__ void __launch_bounds__(256) k_hash_probe_part(const long long* __rest
       act[u] = p < n;
       row[u] = act[u] ? rows_part[p] : 0u;
       key[u] = act[u] ? keys_part[p] : 0;
-      h[u] = act[u] ? h32_part[p] : 0u;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      h[u] = key_hash32(key[u], row[u] >> 31);
       const unsigned int b = h[u] & ((1u << kPartBits) - 1);
       idx[u] = (h[u] >> kPartBits) & rmask;
       phys[u] = b * region + idx[u];
@@ -224,7 +233,7 @@ __global__ void __launch_bounds__(256) k_hash_probe_part(const long long* __rest
 constexpr int kLdsRegionMax = 8192;
 constexpr int kProbeBlock = 1024;
 __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long* __restrict__ keys_part, const uint32_t* __restrict__ rows_part,
-                                                                const uint32_t* __restrict__ h32_part, const uint32_t* __restrict__ bucket_off,
+                                                                const uint32_t* __restrict__ bucket_off,
                                                                 int64_t n, Slot* table, unsigned int cap, unsigned int region,
                                                                 uint32_t* __restrict__ slot_part, HashCtl* ctl) {
   __shared__ unsigned long long lkeys[kLdsRegionMax];
@@ -259,11 +268,11 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
       act[u] = p < end;
       row[u] = act[u] ? rows_part[p] : 0u;
       key[u] = act[u] ? keys_part[p] : 0;
-      h[u] = act[u] ? h32_part[p] : 0u;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (!act[u]) continue;
+      h[u] = key_hash32(key[u], row[u] >> 31);
       const unsigned int r = row[u] & 0x7FFFFFFFu;
       unsigned int logical;
       if ((row[u] >> 31) || key[u] == kEmptyKey) {  // null key / INT64_MIN key: dedicated global slots (rare)
@@ -1198,7 +1207,7 @@ struct pdx_groupby {
   int slot_bits = 0;
   int dense = 0;                    // 1: slots are key - min (dense integer key domain), 0: open-addressing hash table
   // partitioned hash build (slot_of_row == nullptr): rows live in hash-partition order
-  uint32_t* h32 = nullptr;          // n, row order: low kPartBits = partition
+  uint8_t* bucket8 = nullptr;          // n, row order: low kPartBits = partition
   uint32_t* part_off = nullptr;     // [tiles][256] scatter offsets of the partition pass
   uint32_t* slot_part = nullptr;    // n, logical slot per partitioned position
   uint32_t* rows_part = nullptr;    // n, original row (bit 31: key is null)
@@ -1258,7 +1267,7 @@ static int sort_values_by_slot(pdx_groupby* gb, const uint64_t* vals, const uint
   if (gb->slot_part) {
     uint64_t* vals_part = static_cast<uint64_t*>(alloc((size_t)n * 8));
     if (!vals_part) return PDX_OOM;
-    PDX_TRY((radix_scatter_only<kPartBits, uint64_t>(gb->h32, vals, nullptr, vals_part, n, 0, false, gb->part_off, st)));
+    PDX_TRY((radix_scatter_only<kPartBits, uint64_t, uint8_t>(gb->bucket8, vals, nullptr, vals_part, n, 0, false, gb->part_off, st)));
     const uint32_t* kin = gb->slot_part;
     if (vvalid) {
       uint32_t* fk = static_cast<uint32_t*>(alloc((size_t)n * 4));
@@ -1436,6 +1445,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
 
   MinMaxPartial<long long> mm;
   bool have_mm = false;
+  bool sample_rules_out_dense = !allow_dense;
   // ---- speculative single pass: guess the width of the key window from a sample, build the residue-form dense domain and the
   // exact min/max together (saves the separate 8 B/row min/max pass), accept when the exact span fits the guessed width
   static const bool spec_ok = [] { const char* e = getenv("PDX_DENSE_SPECULATE"); return !(e && e[0] == '0'); }();
@@ -1458,6 +1468,9 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
       const unsigned long long span_s = (unsigned long long)hs.vmax - (unsigned long long)hs.vmin;
       b = 4;
       while (b < 64 && (span_s >> b)) ++b;  // smallest width (>= 4 bits) with sample span < 2^b
+      // the sample range lies inside the exact range: a sample already too wide for the dense domain settles the question
+      // without the full min/max pass
+      if (span_s >= dense_lim) sample_rules_out_dense = true;
     }
     if (b <= 20 && (1ull << b) <= dense_lim) {
       dense_mask = (1u << b) - 1;
@@ -1487,7 +1500,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
       }
     }
   }
-  if (!gb->dense) {
+  if (!gb->dense && !sample_rules_out_dense) {
     if (!have_mm) {
       int rc0 = minmax_keys_host(keys, valid, key->offset, n, &mm, s, st);
       if (rc0 != PDX_OK) return rc0;
@@ -1523,23 +1536,25 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   } else if (use_partition) {
     // ---- general keys, partitioned build: hash -> stable partition by the low 8 hash bits (== first LSD pass of the sort by slot)
     const int64_t ntiles = ceil_div(n, kSortTile), nchunks = ceil_div(ntiles, kColChunk);
-    gb->h32 = gb->own<uint32_t>((size_t)n);
+    gb->bucket8 = gb->own<uint8_t>((size_t)n);
     gb->part_off = gb->own<uint32_t>((size_t)ntiles << kPartBits);
     gb->slot_part = gb->own<uint32_t>((size_t)n);
     gb->rows_part = gb->own<uint32_t>((size_t)n);
     uint32_t* chunk_sum = s.get<uint32_t>((size_t)(nchunks + 1) << kPartBits);  // + digit totals row
-    uint32_t* h32_part = s.get<uint32_t>((size_t)n);
     long long* keys_part = s.get<long long>((size_t)n);
-    if (s.failed || !gb->h32 || !gb->part_off || !gb->slot_part || !gb->rows_part) return PDX_OOM;
+    if (s.failed || !gb->bucket8 || !gb->part_off || !gb->slot_part || !gb->rows_part) return PDX_OOM;
     {
-      PDX_PROFILE("hash32", st);
-      hipLaunchKernelGGL(k_hash32, dim3(grid_for(n, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, n, gb->h32);
+      // one pass over the keys: bucket byte per row (kept: it is the digit of the value partition of every later aggregation)
+      // + the partition histogram
+      PDX_PROFILE("hash_bucket_hist", st);
+      hipLaunchKernelGGL(k_hash_bucket_hist, dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, keys, valid, key->offset, n, gb->bucket8, gb->part_off);
     }
-    int rcp = radix_offsets<kPartBits>(gb->h32, n, 0, gb->part_off, chunk_sum, true, st);
+    int rcp = radix_scan_only<kPartBits>(gb->part_off, ntiles, chunk_sum, true, st);
     if (rcp == PDX_OK)
-      rcp = radix_scatter_only<kPartBits, uint64_t>(gb->h32, reinterpret_cast<const uint64_t*>(keys), h32_part, reinterpret_cast<uint64_t*>(keys_part), n, 0,
-                                                    true, gb->part_off, st);
-    if (rcp == PDX_OK) rcp = radix_scatter_iota<kPartBits>(gb->h32, nullptr, gb->rows_part, n, 0, false, gb->part_off, valid, key->offset, st);
+      rcp = radix_scatter_only<kPartBits, uint64_t, uint8_t>(gb->bucket8, reinterpret_cast<const uint64_t*>(keys), nullptr,
+                                                             reinterpret_cast<uint64_t*>(keys_part), n, 0, false, gb->part_off, st);
+    if (rcp == PDX_OK)
+      rcp = radix_scatter_iota<kPartBits, uint8_t>(gb->bucket8, nullptr, gb->rows_part, n, 0, false, gb->part_off, valid, key->offset, st);
     if (rcp != PDX_OK) return rcp;
     uint64_t want = std::max<uint64_t>(next_pow2((uint64_t)n * 2), 1u << 16);
     unsigned int cap = (unsigned int)std::min<uint64_t>(want, 1u << 21);
@@ -1554,11 +1569,11 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
       if (region <= (unsigned)kLdsRegionMax && !(lenv && lenv[0] == '0')) {
         PDX_PROFILE("hash_probe_lds", st);
         // bucket starts = offsets row of tile 0 of the partition pass
-        hipLaunchKernelGGL(k_hash_probe_lds, dim3(1 << kPartBits), dim3(kProbeBlock), 0, st, keys_part, gb->rows_part, h32_part, gb->part_off, n, table, cap,
+        hipLaunchKernelGGL(k_hash_probe_lds, dim3(1 << kPartBits), dim3(kProbeBlock), 0, st, keys_part, gb->rows_part, gb->part_off, n, table, cap,
                            region, gb->slot_part, ctl);
       } else {
         PDX_PROFILE("hash_probe_part", st);
-        hipLaunchKernelGGL((k_hash_probe_part<4>), dim3((unsigned int)ceil_div(n, 1024 * kProbeTiles)), dim3(256), 0, st, keys_part, gb->rows_part, h32_part, n, table, cap, region,
+        hipLaunchKernelGGL((k_hash_probe_part<4>), dim3((unsigned int)ceil_div(n, 1024 * kProbeTiles)), dim3(256), 0, st, keys_part, gb->rows_part, n, table, cap, region,
                            limit, gb->slot_part, ctl);
       }
       HashCtl h;
