@@ -91,7 +91,11 @@ typedef enum pdx_compare_op { PDX_EQ = 0, PDX_NE = 1, PDX_LT = 2, PDX_LE = 3, PD
 typedef enum pdx_logical_op { PDX_AND = 0, PDX_OR = 1 } pdx_logical_op;
 typedef enum pdx_agg_kind { PDX_AGG_SUM = 0, PDX_AGG_MEAN = 1, PDX_AGG_MIN = 2, PDX_AGG_MAX = 3, PDX_AGG_COUNT = 4 } pdx_agg_kind;
 typedef enum pdx_origin {
-  PDX_ORIGIN_EPOCH = 0, PDX_ORIGIN_START_DAY = 1, PDX_ORIGIN_START = 2, PDX_ORIGIN_END = 3, PDX_ORIGIN_END_DAY = 4, PDX_ORIGIN_CUSTOM = 5
+  PDX_ORIGIN_EPOCH = 0, PDX_ORIGIN_START_DAY = 1, PDX_ORIGIN_START = 2, PDX_ORIGIN_END = 3, PDX_ORIGIN_END_DAY = 4, PDX_ORIGIN_CUSTOM = 5,
+  /* OR-ed into origin_type by a multi-GPU caller whose `ts` is one row-range shard of a longer axis (bins made whole by the caller,
+   * origin passed as PDX_ORIGIN_CUSTOM from the whole axis): the rows < bins test ("upSampling") belongs to the whole axis, which
+   * the caller has already checked, so it is not applied to the shard */
+  PDX_ORIGIN_SHARD = 0x100
 } pdx_origin;
 
 /* ---------------------------------------------------------------- runtime */
@@ -217,7 +221,7 @@ int pdx_replay_partials(const int64_t* rec_key, const double* rec_val, int64_t m
  * src/group_by.h:255-299).  ts: sorted PDX_TIMESTAMP_NS without nulls.  The handle behaves like a pdx_groupby whose
  * unique keys are the labels of the NON-EMPTY bins (empty bins vanish, as in the reference).
  * Errors (PDX_INVALID): "Values falls before first bin", "Values falls after last bin",
- * "upSampling is not implemented.", unsorted input. */
+ * "upSampling is not implemented.", unsorted input.  Row-range shards of one axis: see PDX_ORIGIN_SHARD. */
 int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right, int label_right, int origin_type,
                         int64_t origin_custom_ns, int64_t offset_ns, void* stream, pdx_groupby** out);
 /* per-row labels (GroupInfo::downsample): device pointer to num_rows int64 */

@@ -311,11 +311,12 @@ def resample_group_info(ts, freq_ns, closed_right=False, label_right=False, orig
     return bins[:nb].copy(), labels[:nb].copy()
 
 
-def resample_row_labels(ts, freq_ns, **kw):
+def resample_row_labels(ts, freq_ns, shard=False, **kw):
+    """shard=True: `ts` is one row-range shard of a longer axis whose rows < bins test was done by the caller (multi-rank tests)."""
     bins, labels = resample_group_info(ts, freq_ns, **kw)
     out = np.zeros(len(ts), np.int64)
     if len(bins):
-        if bins[-1] < len(labels):
+        if bins[-1] < len(labels) and not shard:
             raise OracleError(INVALID, "upSampling is not implemented.")
         lib().orc_resample_expand(_p(bins), _p(labels), _i64(len(bins)), _p(out))
     return out

@@ -1878,6 +1878,8 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
   auto floor_div = [](long long a, long long b) { long long q = a / b, r = a % b; return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q; };
   const long long day = 86400000000000LL;
   long long first = mn, last = mx, origin = 0;
+  const bool is_shard = (origin_type & PDX_ORIGIN_SHARD) != 0;
+  origin_type &= ~PDX_ORIGIN_SHARD;
   switch (origin_type) {
     case PDX_ORIGIN_EPOCH: origin = 0; break;
     case PDX_ORIGIN_START_DAY: origin = floor_div(first, day) * day; break;
@@ -1901,7 +1903,7 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
   if (mn < first) return fail(PDX_INVALID, "Values falls before first bin");
   if (mx > last_edge) return fail(PDX_INVALID, "Values falls after last bin");
   long long nbins = nedges - 1;
-  if (n < nbins) return fail(PDX_INVALID, "upSampling is not implemented.");  // GroupInfo::upsampling, src/resample.h:14-17
+  if (n < nbins && !is_shard) return fail(PDX_INVALID, "upSampling is not implemented.");  // GroupInfo::upsampling, src/resample.h:14-17
   gb->bin = BinParams{t, first, freq_ns, 1.0 / (double)freq_ns, closed_right};
   gb->label_base = first + (label_right ? freq_ns : 0);
   // non-empty bins: boundaries where the bin index changes (timestamps are sorted)

@@ -183,6 +183,24 @@ class HipEngine:
     def replay(self, rec_key, rec_val, gid_lo, n_own):
         return self.K.replay_partials(rec_key, rec_val, gid_lo, n_own)
 
+    # ---- whole-column aggregates / resample / concat over shards
+    def length(self, col):
+        return col.length
+
+    def aggregate(self, kind, col):
+        return self.K.aggregate(kind, col)
+
+    def to_f64(self, col):
+        return self.K.binary(L.MUL, col, 1.0)  # int64 * float64 -> float64 (Arrow's implicit cast)
+
+    def count_below(self, ts_col, edge, inclusive):
+        """rows with ts < edge (<= when inclusive)."""
+        as_int = self.K.Column(L.INT64, ts_col.length, ts_col.values, None, ts_col.offset)
+        return self.K.filter_count(self.K.compare(L.LE if inclusive else L.LT, as_int, int(edge)))
+
+    def resample(self, ts_col, freq_ns, closed_right, label_right, origin, origin_custom_ns, offset_ns):
+        return self.K.GroupByHandle.resample(ts_col, freq_ns, closed_right, label_right, origin, origin_custom_ns, offset_ns)
+
     def select_tensor_eq(self, tensors, by: torch.Tensor, value):
         """stable selection of rows of 1-D int64/float64 tensors where by == value (through the filter kernels)."""
         by_col = self.col(by, L.INT64)
@@ -334,4 +352,205 @@ def check_result(res, n_total):
             out["mean_is_sum_over_count"] = bool(torch.equal(m, s / cnt.to(torch.float64)))
     fr = res["first_rows"]
     out["first_occurrence_order"] = bool((fr[1:] > fr[:-1]).all().item()) if fr.numel() > 1 else True
+    return out
+
+
+# ---------------------------------------------------------------- sharded whole-column aggregates (SURVEY.md 8e, "whole-array sum")
+def _gather_scalars(t: torch.Tensor):
+    """[W, k] stack of a small per-rank tensor, rank order."""
+    W, _ = _world()
+    if W == 1:
+        return t[None]
+    out = [torch.empty_like(t) for _ in range(W)]
+    dist.all_gather(out, t)
+    return torch.stack(out)
+
+
+def aggregate_sharded(engine, col, kind):
+    """``Series::sum/mean/min/max/count`` (src/ndframe.cpp:26-31, 119, 162-166, 220) of a column sharded by row ranges in rank
+    order.  Returns (value | None, valid count) on every rank, bit-identical to the single-process result:
+
+      count / min / max / int64 sum  -- order-free: per-shard scalars, all-gathered, folded in rank order (min/max keep the FIRST
+                                        of ties, as the kernels do; int64 sum wraps)
+      float64 sum, float64/int64 mean -- Arrow's pairwise tree is order sensitive.  Without nulls the whole column is ONE group of
+                                        the partial-tree exchange (boundary-leaf fragments + aligned subtree nodes per shard,
+                                        replayed by one owner); with nulls the 16-value leaves restart at every run of valid
+                                        rows, so the rows themselves are routed to one owner (correctness path)."""
+    W, r = _world()
+    dev = engine.device
+    if W == 1:
+        return engine.aggregate(kind, col)
+    is_f = engine.dtype_of(col) == L.FLOAT64
+    if kind == L.AGG_COUNT or kind in (L.AGG_MIN, L.AGG_MAX) or (kind == L.AGG_SUM and not is_f):
+        v, cnt = engine.aggregate(kind, col)
+        dt = torch.float64 if is_f and kind != L.AGG_COUNT else torch.int64
+        vals = _gather_scalars(torch.tensor([0 if v is None else v], dtype=dt, device=dev))[:, 0].tolist()
+        meta = _gather_scalars(torch.tensor([0 if v is None else 1, cnt], dtype=torch.int64, device=dev)).tolist()
+        total = sum(m[1] for m in meta)
+        if kind == L.AGG_COUNT:
+            return total, total
+        have = [x for x, m in zip(vals, meta) if m[0]]
+        if not have:
+            return None, total
+        if kind == L.AGG_SUM:
+            acc = 0
+            for x in have:
+                acc = (acc + int(x) + (1 << 63)) % (1 << 64) - (1 << 63)  # two's-complement wrap
+            return acc, total
+        best = None
+        for x in have:  # rank order; NaN never replaces a number, a number always replaces NaN
+            if best is None or (best != best and x == x) or (x < best if kind == L.AGG_MIN else x > best):
+                best = x
+        return best, total
+    # order-sensitive fp64 tree
+    x = col if is_f else engine.to_f64(col)
+    n_loc = engine.length(col)
+    any_nulls = any(all_gather_sizes(1 if engine.valid_bools(col) is not None else 0, dev))
+    one_group = engine.col(torch.zeros(n_loc, dtype=torch.int64, device=dev), L.INT64)
+    if not any_nulls:
+        res = groupby_sum_mean_count_sharded(engine, one_group, x, row_offset=0)
+        if res["G"] == 0:
+            return None, 0
+        cnt = int(res["outs"][2][0][0].item())
+        return float(res["outs"][0 if kind == L.AGG_SUM else 1][0][0].item()), cnt
+    res = groupby_agg_sharded(engine, one_group, x, [kind, L.AGG_COUNT])
+    if res["G"] == 0:
+        return None, 0
+    (v, ok), (c, _) = res["outs"]
+    cnt = int(c[0].item())
+    if ok is not None and not bool(ok[0].item()):
+        return None, cnt
+    return float(v[0].item()), cnt
+
+
+# ---------------------------------------------------------------- sharded concat (SURVEY.md 8e): all-gather(v) in rank order
+def concat_sharded(engine, col):
+    """``pd::concat`` (rows, src/concat.cpp:116-190) of the per-rank columns in rank order; every rank gets the whole column."""
+    dev = engine.device
+    sizes = all_gather_sizes(engine.length(col), dev)
+    v = all_gather_v(engine.values(col), sizes)
+    okb = engine.valid_bools(col)
+    ok = None
+    if any(all_gather_sizes(0 if okb is None else 1, dev)):
+        okb = torch.ones(engine.length(col), dtype=torch.bool, device=dev) if okb is None else okb
+        ok = all_gather_v(okb.to(torch.uint8), sizes).to(torch.bool)
+    return engine.col(v, engine.dtype_of(col), ok)
+
+
+# ---------------------------------------------------------------- sharded resample (SURVEY.md 8e)
+_DAY_NS = 86400000000000
+
+
+def _resample_grid(first, last, freq, closed_right, origin_type, origin_custom, offset):
+    """adjustDatesAnchored + date_range on the WHOLE axis (src/resample.cpp:85-178, src/core.cpp:308-331), exact Python ints:
+    (origin without offset, first edge, number of bins)."""
+    if origin_type == L.ORIGIN_EPOCH:
+        origin = 0
+    elif origin_type == L.ORIGIN_START_DAY:
+        origin = first // _DAY_NS * _DAY_NS
+    elif origin_type == L.ORIGIN_START:
+        origin = first
+    elif origin_type == L.ORIGIN_END:
+        origin = last
+    elif origin_type == L.ORIGIN_END_DAY:
+        origin = last // _DAY_NS * _DAY_NS
+    else:
+        origin = origin_custom
+    o = origin + offset
+
+    def cmod(a, b):  # C++ '%' (truncating), as the reference computes the offsets
+        m = abs(a) % b
+        return m if a >= 0 else -m
+
+    fo, lo = cmod(first - o, freq), cmod(last - o, freq)
+    f, l = first, last
+    if closed_right:
+        f = f - fo if fo > 0 else f - freq
+        if lo > 0:
+            l += freq - lo
+    else:
+        if fo > 0:
+            f -= fo
+        l = l + freq - lo if lo > 0 else l + freq
+    if f >= l:
+        raise L.PdxError(L.INVALID, "start date has to be less than end date")
+    nedges = (l - f) // freq + 1
+    return origin, f, nedges - 1
+
+
+def resample_agg_sharded(engine, ts, vals, kinds, freq_ns, closed_right=False, label_right=False, origin=L.ORIGIN_START_DAY,
+                         origin_custom_ns=0, offset_ns=0):
+    """``pd::resample(df, rule).{sum,mean,min,max,count}(col)`` (src/resample.h:91-122, src/group_by.h:255-299) over an axis
+    sharded by row ranges in rank order (sorted timestamps, so shards are time ranges).  Bins are made whole before any
+    arithmetic: the leading rows of a shard that fall into a bin already open on an earlier rank move to that bin's first rank
+    (one all-to-all(v); usually a few hundred rows per boundary).  Every rank then resamples its rows on the WHOLE axis' grid
+    (PDX_ORIGIN_CUSTOM | PDX_ORIGIN_SHARD) and the (label, value) rows are all-gathered in rank order == label order.
+    Returns {"labels": int64 tensor, "outs": [(values, valid|None) per kind]} on every rank."""
+    W, r = _world()
+    dev = engine.device
+    n_loc = engine.length(ts)
+    tv = engine.values(ts)
+    mine = torch.tensor([n_loc, int(tv[0].item()) if n_loc else 0, int(tv[n_loc - 1].item()) if n_loc else 0], dtype=torch.int64, device=dev)
+    info = _gather_scalars(mine).tolist()
+    live = [q for q in range(W) if info[q][0] > 0]
+    N = sum(i[0] for i in info)
+    if N == 0:
+        empty = torch.zeros(0, dtype=torch.int64, device=dev)
+        return {"labels": empty, "outs": [(torch.zeros(0, dtype=torch.float64, device=dev), None) for _ in kinds]}
+    for a, b in zip(live, live[1:]):
+        if info[a][2] > info[b][1]:
+            raise L.PdxError(L.INVALID, "pdx_resample_create: timestamps must be sorted ascending")
+    g_first, g_last = info[live[0]][1], info[live[-1]][2]
+    _, first_edge, nbins = _resample_grid(g_first, g_last, int(freq_ns), bool(closed_right), origin, int(origin_custom_ns), int(offset_ns))
+    if N < nbins:
+        raise L.PdxError(L.INVALID, "upSampling is not implemented.")  # GroupInfo::upsampling on the whole axis (src/resample.h:14-17)
+
+    def bin_of(t):  # closed left: [e_k, e_k + f); closed right: (e_k, e_k + f]
+        return (t - first_edge - (1 if closed_right else 0)) // int(freq_ns)
+
+    # the first rank holding rows of my leading bin
+    send_to, m = r, 0
+    if n_loc:
+        b0 = bin_of(info[r][1])
+        for q in reversed([q for q in live if q < r]):
+            if bin_of(info[q][2]) != b0:
+                break
+            send_to = q
+            if bin_of(info[q][1]) != b0:
+                break
+        if send_to != r:
+            upper = first_edge + (b0 + 1) * int(freq_ns)
+            m = engine.count_below(ts, upper, inclusive=bool(closed_right))
+    vok = engine.valid_bools(vals)
+    has_nulls = any(all_gather_sizes(0 if vok is None else 1, dev))
+    if W > 1:
+        vv = engine.values(vals)
+        head = [tv[:m], vv[:m]]
+        if has_nulls:
+            vok = torch.ones(n_loc, dtype=torch.bool, device=dev) if vok is None else vok
+            head.append(vok[:m].to(torch.int64))
+        recv = []
+        for h in head:
+            chunks = [h if d == send_to and d != r else h[:0] for d in range(W)]
+            recv.append(torch.cat(all_to_all_v(chunks)))
+        ts2 = engine.col(torch.cat([tv[m:], recv[0]]), engine.dtype_of(ts))
+        ok2 = torch.cat([vok[m:], recv[2].to(torch.bool)]) if has_nulls else None
+        vals2 = engine.col(torch.cat([vv[m:], recv[1]]), engine.dtype_of(vals), ok2)
+    else:
+        ts2, vals2 = ts, vals
+    # every shard is anchored at the whole axis' FIRST EDGE (not at the origin: with a negative first offset the reference's grid
+    # starts at the first timestamp itself, src/resample.cpp:85-178), so all shards bin on one grid
+    gb = engine.resample(ts2, int(freq_ns), bool(closed_right), bool(label_right), L.ORIGIN_CUSTOM | L.ORIGIN_SHARD, first_edge, 0)
+    labels, _ = engine.unique_keys(gb)
+    outs_l = engine.agg(gb, vals2, list(kinds))
+    sizes = all_gather_sizes(int(labels.numel()), dev)
+    out = {"labels": all_gather_v(labels, sizes), "outs": []}
+    for c in outs_l:
+        v = all_gather_v(engine.values(c), sizes)
+        okb = engine.valid_bools(c)
+        ok = None
+        if any(all_gather_sizes(0 if okb is None else 1, dev)):
+            okb = torch.ones(int(labels.numel()), dtype=torch.bool, device=dev) if okb is None else okb
+            ok = all_gather_v(okb.to(torch.uint8), sizes).to(torch.bool)
+        out["outs"].append((v, ok))
     return out

@@ -155,6 +155,32 @@ class OracleEngine:
         m = by == value
         return [t[m] for t in tensors]
 
+    # ---- whole-column aggregates / resample over shards
+    def length(self, col):
+        return len(col.values)
+
+    def aggregate(self, kind, col):
+        v, cnt = orc.agg(kind, col.values, col.valid)
+        return (v, v) if kind == orc.AGG_COUNT else (v, cnt)
+
+    def to_f64(self, col):
+        return OCol(col.values.astype(np.float64), col.valid, FLOAT64)
+
+    def count_below(self, ts_col, edge, inclusive):
+        return int(np.count_nonzero(ts_col.values <= edge if inclusive else ts_col.values < edge))
+
+    def resample(self, ts_col, freq_ns, closed_right, label_right, origin, origin_custom_ns, offset_ns):
+        shard = bool(origin & 0x100)
+        g = OGroup.__new__(OGroup)
+        if len(ts_col.values) == 0:
+            g.ids, g.uniq, g.isnull, g.first = np.zeros(0, np.uint32), np.zeros(0, np.int64), np.zeros(0, bool), np.zeros(0, np.int64)
+        else:
+            labels = orc.resample_row_labels(ts_col.values.astype(np.int64), freq_ns, shard=shard, closed_right=closed_right, label_right=label_right,
+                                             origin=origin & 0xFF, origin_custom_ns=origin_custom_ns, offset_ns=offset_ns)
+            g.ids, g.uniq, g.isnull, g.first = orc.group_ids(labels)
+        g.G = len(g.uniq)
+        return g
+
 
 class _Counter:
     """Arrow's binary counter with pushes at arbitrary levels."""

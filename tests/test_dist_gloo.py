@@ -106,3 +106,130 @@ def test_sharded_groupby_matches_single_process(world, name, case):
             assert np.array_equal(gv[eok], ev[eok])
     if case[2] is None and case[3] is None and case[1].dtype == np.float64:  # bench.py's size-independent properties (no nulls, fp64)
         assert all(v for v in got["check"].values() if isinstance(v, bool))
+
+
+# ---------------------------------------------------------------- sharded whole-column aggregates, resample, concat
+def _worker_ops(rank, world, port, case, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from _oracle_engine import OCol, OracleEngine
+        from pandasarrow_amd import dist as pdist
+
+        eng = OracleEngine()
+        kind, payload = case
+        cuts = payload["cuts"]
+        lo, hi = cuts[rank], cuts[rank + 1]
+        out = None
+        if kind == "agg":
+            v, ok = payload["v"], payload["ok"]
+            col = OCol(v[lo:hi], None if ok is None else ok[lo:hi])
+            out = [pdist.aggregate_sharded(eng, col, k) for k in (0, 1, 2, 3, 4)]
+            cat = pdist.concat_sharded(eng, col)
+            out.append((cat.values, cat.valid))
+        elif kind == "resample":
+            ts, v, ok = payload["ts"], payload["v"], payload["ok"]
+            try:
+                res = pdist.resample_agg_sharded(eng, OCol(ts[lo:hi], None, 2), OCol(v[lo:hi], None if ok is None else ok[lo:hi]), [0, 1, 2, 3, 4],
+                                                 payload["freq"], **payload["kw"])
+                out = {"labels": res["labels"].numpy(), "outs": [(a.numpy(), None if b is None else b.numpy()) for a, b in res["outs"]]}
+            except Exception as e:  # the whole-axis errors of the reference surface on every rank
+                out = {"error": str(e)}
+        if rank == 0:
+            q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_ops(world, case):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ops, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return out
+
+
+def _even_cuts(n, world):
+    return [n * r // world for r in range(world + 1)]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name", ["f64", "f64_nulls", "i64", "i64_nulls", "empty_rank", "all_null"])
+def test_sharded_aggregate_and_concat(world, name):
+    rng = np.random.default_rng(11)
+    n = 10007
+    ok = None
+    if name.startswith("f64") or name in ("empty_rank", "all_null"):
+        v = rng.standard_normal(n) * 10.0 ** rng.integers(-6, 9, n)
+        v[::97] = np.nan
+    else:
+        v = rng.integers(-2**62, 2**62, n).astype(np.int64)  # int64 sum wraps
+    if name.endswith("nulls"):
+        ok = rng.random(n) > 0.1
+    if name == "all_null":
+        ok = np.zeros(n, bool)
+    cuts = _even_cuts(n, world)
+    if name == "empty_rank":
+        cuts = [0] + [n] * world  # everything on rank 0
+    got = _run_ops(world, ("agg", {"v": v, "ok": ok, "cuts": cuts}))
+    for kind in (0, 1, 2, 3, 4):
+        ev, ecnt = orc.agg(kind, v, ok)
+        gv, gcnt = got[kind]
+        if kind == 4:
+            assert gv == ev
+            continue
+        assert gcnt == ecnt, (kind, gcnt, ecnt)
+        if ev is None:
+            assert gv is None
+        elif isinstance(ev, float):
+            assert np.float64(gv).view(np.uint64) == np.float64(ev).view(np.uint64), (kind, gv, ev)  # bit-exact
+        else:
+            assert gv == ev
+    cv, cok = got[5]
+    assert np.array_equal(cv.view(np.uint64), np.ascontiguousarray(v).view(np.uint64))
+    assert (cok is None and (ok is None or ok.all())) or np.array_equal(cok, ok)
+
+
+def _resample_cases():
+    rng = np.random.default_rng(5)
+    minute = 60 * 10**9
+    base = 1_600_000_000 * 10**9 + 17 * 10**9
+    n = 6000
+    ts = base + np.sort(rng.integers(0, 400 * minute, n)).astype(np.int64)
+    v = rng.standard_normal(n) * 1e3
+    yield "left_start_day", dict(ts=ts, v=v, ok=None, freq=minute, kw=dict(closed_right=False, label_right=False, origin=1))
+    yield "right_right_epoch", dict(ts=ts, v=v, ok=None, freq=7 * minute, kw=dict(closed_right=True, label_right=True, origin=0))
+    yield "start_origin_nulls", dict(ts=ts, v=v, ok=rng.random(n) > 0.2, freq=5 * minute, kw=dict(closed_right=False, label_right=True, origin=2, offset_ns=13 * 10**9))
+    # one wide bin swallows whole shards (rows of 3 ranks end up on the first), exact edges on the grid
+    ts2 = (base // minute * minute) + np.sort(np.concatenate([np.arange(0, 50) * minute, rng.integers(50 * minute, 51 * minute, 5000), 51 * minute + np.arange(950) * 1000])).astype(np.int64)
+    yield "bin_spans_ranks", dict(ts=ts2, v=rng.standard_normal(len(ts2)), ok=None, freq=minute, kw=dict(closed_right=True, label_right=False, origin=1))
+    yield "upsampling", dict(ts=base + np.arange(10, dtype=np.int64) * 100 * minute, v=np.arange(10.0), ok=None, freq=minute, kw=dict(origin=1))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name,payload", list(_resample_cases()), ids=[n for n, _ in _resample_cases()])
+def test_sharded_resample_matches_single_process(world, name, payload):
+    payload = dict(payload)
+    n = len(payload["ts"])
+    payload["cuts"] = _even_cuts(n, world) if name != "bin_spans_ranks" else [0, 2000, n] if world == 2 else [0, 2000, 4000, n]
+    got = _run_ops(world, ("resample", payload))
+    try:
+        exp = [orc.resample_agg(k, payload["ts"], payload["v"], payload["freq"], valid=payload["ok"], **payload["kw"]) for k in (0, 1, 2, 3, 4)]
+    except orc.OracleError as e:
+        assert "error" in got and str(e).split(": ")[-1] in got["error"], (got, str(e))
+        return
+    assert "error" not in got, got
+    assert np.array_equal(got["labels"], exp[0][0])
+    for (gv, gok), (_, ev, eok) in zip(got["outs"], exp):
+        eok = np.asarray(eok, bool)
+        assert (gok is None and eok.all()) or np.array_equal(gok, eok)
+        if ev.dtype == np.float64:
+            assert np.array_equal(gv.view(np.uint64)[eok], ev.view(np.uint64)[eok])
+        else:
+            assert np.array_equal(gv[eok], ev[eok])

@@ -104,3 +104,90 @@ def test_sharded_three_ranks_one_gpu():
         assert p.exitcode == 0
     _compare(got, *_data(n, nk))
     _compare_fast(got["fast"], *_data(n, nk))
+
+
+# ---------------------------------------------------------------- sharded whole-column aggregates / resample / concat (HipEngine)
+def _ops_data():
+    rng = np.random.default_rng(3)
+    n = 200_003
+    minute = 60 * 10**9
+    ts = 1_600_000_000 * 10**9 + np.sort(rng.integers(0, 900 * minute, n)).astype(np.int64)
+    v = rng.standard_normal(n) * 10.0 ** rng.integers(-4, 7, n)
+    ok = rng.random(n) > 0.07
+    iv = rng.integers(-2**62, 2**62, n).astype(np.int64)
+    return ts, v, ok, iv, minute
+
+
+def _worker_ops(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pandasarrow_amd import _lib as L
+        from pandasarrow_amd import dist as pdist
+        from pandasarrow_amd.column import Column
+
+        torch.cuda.set_device(0)
+        L.check(L.load().pdx_init(0))
+        eng = pdist.HipEngine()
+        ts, v, ok, iv, minute = _ops_data()
+        n = len(ts)
+        lo, hi = n * rank // world, n * (rank + 1) // world
+        out = {}
+        for name, col in (("f64", Column.from_numpy(v[lo:hi])), ("f64_nulls", Column.from_numpy(v[lo:hi], ok[lo:hi])), ("i64", Column.from_numpy(iv[lo:hi]))):
+            out[name] = [pdist.aggregate_sharded(eng, col, k) for k in (0, 1, 2, 3, 4)]
+        cat = pdist.concat_sharded(eng, Column.from_numpy(v[lo:hi], ok[lo:hi]))
+        out["concat"] = cat.to_numpy()
+        for name, vcol, kw in (("rs_plain", Column.from_numpy(v[lo:hi]), dict(closed_right=False, label_right=False, origin=L.ORIGIN_START_DAY)),
+                               ("rs_nulls_right", Column.from_numpy(v[lo:hi], ok[lo:hi]), dict(closed_right=True, label_right=True, origin=L.ORIGIN_START, offset_ns=7 * 10**9))):
+            res = pdist.resample_agg_sharded(eng, Column.from_numpy(ts[lo:hi], dtype=L.TIMESTAMP_NS), vcol, [0, 1, 2, 3, 4], 5 * minute, **kw)
+            out[name] = {"labels": res["labels"].cpu().numpy(), "outs": [(a.cpu().numpy(), None if b is None else b.cpu().numpy()) for a, b in res["outs"]]}
+        if rank == 0:
+            q.put(out)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_ops_three_ranks_one_gpu():
+    import torch.multiprocessing as mp
+
+    world = 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_ops, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ts, v, ok, iv, minute = _ops_data()
+    for name, (vals, valid) in (("f64", (v, None)), ("f64_nulls", (v, ok)), ("i64", (iv, None))):
+        for kind in (0, 1, 2, 3, 4):
+            ev, ecnt = orc.agg(kind, vals, valid)
+            gv, gcnt = got[name][kind]
+            if kind == 4:
+                assert gv == ev
+            elif isinstance(ev, float):
+                assert gcnt == ecnt and np.float64(gv).view(np.uint64) == np.float64(ev).view(np.uint64), (name, kind, gv, ev)
+            else:
+                assert gcnt == ecnt and gv == ev, (name, kind, gv, ev)
+    cv, cok = got["concat"]
+    assert np.array_equal(cv.view(np.uint64), v.view(np.uint64)) and np.array_equal(cok, ok)
+    for name, valid, kw in (("rs_plain", None, dict(closed_right=False, label_right=False, origin=1)),
+                            ("rs_nulls_right", ok, dict(closed_right=True, label_right=True, origin=2, offset_ns=7 * 10**9))):
+        exp = [orc.resample_agg(k, ts, v, 5 * minute, valid=valid, **kw) for k in (0, 1, 2, 3, 4)]
+        assert np.array_equal(got[name]["labels"], exp[0][0])
+        for (gv, gok), (_, ev, eok) in zip(got[name]["outs"], exp):
+            eok = np.asarray(eok, bool)
+            assert (gok is None and eok.all()) or np.array_equal(gok, eok)
+            if ev.dtype == np.float64:
+                assert np.array_equal(gv.view(np.uint64)[eok], ev.view(np.uint64)[eok]), name
+            else:
+                assert np.array_equal(gv[eok], ev[eok]), name
