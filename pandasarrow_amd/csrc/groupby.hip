@@ -543,18 +543,25 @@ __global__ void __launch_bounds__(kDenseLdsBlock) k_dense_slots_tail_hist_lds(co
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         int64_t i = base + c * 1024 + u * 64 + lane;
-        if (i >= n) continue;
+        const bool in = i < n;
         unsigned int sl = range;
-        if (!valid || bit_get(valid, off + i)) {
+        if (in && (!valid || bit_get(valid, off + i))) {
           sl = dense_slot_of(k[u], mn, mask);
           kmn = k[u] < kmn ? k[u] : kmn;
           kmx = k[u] > kmx ? k[u] : kmx;
           any = 1;
         }
         const uint32_t w = lseen[sl >> 5];
-        slot_of_row[i] = sl;
-        atomicAdd(&lh[wave][sl & (R - 1)], 1u);
-        if (!((w >> (sl & 31)) & 1u) && i >= track_from) {
+        if (in) slot_of_row[i] = sl;
+        // one LDS add per wave when every row has the same digit (few distinct keys): 64 lanes adding to one word serialise
+        const unsigned int d = sl & (R - 1), d0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)d);
+        const uint64_t act = __ballot(in), same = __ballot(in && d == d0);
+        if (same == act) {
+          if (lane == 0 && act) atomicAdd(&lh[wave][d0], (uint32_t)__popcll(act));
+        } else if (in) {
+          atomicAdd(&lh[wave][d], 1u);
+        }
+        if (in && !((w >> (sl & 31)) & 1u) && i >= track_from) {
           if ((unsigned int)i < first[sl]) atomicMin(&first[sl], (unsigned int)i);
         }
       }
@@ -701,6 +708,8 @@ struct SegOut {
 };
 
 constexpr int kSegWaves = 4;
+constexpr int64_t kBigSeg = 65536;  // rows per sub-segment of a long group = 2^12 sixteen-value leaves: a full one is ONE level-12 node
+constexpr int kBigLevels = 16;      // counter levels kept per sub-segment (0..12 are used)
 
 template <typename T>
 __device__ __forceinline__ double seg_to_f64(T x) { return (double)x; }
@@ -738,11 +747,18 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
   const int64_t nw = (int64_t)gridDim.x * kSegWaves;
   int64_t k = (int64_t)blockIdx.x * kSegWaves + wave;
   if (k >= nseg) return;
+  // groups longer than kBigSeg rows are reduced by k_seg_reduce_sub / k_seg_combine_big (many waves per group): here they
+  // are walked as empty segments whose result is not written
   int64_t s = seg_start[k], e = seg_start[k + 1];
+  bool big = e - s > kBigSeg;
+  if (big) e = s;
   int64_t s_next = 0, e_next = 0;  // bounds of group k + nw
+  bool big_next = false;
   if (k + nw < nseg) {
     s_next = seg_start[k + nw];
     e_next = seg_start[k + nw + 1];
+    big_next = e_next - s_next > kBigSeg;
+    if (big_next) e_next = s_next;
   }
   int64_t c0 = 0;
   T cur[LEAF];
@@ -782,9 +798,12 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
       }
     }
     int64_t s_nn = 0, e_nn = 0;
+    bool big_nn = false;
     if (last_chunk && nk + nw < nseg) {  // bounds two groups ahead, consumed when the next group finishes
       s_nn = seg_start[nk + nw];
       e_nn = seg_start[nk + nw + 1];
+      big_nn = e_nn - s_nn > kBigSeg;
+      if (big_nn) e_nn = s_nn;
     }
     // ---- current chunk
 #pragma unroll
@@ -856,7 +875,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
       if (WANT_ISUM) {
         for (int d = 32; d > 0; d >>= 1) isum += __shfl_down(isum, d, 64);
       }
-      if (lane == 0) {
+      if (lane == 0 && !big) {
         if (WANT_PAIRWISE) {
           if (out.sum_f) out.sum_f[oi] = total;
           if (out.mean) out.mean[oi] = total / (double)len;
@@ -877,8 +896,10 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
       mask = 0;
       root = 0;
       single = 0.0;
+      big = big_next;
       s_next = s_nn;
       e_next = e_nn;
+      big_next = big_nn;
       if (WANT_PAIRWISE && (ne - ns) > kSegChunk) {
         __builtin_amdgcn_wave_barrier();
         if (lane < 48) csum[lane] = 0.0;
@@ -902,6 +923,7 @@ __global__ void __launch_bounds__(256) k_seg_reduce_small(const T* __restrict__ 
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += stride) {
     const int64_t s = seg_start[k], e = seg_start[k + 1];
+    if (e - s > kBigSeg) continue;  // reduced by k_seg_reduce_sub / k_seg_combine_big
     const uint32_t oi = out_index ? out_index[k] : (uint32_t)k;
     PairwiseCounter c;
     if (WANT_PAIRWISE) c.init();
@@ -939,6 +961,199 @@ __global__ void __launch_bounds__(256) k_seg_reduce_small(const T* __restrict__ 
     }
     if (out.count) out.count[oi] = (long long)(e - s);
   }
+}
+
+// ---------------------------------------------------------------- long groups: many waves per group.
+// A group of more than kBigSeg rows is cut into sub-segments of kBigSeg rows (aligned to the group start, so every full
+// sub-segment is a perfect subtree of 2^12 leaves = one level-12 node of Arrow's counter).  One wave reduces one sub-segment to
+// its counter state; one thread per long group then replays the states in order (full ones are a single level-12 push, the last
+// one pushes its <= 13 nodes from the highest level down, which is legal because everything before it is 2^12-aligned).
+template <typename T>
+struct SubState {
+  double csum[kBigLevels];
+  unsigned long long mask;
+  unsigned long long isum;
+  T vmin, vmax;
+  long long rmin, rmax;
+};
+struct BigPred {
+  const uint32_t* seg_start;
+  __device__ bool operator()(int64_t k) const { return (int64_t)seg_start[k + 1] - (int64_t)seg_start[k] > kBigSeg; }
+};
+struct BigEmit {
+  uint32_t* big_idx;
+  __device__ void operator()(int64_t pos, int64_t k) const { big_idx[pos] = (uint32_t)k; }
+};
+// item_off[b] = first work item (sub-segment) of long group b; item_off[B] = number of items.  One workgroup.
+__global__ void __launch_bounds__(256) k_big_offsets(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ big_idx, int64_t B,
+                                                     int64_t* __restrict__ item_off) {
+  __shared__ int64_t smem[8];
+  int64_t carry = 0;
+  for (int64_t b0 = 0; b0 < B; b0 += 256) {
+    int64_t b = b0 + threadIdx.x;
+    int64_t nsub = 0;
+    if (b < B) {
+      const uint32_t k = big_idx[b];
+      nsub = ((int64_t)seg_start[k + 1] - (int64_t)seg_start[k] + kBigSeg - 1) / kBigSeg;
+    }
+    int64_t total;
+    int64_t pre = block_exclusive_scan(nsub, SumOp(), &total, smem);
+    if (b < B) item_off[b] = carry + pre;
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) item_off[B] = carry;
+}
+template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM>
+__global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_sub(const T* __restrict__ vals, const uint32_t* __restrict__ seg_start,
+                                                                   const uint32_t* __restrict__ big_idx, const int64_t* __restrict__ item_off,
+                                                                   int64_t B, SubState<T>* __restrict__ state) {
+  constexpr int LEAF = 16;
+  constexpr int kSegChunk = 64 * LEAF;
+  __shared__ double stage[kSegWaves][64 * 17];
+  __shared__ double csum_all[kSegWaves][48];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* lds = stage[wave];
+  double* csum = csum_all[wave];
+  const int64_t nitems = item_off[B];
+  const int64_t nw = (int64_t)gridDim.x * kSegWaves;
+  for (int64_t t = (int64_t)blockIdx.x * kSegWaves + wave; t < nitems; t += nw) {
+    // long group of item t: last b with item_off[b] <= t
+    int64_t lo = 0, hi = B - 1;
+    while (lo < hi) {
+      int64_t mid = (lo + hi + 1) >> 1;
+      if (item_off[mid] <= t) lo = mid;
+      else hi = mid - 1;
+    }
+    const uint32_t k = big_idx[lo];
+    const int64_t j = t - item_off[lo];
+    const int64_t s = (int64_t)seg_start[k] + j * kBigSeg;
+    const int64_t gend = seg_start[k + 1];
+    const int64_t e = s + kBigSeg < gend ? s + kBigSeg : gend;
+    const int64_t len = e - s;
+    Extreme<T> ext;
+    ext.init();
+    unsigned long long isum = 0;
+    uint64_t mask = 0;
+    int root = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 48) csum[lane] = 0.0;
+    T cur[LEAF];
+    {
+      const int cl = (int)(len < kSegChunk ? len : kSegChunk);
+#pragma unroll
+      for (int q = 0; q < LEAF; ++q) {
+        int idx = q * 64 + lane;
+        cur[q] = idx < cl ? vals[s + idx] : T(0);
+      }
+    }
+    for (int64_t c0 = 0; c0 < len; c0 += kSegChunk) {
+      const int cl = (int)((len - c0) < kSegChunk ? (len - c0) : kSegChunk);
+      T nxt[LEAF];
+      {
+        const int64_t n0 = c0 + kSegChunk;
+        const int ncl = n0 < len ? (int)((len - n0) < kSegChunk ? (len - n0) : kSegChunk) : 0;
+#pragma unroll
+        for (int q = 0; q < LEAF; ++q) {
+          int idx = q * 64 + lane;
+          nxt[q] = idx < ncl ? vals[s + n0 + idx] : T(0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < LEAF; ++q) {
+        int idx = q * 64 + lane;
+        if (idx < cl) {
+          T x = cur[q];
+          if (WANT_PAIRWISE) lds[idx + (idx >> 4)] = seg_to_f64(x);
+          if (WANT_MINMAX) {
+            if (x == x) ext.add(x, (long long)(j * kBigSeg + c0 + idx));
+          }
+          if (WANT_ISUM) isum += (unsigned long long)x;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (WANT_PAIRWISE) {
+        const int m = (cl + LEAF - 1) / LEAF;
+        double x = 0.0;
+        const int first = lane * LEAF;
+        if (first < cl) {
+          int cnt = cl - first < 16 ? cl - first : 16;
+          x = leaf_sum(&lds[lane * 17], cnt);
+        }
+        double node[7];
+#pragma unroll
+        for (int sft = 0; sft < 6; ++sft) {
+          node[sft] = 0.0;
+          if ((m >> sft) & 1) node[sft] = __shfl(x, m & ~((2 << sft) - 1), 64);
+          double y = __shfl_down(x, 1 << sft, 64);
+          x = x + y;
+        }
+        node[6] = __shfl(x, 0, 64);
+#pragma unroll
+        for (int sft = 6; sft >= 0; --sft)
+          if ((m >> sft) & 1) lds_counter_push(csum, mask, root, node[sft], sft, lane);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < LEAF; ++q) cur[q] = nxt[q];
+    }
+    if (WANT_MINMAX) {
+      for (int d = 32; d > 0; d >>= 1) {
+        T omin = __shfl_down(ext.vmin, d, 64), omax = __shfl_down(ext.vmax, d, 64);
+        long long ormin = __shfl_down(ext.rmin, d, 64), ormax = __shfl_down(ext.rmax, d, 64);
+        ext.merge(omin, ormin, omax, ormax);
+      }
+    }
+    if (WANT_ISUM) {
+      for (int d = 32; d > 0; d >>= 1) isum += __shfl_down(isum, d, 64);
+    }
+    if (lane < kBigLevels) state[t].csum[lane] = csum[lane];
+    if (lane == 0) {
+      state[t].mask = mask;
+      state[t].isum = isum;
+      state[t].vmin = ext.vmin;
+      state[t].vmax = ext.vmax;
+      state[t].rmin = ext.rmin;
+      state[t].rmax = ext.rmax;
+    }
+  }
+}
+template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM>
+__global__ void __launch_bounds__(64) k_seg_combine_big(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ big_idx,
+                                                        const int64_t* __restrict__ item_off, int64_t B, const SubState<T>* __restrict__ state,
+                                                        const uint32_t* __restrict__ out_index, SegOut out) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const uint32_t k = big_idx[b];
+  const uint32_t oi = out_index ? out_index[k] : k;
+  const long long len = (long long)seg_start[k + 1] - (long long)seg_start[k];
+  PairwiseCounter c;
+  c.init();
+  Extreme<T> ext;
+  ext.init();
+  unsigned long long isum = 0;
+  for (int64_t t = item_off[b]; t < item_off[b + 1]; ++t) {
+    const SubState<T>& st = state[t];
+    if (WANT_PAIRWISE) {
+      for (int lvl = kBigLevels - 1; lvl >= 0; --lvl)
+        if ((st.mask >> lvl) & 1) c.push(st.csum[lvl], lvl);
+    }
+    if (WANT_MINMAX) ext.merge(st.vmin, st.rmin, st.vmax, st.rmax);
+    if (WANT_ISUM) isum += st.isum;
+  }
+  if (WANT_PAIRWISE) {
+    const double total = c.finish();
+    if (out.sum_f) out.sum_f[oi] = total;
+    if (out.mean) out.mean[oi] = total / (double)len;
+  }
+  if (WANT_ISUM && out.sum_i) out.sum_i[oi] = (long long)isum;
+  if (WANT_MINMAX) {
+    T nanv = T(0);
+    if constexpr (__is_same(T, double)) nanv = __builtin_nan("");
+    if (out.vmin) static_cast<T*>(out.vmin)[oi] = ext.rmin < 0 ? nanv : ext.vmin;
+    if (out.vmax) static_cast<T*>(out.vmax)[oi] = ext.rmax < 0 ? nanv : ext.vmax;
+  }
+  if (out.count) out.count[oi] = len;
 }
 
 // ---------------------------------------------------------------- segmented reduce (nullable values): one wave per group.
@@ -1290,17 +1505,47 @@ static int sort_values_by_slot(pdx_groupby* gb, const uint64_t* vals, const uint
 
 template <typename T>
 static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int64_t nseg, const uint32_t* out_index, const SegOut& o,
-                                   bool want_pw, bool want_mm, bool want_is, int64_t nrows, hipStream_t st) {
+                                   bool want_pw, bool want_mm, bool want_is, int64_t nrows, Scratch& s, hipStream_t st) {
   if (nseg == 0) return PDX_OK;
+  // flag combination -> one of five instantiations (the mixed ones share <true, true, true>)
+  const int combo = (want_pw && !want_mm && !want_is) ? 0 : (!want_pw && want_mm && !want_is) ? 1 : (!want_pw && !want_mm && want_is) ? 2
+                    : (!want_pw && !want_mm && !want_is) ? 3 : 4;
+#define SEG_DISPATCH(LAUNCH)          \
+  switch (combo) {                    \
+    case 0: LAUNCH(true, false, false); break;  \
+    case 1: LAUNCH(false, true, false); break;  \
+    case 2: LAUNCH(false, false, true); break;  \
+    case 3: LAUNCH(false, false, false); break; \
+    default: LAUNCH(true, true, true); break;   \
+  }
+  // ---- long groups first (their outputs are skipped by the per-group kernels below)
+  if (nrows > kBigSeg) {
+    const int64_t maxB = nrows / kBigSeg + 1;  // a long group has more than kBigSeg rows
+    uint32_t* big_idx = s.get<uint32_t>((size_t)std::min<int64_t>(nseg, maxB));
+    PDX_SCRATCH_CHECK(s);
+    int64_t B = 0;
+    PDX_TRY(compact_indices(nseg, BigPred{seg_start}, BigEmit{big_idx}, &B, s, st));
+    if (B > 0) {
+      const int64_t max_items = nrows / kBigSeg + B;
+      int64_t* item_off = s.get<int64_t>((size_t)B + 1);
+      SubState<T>* state = s.get<SubState<T>>((size_t)max_items);
+      PDX_SCRATCH_CHECK(s);
+      hipLaunchKernelGGL(k_big_offsets, dim3(1), dim3(256), 0, st, seg_start, big_idx, B, item_off);
+      const int grid_sub = (int)std::min<int64_t>(ceil_div(max_items, kSegWaves), (int64_t)kCUs * 8);
+#define SEG_SUB(PW, MM, IS)                                                                                                                   \
+  hipLaunchKernelGGL((k_seg_reduce_sub<T, PW, MM, IS>), dim3(grid_sub), dim3(kSegWaves * 64), 0, st, vals, seg_start, big_idx, item_off, B, state); \
+  hipLaunchKernelGGL((k_seg_combine_big<T, PW, MM, IS>), dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, st, seg_start, big_idx, item_off, B, state, \
+                     out_index, o)
+      SEG_DISPATCH(SEG_SUB)
+#undef SEG_SUB
+      PDX_LAUNCH_CHECK();
+    }
+  }
   static const int64_t small_max = [] { const char* e = getenv("PDX_SEG_SMALL_MAX"); return e ? atoll(e) : 48ll; }();
   if (nrows / nseg < small_max) {  // small groups on average: thread per group
     dim3 g(grid_for(nseg, 256)), b(256);
 #define SEG_SMALL(PW, MM, IS) hipLaunchKernelGGL((k_seg_reduce_small<T, PW, MM, IS>), g, b, 0, st, vals, seg_start, nseg, out_index, o)
-    if (want_pw && !want_mm && !want_is) SEG_SMALL(true, false, false);
-    else if (!want_pw && want_mm && !want_is) SEG_SMALL(false, true, false);
-    else if (!want_pw && !want_mm && want_is) SEG_SMALL(false, false, true);
-    else if (!want_pw && !want_mm && !want_is) SEG_SMALL(false, false, false);
-    else SEG_SMALL(true, true, true);
+    SEG_DISPATCH(SEG_SMALL)
 #undef SEG_SMALL
     PDX_LAUNCH_CHECK();
     return PDX_OK;
@@ -1308,12 +1553,9 @@ static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int
   int grid = (int)std::min<int64_t>(ceil_div(nseg, kSegWaves), (int64_t)kCUs * 8);
   dim3 g(grid), b(kSegWaves * 64);
 #define SEG_LAUNCH(PW, MM, IS) hipLaunchKernelGGL((k_seg_reduce<T, PW, MM, IS>), g, b, 0, st, vals, seg_start, nseg, out_index, o)
-  if (want_pw && !want_mm && !want_is) SEG_LAUNCH(true, false, false);
-  else if (!want_pw && want_mm && !want_is) SEG_LAUNCH(false, true, false);
-  else if (!want_pw && !want_mm && want_is) SEG_LAUNCH(false, false, true);
-  else if (!want_pw && !want_mm && !want_is) SEG_LAUNCH(false, false, false);
-  else SEG_LAUNCH(true, true, true);
+  SEG_DISPATCH(SEG_LAUNCH)
 #undef SEG_LAUNCH
+#undef SEG_DISPATCH
   PDX_LAUNCH_CHECK();
   return PDX_OK;
 }
@@ -1805,8 +2047,8 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   }
   PDX_PROFILE("seg_reduce", st);
   if (!vvalid) {
-    if (is_f) PDX_TRY(launch_seg_reduce_dense<double>(static_cast<const double*>(vals_sorted), seg_start, G, out_index, o, want_pw, want_mm, want_is, n, st));
-    else PDX_TRY(launch_seg_reduce_dense<long long>(static_cast<const long long*>(vals_sorted), seg_start, G, out_index, o, want_pw, want_mm, want_is, n, st));
+    if (is_f) PDX_TRY(launch_seg_reduce_dense<double>(static_cast<const double*>(vals_sorted), seg_start, G, out_index, o, want_pw, want_mm, want_is, n, s, st));
+    else PDX_TRY(launch_seg_reduce_dense<long long>(static_cast<const long long*>(vals_sorted), seg_start, G, out_index, o, want_pw, want_mm, want_is, n, s, st));
     for (int k = 0; k < nk; ++k)
       if (outs[k].validity) PDX_HIP(hipMemsetAsync(outs[k].validity, 0xFF, (size_t)((G + 7) / 8), st));
   } else {
