@@ -403,8 +403,20 @@ __global__ void __launch_bounds__(256) k_dense_slots(const long long* __restrict
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     unsigned int s = range;  // the null key's slot
     if (!valid || bit_get(valid, off + i)) s = dense_slot_of(keys[i], mn, mask);
-    if ((unsigned int)i < first[s]) atomicMin(&first[s], (unsigned int)i);
     slot_of_row[i] = s;
+    // only the first lane of every slot present in the wave needs the atomic (lanes hold ascending rows): with a handful of
+    // distinct keys tens of thousands of in-flight atomicMin's on one word otherwise serialise in the L2 (measured 5.8 ms)
+    const bool want = (unsigned int)i < first[s];
+    const int lane = threadIdx.x & 63;
+    uint64_t rem = __ballot(want);
+    for (int rounds = 0; rem && rounds < 4; ++rounds) {
+      const int leader = __ffsll((unsigned long long)rem) - 1;
+      const unsigned int sl = (unsigned int)__shfl((int)s, leader, 64);
+      const uint64_t grp = __ballot(want && s == sl) & rem;
+      if (lane == leader) atomicMin(&first[s], (unsigned int)i);
+      rem &= ~grp;
+    }
+    if ((rem >> lane) & 1) atomicMin(&first[s], (unsigned int)i);
   }
 }
 
@@ -530,6 +542,7 @@ __global__ void __launch_bounds__(kDenseLdsBlock) k_dense_slots_tail_hist_lds(co
   const int64_t nw = (int64_t)gridDim.x * W;
   long long kmn = 0x7FFFFFFFFFFFFFFFll, kmx = (long long)0x8000000000000000ull;
   int any = 0;
+  bool few = true;  // wave-uniform
   for (int64_t tile = tile0 + (int64_t)blockIdx.x * W + wave; tile < ntiles; tile += nw) {
     const int64_t base = tile * kSortTile;
 #pragma unroll 1
@@ -553,11 +566,24 @@ __global__ void __launch_bounds__(kDenseLdsBlock) k_dense_slots_tail_hist_lds(co
         }
         const uint32_t w = lseen[sl >> 5];
         if (in) slot_of_row[i] = sl;
-        // one LDS add per wave when every row has the same digit (few distinct keys): 64 lanes adding to one word serialise
-        const unsigned int d = sl & (R - 1), d0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)d);
-        const uint64_t act = __ballot(in), same = __ballot(in && d == d0);
-        if (same == act) {
-          if (lane == 0 && act) atomicAdd(&lh[wave][d0], (uint32_t)__popcll(act));
+        // few distinct digits (few distinct keys): lanes adding to the same LDS word serialise, so peel the rows off digit by
+        // digit and add each digit's count once.  `few` is dropped for good the first time a step needs more than 4 rounds (a round costs about as much as a 4-way conflict).
+        const unsigned int d = sl & (R - 1);
+        if (few) {
+          uint64_t rem = __ballot(in);
+          int rounds = 0;
+          while (rem && rounds < 4) {
+            const int leader = __ffsll((unsigned long long)rem) - 1;
+            const unsigned int dl = (unsigned int)__shfl((int)d, leader, 64);
+            const uint64_t grp = __ballot(in && d == dl) & rem;
+            if (lane == leader) atomicAdd(&lh[wave][dl], (uint32_t)__popcll(grp));
+            rem &= ~grp;
+            ++rounds;
+          }
+          if (rem) {
+            few = false;
+            if ((rem >> lane) & 1) atomicAdd(&lh[wave][d], 1u);
+          }
         } else if (in) {
           atomicAdd(&lh[wave][d], 1u);
         }
@@ -1122,25 +1148,56 @@ template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM>
 __global__ void __launch_bounds__(64) k_seg_combine_big(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ big_idx,
                                                         const int64_t* __restrict__ item_off, int64_t B, const SubState<T>* __restrict__ state,
                                                         const uint32_t* __restrict__ out_index, SegOut out) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  // one wave per long group.  64 consecutive FULL sub-segments (64-aligned within the group) are a perfect subtree of level-12
+  // nodes: one butterfly makes their level-18 node; everything else is replayed by lane 0.
+  const int64_t b = blockIdx.x;
+  const int lane = threadIdx.x;
   const uint32_t k = big_idx[b];
   const uint32_t oi = out_index ? out_index[k] : k;
   const long long len = (long long)seg_start[k + 1] - (long long)seg_start[k];
-  PairwiseCounter c;
-  c.init();
+  PairwiseCounter c;  // used by lane 0 only
+  if (lane == 0) c.init();
   Extreme<T> ext;
   ext.init();
   unsigned long long isum = 0;
-  for (int64_t t = item_off[b]; t < item_off[b + 1]; ++t) {
-    const SubState<T>& st = state[t];
-    if (WANT_PAIRWISE) {
-      for (int lvl = kBigLevels - 1; lvl >= 0; --lvl)
-        if ((st.mask >> lvl) & 1) c.push(st.csum[lvl], lvl);
+  const int64_t begin = item_off[b], end = item_off[b + 1];
+  for (int64_t t0 = begin; t0 < end; t0 += 64) {
+    const int64_t t = t0 + lane;
+    const bool have = t < end;
+    unsigned long long m = 0;
+    double v = 0.0;
+    if (have) {
+      m = state[t].mask;
+      v = state[t].csum[12];
+      if (WANT_MINMAX) ext.merge(state[t].vmin, state[t].rmin, state[t].vmax, state[t].rmax);
+      if (WANT_ISUM) isum += state[t].isum;
     }
-    if (WANT_MINMAX) ext.merge(st.vmin, st.rmin, st.vmax, st.rmax);
-    if (WANT_ISUM) isum += st.isum;
+    if (WANT_PAIRWISE) {
+      const bool all_full = (end - t0 >= 64) && __all(m == (1ull << 12));
+      if (all_full) {
+        const double node = wave_tree64(v);
+        if (lane == 0) c.push(node, 18);
+      } else if (lane == 0) {
+        const int64_t cnt = end - t0 < 64 ? end - t0 : 64;
+        for (int64_t i = 0; i < cnt; ++i) {
+          const SubState<T>& st = state[t0 + i];
+          for (int lvl = kBigLevels - 1; lvl >= 0; --lvl)
+            if ((st.mask >> lvl) & 1) c.push(st.csum[lvl], lvl);
+        }
+      }
+    }
   }
+  if (WANT_MINMAX) {
+    for (int d = 32; d > 0; d >>= 1) {
+      T omin = __shfl_down(ext.vmin, d, 64), omax = __shfl_down(ext.vmax, d, 64);
+      long long ormin = __shfl_down(ext.rmin, d, 64), ormax = __shfl_down(ext.rmax, d, 64);
+      ext.merge(omin, ormin, omax, ormax);
+    }
+  }
+  if (WANT_ISUM) {
+    for (int d = 32; d > 0; d >>= 1) isum += __shfl_down(isum, d, 64);
+  }
+  if (lane != 0) return;
   if (WANT_PAIRWISE) {
     const double total = c.finish();
     if (out.sum_f) out.sum_f[oi] = total;
@@ -1534,7 +1591,7 @@ static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int
       const int grid_sub = (int)std::min<int64_t>(ceil_div(max_items, kSegWaves), (int64_t)kCUs * 8);
 #define SEG_SUB(PW, MM, IS)                                                                                                                   \
   hipLaunchKernelGGL((k_seg_reduce_sub<T, PW, MM, IS>), dim3(grid_sub), dim3(kSegWaves * 64), 0, st, vals, seg_start, big_idx, item_off, B, state); \
-  hipLaunchKernelGGL((k_seg_combine_big<T, PW, MM, IS>), dim3((unsigned)ceil_div(B, 64)), dim3(64), 0, st, seg_start, big_idx, item_off, B, state, \
+  hipLaunchKernelGGL((k_seg_combine_big<T, PW, MM, IS>), dim3((unsigned)B), dim3(64), 0, st, seg_start, big_idx, item_off, B, state, \
                      out_index, o)
       SEG_DISPATCH(SEG_SUB)
 #undef SEG_SUB

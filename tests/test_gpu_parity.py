@@ -528,7 +528,7 @@ def test_resample_large_vs_oracle(px):
     assert_f64_bits(r.mean()["v"].values(), means)
 
 
-@pytest.mark.parametrize("case", ["uniform", "outlier_small", "outlier_huge", "null_keys", "negative", "window_edge", "no_spec"])
+@pytest.mark.parametrize("case", ["uniform", "outlier_small", "outlier_huge", "null_keys", "negative", "window_edge", "no_spec", "two_keys"])
 def test_groupby_dense_speculation(px, monkeypatch, case):
     """>= 2^23 rows: the dense build speculates on the width of the key window from a 65536-key sample and computes the exact
     min/max in the same pass (residue slots, key & mask).  Accepted guesses, rejected guesses (an unsampled outlier widens the
@@ -551,6 +551,8 @@ def test_groupby_dense_speculation(px, monkeypatch, case):
         keys = keys + (1 << 17) - 7    # [2^17 - 7, 2^17 - 7 + 1e5): residues wrap around
     elif case == "no_spec":
         monkeypatch.setenv("PDX_DENSE_SPECULATE", "0")
+    elif case == "two_keys":
+        keys = keys % 2               # 4.5 M rows per group: 68 sub-segments each -> the 64-wide level-12 butterfly + a serial tail
     vals = orc.synth_vals(0, n) - 0.5
     gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys, kvalid))
     s, m, cnt = gb.agg(px.Column.from_numpy(vals), [0, 1, 4])
