@@ -762,7 +762,8 @@ __device__ __forceinline__ void lds_counter_push(double* csum, uint64_t& mask, i
 // dependent seg_start -> values memory round trip with nothing else to do (measured 3.0 -> see DESIGN.md).
 template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM>
 __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restrict__ vals, const uint32_t* __restrict__ seg_start,
-                                                               int64_t nseg, const uint32_t* __restrict__ out_index, SegOut out) {
+                                                               int64_t nseg, const uint32_t* __restrict__ out_index, SegOut out, int64_t min_len) {
+  // groups of <= min_len rows belong to k_seg_reduce_mid (batches of short groups per wave) and are skipped here like the long ones
   constexpr int LEAF = 16;              // Arrow's kBlockSize
   constexpr int kSegChunk = 64 * LEAF;  // values per wave-chunk = 64 leaves
   __shared__ double stage[kSegWaves][64 * 17];
@@ -776,14 +777,14 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
   // groups longer than kBigSeg rows are reduced by k_seg_reduce_sub / k_seg_combine_big (many waves per group): here they
   // are walked as empty segments whose result is not written
   int64_t s = seg_start[k], e = seg_start[k + 1];
-  bool big = e - s > kBigSeg;
+  bool big = e - s > kBigSeg || e - s <= min_len;
   if (big) e = s;
   int64_t s_next = 0, e_next = 0;  // bounds of group k + nw
   bool big_next = false;
   if (k + nw < nseg) {
     s_next = seg_start[k + nw];
     e_next = seg_start[k + nw + 1];
-    big_next = e_next - s_next > kBigSeg;
+    big_next = e_next - s_next > kBigSeg || e_next - s_next <= min_len;
     if (big_next) e_next = s_next;
   }
   int64_t c0 = 0;
@@ -828,7 +829,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
     if (last_chunk && nk + nw < nseg) {  // bounds two groups ahead, consumed when the next group finishes
       s_nn = seg_start[nk + nw];
       e_nn = seg_start[nk + nw + 1];
-      big_nn = e_nn - s_nn > kBigSeg;
+      big_nn = e_nn - s_nn > kBigSeg || e_nn - s_nn <= min_len;
       if (big_nn) e_nn = s_nn;
     }
     // ---- current chunk
@@ -940,52 +941,243 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
   }
 }
 
-// ---------------------------------------------------------------- segmented reduce, small groups: one thread per group.
-// With a few dozen rows per group a wave per group leaves most lanes idle; here neighbouring lanes read neighbouring (contiguous)
-// segments, so the loads still share cache lines.  Literal replay of leaves + binary counter.
+// ---------------------------------------------------------------- one wave reduces one contiguous segment (any length).
+// Chunks of 1024 values (64 leaves), the next chunk's loads in flight while the current one is staged and reduced; the chunk's
+// perfect subtrees go through the LDS-resident counter (csum/mask/root: Arrow's state after the segment; the caller folds it or
+// stores it).  ext (wave-reduced, valid in lane 0) and isum (wave-reduced) cover the whole segment; rows are numbered from row_base.
 template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM>
-__global__ void __launch_bounds__(256) k_seg_reduce_small(const T* __restrict__ vals, const uint32_t* __restrict__ seg_start, int64_t nseg,
-                                                          const uint32_t* __restrict__ out_index, SegOut out) {
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += stride) {
-    const int64_t s = seg_start[k], e = seg_start[k + 1];
-    if (e - s > kBigSeg) continue;  // reduced by k_seg_reduce_sub / k_seg_combine_big
-    const uint32_t oi = out_index ? out_index[k] : (uint32_t)k;
-    PairwiseCounter c;
-    if (WANT_PAIRWISE) c.init();
-    unsigned long long isum = 0;
-    T vmn = T(0), vmx = T(0);
-    bool has = false;
-    for (int64_t i = s; i < e; i += 16) {
-      const int cnt = (int)((e - i) < 16 ? (e - i) : 16);
-      double acc = 0.0;
-      for (int q = 0; q < cnt; ++q) {
-        T x = vals[i + q];
-        if (WANT_PAIRWISE) acc += (double)x;
+__device__ __forceinline__ void seg_chunked(const T* __restrict__ vals, int64_t s, int64_t len, long long row_base, int lane, double* lds /* 64*17 */,
+                                            double* csum /* 48 */, Extreme<T>& ext, unsigned long long& isum, uint64_t& mask, int& root) {
+  constexpr int LEAF = 16;
+  constexpr int kSegChunk = 64 * LEAF;
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 48) csum[lane] = 0.0;
+  T cur[LEAF];
+  {
+    const int cl = (int)(len < kSegChunk ? len : kSegChunk);
+#pragma unroll
+    for (int q = 0; q < LEAF; ++q) {
+      int idx = q * 64 + lane;
+      cur[q] = idx < cl ? vals[s + idx] : T(0);
+    }
+  }
+  for (int64_t c0 = 0; c0 < len; c0 += kSegChunk) {
+    const int cl = (int)((len - c0) < kSegChunk ? (len - c0) : kSegChunk);
+    T nxt[LEAF];
+    {
+      const int64_t n0 = c0 + kSegChunk;
+      const int ncl = n0 < len ? (int)((len - n0) < kSegChunk ? (len - n0) : kSegChunk) : 0;
+#pragma unroll
+      for (int q = 0; q < LEAF; ++q) {
+        int idx = q * 64 + lane;
+        nxt[q] = idx < ncl ? vals[s + n0 + idx] : T(0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < LEAF; ++q) {
+      int idx = q * 64 + lane;
+      if (idx < cl) {
+        T x = cur[q];
+        if (WANT_PAIRWISE) lds[idx + (idx >> 4)] = seg_to_f64(x);
+        if (WANT_MINMAX) {
+          if (x == x) ext.add(x, row_base + (long long)(c0 + idx));
+        }
         if (WANT_ISUM) isum += (unsigned long long)x;
-        if (WANT_MINMAX && x == x) {
-          if (!has) { vmn = vmx = x; has = true; }
-          else {
-            if (x < vmn) vmn = x;
-            if (x > vmx) vmx = x;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (WANT_PAIRWISE) {
+      const int m = (cl + LEAF - 1) / LEAF;
+      double x = 0.0;
+      const int first = lane * LEAF;
+      if (first < cl) {
+        int cnt = cl - first < 16 ? cl - first : 16;
+        x = leaf_sum(&lds[lane * 17], cnt);
+      }
+      double node[7];
+#pragma unroll
+      for (int sft = 0; sft < 6; ++sft) {
+        node[sft] = 0.0;
+        if ((m >> sft) & 1) node[sft] = __shfl(x, m & ~((2 << sft) - 1), 64);
+        double y = __shfl_down(x, 1 << sft, 64);
+        x = x + y;
+      }
+      node[6] = __shfl(x, 0, 64);
+#pragma unroll
+      for (int sft = 6; sft >= 0; --sft)
+        if ((m >> sft) & 1) lds_counter_push(csum, mask, root, node[sft], sft, lane);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < LEAF; ++q) cur[q] = nxt[q];
+  }
+  if (WANT_MINMAX) {
+    for (int d = 32; d > 0; d >>= 1) {
+      T omin = __shfl_down(ext.vmin, d, 64), omax = __shfl_down(ext.vmax, d, 64);
+      long long ormin = __shfl_down(ext.rmin, d, 64), ormax = __shfl_down(ext.rmax, d, 64);
+      ext.merge(omin, ormin, omax, ormax);
+    }
+  }
+  if (WANT_ISUM) {
+    for (int d = 32; d > 0; d >>= 1) isum += __shfl_down(isum, d, 64);
+  }
+}
+
+// ---------------------------------------------------------------- segmented reduce, short groups: batches of groups per wave.
+// Groups of a few to a few hundred rows leave most of a wave idle in k_seg_reduce (and a thread per group thrashes the L1).  Here a wave takes a
+// run of consecutive short groups (<= 64 groups, <= 1024 rows: the grouped values are contiguous), loads the whole run coalesced
+// into LDS, sums the 16-value leaves with one lane per leaf and then combines every group's leaves with one lane per group
+// (in-place perfect subtrees + ascending fold == Arrow's counter).  Groups longer than kMidLen are left to k_seg_reduce.
+constexpr int kMidLen = 256;
+constexpr int kMidRows = 1024;
+template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM>
+__global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_mid(const T* __restrict__ vals, const uint32_t* __restrict__ seg_start, int64_t nseg,
+                                                                   const uint32_t* __restrict__ out_index, SegOut out, int64_t groups_per_wave) {
+  __shared__ T stage_all[kSegWaves][64 * 17];  // >= kMidRows values; the padded 64 x 17 image when a longer group is chunked
+  __shared__ double csum_all[kSegWaves][48];
+  __shared__ double leaf_all[kSegWaves][kMidRows / 16 + 64];
+  __shared__ int lp_all[kSegWaves][65];
+  __shared__ int goff_all[kSegWaves][64];
+  __shared__ int glen_all[kSegWaves][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* stage = stage_all[wave];
+  double* leaf = leaf_all[wave];
+  int* lp = lp_all[wave];
+  int* goff = goff_all[wave];
+  int* glen = glen_all[wave];
+  const int64_t gw = (int64_t)blockIdx.x * kSegWaves + wave;
+  int64_t k0 = gw * groups_per_wave;
+  const int64_t kend = k0 + groups_per_wave < nseg ? k0 + groups_per_wave : nseg;
+  while (k0 < kend) {
+    const int64_t kk = k0 + lane;
+    const int64_t b0 = seg_start[kk < kend ? kk : kend], b1 = seg_start[kk + 1 < kend ? kk + 1 : kend];
+    const int64_t S = __shfl(b0, 0, 64);
+    const int len = (int)(b1 - b0);
+    const bool ok = kk < kend && len <= kMidLen && (b1 - S) <= kMidRows;
+    const uint64_t okm = __ballot(ok);
+    const int g = ~okm ? __ffsll((unsigned long long)~okm) - 1 : 64;  // leading run of short groups that fits
+    if (g == 0) {
+      // a longer group: the whole wave chunks through it (groups beyond kBigSeg belong to the many-waves path)
+      const int64_t glen0 = __shfl(b1, 0, 64) - S;
+      if (glen0 <= kBigSeg) {
+        Extreme<T> ext;
+        ext.init();
+        unsigned long long isum = 0;
+        uint64_t mask = 0;
+        int root = 0;
+        double* csum = csum_all[wave];
+        seg_chunked<T, WANT_PAIRWISE, WANT_MINMAX, WANT_ISUM>(vals, S, glen0, 0ll, lane, reinterpret_cast<double*>(stage), csum, ext, isum, mask, root);
+        double total = 0.0;
+        if (WANT_PAIRWISE) {
+          double acc = csum[0];
+          for (int i = 1; i <= root; ++i) acc = csum[i] + acc;
+          total = acc;
+        }
+        if (lane == 0) {
+          const uint32_t oi = out_index ? out_index[k0] : (uint32_t)k0;
+          if (WANT_PAIRWISE) {
+            if (out.sum_f) out.sum_f[oi] = total;
+            if (out.mean) out.mean[oi] = total / (double)glen0;
+          }
+          if (WANT_ISUM && out.sum_i) out.sum_i[oi] = (long long)isum;
+          if (WANT_MINMAX) {
+            T nanv = T(0);
+            if constexpr (__is_same(T, double)) nanv = __builtin_nan("");
+            if (out.vmin) static_cast<T*>(out.vmin)[oi] = ext.rmin < 0 ? nanv : ext.vmin;
+            if (out.vmax) static_cast<T*>(out.vmax)[oi] = ext.rmax < 0 ? nanv : ext.vmax;
+          }
+          if (out.count) out.count[oi] = (long long)glen0;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      k0 += 1;
+      continue;
+    }
+    const int R = (int)(__shfl(b1, g - 1, 64) - S);
+#pragma unroll
+    for (int q = 0; q < kMidRows / 64; ++q) {
+      int idx = q * 64 + lane;
+      if (idx < R) stage[idx] = vals[S + idx];
+    }
+    const int nl = lane < g ? (len + 15) >> 4 : 0;
+    const int incl = wave_inclusive_scan(nl, SumOp());
+    const int excl = incl - nl;
+    const int NL = __shfl(incl, 63, 64);
+    lp[lane] = excl;
+    if (lane == 63) lp[64] = NL;
+    goff[lane] = (int)(b0 - S);
+    glen[lane] = len;
+    __builtin_amdgcn_wave_barrier();
+    if (WANT_PAIRWISE) {
+      for (int L = lane; L < NL; L += 64) {
+        int lo = 0, hi = g - 1;
+        while (lo < hi) {
+          int mid = (lo + hi + 1) >> 1;
+          if (lp[mid] <= L) lo = mid;
+          else hi = mid - 1;
+        }
+        const int j = L - lp[lo];
+        const int off = goff[lo] + 16 * j;
+        int cnt = glen[lo] - 16 * j;
+        cnt = cnt < 16 ? cnt : 16;
+        double acc = 0.0;
+        if (cnt == 16) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc += seg_to_f64(stage[off + q]);
+        } else {
+          for (int q = 0; q < cnt; ++q) acc += seg_to_f64(stage[off + q]);
+        }
+        leaf[L] = acc;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < g) {
+      const uint32_t oi = out_index ? out_index[kk] : (uint32_t)kk;
+      if (WANT_PAIRWISE) {
+        double* x = leaf + excl;
+        const int m = nl;
+        for (int stride = 1; stride < m; stride <<= 1)
+          for (int i = 0; i + 2 * stride <= m; i += 2 * stride) x[i] = x[i] + x[i + stride];
+        double acc = 0.0;
+        bool have = false;
+        int pos = m;
+        for (int jb = 0; jb < 7; ++jb)
+          if ((m >> jb) & 1) {
+            pos -= 1 << jb;
+            acc = have ? x[pos] + acc : x[pos];
+            have = true;
+          }
+        if (out.sum_f) out.sum_f[oi] = acc;
+        if (out.mean) out.mean[oi] = acc / (double)len;
+      }
+      if (WANT_MINMAX || WANT_ISUM) {
+        const T* v = stage + (int)(b0 - S);
+        unsigned long long isum = 0;
+        T vmn = T(0), vmx = T(0);
+        bool has = false;
+        for (int r = 0; r < len; ++r) {
+          T xv = v[r];
+          if (WANT_ISUM) isum += (unsigned long long)xv;
+          if (WANT_MINMAX && xv == xv) {
+            if (!has) { vmn = vmx = xv; has = true; }
+            else {
+              if (xv < vmn) vmn = xv;
+              if (xv > vmx) vmx = xv;
+            }
           }
         }
+        if (WANT_ISUM && out.sum_i) out.sum_i[oi] = (long long)isum;
+        if (WANT_MINMAX) {
+          T nanv = T(0);
+          if constexpr (__is_same(T, double)) nanv = __builtin_nan("");
+          if (out.vmin) static_cast<T*>(out.vmin)[oi] = has ? vmn : nanv;
+          if (out.vmax) static_cast<T*>(out.vmax)[oi] = has ? vmx : nanv;
+        }
       }
-      if (WANT_PAIRWISE) c.push(acc, 0);
+      if (out.count) out.count[oi] = (long long)len;
     }
-    if (WANT_PAIRWISE) {
-      double total = c.finish();
-      if (out.sum_f) out.sum_f[oi] = total;
-      if (out.mean) out.mean[oi] = total / (double)(e - s);
-    }
-    if (WANT_ISUM && out.sum_i) out.sum_i[oi] = (long long)isum;
-    if (WANT_MINMAX) {
-      T nanv = T(0);
-      if constexpr (__is_same(T, double)) nanv = __builtin_nan("");
-      if (out.vmin) static_cast<T*>(out.vmin)[oi] = has ? vmn : nanv;
-      if (out.vmax) static_cast<T*>(out.vmax)[oi] = has ? vmx : nanv;
-    }
-    if (out.count) out.count[oi] = (long long)(e - s);
+    __builtin_amdgcn_wave_barrier();
+    k0 += g;
   }
 }
 
@@ -1034,8 +1226,6 @@ template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM>
 __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_sub(const T* __restrict__ vals, const uint32_t* __restrict__ seg_start,
                                                                    const uint32_t* __restrict__ big_idx, const int64_t* __restrict__ item_off,
                                                                    int64_t B, SubState<T>* __restrict__ state) {
-  constexpr int LEAF = 16;
-  constexpr int kSegChunk = 64 * LEAF;
   __shared__ double stage[kSegWaves][64 * 17];
   __shared__ double csum_all[kSegWaves][48];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1056,83 +1246,12 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_sub(const T* __re
     const int64_t s = (int64_t)seg_start[k] + j * kBigSeg;
     const int64_t gend = seg_start[k + 1];
     const int64_t e = s + kBigSeg < gend ? s + kBigSeg : gend;
-    const int64_t len = e - s;
     Extreme<T> ext;
     ext.init();
     unsigned long long isum = 0;
     uint64_t mask = 0;
     int root = 0;
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 48) csum[lane] = 0.0;
-    T cur[LEAF];
-    {
-      const int cl = (int)(len < kSegChunk ? len : kSegChunk);
-#pragma unroll
-      for (int q = 0; q < LEAF; ++q) {
-        int idx = q * 64 + lane;
-        cur[q] = idx < cl ? vals[s + idx] : T(0);
-      }
-    }
-    for (int64_t c0 = 0; c0 < len; c0 += kSegChunk) {
-      const int cl = (int)((len - c0) < kSegChunk ? (len - c0) : kSegChunk);
-      T nxt[LEAF];
-      {
-        const int64_t n0 = c0 + kSegChunk;
-        const int ncl = n0 < len ? (int)((len - n0) < kSegChunk ? (len - n0) : kSegChunk) : 0;
-#pragma unroll
-        for (int q = 0; q < LEAF; ++q) {
-          int idx = q * 64 + lane;
-          nxt[q] = idx < ncl ? vals[s + n0 + idx] : T(0);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < LEAF; ++q) {
-        int idx = q * 64 + lane;
-        if (idx < cl) {
-          T x = cur[q];
-          if (WANT_PAIRWISE) lds[idx + (idx >> 4)] = seg_to_f64(x);
-          if (WANT_MINMAX) {
-            if (x == x) ext.add(x, (long long)(j * kBigSeg + c0 + idx));
-          }
-          if (WANT_ISUM) isum += (unsigned long long)x;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (WANT_PAIRWISE) {
-        const int m = (cl + LEAF - 1) / LEAF;
-        double x = 0.0;
-        const int first = lane * LEAF;
-        if (first < cl) {
-          int cnt = cl - first < 16 ? cl - first : 16;
-          x = leaf_sum(&lds[lane * 17], cnt);
-        }
-        double node[7];
-#pragma unroll
-        for (int sft = 0; sft < 6; ++sft) {
-          node[sft] = 0.0;
-          if ((m >> sft) & 1) node[sft] = __shfl(x, m & ~((2 << sft) - 1), 64);
-          double y = __shfl_down(x, 1 << sft, 64);
-          x = x + y;
-        }
-        node[6] = __shfl(x, 0, 64);
-#pragma unroll
-        for (int sft = 6; sft >= 0; --sft)
-          if ((m >> sft) & 1) lds_counter_push(csum, mask, root, node[sft], sft, lane);
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int q = 0; q < LEAF; ++q) cur[q] = nxt[q];
-    }
-    if (WANT_MINMAX) {
-      for (int d = 32; d > 0; d >>= 1) {
-        T omin = __shfl_down(ext.vmin, d, 64), omax = __shfl_down(ext.vmax, d, 64);
-        long long ormin = __shfl_down(ext.rmin, d, 64), ormax = __shfl_down(ext.rmax, d, 64);
-        ext.merge(omin, ormin, omax, ormax);
-      }
-    }
-    if (WANT_ISUM) {
-      for (int d = 32; d > 0; d >>= 1) isum += __shfl_down(isum, d, 64);
-    }
+    seg_chunked<T, WANT_PAIRWISE, WANT_MINMAX, WANT_ISUM>(vals, s, e - s, (long long)(j * kBigSeg), lane, lds, csum, ext, isum, mask, root);
     if (lane < kBigLevels) state[t].csum[lane] = csum[lane];
     if (lane == 0) {
       state[t].mask = mask;
@@ -1598,18 +1717,23 @@ static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int
       PDX_LAUNCH_CHECK();
     }
   }
-  static const int64_t small_max = [] { const char* e = getenv("PDX_SEG_SMALL_MAX"); return e ? atoll(e) : 48ll; }();
-  if (nrows / nseg < small_max) {  // small groups on average: thread per group
-    dim3 g(grid_for(nseg, 256)), b(256);
-#define SEG_SMALL(PW, MM, IS) hipLaunchKernelGGL((k_seg_reduce_small<T, PW, MM, IS>), g, b, 0, st, vals, seg_start, nseg, out_index, o)
-    SEG_DISPATCH(SEG_SMALL)
-#undef SEG_SMALL
+  int grid = (int)std::min<int64_t>(ceil_div(nseg, kSegWaves), (int64_t)kCUs * 8);
+  dim3 g(grid), b(kSegWaves * 64);
+  // mostly short groups: one kernel that batches the groups of <= kMidLen rows per wave and chunks through the longer ones
+  static const int64_t mid_max = [] { const char* e = getenv("PDX_SEG_MID_MAX"); return e ? atoll(e) : 256ll; }();
+  const int64_t min_len = -1;
+  if (nrows / nseg < mid_max) {
+    const int64_t nwaves = (int64_t)kCUs * 8 * kSegWaves;
+    const int64_t gpw = std::max<int64_t>(64, ceil_div(nseg, nwaves));
+    const int grid_mid = (int)ceil_div(ceil_div(nseg, gpw), kSegWaves);
+#define SEG_MID(PW, MM, IS) \
+  hipLaunchKernelGGL((k_seg_reduce_mid<T, PW, MM, IS>), dim3(grid_mid), b, 0, st, vals, seg_start, nseg, out_index, o, gpw)
+    SEG_DISPATCH(SEG_MID)
+#undef SEG_MID
     PDX_LAUNCH_CHECK();
     return PDX_OK;
   }
-  int grid = (int)std::min<int64_t>(ceil_div(nseg, kSegWaves), (int64_t)kCUs * 8);
-  dim3 g(grid), b(kSegWaves * 64);
-#define SEG_LAUNCH(PW, MM, IS) hipLaunchKernelGGL((k_seg_reduce<T, PW, MM, IS>), g, b, 0, st, vals, seg_start, nseg, out_index, o)
+#define SEG_LAUNCH(PW, MM, IS) hipLaunchKernelGGL((k_seg_reduce<T, PW, MM, IS>), g, b, 0, st, vals, seg_start, nseg, out_index, o, min_len)
   SEG_DISPATCH(SEG_LAUNCH)
 #undef SEG_LAUNCH
 #undef SEG_DISPATCH
