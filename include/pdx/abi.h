@@ -89,7 +89,15 @@ typedef struct pdx_scalar {
 typedef enum pdx_binary_op { PDX_ADD = 0, PDX_SUB = 1, PDX_MUL = 2, PDX_DIV = 3 } pdx_binary_op;
 typedef enum pdx_compare_op { PDX_EQ = 0, PDX_NE = 1, PDX_LT = 2, PDX_LE = 3, PDX_GT = 4, PDX_GE = 5 } pdx_compare_op;
 typedef enum pdx_logical_op { PDX_AND = 0, PDX_OR = 1 } pdx_logical_op;
-typedef enum pdx_agg_kind { PDX_AGG_SUM = 0, PDX_AGG_MEAN = 1, PDX_AGG_MIN = 2, PDX_AGG_MAX = 3, PDX_AGG_COUNT = 4 } pdx_agg_kind;
+typedef enum pdx_agg_kind {
+  PDX_AGG_SUM = 0, PDX_AGG_MEAN = 1, PDX_AGG_MIN = 2, PDX_AGG_MAX = 3, PDX_AGG_COUNT = 4,
+  /* group-by only (pdx_groupby_agg; SURVEY 8(f)-3, the reference's GROUPBY_NUMERIC_AGG(variance|stddev), GROUPBY_AGG(product),
+   * GroupBy::first/last, src/dataframe.cpp:1516-1536, 1698-1810).  variance/stddev: Arrow defaults (ddof = 0, nulls skipped,
+   * null for a group without valid values), two pairwise passes -> float64.  product: one multiply per valid value in row
+   * order, int64 wraps, null without valid values -> value dtype.  first/last: the group's first / last ROW (null if that row
+   * is null) -> value dtype. */
+  PDX_AGG_VARIANCE = 5, PDX_AGG_STDDEV = 6, PDX_AGG_PRODUCT = 7, PDX_AGG_FIRST = 8, PDX_AGG_LAST = 9
+} pdx_agg_kind;
 typedef enum pdx_origin {
   PDX_ORIGIN_EPOCH = 0, PDX_ORIGIN_START_DAY = 1, PDX_ORIGIN_START = 2, PDX_ORIGIN_END = 3, PDX_ORIGIN_END_DAY = 4, PDX_ORIGIN_CUSTOM = 5,
   /* OR-ed into origin_type by a multi-GPU caller whose `ts` is one row-range shard of a longer axis (bins made whole by the caller,

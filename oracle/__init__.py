@@ -24,6 +24,7 @@ ADD, SUB, MUL, DIV = 0, 1, 2, 3
 EQ, NE, LT, LE, GT, GE = 0, 1, 2, 3, 4, 5
 AND, OR = 0, 1
 AGG_SUM, AGG_MEAN, AGG_MIN, AGG_MAX, AGG_COUNT = 0, 1, 2, 3, 4
+AGG_VARIANCE, AGG_STDDEV, AGG_PRODUCT, AGG_FIRST, AGG_LAST = 5, 6, 7, 8, 9
 OK, INVALID, INDEX_ERROR = 0, 1, 2
 ORIGIN_EPOCH, ORIGIN_START_DAY, ORIGIN_START, ORIGIN_END, ORIGIN_END_DAY, ORIGIN_CUSTOM = range(6)
 
@@ -275,7 +276,7 @@ def groupby_agg(kind, ids, G, v, valid=None, offset=0, nthreads=1):
     vs = _shift(v.astype(np.float64 if isf else np.int64), offset)
     fn(C.c_int(kind), _p(offsets), _p(rows), _i64(G), _p(vs), _p(pack_bits(valid, offset)), _i64(offset), _p(out_f), _p(out_i), _p(ov),
        C.c_int(nthreads))
-    if kind == AGG_COUNT or (not isf and kind != AGG_MEAN):
+    if kind == AGG_COUNT or (not isf and kind not in (AGG_MEAN, AGG_VARIANCE, AGG_STDDEV)):
         return out_i[:G], ov[:G].astype(bool)
     return out_f[:G], ov[:G].astype(bool)
 

@@ -252,6 +252,7 @@ def reference_groupby(keys, kvalid, cols):
         V = arr(v, valid)
         isf = np.asarray(v).dtype == np.float64
         sums, means, mins, maxs, cnts = [], [], [], [], []
+        varis, stds, prods, firsts, lasts = [], [], [], [], []
         for g in range(G):
             grp = V.take(pa.array(order[offs[g]:offs[g + 1]]))  # ApplyGroupings
             sums.append(pc.sum(grp).as_py())
@@ -259,10 +260,19 @@ def reference_groupby(keys, kvalid, cols):
             mins.append(pc.min(grp).as_py())
             maxs.append(pc.max(grp).as_py())
             cnts.append(pc.count(grp).as_py())
+            # the "next" aggregations of SURVEY 8(f)-3: CallFunction(name, {group}, nullptr) -> default options
+            varis.append(pc.variance(grp).as_py())
+            stds.append(pc.stddev(grp).as_py())
+            prods.append(pc.product(grp).as_py())
+            firsts.append(grp[0].as_py())            # GroupBy::first/last: GetScalar(0) / GetScalar(length - 1)
+            lasts.append(grp[len(grp) - 1].as_py())
         dt = np.float64 if isf else np.int64
         nz = lambda xs, d: np.array([0 if x is None else x for x in xs], d)  # noqa: E731
         res[cname] = dict(sum=nz(sums, dt), mean=nz(means, np.float64), min=nz(mins, dt), max=nz(maxs, dt), count=np.array(cnts, np.int64),
-                          ok=np.array([x is not None for x in sums], bool))
+                          ok=np.array([x is not None for x in sums], bool),
+                          variance=nz(varis, np.float64), stddev=nz(stds, np.float64), product=nz(prods, dt), first=nz(firsts, dt),
+                          last=nz(lasts, dt), ok_first=np.array([x is not None for x in firsts], bool),
+                          ok_last=np.array([x is not None for x in lasts], bool))
     uvals, uvalid = out_np(uniq, np.int64)
     return ids, uvals, uvalid, res
 
@@ -307,7 +317,8 @@ def gen_groupby():
     keys, vals = orc.synth_keys(0, n, nk), orc.synth_vals(0, n, 0)
     ids, uvals, uvalid, res = reference_groupby(keys, None, {"f": (vals, None)})
     put("gb_synth_300000_1000", n=n, num_keys=nk, uniq=uvals, f_sum=res["f"]["sum"], f_mean=res["f"]["mean"], f_count=res["f"]["count"],
-        f_min=res["f"]["min"], f_max=res["f"]["max"])
+        f_min=res["f"]["min"], f_max=res["f"]["max"], f_variance=res["f"]["variance"], f_stddev=res["f"]["stddev"],
+        f_product=res["f"]["product"], f_first=res["f"]["first"], f_last=res["f"]["last"])
     cases.append("gb_synth_300000_1000")
     manifest["cases"]["groupby"] = cases
 

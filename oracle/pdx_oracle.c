@@ -165,6 +165,57 @@ int orc_mean_i64(const int64_t* v, const uint8_t* valid, int64_t off, int64_t n,
   *out = cnt ? pw_finish(&s) / (double)cnt : 0.0;
   return ORC_OK;
 }
+/* variance / stddev with default VarianceOptions (ddof = 0, skip_nulls, min_count = 0), reached per group through
+ * GROUPBY_NUMERIC_AGG(variance|stddev) src/dataframe.cpp:1516-1520 with null options.  Arrow 25.0.0 (VarStdImpl, two passes):
+ * mean = pairwise sum / count, m2 = pairwise sum of (x - mean)^2 over the same valid runs, var = m2 / (count - ddof);
+ * int64 values are converted to double first.  Pinned against pyarrow (tests/golden: *_variance, *_stddev). */
+int orc_var_f64(const double* v, const uint8_t* valid, int64_t off, int64_t n, int want_std, double* out, int64_t* count) {
+  double s = 0.0;
+  orc_sum_f64(v, valid, off, n, &s, count);
+  if (*count == 0) {
+    *out = 0.0;
+    return ORC_OK;
+  }
+  const double mean = s / (double)*count;
+  double* d = (double*)malloc((size_t)(n + off + 1) * sizeof(double));
+  for (int64_t i = 0; i < n; ++i) {
+    double x = v[off + i] - mean;
+    d[off + i] = x * x;
+  }
+  double m2 = 0.0;
+  int64_t c2 = 0;
+  orc_sum_f64(d, valid, off, n, &m2, &c2);
+  free(d);
+  double var = m2 / (double)*count;
+  *out = want_std ? sqrt(var) : var;
+  return ORC_OK;
+}
+/* product (ScalarAggregateOptions default: skip_nulls, min_count = 1): one multiply per valid value in row order;
+ * int64 wraps (GROUPBY_AGG(product) src/dataframe.cpp:1536) */
+int orc_product_f64(const double* v, const uint8_t* valid, int64_t off, int64_t n, double* out, int64_t* count) {
+  double p = 1.0;
+  int64_t c = 0;
+  for (int64_t i = 0; i < n; ++i)
+    if (is_valid(valid, off, i)) {
+      p = p * v[off + i];
+      ++c;
+    }
+  *out = p;
+  *count = c;
+  return ORC_OK;
+}
+int orc_product_i64(const int64_t* v, const uint8_t* valid, int64_t off, int64_t n, int64_t* out, int64_t* count) {
+  uint64_t p = 1;
+  int64_t c = 0;
+  for (int64_t i = 0; i < n; ++i)
+    if (is_valid(valid, off, i)) {
+      p = p * (uint64_t)v[off + i];
+      ++c;
+    }
+  *out = (int64_t)p;
+  *count = c;
+  return ORC_OK;
+}
 /* min/max: nulls skipped; NaN skipped unless every valid value is NaN; first value wins ties
  * (NDFrame::min/max src/ndframe.cpp:163-166; MinMax in src/resample.cpp:223) */
 int orc_minmax_f64(const double* v, const uint8_t* valid, int64_t off, int64_t n, double* mn, double* mx, int64_t* count) {
@@ -457,6 +508,12 @@ int orc_groupby_agg_f64(int kind, const int64_t* offsets, const int64_t* rows, i
       case ORC_AGG_MIN: orc_minmax_f64(gv, gb, 0, len, &lo, &hi, &cnt); out_f64[g] = lo; break;
       case ORC_AGG_MAX: orc_minmax_f64(gv, gb, 0, len, &lo, &hi, &cnt); out_f64[g] = hi; break;
       case ORC_AGG_COUNT: cnt = orc_count(gb, 0, len); out_i64[g] = cnt; break;
+      case ORC_AGG_VARIANCE: orc_var_f64(gv, gb, 0, len, 0, &s, &cnt); out_f64[g] = s; break;
+      case ORC_AGG_STDDEV: orc_var_f64(gv, gb, 0, len, 1, &s, &cnt); out_f64[g] = s; break;
+      case ORC_AGG_PRODUCT: orc_product_f64(gv, gb, 0, len, &s, &cnt); out_f64[g] = s; break;
+      /* GroupBy::first / last (src/dataframe.cpp:1698-1810): the group's first / last ROW, null if that row is null */
+      case ORC_AGG_FIRST: cnt = len > 0 && (!gb || bit_get(gb, 0)); out_f64[g] = len > 0 ? gv[0] : 0.0; break;
+      case ORC_AGG_LAST: cnt = len > 0 && (!gb || bit_get(gb, len - 1)); out_f64[g] = len > 0 ? gv[len - 1] : 0.0; break;
     }
     if (out_valid) out_valid[g] = (kind == ORC_AGG_COUNT) ? 1 : (cnt > 0);
     free(gv);
@@ -487,6 +544,18 @@ int orc_groupby_agg_i64(int kind, const int64_t* offsets, const int64_t* rows, i
       case ORC_AGG_MIN: orc_minmax_i64(gv, gb, 0, len, &lo, &hi, &cnt); out_i64[g] = lo; break;
       case ORC_AGG_MAX: orc_minmax_i64(gv, gb, 0, len, &lo, &hi, &cnt); out_i64[g] = hi; break;
       case ORC_AGG_COUNT: cnt = orc_count(gb, 0, len); out_i64[g] = cnt; break;
+      case ORC_AGG_VARIANCE:
+      case ORC_AGG_STDDEV: {
+        double* d = (double*)malloc((size_t)(len ? len : 1) * sizeof(double));
+        for (int64_t j = 0; j < len; ++j) d[j] = (double)gv[j];
+        orc_var_f64(d, gb, 0, len, kind == ORC_AGG_STDDEV, &m, &cnt);
+        free(d);
+        out_f64[g] = m;
+        break;
+      }
+      case ORC_AGG_PRODUCT: orc_product_i64(gv, gb, 0, len, &s, &cnt); out_i64[g] = s; break;
+      case ORC_AGG_FIRST: cnt = len > 0 && (!gb || bit_get(gb, 0)); out_i64[g] = len > 0 ? gv[0] : 0; break;
+      case ORC_AGG_LAST: cnt = len > 0 && (!gb || bit_get(gb, len - 1)); out_i64[g] = len > 0 ? gv[len - 1] : 0; break;
     }
     if (out_valid) out_valid[g] = (kind == ORC_AGG_COUNT) ? 1 : (cnt > 0);
     free(gv);

@@ -35,7 +35,8 @@ extern "C" {
 enum { ORC_ADD = 0, ORC_SUB = 1, ORC_MUL = 2, ORC_DIV = 3 };
 enum { ORC_EQ = 0, ORC_NE = 1, ORC_LT = 2, ORC_LE = 3, ORC_GT = 4, ORC_GE = 5 };
 enum { ORC_AND = 0, ORC_OR = 1 };
-enum { ORC_AGG_SUM = 0, ORC_AGG_MEAN = 1, ORC_AGG_MIN = 2, ORC_AGG_MAX = 3, ORC_AGG_COUNT = 4 };
+enum { ORC_AGG_SUM = 0, ORC_AGG_MEAN = 1, ORC_AGG_MIN = 2, ORC_AGG_MAX = 3, ORC_AGG_COUNT = 4,
+       ORC_AGG_VARIANCE = 5, ORC_AGG_STDDEV = 6, ORC_AGG_PRODUCT = 7, ORC_AGG_FIRST = 8, ORC_AGG_LAST = 9 };
 
 /* ---- synthetic inputs (counter based) ---- */
 uint64_t orc_splitmix64(uint64_t x);

@@ -19,6 +19,7 @@ ADD, SUB, MUL, DIV = range(4)
 EQ, NE, LT, LE, GT, GE = range(6)
 AND, OR = range(2)
 AGG_SUM, AGG_MEAN, AGG_MIN, AGG_MAX, AGG_COUNT = range(5)
+AGG_VARIANCE, AGG_STDDEV, AGG_PRODUCT, AGG_FIRST, AGG_LAST = range(5, 10)  # group-by only (include/pdx/abi.h)
 ORIGIN_EPOCH, ORIGIN_START_DAY, ORIGIN_START, ORIGIN_END, ORIGIN_END_DAY, ORIGIN_CUSTOM = range(6)
 ORIGIN_SHARD = 0x100  # OR-ed into the origin type for a row-range shard of a longer axis (include/pdx/abi.h)
 

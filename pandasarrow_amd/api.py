@@ -284,6 +284,12 @@ class GroupBy:
     def min(self, args): return self._agg_frame(L.AGG_MIN, args)
     def max(self, args): return self._agg_frame(L.AGG_MAX, args)
     def count(self, args): return self._agg_frame(L.AGG_COUNT, args)
+    # GROUPBY_NUMERIC_AGG(variance|stddev), GROUPBY_AGG(product), GroupBy::first/last (src/dataframe.cpp:1516-1536, 1698-1810)
+    def variance(self, args): return self._agg_frame(L.AGG_VARIANCE, args)
+    def stddev(self, args): return self._agg_frame(L.AGG_STDDEV, args)
+    def product(self, args): return self._agg_frame(L.AGG_PRODUCT, args)
+    def first(self, args): return self._agg_frame(L.AGG_FIRST, args)
+    def last(self, args): return self._agg_frame(L.AGG_LAST, args)
 
     def agg(self, name, kinds):
         """sum/mean/count of one column from a single grouped pass (the headline query)."""

@@ -259,7 +259,8 @@ def concat(parts) -> Column:
 
 # ---------------------------------------------------------------- group-by / resample handles
 _AGG_OUT_DT = {L.AGG_MEAN: lambda dt: L.FLOAT64, L.AGG_COUNT: lambda dt: L.INT64, L.AGG_SUM: lambda dt: dt, L.AGG_MIN: lambda dt: dt,
-               L.AGG_MAX: lambda dt: dt}
+               L.AGG_MAX: lambda dt: dt, L.AGG_VARIANCE: lambda dt: L.FLOAT64, L.AGG_STDDEV: lambda dt: L.FLOAT64,
+               L.AGG_PRODUCT: lambda dt: dt, L.AGG_FIRST: lambda dt: dt, L.AGG_LAST: lambda dt: dt}
 
 
 class GroupByHandle:

@@ -499,7 +499,7 @@ struct GroupBy {
   }
   Array agg_array(const std::string& arg, int kind) const {
     const Array& v = df.m_columns[(size_t)df.column_index(arg)];
-    int out_dt = kind == PDX_AGG_MEAN ? PDX_FLOAT64 : kind == PDX_AGG_COUNT ? PDX_INT64 : v.dtype;
+    int out_dt = (kind == PDX_AGG_MEAN || kind == PDX_AGG_VARIANCE || kind == PDX_AGG_STDDEV) ? PDX_FLOAT64 : kind == PDX_AGG_COUNT ? PDX_INT64 : v.dtype;
     Array out = Array::Empty(out_dt, (int64_t)groupSize(), v.has_nulls() && kind != PDX_AGG_COUNT);
     auto c = v.c();
     auto m = out.mut();
@@ -520,11 +520,22 @@ struct GroupBy {
   Series min(const std::string& a) const { return agg(a, PDX_AGG_MIN); }
   Series max(const std::string& a) const { return agg(a, PDX_AGG_MAX); }
   Series count(const std::string& a) const { return agg(a, PDX_AGG_COUNT); }
+  // src/dataframe.cpp:1516-1536 (variance, stddev, product), 1698-1810 (first, last)
+  Series variance(const std::string& a) const { return agg(a, PDX_AGG_VARIANCE); }
+  Series stddev(const std::string& a) const { return agg(a, PDX_AGG_STDDEV); }
+  Series product(const std::string& a) const { return agg(a, PDX_AGG_PRODUCT); }
+  Series first(const std::string& a) const { return agg(a, PDX_AGG_FIRST); }
+  Series last(const std::string& a) const { return agg(a, PDX_AGG_LAST); }
   DataFrame sum(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_SUM); }
   DataFrame mean(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_MEAN); }
   DataFrame min(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_MIN); }
   DataFrame max(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_MAX); }
   DataFrame count(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_COUNT); }
+  DataFrame variance(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_VARIANCE); }
+  DataFrame stddev(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_STDDEV); }
+  DataFrame product(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_PRODUCT); }
+  DataFrame first(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_FIRST); }
+  DataFrame last(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_LAST); }
 };
 
 // ---------------------------------------------------------------- pd::Resampler (src/group_by.h:255-299)

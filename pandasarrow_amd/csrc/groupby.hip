@@ -1741,6 +1741,71 @@ static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int
   return PDX_OK;
 }
 
+// ---------------------------------------------------------------- "next" aggregations on the grouped layout
+__device__ __forceinline__ bool seg_row_is_null(const uint32_t* sorted_keys, const uint8_t* row_valid, int64_t valid_off, int64_t i) {
+  if (sorted_keys) return (sorted_keys[i] >> 31) != 0;          // grouped (sorted) layout: the flag travelled with the slot
+  return row_valid && !bit_get(row_valid, valid_off + i);       // segments of the original order (resample)
+}
+// d[i] = (x[i] - mean of x's segment)^2: the second pass of Arrow's variance.  One wave per segment, coalesced.
+template <typename T>
+__global__ void __launch_bounds__(256) k_seg_sqdev(const T* __restrict__ vals, const uint32_t* __restrict__ seg_start, int64_t nseg,
+                                                   const double* __restrict__ mean_seg, double* __restrict__ d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < nseg; k += nw) {
+    const int64_t s = seg_start[k], e = seg_start[k + 1];
+    const double mu = mean_seg[k];
+    for (int64_t i = s + lane; i < e; i += 64) {
+      const double x = (double)vals[i] - mu;
+      d[i] = x * x;
+    }
+  }
+}
+// product of the valid values of every segment in row order (sequential by definition); first / last row of every segment
+template <typename T>
+__global__ void __launch_bounds__(256) k_seg_product_first_last(const T* __restrict__ vals, const uint32_t* __restrict__ sorted_keys,
+                                                                const uint8_t* __restrict__ row_valid, int64_t valid_off,
+                                                                const uint32_t* __restrict__ seg_start, int64_t nseg,
+                                                                const uint32_t* __restrict__ out_index, T* __restrict__ prod,
+                                                                uint8_t* __restrict__ prod_ok, T* __restrict__ first, uint8_t* __restrict__ first_ok,
+                                                                T* __restrict__ last, uint8_t* __restrict__ last_ok) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += stride) {
+    const int64_t s = seg_start[k], e = seg_start[k + 1];
+    const uint32_t oi = out_index ? out_index[k] : (uint32_t)k;
+    if (prod) {
+      T p = T(1);
+      bool any = false;
+      for (int64_t i = s; i < e; ++i)
+        if (!seg_row_is_null(sorted_keys, row_valid, valid_off, i)) {
+          if constexpr (__is_same(T, double)) p = p * vals[i];
+          else p = (T)((unsigned long long)p * (unsigned long long)vals[i]);
+          any = true;
+        }
+      prod[oi] = p;
+      if (prod_ok) prod_ok[oi] = any;
+    }
+    if (first) {
+      first[oi] = e > s ? vals[s] : T(0);
+      if (first_ok) first_ok[oi] = e > s && !seg_row_is_null(sorted_keys, row_valid, valid_off, s);
+    }
+    if (last) {
+      last[oi] = e > s ? vals[e - 1] : T(0);
+      if (last_ok) last_ok[oi] = e > s && !seg_row_is_null(sorted_keys, row_valid, valid_off, e - 1);
+    }
+  }
+}
+// var = m2 / count (ddof = 0); stddev = sqrt(var)
+__global__ void k_var_finish(const double* __restrict__ m2, const long long* __restrict__ count, int64_t G, double* __restrict__ var,
+                             double* __restrict__ sd) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) {
+    const double v = count[g] > 0 ? m2[g] / (double)count[g] : 0.0;
+    if (var) var[g] = v;
+    if (sd) sd[g] = sqrt(v);
+  }
+}
+
 }  // namespace pdx
 
 extern "C" {
@@ -2175,29 +2240,39 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   const int64_t n = gb->n, G = gb->G;
   const uint8_t* vvalid = validity_or_null(values);
   SegOut o{};
-  bool want_pw = false, want_mm = false, want_is = false;
+  bool want_pw = false, want_mm = false, want_is = false, want_std5 = false;
+  // the "next" kinds (variance, stddev, product, first, last) run after the five standard ones on the same grouped values
+  double *var_out = nullptr, *std_out = nullptr;
+  void *prod_out = nullptr, *first_out = nullptr, *last_out = nullptr;
   for (int k = 0; k < nk; ++k) {
     pdx_mut_column* oc = &outs[k];
     if (oc->length < G) return fail(PDX_INVALID, "pdx_groupby_agg: output too small");
     if (G && !oc->values) return fail(PDX_INVALID, "pdx_groupby_agg: null output buffer");
     int want_dt;
+    bool needs_validity = vvalid != nullptr;
     switch (kinds[k]) {
       case PDX_AGG_SUM:
         want_dt = is_f ? PDX_FLOAT64 : PDX_INT64;
         if (is_f) { o.sum_f = static_cast<double*>(oc->values); want_pw = true; }
         else { o.sum_i = static_cast<long long*>(oc->values); want_is = true; }
+        want_std5 = true;
         break;
-      case PDX_AGG_MEAN: want_dt = PDX_FLOAT64; o.mean = static_cast<double*>(oc->values); want_pw = true; break;
-      case PDX_AGG_MIN: want_dt = values->dtype; o.vmin = oc->values; want_mm = true; break;
-      case PDX_AGG_MAX: want_dt = values->dtype; o.vmax = oc->values; want_mm = true; break;
-      case PDX_AGG_COUNT: want_dt = PDX_INT64; o.count = static_cast<long long*>(oc->values); break;
+      case PDX_AGG_MEAN: want_dt = PDX_FLOAT64; o.mean = static_cast<double*>(oc->values); want_pw = true; want_std5 = true; break;
+      case PDX_AGG_MIN: want_dt = values->dtype; o.vmin = oc->values; want_mm = true; want_std5 = true; break;
+      case PDX_AGG_MAX: want_dt = values->dtype; o.vmax = oc->values; want_mm = true; want_std5 = true; break;
+      case PDX_AGG_COUNT: want_dt = PDX_INT64; o.count = static_cast<long long*>(oc->values); needs_validity = false; want_std5 = true; break;
+      case PDX_AGG_VARIANCE: want_dt = PDX_FLOAT64; var_out = static_cast<double*>(oc->values); break;
+      case PDX_AGG_STDDEV: want_dt = PDX_FLOAT64; std_out = static_cast<double*>(oc->values); break;
+      case PDX_AGG_PRODUCT: want_dt = values->dtype; prod_out = oc->values; break;
+      case PDX_AGG_FIRST: want_dt = values->dtype; first_out = oc->values; break;
+      case PDX_AGG_LAST: want_dt = values->dtype; last_out = oc->values; break;
       default: return fail(PDX_INVALID, "pdx_groupby_agg: unknown aggregate kind");
     }
     if (oc->dtype != want_dt) return fail(PDX_INVALID, "pdx_groupby_agg: output dtype does not match the aggregate's result type");
-    if (vvalid && kinds[k] != PDX_AGG_COUNT && !oc->validity)
+    if (needs_validity && !oc->validity)
       return fail(PDX_INVALID, "pdx_groupby_agg: values carry nulls but an output has no validity buffer");
     oc->length = G;
-    oc->null_count = vvalid && kinds[k] != PDX_AGG_COUNT ? -1 : 0;
+    oc->null_count = needs_validity ? -1 : 0;
   }
   if (G == 0) return PDX_OK;
   Scratch s;
@@ -2226,28 +2301,88 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
     seg_start = gb->seg_start;
     row_valid = vvalid;
   }
-  PDX_PROFILE("seg_reduce", st);
-  if (!vvalid) {
-    if (is_f) PDX_TRY(launch_seg_reduce_dense<double>(static_cast<const double*>(vals_sorted), seg_start, G, out_index, o, want_pw, want_mm, want_is, n, s, st));
-    else PDX_TRY(launch_seg_reduce_dense<long long>(static_cast<const long long*>(vals_sorted), seg_start, G, out_index, o, want_pw, want_mm, want_is, n, s, st));
-    for (int k = 0; k < nk; ++k)
-      if (outs[k].validity) PDX_HIP(hipMemsetAsync(outs[k].validity, 0xFF, (size_t)((G + 7) / 8), st));
-  } else {
-    uint8_t* ok = s.get<uint8_t>((size_t)G);
-    PDX_SCRATCH_CHECK(s);
+  const uint32_t* fk = (gb->mode == 0 && vvalid) ? keys_sorted : nullptr;  // null flags of the grouped layout
+  // one segmented reduce of `vals` (float64 or int64 per f64) into `oo`; ok_bytes (nullable values only): 1 = the group has a valid value
+  auto reduce = [&](const void* vals, bool f64, const SegOut& oo, bool pw, bool mm, bool is, const uint32_t* oidx, uint8_t* ok_bytes) -> int {
+    PDX_PROFILE("seg_reduce", st);
+    if (!vvalid) {
+      if (f64) return launch_seg_reduce_dense<double>(static_cast<const double*>(vals), seg_start, G, oidx, oo, pw, mm, is, n, s, st);
+      return launch_seg_reduce_dense<long long>(static_cast<const long long*>(vals), seg_start, G, oidx, oo, pw, mm, is, n, s, st);
+    }
     int grid = (int)std::min<int64_t>(ceil_div(G, kSegWaves), (int64_t)kCUs * 8);
-    const uint32_t* fk = gb->mode == 0 ? keys_sorted : nullptr;
-    if (is_f)
-      hipLaunchKernelGGL((k_seg_reduce_nullable<double>), dim3(grid), dim3(kSegWaves * 64), 0, st, static_cast<const double*>(vals_sorted), fk, row_valid,
-                         values->offset, seg_start, G, out_index, o, ok);
+    if (f64)
+      hipLaunchKernelGGL((k_seg_reduce_nullable<double>), dim3(grid), dim3(kSegWaves * 64), 0, st, static_cast<const double*>(vals), fk, row_valid,
+                         values->offset, seg_start, G, oidx, oo, ok_bytes);
     else
-      hipLaunchKernelGGL((k_seg_reduce_nullable<long long>), dim3(grid), dim3(kSegWaves * 64), 0, st, static_cast<const long long*>(vals_sorted), fk,
-                         row_valid, values->offset, seg_start, G, out_index, o, ok);
+      hipLaunchKernelGGL((k_seg_reduce_nullable<long long>), dim3(grid), dim3(kSegWaves * 64), 0, st, static_cast<const long long*>(vals), fk,
+                         row_valid, values->offset, seg_start, G, oidx, oo, ok_bytes);
     PDX_LAUNCH_CHECK();
+    return PDX_OK;
+  };
+  auto pack_validity = [&](uint8_t* bits, const uint8_t* ok_bytes) {
+    if (!bits) return;
+    if (!ok_bytes) hipMemsetAsync(bits, 0xFF, (size_t)((G + 7) / 8), st);
+    else hipLaunchKernelGGL(k_pack_bytes, dim3(grid_for((G + 7) / 8, 256)), dim3(256), 0, st, ok_bytes, G, bits);
+  };
+  uint8_t* ok = nullptr;
+  if (vvalid) {
+    ok = s.get<uint8_t>((size_t)G);
+    PDX_SCRATCH_CHECK(s);
+  }
+  if (want_std5) {
+    PDX_TRY(reduce(vals_sorted, is_f, o, want_pw, want_mm, want_is, out_index, ok));
+    for (int k = 0; k < nk; ++k)
+      if (kinds[k] <= PDX_AGG_COUNT) pack_validity(static_cast<uint8_t*>(outs[k].validity), kinds[k] == PDX_AGG_COUNT ? nullptr : ok);
+    PDX_LAUNCH_CHECK();
+  }
+  if (var_out || std_out) {
+    // Arrow's two passes: mean = pairwise sum / count, then the pairwise sum of (x - mean)^2 over the same valid runs
+    double* mean_seg = s.get<double>((size_t)G);
+    double* d = s.get<double>((size_t)n);
+    double* m2 = s.get<double>((size_t)G);
+    long long* cnt_g = s.get<long long>((size_t)G);
+    uint8_t* ok2 = vvalid ? s.get<uint8_t>((size_t)G) : nullptr;
+    uint8_t* ok_seg = vvalid ? s.get<uint8_t>((size_t)G) : nullptr;
+    PDX_SCRATCH_CHECK(s);
+    SegOut o1{};
+    o1.mean = mean_seg;
+    PDX_TRY(reduce(vals_sorted, is_f, o1, true, false, false, nullptr, ok_seg));  // segment order
+    {
+      PDX_PROFILE("seg_sqdev", st);
+      const int grid = (int)std::min<int64_t>(ceil_div(G, 4), (int64_t)kCUs * 16);
+      if (is_f) hipLaunchKernelGGL((k_seg_sqdev<double>), dim3(grid), dim3(256), 0, st, static_cast<const double*>(vals_sorted), seg_start, G, mean_seg, d);
+      else hipLaunchKernelGGL((k_seg_sqdev<long long>), dim3(grid), dim3(256), 0, st, static_cast<const long long*>(vals_sorted), seg_start, G, mean_seg, d);
+      PDX_LAUNCH_CHECK();
+    }
+    SegOut o2{};
+    o2.sum_f = m2;
+    o2.count = cnt_g;
+    PDX_TRY(reduce(d, true, o2, true, false, false, out_index, ok2));
+    hipLaunchKernelGGL(k_var_finish, dim3(grid_for(G, 256)), dim3(256), 0, st, m2, cnt_g, G, var_out, std_out);
+    for (int k = 0; k < nk; ++k)
+      if (kinds[k] == PDX_AGG_VARIANCE || kinds[k] == PDX_AGG_STDDEV) pack_validity(static_cast<uint8_t*>(outs[k].validity), ok2);
+    PDX_LAUNCH_CHECK();
+  }
+  if (prod_out || first_out || last_out) {
+    uint8_t* pok = (vvalid && prod_out) ? s.get<uint8_t>((size_t)G) : nullptr;
+    uint8_t* fok = (vvalid && first_out) ? s.get<uint8_t>((size_t)G) : nullptr;
+    uint8_t* lok = (vvalid && last_out) ? s.get<uint8_t>((size_t)G) : nullptr;
+    PDX_SCRATCH_CHECK(s);
+    {
+      PDX_PROFILE("seg_product_first_last", st);
+      if (is_f)
+        hipLaunchKernelGGL((k_seg_product_first_last<double>), dim3(grid_for(G, 256)), dim3(256), 0, st, static_cast<const double*>(vals_sorted), fk,
+                           row_valid, values->offset, seg_start, G, out_index, static_cast<double*>(prod_out), pok, static_cast<double*>(first_out), fok,
+                           static_cast<double*>(last_out), lok);
+      else
+        hipLaunchKernelGGL((k_seg_product_first_last<long long>), dim3(grid_for(G, 256)), dim3(256), 0, st, static_cast<const long long*>(vals_sorted),
+                           fk, row_valid, values->offset, seg_start, G, out_index, static_cast<long long*>(prod_out), pok,
+                           static_cast<long long*>(first_out), fok, static_cast<long long*>(last_out), lok);
+    }
     for (int k = 0; k < nk; ++k) {
-      if (!outs[k].validity) continue;
-      if (kinds[k] == PDX_AGG_COUNT) PDX_HIP(hipMemsetAsync(outs[k].validity, 0xFF, (size_t)((G + 7) / 8), st));
-      else hipLaunchKernelGGL(k_pack_bytes, dim3(grid_for((G + 7) / 8, 256)), dim3(256), 0, st, ok, G, static_cast<uint8_t*>(outs[k].validity));
+      if (kinds[k] == PDX_AGG_PRODUCT) pack_validity(static_cast<uint8_t*>(outs[k].validity), pok);
+      if (kinds[k] == PDX_AGG_FIRST) pack_validity(static_cast<uint8_t*>(outs[k].validity), fok);
+      if (kinds[k] == PDX_AGG_LAST) pack_validity(static_cast<uint8_t*>(outs[k].validity), lok);
     }
     PDX_LAUNCH_CHECK();
   }

@@ -120,6 +120,13 @@ static void test_groupby() {
   REQUIRE((g.min("age").values<int>() == std::vector<int>{10, 10}));
   REQUIRE((g.sum("age").values<int64_t>() == std::vector<int64_t>{181, 65}));
   REQUIRE((g.count("age").values<int64_t>() == std::vector<int64_t>{7, 3}));
+  // the "next" group-by aggregations (src/dataframe.cpp:1516-1536, 1698-1810); expected values from Arrow 25.0.0's kernels
+  REQUIRE(g.variance("age").values<double>()[0] == 164.40816326530611);
+  REQUIRE(g.variance("age").values<double>()[1] == 72.22222222222223);
+  REQUIRE(g.stddev("age").values<double>()[0] == 12.822174669895357);
+  REQUIRE((g.product("age").values<int64_t>() == std::vector<int64_t>{3024000000LL, 7500}));
+  REQUIRE((g.first("age").values<int>() == std::vector<int>{16, 10}));
+  REQUIRE((g.last("age").values<int>() == std::vector<int>{45, 25}));
 }
 
 // tests/series_resample_test.cpp:12-85

@@ -568,3 +568,74 @@ def test_groupby_dense_speculation(px, monkeypatch, case):
     assert_f64_bits(m.to_numpy()[0], orc.groupby_agg(orc.AGG_MEAN, ids, G, vals, nthreads=8)[0], what="mean")
     assert np.array_equal(cnt.to_numpy()[0], np.bincount(ids, minlength=G))
     assert np.array_equal(gb.group_ids().cpu().numpy(), ids)
+
+
+# ---------------------------------------------------------------- variance / stddev / product / first / last per group
+GB_NEXT = {"variance": 5, "stddev": 6, "product": 7, "first": 8, "last": 9}
+
+
+@pytest.mark.parametrize("hashmode", ["default", "partitioned"])
+@pytest.mark.parametrize("name", [c for c in G.cases("groupby") if "synth" not in c])
+def test_groupby_next_aggs_golden(px, monkeypatch, name, hashmode):
+    """golden vectors made with Arrow's scalar variance / stddev / product kernels and positional first / last per group"""
+    if hashmode != "default":
+        monkeypatch.setenv("PDX_GROUPBY_DENSE", "0")
+        monkeypatch.setenv("PDX_HASH_PARTITION", "2")
+    c = G.case(name)
+    Gn = len(c["uniq"])
+    if Gn == 0:
+        return
+    kvalid = _valid_or_none(c["kvalid"]) if "kvalid" in c else None
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(c["keys"], kvalid, offset=1))
+    vvalid = _valid_or_none(c["vvalid"]) if "vvalid" in c else None
+    for col, keyname in (("f", "vf"), ("i", "vi")):
+        if keyname not in c:
+            continue
+        vcol = px.Column.from_numpy(c[keyname], vvalid, offset=2)
+        outs = gb.agg(vcol, [0] + list(GB_NEXT.values()))  # together with a standard kind in one call
+        for (k, kind), out in zip(GB_NEXT.items(), outs[1:]):
+            vals, ok = out.to_numpy()
+            exp = c[f"{col}_{k}"]
+            eok = c[f"{col}_ok_{k}"] if k in ("first", "last") else c[f"{col}_ok"]
+            assert (ok is None and eok.all()) or np.array_equal(ok, eok), f"{name} {col} {k} validity"
+            if vals.dtype == np.float64:
+                assert_f64_bits(vals, exp, valid=eok, what=f"{name} {col} {k}")
+            else:
+                assert np.array_equal(vals[eok], exp[eok]), f"{name} {col} {k}"
+
+
+@pytest.mark.parametrize("nulls", [False, True])
+@pytest.mark.parametrize("n,nk,dtype", [(300_007, 1000, "f"), (300_007, 3, "f"), (1_200_011, 300_000, "i"), (70_001, 1, "f")])
+def test_groupby_next_aggs_vs_oracle(px, n, nk, dtype, nulls):
+    """group sizes from a few rows to > 65536 rows (the many-waves path under the variance passes), float64 and int64 values"""
+    rng = np.random.default_rng(n + nk)
+    keys = orc.synth_keys(0, n, nk)
+    vals = (1.0 + (orc.synth_vals(0, n) - 0.5) * 1e-3) if dtype == "f" else rng.integers(-3, 4, n).astype(np.int64)
+    vvalid = (rng.random(n) > 0.15) if nulls else None
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys))
+    outs = gb.agg(px.Column.from_numpy(vals, vvalid), list(GB_NEXT.values()))
+    ids, uniq, _, _ = orc.group_ids(keys)
+    for (k, kind), out in zip(GB_NEXT.items(), outs):
+        got, ok = out.to_numpy()
+        exp, eok = orc.groupby_agg(kind, ids, len(uniq), vals, vvalid, nthreads=8)
+        assert (ok is None and eok.all()) or np.array_equal(ok, eok), k
+        if exp.dtype == np.float64:
+            assert_f64_bits(got, exp, valid=eok, what=k)
+        else:
+            assert np.array_equal(got[eok], exp[eok]), k
+
+
+def test_resample_next_aggs_vs_oracle(px):
+    """the resample handle is a group-by handle over bins: same kinds, values in their original order"""
+    n, minute = 200_003, 60 * 10**9
+    rng = np.random.default_rng(9)
+    ts = 1_600_000_000 * 10**9 + np.sort(rng.integers(0, 700 * minute, n)).astype(np.int64)
+    vals = 1.0 + rng.standard_normal(n) * 1e-3
+    vvalid = rng.random(n) > 0.1
+    gb = px.K.GroupByHandle.resample(px.Column.from_numpy(ts, dtype=px.L.TIMESTAMP_NS), 5 * minute)
+    outs = gb.agg(px.Column.from_numpy(vals, vvalid), list(GB_NEXT.values()))
+    for (k, kind), out in zip(GB_NEXT.items(), outs):
+        got, ok = out.to_numpy()
+        _, exp, eok = orc.resample_agg(kind, ts, vals, 5 * minute, valid=vvalid)
+        assert np.array_equal(ok, eok), k
+        assert_f64_bits(got, exp, valid=eok, what=k)

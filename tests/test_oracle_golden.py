@@ -165,6 +165,16 @@ def test_take_errors_and_kat(kat):
 
 # ------------------------------------------------------------------ group-by
 GB_KINDS = {"sum": orc.AGG_SUM, "mean": orc.AGG_MEAN, "min": orc.AGG_MIN, "max": orc.AGG_MAX, "count": orc.AGG_COUNT}
+# SURVEY 8(f)-3 ("next" aggregations on the same grouped layout)
+GB_NEXT = {"variance": orc.AGG_VARIANCE, "stddev": orc.AGG_STDDEV, "product": orc.AGG_PRODUCT, "first": orc.AGG_FIRST, "last": orc.AGG_LAST}
+
+
+def gb_expected_valid(c, col, k, G):
+    if k == "count":
+        return np.ones(G, bool)
+    if k in ("first", "last"):
+        return c[f"{col}_ok_{k}"]
+    return c[f"{col}_ok"]
 
 
 @pytest.mark.parametrize("name", [c for c in G.cases("groupby") if "synth" not in c])
@@ -184,10 +194,10 @@ def test_groupby(name):
     for col, key in (("f", "vf"), ("i", "vi")):
         if key not in c:
             continue
-        for k, kind in GB_KINDS.items():
+        for k, kind in {**GB_KINDS, **GB_NEXT}.items():
             vals, ok = orc.groupby_agg(kind, ids, len(uniq), c[key], vvalid, offset=2, nthreads=2)
             exp = c[f"{col}_{k}"]
-            eok = np.ones(len(uniq), bool) if k == "count" else c[f"{col}_ok"]
+            eok = gb_expected_valid(c, col, k, len(uniq))
             assert np.array_equal(ok, eok), f"{name} {col} {k} validity"
             if vals.dtype == np.float64:
                 assert_f64_bits(vals, exp, valid=eok, what=f"{name} {col} {k}")
