@@ -235,6 +235,17 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
 /* per-row labels (GroupInfo::downsample): device pointer to num_rows int64 */
 int pdx_resample_row_labels(pdx_groupby* gb, int64_t* out_labels, void* stream);
 
+/* ---------------------------------------------------------------- index alignment (the callers' slow path)
+ * Binary operators on Series with UNEQUAL indexes go through Series::broadcast (src/series.cpp:212-227):
+ * Concatenate(index_a, index_b) -> Unique -> array_sort_indices(ascending) -> Take, then Series::reindex of both operands
+ * (src/series.cpp:1255-1309: std::unordered_map label -> LAST position, absent labels -> null).
+ * pdx_index_union: the sorted distinct labels of a and b (same dtype: int64 / uint64 / timestamp[ns], no nulls).
+ *   out: same dtype, capacity a.length + b.length; out->length is set to the number of labels.
+ * pdx_reindex_indices: for every label of new_index its LAST position in old_index as int64 take indices with a validity
+ *   bitmap (absent label -> null index); feed it to pdx_take, whose null indices produce null rows (== AppendNull). */
+int pdx_index_union(const pdx_column* a, const pdx_column* b, pdx_mut_column* out, void* stream);
+int pdx_reindex_indices(const pdx_column* old_index, const pdx_column* new_index, pdx_mut_column* out_idx, void* stream);
+
 /* ---------------------------------------------------------------- concat (rows)
  * Replaces arrow::ConcatenateTables + CombineChunksToBatch at src/concat.cpp:152-154 for same-dtype parts
  * (the all-gatherv merge of sharded results).  out->length must be >= sum of part lengths. */

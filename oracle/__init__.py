@@ -350,3 +350,22 @@ def concat(parts, valids=None):
     nulls = C.c_int64(0)
     lib().orc_concat_64(pp, pv, _p(offs), _p(lens), C.c_int(k), _p(out), _p(ov), C.byref(nulls))
     return out.view(dtype), (None if valids is None else unpack_bits(ov, total))
+
+
+# ------------------------------------------------------------------ index alignment
+def index_union(a, b):
+    """Series::broadcast's new index (src/series.cpp:212-227): Unique(Concatenate(a, b)) sorted ascending."""
+    return np.unique(np.concatenate([np.asarray(a), np.asarray(b)]))
+
+
+def reindex_indices(old_index, new_index):
+    """Series::reindex (src/series.cpp:1255-1309): position of every new label in the old index -- insert_or_assign keeps the
+    LAST position of a duplicated label -- and a bool mask of the labels that are present (absent -> AppendNull)."""
+    old_index, new_index = np.asarray(old_index), np.asarray(new_index)
+    if len(old_index) == 0:
+        return np.zeros(len(new_index), np.int64), np.zeros(len(new_index), bool)
+    order = np.argsort(old_index, kind="stable")
+    so = old_index[order]
+    j = np.searchsorted(so, new_index, side="right") - 1
+    present = (j >= 0) & (so[np.maximum(j, 0)] == new_index)
+    return np.where(present, order[np.maximum(j, 0)], 0).astype(np.int64), present

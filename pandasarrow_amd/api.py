@@ -19,6 +19,7 @@ from __future__ import annotations
 import re
 
 import numpy as np
+import torch
 
 from . import _lib as L
 from . import column as K
@@ -93,18 +94,61 @@ class Series:
         if isinstance(other, Series):
             if other.size() != self.size():
                 raise L.PdxError(L.INVALID, f"Array arguments must all be the same length: {self.size()} vs {other.size()}")
-            if (self.index is None) != (other.index is None):
-                raise L.PdxError(L.NOT_IMPLEMENTED, "index alignment of unequal indexes (Series::broadcast slow path) is not on the hot path")
             return other.col, False
         if isinstance(other, Scalar):
             other = other.value
         return other, True
 
+    # ---- index alignment (Series::broadcast src/series.cpp:212-227, Series::reindex 1255-1309)
+    def _explicit_index(self):
+        """the index as a column; the implicit range becomes the uint64 0..n-1 the reference materialises (src/ndframe.cpp:100-107)"""
+        if self.index is not None:
+            return self.index
+        return Column(L.UINT64, self.size(), torch.arange(max(self.size(), 1), dtype=torch.int64, device=K._device()), None)
+
+    def _same_index(self, other):
+        if self.index is None and other.index is None:
+            return self.size() == other.size()
+        a, b = self._explicit_index(), other._explicit_index()
+        if a.length != b.length or a.dtype != b.dtype:
+            return False
+        if a.length == 0:
+            return True
+        ai, bi = (Column(L.INT64, c.length, c.values, None, c.offset) for c in (a, b))  # labels compare as 64-bit patterns
+        return K.filter_count(K.compare(L.EQ, ai, bi)) == a.length
+
+    def reindex(self, new_index, fill_value=None):
+        """values at the LAST position of every new label, null where the label is absent"""
+        if fill_value is not None:
+            raise L.PdxError(L.NOT_IMPLEMENTED, "reindex(fill_value=...) is not implemented on the device path")
+        if not isinstance(new_index, Column):
+            new_index = Column.from_numpy(np.asarray(new_index))
+        old = self._explicit_index()
+        if old.dtype != new_index.dtype:
+            raise L.PdxError(L.INVALID, "type(NewIndex) != type(CurrentIndex).")
+        idx = K.reindex_indices(old, new_index)
+        return Series(K.take([self.col], idx)[0], index=new_index, name=self.name)
+
+    def broadcast(self, other):
+        if self._same_index(other):
+            return self, other
+        a, b = self._explicit_index(), other._explicit_index()
+        if a.dtype != b.dtype:
+            raise L.PdxError(L.INVALID, "type(NewIndex) != type(CurrentIndex).")
+        union = K.index_union(a, b)
+        return self.reindex(union), other.reindex(union)
+
     def _bin(self, op, other):
+        if isinstance(other, Series) and not self._same_index(other):
+            x, y = self.broadcast(other)
+            return x._wrap(K.binary(op, x.col, y.col, False))
         b, scalar = self._rhs(other)
         return self._wrap(K.binary(op, self.col, b, scalar))
 
     def _cmp(self, op, other):
+        if isinstance(other, Series) and not self._same_index(other):
+            x, y = self.broadcast(other)
+            return x._wrap(K.compare(op, x.col, y.col, False))
         b, scalar = self._rhs(other)
         return self._wrap(K.compare(op, self.col, b, scalar))
 

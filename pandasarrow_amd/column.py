@@ -257,6 +257,25 @@ def concat(parts) -> Column:
     return out._adopt(m)
 
 
+# ---------------------------------------------------------------- index alignment (Series::broadcast / reindex)
+def index_union(a: Column, b: Column) -> Column:
+    """sorted distinct labels of both indexes (pdx_index_union)."""
+    out = Column.empty(a.dtype, a.length + b.length)
+    m = out.mut()
+    ca, cb = a.c(), b.c()
+    L.check(L.load().pdx_index_union(C.byref(ca), C.byref(cb), C.byref(m), _stream()))
+    return out._adopt(m)
+
+
+def reindex_indices(old_index: Column, new_index: Column) -> Column:
+    """int64 take indices (LAST position of every new label in old_index, null where absent)."""
+    out = Column.empty(L.INT64, new_index.length, with_validity=True)
+    m = out.mut()
+    co, cn = old_index.c(), new_index.c()
+    L.check(L.load().pdx_reindex_indices(C.byref(co), C.byref(cn), C.byref(m), _stream()))
+    return out._adopt(m)
+
+
 # ---------------------------------------------------------------- group-by / resample handles
 _AGG_OUT_DT = {L.AGG_MEAN: lambda dt: L.FLOAT64, L.AGG_COUNT: lambda dt: L.INT64, L.AGG_SUM: lambda dt: dt, L.AGG_MIN: lambda dt: dt,
                L.AGG_MAX: lambda dt: dt, L.AGG_VARIANCE: lambda dt: L.FLOAT64, L.AGG_STDDEV: lambda dt: L.FLOAT64,

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <array>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -217,8 +218,47 @@ class Series {
     return Scalar(s);
   }
 
-  // ---- BINARY_OPERATOR (src/series.cpp:19-33): Series rhs needs equal length (equal-index fast path of broadcast(), 212-216)
+  // ---- Series::broadcast / reindex (src/series.cpp:212-227, 1255-1309): operands with different EXPLICIT indexes are aligned
+  // on the sorted union of their labels; labels missing on one side give null rows
+  bool same_index(const Series& o) const {
+    if (!m_index || !o.m_index) return o.size() == size();  // implicit ranges: positional
+    if (m_index->length != o.m_index->length || m_index->dtype != o.m_index->dtype) return false;
+    if (m_index->length == 0) return true;
+    Array a = *m_index, b = *o.m_index;
+    a.dtype = b.dtype = PDX_INT64;  // labels compare as 64-bit patterns
+    Array eq = run_compare(PDX_EQ, a, b, false);
+    auto cm = eq.c();
+    int64_t m = 0;
+    ThrowOnFailure(pdx_filter_count(&cm, /*emit_null=*/0, &m, nullptr));
+    return m == m_index->length;
+  }
+  Series reindex(const Array& newIndex) const {
+    if (!m_index) throw std::runtime_error("reindex needs an explicit index");
+    if (newIndex.dtype != m_index->dtype) throw std::runtime_error("type(NewIndex) != type(CurrentIndex).");
+    Array idx = Array::Empty(PDX_INT64, newIndex.length, true);
+    auto co = m_index->c(), cn = newIndex.c();
+    auto mi = idx.mut();
+    ThrowOnFailure(pdx_reindex_indices(&co, &cn, &mi, nullptr));
+    idx.null_count = mi.null_count;
+    return Series(run_take({m_array}, idx)[0], newIndex, m_name);
+  }
+  std::array<Series, 2> broadcast(const Series& o) const {
+    if (same_index(o)) return {*this, o};
+    if (m_index->dtype != o.m_index->dtype) throw std::runtime_error("type(NewIndex) != type(CurrentIndex).");
+    Array u = Array::Empty(m_index->dtype, m_index->length + o.m_index->length, false);
+    auto ca = m_index->c(), cb = o.m_index->c();
+    auto mu = u.mut();
+    ThrowOnFailure(pdx_index_union(&ca, &cb, &mu, nullptr));
+    u.length = mu.length;
+    return {reindex(u), o.reindex(u)};
+  }
+
+  // ---- BINARY_OPERATOR (src/series.cpp:19-33): `auto [x, y] = broadcast(a)` then one kernel over equal-length operands
   Series binary(int op, const Series& o) const {
+    if (m_index && o.m_index && !same_index(o)) {
+      auto xy = broadcast(o);
+      return xy[0].wrap(run_binary(op, xy[0].m_array, xy[1].m_array, false));
+    }
     if (o.size() != size()) throw std::runtime_error("Array arguments must all be the same length");
     return wrap(run_binary(op, m_array, o.m_array, false));
   }

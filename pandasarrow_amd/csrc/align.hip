@@ -1,0 +1,178 @@
+// align.hip -- index alignment for binary operations on UNEQUAL indexes (the first caller-side "next" row).
+//
+// Reference: Series::broadcast (src/series.cpp:212-227) = Concatenate(index_a, index_b) -> Unique -> array_sort_indices
+// (ascending) -> Take, then Series::reindex (src/series.cpp:1255-1309) of both operands onto that index: a host
+// std::unordered_map<int64, int64> built with insert_or_assign (so the LAST position of a duplicated label wins) and one
+// GetScalar/AppendScalar per new label; labels that are absent become null.
+//
+// Device form: both steps are the group-by dictionary (csrc/groupby.hip) applied to a concatenation.
+//   union   : uniques of concat(a, b) (first-occurrence dictionary), then a stable LSD radix sort of the 64-bit labels
+//             (three rounds of <= 22 key bits through the 32-bit pair sort, sign bit flipped for signed labels)
+//   reindex : group ids of concat(reverse(old), new); a new label is present iff its group's first row lies in the reversed old
+//             part, and that first row is the LAST position of the label in the old index.  Output = take indices with a
+//             validity bitmap (absent -> null); values then go through pdx_take, whose null indices yield null rows.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "compact.hpp"
+#include "pdx/abi.h"
+#include "pdx_common.hpp"
+#include "radix_sort.hpp"
+
+namespace pdx {
+
+__global__ void k_concat2_i64(const long long* __restrict__ a, int64_t na, int reverse_a, const long long* __restrict__ b, int64_t nb,
+                              long long* __restrict__ out) {
+  const int64_t n = na + nb, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = i < na ? a[reverse_a ? na - 1 - i : i] : b[i - na];
+}
+__global__ void k_align_iota(uint32_t* __restrict__ out, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (uint32_t)i;
+}
+// sort key of one round: bits [shift, shift + nbits) of the order-preserving unsigned image of the label at perm[i]
+__global__ void k_label_chunk(const long long* __restrict__ labels, const uint32_t* __restrict__ perm, int64_t n, int shift, uint32_t mask,
+                              unsigned long long flip, uint32_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = (uint32_t)((((unsigned long long)labels[perm[i]]) ^ flip) >> shift) & mask;
+}
+__global__ void k_gather_labels(const long long* __restrict__ labels, const uint32_t* __restrict__ perm, int64_t n, long long* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = labels[perm[i]];
+}
+__global__ void k_reindex_emit(const uint32_t* __restrict__ gids, const int64_t* __restrict__ first_rows, int64_t n_old, int64_t n_new,
+                               long long* __restrict__ out_idx, uint8_t* __restrict__ ok) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_new; j += stride) {
+    const int64_t f = first_rows[gids[n_old + j]];
+    const bool present = f < n_old;
+    out_idx[j] = present ? n_old - 1 - f : 0;
+    ok[j] = present;
+  }
+}
+
+static int check_index(const pdx_column* c, const char* what) {
+  PDX_TRY(check_column(c, what));
+  if (!is_int_like(c->dtype)) return fail(PDX_NOT_IMPLEMENTED, std::string(what) + ": index must be int64 / uint64 / timestamp[ns]");
+  if (validity_or_null(c)) return fail(PDX_NOT_IMPLEMENTED, std::string(what) + ": null index labels are not supported");
+  return PDX_OK;
+}
+struct GroupByOwner {  // RAII for the internal dictionary handle
+  pdx_groupby* h = nullptr;
+  ~GroupByOwner() {
+    if (h) pdx_groupby_destroy(h);
+  }
+};
+
+}  // namespace pdx
+
+using namespace pdx;
+
+extern "C" {
+
+int pdx_index_union(const pdx_column* a, const pdx_column* b, pdx_mut_column* out, void* stream) {
+  PDX_TRY(check_index(a, "pdx_index_union"));
+  PDX_TRY(check_index(b, "pdx_index_union"));
+  if (!out) return fail(PDX_INVALID, "pdx_index_union: null output");
+  if (a->dtype != b->dtype) return fail(PDX_INVALID, "type(NewIndex) != type(CurrentIndex).");
+  const int64_t na = a->length, nb = b->length, n = na + nb;
+  if (out->dtype != a->dtype) return fail(PDX_INVALID, "pdx_index_union: output dtype must be the index dtype");
+  if (out->length < n || (n && !out->values)) return fail(PDX_INVALID, "pdx_index_union: output must hold a.length + b.length labels");
+  out->length = 0;
+  out->null_count = 0;
+  if (n == 0) return PDX_OK;
+  if (n > 0x7FFFFFFFll) return fail(PDX_NOT_IMPLEMENTED, "pdx_index_union: more than 2^31-1 labels per call is not supported yet");
+  hipStream_t st = as_stream(stream);
+  Scratch s;
+  long long* cat = s.get<long long>((size_t)n);
+  PDX_SCRATCH_CHECK(s);
+  hipLaunchKernelGGL(k_concat2_i64, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, static_cast<const long long*>(a->values) + a->offset, na, 0,
+                     static_cast<const long long*>(b->values) + b->offset, nb, cat);
+  PDX_LAUNCH_CHECK();
+  // Unique (first-occurrence dictionary)
+  pdx_column cc{};
+  cc.dtype = a->dtype;
+  cc.length = n;
+  cc.values = cat;
+  GroupByOwner gb;
+  PDX_TRY(pdx_groupby_create(&cc, stream, &gb.h));
+  const int64_t G = pdx_groupby_num_groups(gb.h);
+  long long* uniq = s.get<long long>((size_t)G);
+  uint8_t* uniq_ok = s.get<uint8_t>((size_t)(G + 7) / 8 + 8);
+  PDX_SCRATCH_CHECK(s);
+  pdx_mut_column um{};
+  um.dtype = a->dtype;
+  um.length = G;
+  um.values = uniq;
+  um.validity = uniq_ok;
+  PDX_TRY(pdx_groupby_unique_keys(gb.h, &um, stream));
+  // array_sort_indices ascending + Take: stable LSD sort of the 64-bit labels, three rounds through the 32-bit pair sort
+  uint32_t* perm = s.get<uint32_t>((size_t)G);
+  uint32_t* chunk = s.get<uint32_t>((size_t)G);
+  uint32_t* k0 = s.get<uint32_t>((size_t)G);
+  uint32_t* k1 = s.get<uint32_t>((size_t)G);
+  uint32_t* v0 = s.get<uint32_t>((size_t)G);
+  uint32_t* v1 = s.get<uint32_t>((size_t)G);
+  PDX_SCRATCH_CHECK(s);
+  hipLaunchKernelGGL(k_align_iota, dim3(grid_for(G, 256, 4)), dim3(256), 0, st, perm, G);
+  const unsigned long long flip = a->dtype == PDX_UINT64 ? 0ull : 0x8000000000000000ull;
+  const int shifts[3] = {0, 22, 43}, widths[3] = {22, 21, 21};
+  for (int r = 0; r < 3; ++r) {
+    hipLaunchKernelGGL(k_label_chunk, dim3(grid_for(G, 256, 4)), dim3(256), 0, st, uniq, perm, G, shifts[r], (1u << widths[r]) - 1, flip, chunk);
+    PDX_LAUNCH_CHECK();
+    const uint32_t* ks = nullptr;
+    const uint32_t* vs = nullptr;
+    PDX_TRY((radix_sort_pairs<uint32_t>(chunk, perm, k0, v0, k1, v1, G, widths[r], &ks, &vs, false, s, st)));
+    PDX_HIP(hipMemcpyAsync(perm, vs, (size_t)G * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  }
+  hipLaunchKernelGGL(k_gather_labels, dim3(grid_for(G, 256, 4)), dim3(256), 0, st, uniq, perm, G, static_cast<long long*>(out->values));
+  PDX_LAUNCH_CHECK();
+  if (out->validity) PDX_HIP(hipMemsetAsync(out->validity, 0xFF, (size_t)((G + 7) / 8), st));
+  PDX_HIP(hipStreamSynchronize(st));
+  out->length = G;
+  return PDX_OK;
+}
+
+int pdx_reindex_indices(const pdx_column* old_index, const pdx_column* new_index, pdx_mut_column* out_idx, void* stream) {
+  PDX_TRY(check_index(old_index, "pdx_reindex_indices"));
+  PDX_TRY(check_index(new_index, "pdx_reindex_indices"));
+  if (!out_idx) return fail(PDX_INVALID, "pdx_reindex_indices: null output");
+  if (old_index->dtype != new_index->dtype) return fail(PDX_INVALID, "type(NewIndex) != type(CurrentIndex).");
+  const int64_t n_old = old_index->length, n_new = new_index->length, n = n_old + n_new;
+  if (out_idx->dtype != PDX_INT64) return fail(PDX_INVALID, "pdx_reindex_indices: output must be int64 take indices");
+  if (out_idx->length < n_new || (n_new && (!out_idx->values || !out_idx->validity)))
+    return fail(PDX_INVALID, "pdx_reindex_indices: output needs new_index.length indices and a validity buffer");
+  out_idx->length = n_new;
+  out_idx->null_count = -1;
+  if (n_new == 0) return PDX_OK;
+  if (n > 0x7FFFFFFFll) return fail(PDX_NOT_IMPLEMENTED, "pdx_reindex_indices: more than 2^31-1 labels per call is not supported yet");
+  hipStream_t st = as_stream(stream);
+  Scratch s;
+  long long* cat = s.get<long long>((size_t)n);
+  uint32_t* gids = s.get<uint32_t>((size_t)n);
+  uint8_t* ok = s.get<uint8_t>((size_t)n_new);
+  PDX_SCRATCH_CHECK(s);
+  hipLaunchKernelGGL(k_concat2_i64, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, static_cast<const long long*>(old_index->values) + old_index->offset,
+                     n_old, 1, static_cast<const long long*>(new_index->values) + new_index->offset, n_new, cat);
+  PDX_LAUNCH_CHECK();
+  pdx_column cc{};
+  cc.dtype = old_index->dtype;
+  cc.length = n;
+  cc.values = cat;
+  GroupByOwner gb;
+  PDX_TRY(pdx_groupby_create(&cc, stream, &gb.h));
+  const int64_t G = pdx_groupby_num_groups(gb.h);
+  int64_t* first_rows = s.get<int64_t>((size_t)G);
+  PDX_SCRATCH_CHECK(s);
+  PDX_TRY(pdx_groupby_group_ids(gb.h, gids, stream));
+  PDX_TRY(pdx_groupby_first_rows(gb.h, first_rows, stream));
+  hipLaunchKernelGGL(k_reindex_emit, dim3(grid_for(n_new, 256, 4)), dim3(256), 0, st, gids, first_rows, n_old, n_new,
+                     static_cast<long long*>(out_idx->values), ok);
+  hipLaunchKernelGGL(k_pack_bytes, dim3(grid_for((n_new + 7) / 8, 256)), dim3(256), 0, st, ok, n_new, static_cast<uint8_t*>(out_idx->validity));
+  PDX_LAUNCH_CHECK();
+  PDX_HIP(hipStreamSynchronize(st));
+  return PDX_OK;
+}
+
+}  // extern "C"

@@ -95,6 +95,20 @@ static void test_series_aggregations() {
   REQUIRE(!Series(std::vector<double>{}).sum().isValid());  // min_count = 1
 }
 
+// Series::broadcast / reindex (src/series.cpp:212-227, 1255-1309): labels {1,2,3} + {2,3,4} -> {1,2,3,4}, ends null
+static void test_broadcast_unequal_indexes() {
+  Series a(Array::Make(std::vector<double>{10.0, 20.0, 30.0}), Array::Make(std::vector<long>{3, 1, 2}), "a");
+  Series b(Array::Make(std::vector<double>{1.0, 2.0, 3.0}), Array::Make(std::vector<long>{2, 4, 3}), "b");
+  Series c = a + b;
+  REQUIRE(c.size() == 4);
+  REQUIRE((c.m_index->values_as<long>() == std::vector<long>{1, 2, 3, 4}));
+  REQUIRE(!c.at(0).isValid() && !c.at(3).isValid());
+  REQUIRE(c.at(1) == 31.0);  // label 2: 30 + 1
+  REQUIRE(c.at(2) == 13.0);  // label 3: 10 + 3
+  Series r = a.reindex(Array::Make(std::vector<long>{2, 9}));
+  REQUIRE(r.at(0) == 30.0 && !r.at(1).isValid());
+}
+
 // tests/dataframe_iterator_test.cpp:11-77
 static void test_groupby() {
   DataFrame df(std::map<std::string, std::vector<int32_t>>{{"a", {1, 1, 3, 1, 1, 1, 3, 8, 2, 2}}, {"b", {10, 9, 8, 7, 6, 5, 4, 3, 2, 1}}});
@@ -178,6 +192,7 @@ int main() {
   test_series_math();
   test_series_where_take();
   test_series_aggregations();
+  test_broadcast_unequal_indexes();
   test_groupby();
   test_resample();
   test_concat_and_frame_ops();

@@ -82,3 +82,50 @@ def test_tile_boundaries_groupby_and_filter(px, n):
     mask = vals > 0
     out = K.filter([C.from_numpy(vals)], C.from_numpy(mask))[0].to_numpy()[0]
     assert np.array_equal(out, vals[mask])
+
+
+# ---------------------------------------------------------------- index alignment: Series::broadcast / reindex
+@pytest.mark.parametrize("dtype", ["int64", "uint64", "timestamp"])
+@pytest.mark.parametrize("na,nb", [(0, 5), (1, 1), (1000, 700), (200_003, 150_001)])
+def test_index_union_and_reindex_vs_oracle(px, na, nb, dtype):
+    rng = np.random.default_rng(na * 7 + nb)
+    lo, hi = (-3 * max(na, nb, 1), 3 * max(na, nb, 1)) if dtype != "uint64" else (0, 6 * max(na, nb, 1))
+    a = rng.integers(lo, hi, na).astype(np.int64) * (10**9 if dtype == "timestamp" else 1)
+    b = rng.integers(lo, hi, nb).astype(np.int64) * (10**9 if dtype == "timestamp" else 1)
+    if dtype == "int64" and na > 10:
+        a[:3] = [np.iinfo(np.int64).min, np.iinfo(np.int64).max, -1]  # sign handling of the 64-bit label sort
+    dt = {"int64": px.L.INT64, "uint64": px.L.UINT64, "timestamp": px.L.TIMESTAMP_NS}[dtype]
+    ca, cb = px.Column.from_numpy(a, dtype=dt), px.Column.from_numpy(b, dtype=dt)
+    got = px.K.index_union(ca, cb).to_numpy()[0].astype(np.int64)
+    exp = orc.index_union(a.view(np.uint64) if dtype == "uint64" else a, b.view(np.uint64) if dtype == "uint64" else b).astype(np.int64)
+    assert np.array_equal(got, exp)
+    idx, ok = px.K.reindex_indices(ca, cb).to_numpy()   # duplicates in `a`: the LAST position wins
+    eidx, eok = orc.reindex_indices(a, b)
+    assert np.array_equal(ok, eok) and np.array_equal(idx[eok], eidx[eok])
+
+
+def test_series_binary_ops_align_unequal_indexes(px):
+    """Series + Series with different indexes: union of the labels, values aligned by label, labels missing on one side -> null"""
+    api = px.api
+    rng = np.random.default_rng(4)
+    ia = rng.permutation(5000)[:3000].astype(np.int64)
+    ib = rng.permutation(5000)[:2500].astype(np.int64)
+    va, vb = rng.standard_normal(3000), rng.standard_normal(2500)
+    sa = api.Series(va, index=px.Column.from_numpy(ia))
+    sb = api.Series(vb, index=px.Column.from_numpy(ib))
+    out = sa + sb
+    labels = out.index.to_numpy()[0]
+    vals, ok = out.to_numpy()
+    exp_labels = orc.index_union(ia, ib)
+    assert np.array_equal(labels, exp_labels)
+    pa_, oka = orc.reindex_indices(ia, exp_labels)
+    pb_, okb = orc.reindex_indices(ib, exp_labels)
+    eok = oka & okb
+    assert np.array_equal(ok, eok)
+    assert_bits = (va[pa_] + vb[pb_])[eok]
+    assert np.array_equal(vals[eok].view(np.uint64), assert_bits.view(np.uint64))
+    # equal indexes keep the fast path and the index object
+    same = sa + api.Series(va * 2, index=px.Column.from_numpy(ia))
+    assert same.index is sa.index and np.array_equal(same.values(), va + va * 2)
+    with pytest.raises(px.L.PdxError):
+        _ = sa + api.Series(vb, index=px.Column.from_numpy(ib.astype(np.uint64), dtype=px.L.UINT64))  # type(NewIndex) != type(CurrentIndex)
