@@ -12,4 +12,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-check > "$OUT/pmc_$c.log" 2>&1
 done
 python bench.py --steps 5 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"
+PDX_GROUPBY_DENSE=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_general_keys.json" 2> "$OUT/bench_general_keys.err"
 tail -1 "$OUT/bench.json"

@@ -27,6 +27,8 @@ def newest(pattern):
 stats = [newest(os.path.join(src, "kt", "*", "*kernel_stats.csv"))]
 shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
+if os.path.exists(os.path.join(src, "bench_general_keys.json")):
+    shutil.copy(os.path.join(src, "bench_general_keys.json"), os.path.join(dst, f"{tag}_bench_general_keys.json"))
 
 
 def short(name):
