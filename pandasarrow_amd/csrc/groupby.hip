@@ -1761,7 +1761,9 @@ __global__ void __launch_bounds__(256) k_seg_sqdev(const T* __restrict__ vals, c
     }
   }
 }
-// product of the valid values of every segment in row order (sequential by definition); first / last row of every segment
+// product of the valid values of every segment in row order (sequential by definition: one multiply chain per group); first /
+// last row of every segment.  One wave per segment: 1024 values at a time are loaded coalesced into LDS (null rows as the
+// multiplicative identity), lane 0 runs the chain -- the loads, not the chain, bound the kernel.
 template <typename T>
 __global__ void __launch_bounds__(256) k_seg_product_first_last(const T* __restrict__ vals, const uint32_t* __restrict__ sorted_keys,
                                                                 const uint8_t* __restrict__ row_valid, int64_t valid_off,
@@ -1769,29 +1771,63 @@ __global__ void __launch_bounds__(256) k_seg_product_first_last(const T* __restr
                                                                 const uint32_t* __restrict__ out_index, T* __restrict__ prod,
                                                                 uint8_t* __restrict__ prod_ok, T* __restrict__ first, uint8_t* __restrict__ first_ok,
                                                                 T* __restrict__ last, uint8_t* __restrict__ last_ok) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += stride) {
+  __shared__ T stage_all[4][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* stage = stage_all[wave];
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t k = (int64_t)blockIdx.x * 4 + wave; k < nseg; k += nw) {
     const int64_t s = seg_start[k], e = seg_start[k + 1];
     const uint32_t oi = out_index ? out_index[k] : (uint32_t)k;
     if (prod) {
       T p = T(1);
       bool any = false;
-      for (int64_t i = s; i < e; ++i)
-        if (!seg_row_is_null(sorted_keys, row_valid, valid_off, i)) {
-          if constexpr (__is_same(T, double)) p = p * vals[i];
-          else p = (T)((unsigned long long)p * (unsigned long long)vals[i]);
-          any = true;
+      for (int64_t c0 = s; c0 < e; c0 += 1024) {
+        const int cl = (int)(e - c0 < 1024 ? e - c0 : 1024);
+        bool mine = false;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int idx = q * 64 + lane;
+          if (idx < cl) {
+            const bool isnull = seg_row_is_null(sorted_keys, row_valid, valid_off, c0 + idx);
+            stage[idx] = isnull ? T(1) : vals[c0 + idx];
+            mine |= !isnull;
+          }
         }
-      prod[oi] = p;
-      if (prod_ok) prod_ok[oi] = any;
+        any |= __any(mine);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+          int i = 0;
+          for (; i + 16 <= cl; i += 16) {  // the 16 LDS reads are issued together; only the multiplies form the chain
+            T x[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x[q] = stage[i + q];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              if constexpr (__is_same(T, double)) p = p * x[q];
+              else p = (T)((unsigned long long)p * (unsigned long long)x[q]);
+            }
+          }
+          for (; i < cl; ++i) {
+            if constexpr (__is_same(T, double)) p = p * stage[i];
+            else p = (T)((unsigned long long)p * (unsigned long long)stage[i]);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (lane == 0) {
+        prod[oi] = p;
+        if (prod_ok) prod_ok[oi] = any;
+      }
     }
-    if (first) {
-      first[oi] = e > s ? vals[s] : T(0);
-      if (first_ok) first_ok[oi] = e > s && !seg_row_is_null(sorted_keys, row_valid, valid_off, s);
-    }
-    if (last) {
-      last[oi] = e > s ? vals[e - 1] : T(0);
-      if (last_ok) last_ok[oi] = e > s && !seg_row_is_null(sorted_keys, row_valid, valid_off, e - 1);
+    if (lane == 0) {
+      if (first) {
+        first[oi] = e > s ? vals[s] : T(0);
+        if (first_ok) first_ok[oi] = e > s && !seg_row_is_null(sorted_keys, row_valid, valid_off, s);
+      }
+      if (last) {
+        last[oi] = e > s ? vals[e - 1] : T(0);
+        if (last_ok) last_ok[oi] = e > s && !seg_row_is_null(sorted_keys, row_valid, valid_off, e - 1);
+      }
     }
   }
 }
@@ -2370,12 +2406,13 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
     PDX_SCRATCH_CHECK(s);
     {
       PDX_PROFILE("seg_product_first_last", st);
+      const int pf_grid = (int)std::min<int64_t>(ceil_div(G, 4), (int64_t)kCUs * 16);
       if (is_f)
-        hipLaunchKernelGGL((k_seg_product_first_last<double>), dim3(grid_for(G, 256)), dim3(256), 0, st, static_cast<const double*>(vals_sorted), fk,
+        hipLaunchKernelGGL((k_seg_product_first_last<double>), dim3(pf_grid), dim3(256), 0, st, static_cast<const double*>(vals_sorted), fk,
                            row_valid, values->offset, seg_start, G, out_index, static_cast<double*>(prod_out), pok, static_cast<double*>(first_out), fok,
                            static_cast<double*>(last_out), lok);
       else
-        hipLaunchKernelGGL((k_seg_product_first_last<long long>), dim3(grid_for(G, 256)), dim3(256), 0, st, static_cast<const long long*>(vals_sorted),
+        hipLaunchKernelGGL((k_seg_product_first_last<long long>), dim3(pf_grid), dim3(256), 0, st, static_cast<const long long*>(vals_sorted),
                            fk, row_valid, values->offset, seg_start, G, out_index, static_cast<long long*>(prod_out), pok,
                            static_cast<long long*>(first_out), fok, static_cast<long long*>(last_out), lok);
     }

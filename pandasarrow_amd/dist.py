@@ -116,13 +116,23 @@ class HipEngine:
         self.device = K._device()
 
     # columns <-> tensors (communication buffers)
+    # Arrow validity bitmaps <-> bool tensors, on the device (communication buffers carry bools)
+    def _pack_bits(self, ok: torch.Tensor) -> torch.Tensor:
+        n = ok.numel()
+        pad = torch.zeros(((n + 7) // 8 + 16) * 8, dtype=torch.uint8, device=self.device)  # 16 bytes of slack like Column.empty
+        pad[:n] = ok.to(torch.uint8)
+        w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=self.device)
+        return (pad.view(-1, 8) * w).sum(dim=1, dtype=torch.uint8)
+
+    def _unpack_bits(self, bits: torch.Tensor, offset: int, n: int) -> torch.Tensor:
+        i = torch.arange(offset, offset + n, dtype=torch.int64, device=self.device)
+        return ((bits[i >> 3] >> (i & 7).to(torch.uint8)) & 1).to(torch.bool)
+
     def col(self, t: torch.Tensor, dtype, ok: torch.Tensor | None = None):
         K = self.K
         vb = None
         if ok is not None and not bool(ok.all()):
-            import numpy as np
-
-            vb = torch.from_numpy(K.pack_bits_host(ok.cpu().numpy().astype(bool))).to(self.device)
+            vb = self._pack_bits(ok)
         vals = t if t.numel() else torch.zeros(1, dtype=t.dtype, device=self.device)
         return K.Column(dtype, t.numel(), vals.contiguous(), vb)
 
@@ -134,8 +144,9 @@ class HipEngine:
 
     def unique_keys(self, gb):
         c = gb.unique_keys()
-        vals, ok = c.to_numpy()
-        return self.values(c), torch.from_numpy(ok).to(self.device)
+        if c.validity is None or c.null_count == 0:
+            return self.values(c), torch.ones(c.length, dtype=torch.bool, device=self.device)
+        return self.values(c), self._unpack_bits(c.validity, c.offset, c.length)
 
     def first_rows(self, gb):
         return gb.first_rows()
@@ -167,7 +178,7 @@ class HipEngine:
     def valid_bools(self, col):
         if not col.has_nulls():
             return None
-        return torch.from_numpy(col.to_numpy()[1]).to(self.device)
+        return self._unpack_bits(col.validity, col.offset, col.length)
 
     # ---- partial-tree exchange primitives (exact fp64 sum without shipping rows)
     def group_values(self, gb, values_col):

@@ -80,6 +80,21 @@ def main():
     # concat of 8 shards (the all-gatherv merge)
     parts = [K.synth_vals(i, n // 8, 0) for i in range(8)]
     report("concat_8parts[1e9]", n // 8 * 8, 16.0 * (n // 8 * 8), timeit(lambda: K.concat(parts)))
+    del parts, ser, ts
+    # "next" rows: more group-by aggregations on the grouped layout, 1e9 rows / 1e6 keys (16 B/row algorithmic)
+    keys, vals = K.synth_keys(0, n, 1_000_000), K.synth_vals(0, n)
+    gb = K.GroupByHandle.create(keys)
+    for nm, kinds in (("variance", [L.AGG_VARIANCE]), ("stddev+mean", [L.AGG_STDDEV, L.AGG_MEAN]), ("product", [L.AGG_PRODUCT]),
+                      ("first+last", [L.AGG_FIRST, L.AGG_LAST])):
+        report(f"groupby_agg_{nm}[1e9/1e6]", n, 16.0 * n, timeit(lambda: gb.agg(vals, kinds), reps=3, warm=1))
+    del gb, keys, vals
+    # index alignment: union of two 1e8-label indexes sharing half of their labels, and the reindex of one onto the union
+    m = int(1e8 * sc)
+    ia = K.binary(L.MUL, K.synth_keys(0, m, 1 << 40), 1)          # ~unique int64 labels
+    ib = K.concat([ia.slice(m // 2, m - m // 2), K.binary(L.ADD, K.synth_keys(11, m // 2, 1 << 40), 1 << 41)])
+    report("index_union[1e8+1e8]", 2 * m, 8.0 * 2 * m + 8.0 * 1.5 * m, timeit(lambda: K.index_union(ia, ib), reps=3, warm=1))
+    uni = K.index_union(ia, ib)
+    report("reindex_indices[1e8 -> 1.5e8]", uni.length, 8.0 * m + 16.0 * uni.length, timeit(lambda: K.reindex_indices(ia, uni), reps=3, warm=1))
 
 
 if __name__ == "__main__":
