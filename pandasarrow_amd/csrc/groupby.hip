@@ -41,7 +41,8 @@ constexpr unsigned int kNoRow = 0xFFFFFFFFu;
 struct HashCtl {
   unsigned int inserted;
   unsigned int overflow;
-  unsigned long long rows_seen;  // LDS build only: rows consumed before the buckets finished / gave up (cardinality estimate)
+  unsigned long long rows_seen;     // LDS build only: rows consumed before the buckets finished / gave up ...
+  unsigned long long est_distinct;  // ... and the distinct keys among exactly those rows (cardinality estimate)
 };
 
 __global__ void k_table_init(Slot* __restrict__ table, int64_t nslots) {
@@ -139,6 +140,42 @@ __global__ void __launch_bounds__(kSortBlock) k_hash_bucket_hist(const long long
   __syncthreads();
   for (int d = threadIdx.x; d < R; d += kSortBlock) hist[(int64_t)blockIdx.x * R + d] = h[d];
 }
+// second partition level (very many groups: the buckets are split until a bucket's table fits in LDS): digit = hash bits
+// [shift, shift + BITS) of the rows in their CURRENT (first-level) order, + the per-tile histogram of that digit
+template <int BITS>
+__global__ void __launch_bounds__(kSortBlock) k_hash_digit_hist(const long long* __restrict__ keys_cur, const uint32_t* __restrict__ rows_cur, int64_t n,
+                                                                int shift, uint8_t* __restrict__ digit, uint32_t* __restrict__ hist) {
+  constexpr int R = 1 << BITS;
+  __shared__ uint32_t h[R];
+  for (int d = threadIdx.x; d < R; d += kSortBlock) h[d] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kSortTile;
+#pragma unroll
+  for (int u = 0; u < kSortItems; ++u) {
+    int64_t i = base + u * kSortBlock + threadIdx.x;
+    if (i >= n) continue;
+    const uint32_t d = (key_hash32(keys_cur[i], rows_cur[i] >> 31) >> shift) & (R - 1);
+    digit[i] = (uint8_t)d;
+    atomicAdd(&h[d], 1u);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < R; d += kSortBlock) hist[(int64_t)blockIdx.x * R + d] = h[d];
+}
+// start of every bucket in the final partitioned order (ascending low `pb` hash bits): lower bounds by binary search
+__global__ void k_bucket_starts(const long long* __restrict__ keys_part, const uint32_t* __restrict__ rows_part, int64_t n, unsigned int pb,
+                                uint32_t* __restrict__ starts) {
+  const int64_t nb = (int64_t)1 << pb, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nb; g += stride) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      int64_t mid = (lo + hi) >> 1;
+      const unsigned int b = key_hash32(keys_part[mid], rows_part[mid] >> 31) & (unsigned int)(nb - 1);
+      if ((int64_t)b < g) lo = mid + 1;
+      else hi = mid;
+    }
+    starts[g] = (uint32_t)lo;
+  }
+}
 constexpr int kProbeTiles = 4;
 // inputs in partitioned order; rows carry the null flag in bit 31.  U rows per thread are kept in flight: the stream loads and
 // the first table probe of all U rows are issued before any of them is consumed.
@@ -146,9 +183,12 @@ template <int U>
 __global__ void __launch_bounds__(256) k_hash_probe_part(const long long* __restrict__ keys_part, const uint32_t* __restrict__ rows_part,
                                                          int64_t n, Slot* table, unsigned int cap,
                                                          unsigned int region, unsigned int limit, uint32_t* __restrict__ slot_part,
-                                                         HashCtl* ctl) {
+                                                         HashCtl* ctl, unsigned int sweep_shift, unsigned int sweep, unsigned int pb) {
   // One contiguous run of kProbeTiles*U*256 partition-ordered rows per workgroup, runs dispatched in order: the workgroups
   // resident at any moment work on one or two neighbouring buckets, so a table far larger than the L2 is probed a few MB at a time.
+  // Regions beyond ~2 MB fall out of the 4 MB L2 of an XCD and the build collapses (measured: 26 ms at 2 MB regions, 1.4 s at
+  // 4 MB -- every probe and atomic goes to memory), so such tables are built in SWEEPS: sweep j handles only the rows whose home
+  // slot lies in window j (2^sweep_shift slots) of their region; every sweep re-streams the rows but probes a 1 MB window.
   // Insertions are counted per thread and flushed once per wave: with tens of millions of groups a per-insert atomic on the one
   // counter word serialises the whole build (measured 0.9 s for 1e8 groups).
   const unsigned int rmask = region - 1;
@@ -158,6 +198,8 @@ __global__ void __launch_bounds__(256) k_hash_probe_part(const long long* __rest
   for (int t = 0; t < kProbeTiles && !dead; ++t) {
     const int64_t p0 = ((int64_t)blockIdx.x * kProbeTiles + t) * blockDim.x * U + threadIdx.x;
     if (p0 - threadIdx.x >= n) break;
+    // a failed attempt must end quickly: once the load limit is passed (or a chain got too long) nobody starts another tile
+    if (__hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
     unsigned int row[U], h[U], phys[U], idx[U];
     long long key[U], cur[U];
     bool act[U];
@@ -171,11 +213,13 @@ __global__ void __launch_bounds__(256) k_hash_probe_part(const long long* __rest
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       h[u] = key_hash32(key[u], row[u] >> 31);
-      const unsigned int b = h[u] & ((1u << kPartBits) - 1);
-      idx[u] = (h[u] >> kPartBits) & rmask;
+      const unsigned int b = h[u] & ((1u << pb) - 1);
+      idx[u] = (h[u] >> pb) & rmask;
       phys[u] = b * region + idx[u];
-      if (row[u] >> 31) phys[u] = cap;
-      else if (key[u] == kEmptyKey) phys[u] = cap + 1;
+      unsigned int win = idx[u] >> sweep_shift;
+      if (row[u] >> 31) { phys[u] = cap; win = 0; }
+      else if (key[u] == kEmptyKey) { phys[u] = cap + 1; win = 0; }
+      act[u] = act[u] && win == sweep;
       cur[u] = act[u] ? table[phys[u]].key : 0;
     }
 #pragma unroll
@@ -187,7 +231,7 @@ __global__ void __launch_bounds__(256) k_hash_probe_part(const long long* __rest
       if (special) {
         logical = phys[u];
       } else {
-        const unsigned int b = h[u] & ((1u << kPartBits) - 1), base = b * region;
+        const unsigned int b = h[u] & ((1u << pb) - 1), base = b * region;
         unsigned int probes = 0;
         long long c = cur[u];
         for (;;) {
@@ -213,7 +257,7 @@ __global__ void __launch_bounds__(256) k_hash_probe_part(const long long* __rest
         }
         if (dead) continue;
         phys[u] = base + idx[u];
-        logical = (idx[u] << kPartBits) | b;
+        logical = (idx[u] << pb) | b;
       }
       if (r < table[phys[u]].first) atomicMin(&table[phys[u]].first, r);
       slot_part[p0 + u * stride] = logical;
@@ -235,7 +279,7 @@ constexpr int kProbeBlock = 1024;
 __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long* __restrict__ keys_part, const uint32_t* __restrict__ rows_part,
                                                                 const uint32_t* __restrict__ bucket_off,
                                                                 int64_t n, Slot* table, unsigned int cap, unsigned int region,
-                                                                uint32_t* __restrict__ slot_part, HashCtl* ctl) {
+                                                                uint32_t* __restrict__ slot_part, HashCtl* ctl, unsigned int pb) {
   __shared__ unsigned long long lkeys[kLdsRegionMax];
   __shared__ unsigned int lfirst[kLdsRegionMax];
   __shared__ unsigned int linserted;
@@ -243,7 +287,7 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
   const unsigned int b = blockIdx.x;
   const unsigned int rmask = region - 1;
   const int64_t start = bucket_off[b];
-  const int64_t end = (b + 1 < (1u << kPartBits)) ? (int64_t)bucket_off[b + 1] : n;
+  const int64_t end = (b + 1 < (1u << pb)) ? (int64_t)bucket_off[b + 1] : n;
   for (int i = tid; i < (int)region; i += kProbeBlock) {
     lkeys[i] = (unsigned long long)kEmptyKey;
     lfirst[i] = kNoRow;
@@ -251,12 +295,13 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
   if (tid == 0) linserted = 0;
   __syncthreads();
   constexpr int U = 4;
-  const unsigned int dense_limit = region - (region >> 3);  // 87.5 % full: give up early, the host retries with a larger table
-  int64_t rows_done = end - start;
-  for (int64_t p0 = start + tid; p0 < end; p0 += (int64_t)U * kProbeBlock) {
+  const unsigned int dense_limit = region - (region >> 2);  // 75 % full: give up early, the host retries with a larger table
+  bool sampled = false;
+  // (the trip count is uniform over the workgroup -- rows are masked by act[] -- so the barrier after the first trip is safe)
+  for (int64_t base0 = start; base0 < end; base0 += (int64_t)U * kProbeBlock) {
+    const int64_t p0 = base0 + tid;
     if (linserted > dense_limit) {  // (LDS word, read by every thread each iteration: a handful of cycles)
       if (tid == 0) atomicExch(&ctl->overflow, 1u);
-      rows_done = p0 - tid - start;
       break;
     }
     unsigned int row[U], h[U];
@@ -280,7 +325,7 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
         atomicMin(&table[sp].first, r);
         logical = sp;
       } else {
-        unsigned int idx = (h[u] >> kPartBits) & rmask, probes = 0;
+        unsigned int idx = (h[u] >> pb) & rmask, probes = 0;
         for (;;) {
           unsigned long long cur = lkeys[idx];
           if (cur == (unsigned long long)key[u]) break;
@@ -299,9 +344,20 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
           }
         }
         if (r < lfirst[idx]) atomicMin(&lfirst[idx], r);
-        logical = (idx << kPartBits) | b;
+        logical = (idx << pb) | b;
       }
       slot_part[p0 + (int64_t)u * kProbeBlock] = logical;
+    }
+    if (!sampled) {
+      // cardinality sample: after the bucket's first U*kProbeBlock rows every thread has inserted its rows, so (rows, distinct)
+      // is an exact pair (the table is at most half full: no saturation)
+      sampled = true;
+      __syncthreads();
+      if (tid == 0) {
+        const int64_t seen = end - start < (int64_t)U * kProbeBlock ? end - start : (int64_t)U * kProbeBlock;
+        atomicAdd(&ctl->rows_seen, (unsigned long long)seen);
+        atomicAdd(&ctl->est_distinct, (unsigned long long)linserted);
+      }
     }
   }
   __syncthreads();
@@ -312,15 +368,13 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
     sl.gid = kNoRow;
     table[(int64_t)b * region + i] = sl;
   }
-  if (tid == 0) {
-    if (linserted) atomicAdd(&ctl->inserted, linserted);
-    atomicAdd(&ctl->rows_seen, (unsigned long long)(rows_done < end - start ? rows_done : end - start));
-  }
+  if (tid == 0 && linserted) atomicAdd(&ctl->inserted, linserted);
 }
 
 __device__ __forceinline__ int64_t phys_slot(int64_t logical, unsigned int region, unsigned int cap) {
   if (region == 0 || logical >= (int64_t)cap) return logical;
-  return (logical & ((1 << kPartBits) - 1)) * (int64_t)region + (logical >> kPartBits);
+  const int pb = (__ffs((int)cap) - 1) - (__ffs((int)region) - 1);  // cap = region << pb, both powers of two
+  return (logical & ((1 << pb) - 1)) * (int64_t)region + (logical >> pb);
 }
 // row-order views from the partitioned arrays (on demand: group ids / mapped ids)
 __global__ void k_part_row_gids(const uint32_t* __restrict__ gid_of_slot, const uint32_t* __restrict__ slot_part,
@@ -1598,6 +1652,10 @@ struct pdx_groupby {
   int slot_bits = 0;
   int dense = 0;                    // 1: slots are key - min (dense integer key domain), 0: open-addressing hash table
   // partitioned hash build (slot_of_row == nullptr): rows live in hash-partition order
+  int part_bits = 0;                   // hash bits the rows are partitioned by (8, or 8 + digit2_bits after a second level)
+  uint8_t* digit2 = nullptr;           // second-level digit of every row in FIRST-LEVEL order (very many groups only)
+  uint32_t* part_off2 = nullptr;       // its scatter offsets [tiles][1 << digit2_bits]
+  int digit2_bits = 0;
   uint8_t* bucket8 = nullptr;          // n, row order: low kPartBits = partition
   uint32_t* part_off = nullptr;     // [tiles][256] scatter offsets of the partition pass
   uint32_t* slot_part = nullptr;    // n, logical slot per partitioned position
@@ -1659,6 +1717,18 @@ static int sort_values_by_slot(pdx_groupby* gb, const uint64_t* vals, const uint
     uint64_t* vals_part = static_cast<uint64_t*>(alloc((size_t)n * 8));
     if (!vals_part) return PDX_OOM;
     PDX_TRY((radix_scatter_only<kPartBits, uint64_t, uint8_t>(gb->bucket8, vals, nullptr, vals_part, n, 0, false, gb->part_off, st)));
+    if (gb->digit2) {  // second partition level: one more stable scatter with the stored digits / offsets
+      uint64_t* vals_part2 = static_cast<uint64_t*>(alloc((size_t)n * 8));
+      if (!vals_part2) return PDX_OOM;
+      switch (gb->digit2_bits) {
+        case 4: PDX_TRY((radix_scatter_only<4, uint64_t, uint8_t>(gb->digit2, vals_part, nullptr, vals_part2, n, 0, false, gb->part_off2, st))); break;
+        case 5: PDX_TRY((radix_scatter_only<5, uint64_t, uint8_t>(gb->digit2, vals_part, nullptr, vals_part2, n, 0, false, gb->part_off2, st))); break;
+        case 6: PDX_TRY((radix_scatter_only<6, uint64_t, uint8_t>(gb->digit2, vals_part, nullptr, vals_part2, n, 0, false, gb->part_off2, st))); break;
+        case 7: PDX_TRY((radix_scatter_only<7, uint64_t, uint8_t>(gb->digit2, vals_part, nullptr, vals_part2, n, 0, false, gb->part_off2, st))); break;
+        default: PDX_TRY((radix_scatter_only<8, uint64_t, uint8_t>(gb->digit2, vals_part, nullptr, vals_part2, n, 0, false, gb->part_off2, st))); break;
+      }
+      vals_part = vals_part2;
+    }
     const uint32_t* kin = gb->slot_part;
     if (vvalid) {
       uint32_t* fk = static_cast<uint32_t*>(alloc((size_t)n * 4));
@@ -1666,7 +1736,7 @@ static int sort_values_by_slot(pdx_groupby* gb, const uint64_t* vals, const uint
       hipLaunchKernelGGL(k_flag_keys_part, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, gb->slot_part, gb->rows_part, vvalid, voff, n, fk);
       kin = fk;
     }
-    return radix_sort_pairs<uint64_t>(kin, vals_part, k0, v0, k1, v1, n, gb->slot_bits - kPartBits, keys_sorted, vals_sorted, true, s, st, kPartBits);
+    return radix_sort_pairs<uint64_t>(kin, vals_part, k0, v0, k1, v1, n, gb->slot_bits - gb->part_bits, keys_sorted, vals_sorted, true, s, st, gb->part_bits);
   }
   const uint32_t* kin = gb->slot_of_row;
   if (vvalid) {
@@ -2082,23 +2152,30 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     if (rcp != PDX_OK) return rcp;
     uint64_t want = std::max<uint64_t>(next_pow2((uint64_t)n * 2), 1u << 16);
     unsigned int cap = (unsigned int)std::min<uint64_t>(want, 1u << 21);
+    unsigned int pb = kPartBits;              // hash bits the rows are currently partitioned by
+    uint32_t* bucket_starts = nullptr;        // starts of the 2^pb buckets after a second partition level
+    bool lds_failed_at_pb = false;
     for (;;) {
       table = static_cast<Slot*>(pool_alloc(((size_t)cap + 2) * sizeof(Slot)));
       if (!table) return PDX_OOM;
-      region = cap >> kPartBits;
+      region = cap >> pb;
       hipLaunchKernelGGL(k_table_init, dim3(grid_for((int64_t)cap + 2, 256, 4)), dim3(256), 0, st, table, (int64_t)cap + 2);
       hipMemsetAsync(ctl, 0, sizeof(HashCtl), st);
       unsigned int limit = (unsigned int)((uint64_t)cap * 7 / 10);
       const char* lenv = getenv("PDX_HASH_LDS");
-      if (region <= (unsigned)kLdsRegionMax && !(lenv && lenv[0] == '0')) {
+      const bool use_lds = region <= (unsigned)kLdsRegionMax && !(lenv && lenv[0] == '0') && !lds_failed_at_pb;
+      if (use_lds) {
         PDX_PROFILE("hash_probe_lds", st);
-        // bucket starts = offsets row of tile 0 of the partition pass
-        hipLaunchKernelGGL(k_hash_probe_lds, dim3(1 << kPartBits), dim3(kProbeBlock), 0, st, keys_part, gb->rows_part, gb->part_off, n, table, cap,
-                           region, gb->slot_part, ctl);
+        // bucket starts: the offsets row of tile 0 of the partition pass, or the searched starts after a second level
+        hipLaunchKernelGGL(k_hash_probe_lds, dim3(1u << pb), dim3(kProbeBlock), 0, st, keys_part, gb->rows_part, bucket_starts ? bucket_starts : gb->part_off, n,
+                           table, cap, region, gb->slot_part, ctl, pb);
       } else {
         PDX_PROFILE("hash_probe_part", st);
-        hipLaunchKernelGGL((k_hash_probe_part<4>), dim3((unsigned int)ceil_div(n, 1024 * kProbeTiles)), dim3(256), 0, st, keys_part, gb->rows_part, n, table, cap, region,
-                           limit, gb->slot_part, ctl);
+        constexpr unsigned int kWindowBits = 16;  // 2^16 slots = 1 MB per bucket window; about two buckets are active at a time
+        const unsigned int nsweeps = region > (1u << kWindowBits) ? region >> kWindowBits : 1u;
+        for (unsigned int sw = 0; sw < nsweeps; ++sw)
+          hipLaunchKernelGGL((k_hash_probe_part<4>), dim3((unsigned int)ceil_div(n, 1024 * kProbeTiles)), dim3(256), 0, st, keys_part, gb->rows_part, n, table,
+                             cap, region, limit, gb->slot_part, ctl, nsweeps > 1 ? kWindowBits : 31u, sw, pb);
       }
       HashCtl h;
       hipError_t e = hipMemcpyAsync(&h, ctl, sizeof(h), hipMemcpyDeviceToHost, st);
@@ -2107,16 +2184,23 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
         pool_free(table);
         return hip_fail(e, "k_hash_probe_part");
       }
-      if (!h.overflow && h.inserted <= limit) break;  // (the LDS build only flags a completely full region: keep the load factor sane)
+      if (getenv("PDX_HASH_DEBUG"))
+        fprintf(stderr, "[pdx] hash build attempt: pb=%u cap=%u region=%u lds=%d inserted=%u overflow=%u rows_seen=%llu distinct_seen=%llu\n", pb, cap,
+                region, (int)use_lds, h.inserted, h.overflow, (unsigned long long)h.rows_seen, (unsigned long long)h.est_distinct);
+      if (!h.overflow && h.inserted <= limit) break;
       pool_free(table);
+      table = nullptr;
       if (cap >= want * 4 || cap >= (1u << 30)) return fail(PDX_DEVICE, "pdx_groupby_create: hash table overflow at maximum capacity");
+      if (use_lds && pb > (unsigned)kPartBits) lds_failed_at_pb = true;  // a skewed bucket outgrew LDS even after the split: memory-side build
       uint64_t next = (uint64_t)cap * 8;
+      double groups = 0.0;
       if (h.rows_seen) {
-        // the LDS attempt saw d distinct keys in its first r rows: size the retry for the cardinality that predicts
-        // (d = K (1 - exp(-r / K)) for uniformly mixed keys; keys that are all new so far predict "every row its own group")
-        const double d = (double)h.inserted, r = (double)h.rows_seen;
-        double groups = (double)n;
-        if (d < 0.95 * r) {
+        // the LDS attempt saw d distinct keys in its first r rows (an exact pair, taken after every bucket's first 4096 rows):
+        // size the retry for the cardinality K that predicts, d = K (1 - exp(-r / K)) for uniformly mixed keys.  Too few
+        // repeats to tell means "more groups than the sample can resolve": plan for min(n, 2^28) keys.
+        const double d = (double)h.est_distinct, r = (double)h.rows_seen;
+        groups = std::min((double)n, 268435456.0);
+        if (r - d > 0.001 * r && r - d >= 512.0) {
           double lo = d, hi = 1e18;  // bisection on K
           for (int it = 0; it < 200; ++it) {
             double mid = std::sqrt(lo * hi);
@@ -2125,10 +2209,67 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
           }
           groups = std::min((double)n, hi * -std::expm1(-(double)n / hi));
         }
-        next = std::max<uint64_t>(next, next_pow2((uint64_t)(groups / 0.55) + 1));
+        next = std::max<uint64_t>(next, next_pow2((uint64_t)(groups / 0.4) + 1));  // aim at <= 40 % load: the estimate is noisy
       }
-      cap = (unsigned int)std::min<uint64_t>(next, std::max<uint64_t>(want * 4, 1u << 16));
+      // Very many groups: instead of a table that falls out of the L2 (every probe and atomic then goes to memory: 1.4 s per 1e9
+      // rows measured), split the buckets by a second partition level until a bucket's table (<= 8192 slots at <= ~35 % load)
+      // fits in LDS again.  The second level is one more stable scatter of (key, row) by the next hash bits; the logical slot id
+      // keeps the (index << pb) | bucket form with pb = 8 + extra, so the later sort by slot just sees a longer partitioned prefix.
+      static const bool split_ok = [] { const char* e = getenv("PDX_HASH_SPLIT"); return !(e && e[0] == '0'); }();
+      if (split_ok && pb == (unsigned)kPartBits && groups > 0.0 && next > (1u << 21) && !(lenv && lenv[0] == '0')) {
+        int extra = 4;
+        while (extra < 8 && groups / (double)((uint64_t)1 << (kPartBits + extra)) > 2800.0) ++extra;
+        if (groups / (double)((uint64_t)1 << (kPartBits + extra)) <= 2800.0) {
+          const int64_t ntiles2 = ntiles, nchunks2 = nchunks;
+          gb->digit2 = gb->own<uint8_t>((size_t)n);
+          gb->part_off2 = gb->own<uint32_t>((size_t)ntiles2 << extra);
+          uint32_t* chunk_sum2 = s.get<uint32_t>((size_t)(nchunks2 + 1) << extra);
+          long long* keys_part2 = s.get<long long>((size_t)n);
+          uint32_t* rows_part2 = gb->own<uint32_t>((size_t)n);
+          bucket_starts = s.get<uint32_t>(((size_t)1 << (kPartBits + extra)) + 1);
+          if (s.failed || !gb->digit2 || !gb->part_off2 || !rows_part2) return PDX_OOM;
+          int rc2 = PDX_OK;
+          {
+            PDX_PROFILE("hash_bucket_hist", st);
+#define DIGIT_HIST(B) hipLaunchKernelGGL((k_hash_digit_hist<B>), dim3((unsigned)ntiles2), dim3(kSortBlock), 0, st, keys_part, gb->rows_part, n, kPartBits, \
+                                         gb->digit2, gb->part_off2)
+            switch (extra) {
+              case 4: DIGIT_HIST(4); break;
+              case 5: DIGIT_HIST(5); break;
+              case 6: DIGIT_HIST(6); break;
+              case 7: DIGIT_HIST(7); break;
+              default: DIGIT_HIST(8); break;
+            }
+#undef DIGIT_HIST
+          }
+          rc2 = radix_scan_dispatch(extra, gb->part_off2, ntiles2, chunk_sum2, true, st);
+#define SCATTER2(B)                                                                                                                                   \
+  if (rc2 == PDX_OK)                                                                                                                                  \
+    rc2 = radix_scatter_only<B, uint64_t, uint8_t>(gb->digit2, reinterpret_cast<const uint64_t*>(keys_part), nullptr,                                   \
+                                                   reinterpret_cast<uint64_t*>(keys_part2), n, 0, false, gb->part_off2, st);                           \
+  if (rc2 == PDX_OK) rc2 = radix_scatter_only<B, uint32_t, uint8_t>(gb->digit2, gb->rows_part, nullptr, rows_part2, n, 0, false, gb->part_off2, st)
+          switch (extra) {
+            case 4: SCATTER2(4); break;
+            case 5: SCATTER2(5); break;
+            case 6: SCATTER2(6); break;
+            case 7: SCATTER2(7); break;
+            default: SCATTER2(8); break;
+          }
+#undef SCATTER2
+          if (rc2 != PDX_OK) return rc2;
+          keys_part = keys_part2;
+          gb->rows_part = rows_part2;  // (the first-level array stays owned by the handle until it is destroyed)
+          pb = kPartBits + extra;
+          gb->digit2_bits = extra;
+          hipLaunchKernelGGL(k_bucket_starts, dim3(grid_for((int64_t)1 << pb, 256)), dim3(256), 0, st, keys_part, gb->rows_part, n, pb, bucket_starts);
+          PDX_LAUNCH_CHECK();
+          cap = (unsigned int)kLdsRegionMax << pb;
+          continue;
+        }
+      }
+      cap = (unsigned int)std::min<uint64_t>(std::max<uint64_t>(next, (uint64_t)cap * 2), std::max<uint64_t>(want * 4, 1u << 16));
     }
+    gb->part_bits = (int)pb;
     gb->owned.push_back(table);
     null_slot = cap;
     nslots = (int64_t)cap + 2;
