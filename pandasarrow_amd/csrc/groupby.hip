@@ -2218,8 +2218,8 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
       static const bool split_ok = [] { const char* e = getenv("PDX_HASH_SPLIT"); return !(e && e[0] == '0'); }();
       if (split_ok && pb == (unsigned)kPartBits && groups > 0.0 && next > (1u << 21) && !(lenv && lenv[0] == '0')) {
         int extra = 4;
-        while (extra < 8 && groups / (double)((uint64_t)1 << (kPartBits + extra)) > 2800.0) ++extra;
-        if (groups / (double)((uint64_t)1 << (kPartBits + extra)) <= 2800.0) {
+        while (extra < 8 && groups / (double)((uint64_t)1 << (kPartBits + extra)) > 2800.0) ++extra;  // ~35 % load when there is room ...
+        if (groups / (double)((uint64_t)1 << (kPartBits + extra)) <= 4200.0) {  // ... up to ~51 % at the last level (2.7e8 groups)
           const int64_t ntiles2 = ntiles, nchunks2 = nchunks;
           gb->digit2 = gb->own<uint8_t>((size_t)n);
           gb->part_off2 = gb->own<uint32_t>((size_t)ntiles2 << extra);
