@@ -641,3 +641,32 @@ def test_resample_next_aggs_vs_oracle(px):
         _, exp, eok = orc.resample_agg(kind, ts, vals, 5 * minute, valid=vvalid)
         assert np.array_equal(ok, eok), k
         assert_f64_bits(got, exp, valid=eok, what=k)
+
+
+def test_groupby_split_partition_special_keys(px, monkeypatch):
+    """general keys with millions of groups (second partition level), null keys and the INT64_MIN key (both live in dedicated
+    slots outside the partitioned table) and nullable values"""
+    monkeypatch.setenv("PDX_GROUPBY_DENSE", "0")
+    n = 5_000_003
+    rng = np.random.default_rng(77)
+    keys = orc.synth_keys(0, n, 3_000_000) * 1000003 - 12345
+    keys[::50021] = np.iinfo(np.int64).min
+    kvalid = rng.random(n) > 0.01
+    vals = orc.synth_vals(0, n) - 0.5
+    vvalid = rng.random(n) > 0.1
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys, kvalid))
+    ids, uniq, isnull, first = orc.group_ids(keys, kvalid)
+    assert gb.num_groups == len(uniq)
+    assert np.array_equal(gb.group_ids().cpu().numpy().astype(np.uint32), ids)
+    uk, uok = gb.unique_keys().to_numpy()
+    assert np.array_equal(uok, ~isnull) and np.array_equal(uk[uok], uniq[~isnull])
+    assert np.array_equal(gb.first_rows().cpu().numpy(), first)
+    s, c, mx = gb.agg(px.Column.from_numpy(vals, vvalid), [0, 4, 3])
+    for out, kind in ((s, 0), (c, 4), (mx, 3)):
+        got, ok = out.to_numpy()
+        exp, eok = orc.groupby_agg(kind, ids, len(uniq), vals, vvalid, nthreads=8)
+        assert ok is None or np.array_equal(ok, eok)
+        if exp.dtype == np.float64:
+            assert_f64_bits(got, exp, valid=eok, what=str(kind))
+        else:
+            assert np.array_equal(got[eok], exp[eok])
