@@ -533,8 +533,12 @@ __global__ void __launch_bounds__(256) k_dense_slots_tail(const long long* __res
 template <int BITS>
 __global__ void __launch_bounds__(kSortBlock) k_dense_slots_tail_hist(const long long* __restrict__ keys, const uint8_t* __restrict__ valid,
                                                                       int64_t off, int64_t tile0, int64_t n, long long mn, unsigned int mask,
-                                                                      unsigned int range, const uint32_t* __restrict__ seen, unsigned int* first,
-                                                                      uint32_t* __restrict__ slot_of_row, uint32_t* __restrict__ hist) {
+                                                                      unsigned int range, const uint32_t* __restrict__ seen, int64_t track_from,
+                                                                      unsigned int* first, uint32_t* __restrict__ slot_of_row,
+                                                                      uint32_t* __restrict__ hist, long long* __restrict__ tile_min,
+                                                                      long long* __restrict__ tile_max) {
+  // rows < track_from went through the full first-row protocol already; tile_min / tile_max (optional): key range of the tile
+  // (MAX / MIN sentinels when it has no valid key), reduced afterwards -- a shared accumulator would serialise 1e7 atomics
   constexpr int R = 1 << BITS;
   __shared__ uint32_t h[R];
   for (int d = threadIdx.x; d < R; d += kSortBlock) h[d] = 0;
@@ -549,11 +553,16 @@ __global__ void __launch_bounds__(kSortBlock) k_dense_slots_tail_hist(const long
   }
   unsigned int sl[kSortItems];
   uint32_t w[kSortItems];
+  long long kmn = 0x7FFFFFFFFFFFFFFFll, kmx = (long long)0x8000000000000000ull;
 #pragma unroll
   for (int u = 0; u < kSortItems; ++u) {
     int64_t i = base + u * kSortBlock + threadIdx.x;
     sl[u] = range;
-    if (i < n && (!valid || bit_get(valid, off + i))) sl[u] = dense_slot_of(k[u], mn, mask);
+    if (i < n && (!valid || bit_get(valid, off + i))) {
+      sl[u] = dense_slot_of(k[u], mn, mask);
+      kmn = k[u] < kmn ? k[u] : kmn;
+      kmx = k[u] > kmx ? k[u] : kmx;
+    }
     w[u] = i < n ? seen[sl[u] >> 5] : ~0u;
   }
 #pragma unroll
@@ -562,11 +571,31 @@ __global__ void __launch_bounds__(kSortBlock) k_dense_slots_tail_hist(const long
     if (i >= n) continue;
     slot_of_row[i] = sl[u];
     atomicAdd(&h[sl[u] & (R - 1)], 1u);
-    if (!((w[u] >> (sl[u] & 31)) & 1u)) {
+    if (!((w[u] >> (sl[u] & 31)) & 1u) && i >= track_from) {
       if ((unsigned int)i < first[sl[u]]) atomicMin(&first[sl[u]], (unsigned int)i);
     }
   }
+  __shared__ long long smn[kSortWaves], smx[kSortWaves];
+  if (tile_min) {
+    for (int d = 32; d >= 1; d >>= 1) {
+      long long a = __shfl_xor(kmn, d, 64), b = __shfl_xor(kmx, d, 64);
+      kmn = a < kmn ? a : kmn;
+      kmx = b > kmx ? b : kmx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+      smn[threadIdx.x >> 6] = kmn;
+      smx[threadIdx.x >> 6] = kmx;
+    }
+  }
   __syncthreads();
+  if (tile_min && threadIdx.x == 0) {
+    for (int w = 1; w < kSortWaves; ++w) {
+      kmn = smn[w] < kmn ? smn[w] : kmn;
+      kmx = smx[w] > kmx ? smx[w] : kmx;
+    }
+    tile_min[tile] = kmn;
+    tile_max[tile] = kmx;
+  }
   for (int d = threadIdx.x; d < R; d += kSortBlock) hist[tile * R + d] = h[d];
 }
 
@@ -1965,7 +1994,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     const int64_t nwords = (nslots + 31) >> 5;
     const int64_t tile_first_tail = prefix / kSortTile;
     const bool lds_bitmap = fuse && lds_ok && prefix < n && nwords <= kDenseLdsWords && ntiles - tile_first_tail >= 256;
-    if (range_out && !lds_bitmap) return fail(PDX_DEVICE, "dense_build: fused key range needs the LDS tail");
+    if (range_out && !(fuse && prefix < n)) return fail(PDX_DEVICE, "dense_build: fused key range needs the histogram tail");
     uint32_t* chunk_sum = nullptr;
     if (fuse) {
       gb->pass0_off = gb->own<uint32_t>((size_t)ntiles << bits0);
@@ -1973,9 +2002,15 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
       if (!gb->pass0_off || s.failed) return PDX_OOM;
     }
     KeyRange* wg_range = nullptr;
+    long long *tile_min = nullptr, *tile_max = nullptr;
     if (range_out) {
       wg_range = s.get<KeyRange>((size_t)kCUs);
       if (s.failed) return PDX_OOM;
+      if (!lds_bitmap) {  // the global-bitmap tail writes one (min, max) per tile
+        tile_min = s.get<long long>((size_t)ntiles);
+        tile_max = s.get<long long>((size_t)ntiles);
+        if (s.failed) return PDX_OOM;
+      }
     }
     {
       PDX_PROFILE("dense_slots", st);
@@ -1991,9 +2026,12 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   if (lds_bitmap)                                                                                                                                 \
     hipLaunchKernelGGL((k_dense_slots_tail_hist_lds<B>), dim3(kCUs), dim3(kDenseLdsBlock), 0, st, keys, valid, key->offset, (int64_t)0, ntiles, n,  \
                        mn, mask, null_slot, seen, (int)nwords, prefix, dense_first, gb->slot_of_row, gb->pass0_off, wg_range);                    \
+  else if (range_out) /* all tiles: slots, histogram and key range of the prefix rows too */                                                     \
+    hipLaunchKernelGGL((k_dense_slots_tail_hist<B>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, keys, valid, key->offset, (int64_t)0, n, mn,  \
+                       mask, null_slot, seen, prefix, dense_first, gb->slot_of_row, gb->pass0_off, tile_min, tile_max);                           \
   else                                                                                                                                            \
     hipLaunchKernelGGL((k_dense_slots_tail_hist<B>), dim3(tail_tiles), dim3(kSortBlock), 0, st, keys, valid, key->offset, tile_first_tail, n, mn,  \
-                       mask, null_slot, seen, dense_first, gb->slot_of_row, gb->pass0_off)
+                       mask, null_slot, seen, prefix, dense_first, gb->slot_of_row, gb->pass0_off, (long long*)nullptr, (long long*)nullptr)
         if (!fuse)
           hipLaunchKernelGGL(k_dense_slots_tail, dim3(grid_for(n - prefix, 256, 8)), dim3(256), 0, st, keys, valid, key->offset, prefix, n, mn, mask,
                              null_slot, seen, dense_first, gb->slot_of_row);
@@ -2007,7 +2045,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     }
     PDX_LAUNCH_CHECK();
     if (fuse) {
-      if (!lds_bitmap) {
+      if (!lds_bitmap && !range_out) {
         // histogram of the prefix tiles (the prefix is a whole number of tiles unless it is the whole input)
 #define PREFIX_HIST(B) hipLaunchKernelGGL((k_radix_hist<B>), dim3((unsigned)ceil_div(prefix, kSortTile)), dim3(kSortBlock), 0, st, gb->slot_of_row, prefix, 0, \
                                           gb->pass0_off)
@@ -2021,15 +2059,20 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
       int rcs = radix_scan_dispatch(bits0, gb->pass0_off, ntiles, chunk_sum, true, st);
       if (rcs != PDX_OK) return rcs;
     }
-    if (range_out) {
+    if (range_out && !lds_bitmap) {
+      long long lo = 0, hi = 0, dummy = 0;
+      PDX_TRY(minmax_i64_host(tile_min, ntiles, &lo, &dummy, s, st));
+      PDX_TRY(minmax_i64_host(tile_max, ntiles, &dummy, &hi, s, st));
+      *range_out = KeyRange{lo, hi, lo <= hi ? 1 : 0, 0};
+    } else if (range_out) {
       std::vector<KeyRange> h((size_t)kCUs);
       PDX_HIP(hipMemcpyAsync(h.data(), wg_range, sizeof(KeyRange) * kCUs, hipMemcpyDeviceToHost, st));
       PDX_HIP(hipStreamSynchronize(st));
       KeyRange r{0x7FFFFFFFFFFFFFFFll, (long long)0x8000000000000000ull, 0, 0};
-      for (const KeyRange& w : h)
-        if (w.any) {
-          r.vmin = std::min(r.vmin, w.vmin);
-          r.vmax = std::max(r.vmax, w.vmax);
+      for (size_t wi = 0; wi < h.size(); ++wi)
+        if (h[wi].any) {
+          r.vmin = std::min(r.vmin, h[wi].vmin);
+          r.vmax = std::max(r.vmax, h[wi].vmax);
           r.any = 1;
         }
       *range_out = r;
@@ -2066,7 +2109,11 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
       // without the full min/max pass
       if (span_s >= dense_lim) sample_rules_out_dense = true;
     }
-    if (b <= 20 && (1ull << b) <= dense_lim) {
+    // Only windows of <= 20 bits (LDS-resident bitmap).  Wider windows work too (global bitmap, tile min/max in the same pass) but
+    // do not pay: the power-of-two residue domain makes the bitmap up to 2x larger than key - min and costs more than the
+    // saved min/max pass (measured at 1e7 keys: 42.6 vs 39.7 ms).
+    static const int spec_max_bits = [] { const char* e = getenv("PDX_DENSE_SPECULATE_BITS"); return e ? atoi(e) : 20; }();
+    if (b <= spec_max_bits && b <= 26 && (1ull << b) <= dense_lim && (int64_t)16 * (((int64_t)1 << b) + 1) + 2 * kSortTile < n) {
       dense_mask = (1u << b) - 1;
       null_slot = 1u << b;
       nslots = (int64_t)null_slot + (valid ? 1 : 0);
