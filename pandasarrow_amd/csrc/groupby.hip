@@ -1028,15 +1028,16 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
 // Chunks of 1024 values (64 leaves), the next chunk's loads in flight while the current one is staged and reduced; the chunk's
 // perfect subtrees go through the LDS-resident counter (csum/mask/root: Arrow's state after the segment; the caller folds it or
 // stores it).  ext (wave-reduced, valid in lane 0) and isum (wave-reduced) cover the whole segment; rows are numbered from row_base.
-template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM>
+template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM, bool PREFETCH = true>
 __device__ __forceinline__ void seg_chunked(const T* __restrict__ vals, int64_t s, int64_t len, long long row_base, int lane, double* lds /* 64*17 */,
                                             double* csum /* 48 */, Extreme<T>& ext, unsigned long long& isum, uint64_t& mask, int& root) {
   constexpr int LEAF = 16;
   constexpr int kSegChunk = 64 * LEAF;
   __builtin_amdgcn_wave_barrier();
   if (lane < 48) csum[lane] = 0.0;
+  // PREFETCH = false (callers with many live registers of their own): plain load-then-reduce per chunk, half the registers
   T cur[LEAF];
-  {
+  if (PREFETCH) {
     const int cl = (int)(len < kSegChunk ? len : kSegChunk);
 #pragma unroll
     for (int q = 0; q < LEAF; ++q) {
@@ -1046,14 +1047,20 @@ __device__ __forceinline__ void seg_chunked(const T* __restrict__ vals, int64_t 
   }
   for (int64_t c0 = 0; c0 < len; c0 += kSegChunk) {
     const int cl = (int)((len - c0) < kSegChunk ? (len - c0) : kSegChunk);
-    T nxt[LEAF];
-    {
+    T nxt[PREFETCH ? LEAF : 1];
+    if (PREFETCH) {
       const int64_t n0 = c0 + kSegChunk;
       const int ncl = n0 < len ? (int)((len - n0) < kSegChunk ? (len - n0) : kSegChunk) : 0;
 #pragma unroll
       for (int q = 0; q < LEAF; ++q) {
         int idx = q * 64 + lane;
-        nxt[q] = idx < ncl ? vals[s + n0 + idx] : T(0);
+        nxt[PREFETCH ? q : 0] = idx < ncl ? vals[s + n0 + idx] : T(0);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < LEAF; ++q) {
+        int idx = q * 64 + lane;
+        cur[q] = idx < cl ? vals[s + c0 + idx] : T(0);
       }
     }
 #pragma unroll
@@ -1091,8 +1098,10 @@ __device__ __forceinline__ void seg_chunked(const T* __restrict__ vals, int64_t 
         if ((m >> sft) & 1) lds_counter_push(csum, mask, root, node[sft], sft, lane);
     }
     __builtin_amdgcn_wave_barrier();
+    if (PREFETCH) {
 #pragma unroll
-    for (int q = 0; q < LEAF; ++q) cur[q] = nxt[q];
+      for (int q = 0; q < LEAF; ++q) cur[q] = nxt[PREFETCH ? q : 0];
+    }
   }
   if (WANT_MINMAX) {
     for (int d = 32; d > 0; d >>= 1) {
@@ -1149,7 +1158,8 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_mid(const T* __re
         uint64_t mask = 0;
         int root = 0;
         double* csum = csum_all[wave];
-        seg_chunked<T, WANT_PAIRWISE, WANT_MINMAX, WANT_ISUM>(vals, S, glen0, 0ll, lane, reinterpret_cast<double*>(stage), csum, ext, isum, mask, root);
+        seg_chunked<T, WANT_PAIRWISE, WANT_MINMAX, WANT_ISUM, false>(vals, S, glen0, 0ll, lane, reinterpret_cast<double*>(stage), csum, ext, isum, mask,
+                                                                     root);
         double total = 0.0;
         if (WANT_PAIRWISE) {
           double acc = csum[0];
