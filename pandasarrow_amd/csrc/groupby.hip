@@ -1865,8 +1865,11 @@ __global__ void __launch_bounds__(256) k_seg_sqdev(const T* __restrict__ vals, c
     const int64_t s = seg_start[k], e = seg_start[k + 1];
     const double mu = mean_seg[k];
     for (int64_t i = s + lane; i < e; i += 64) {
-      const double x = (double)vals[i] - mu;
-      d[i] = x * x;
+      // NaN operands: x86 SUBSD/MULSD hand back the first NaN operand unchanged, v_add_f64 with a negated source flips its sign;
+      // spell the x86 result out so the NaN bits agree too
+      const double v = (double)vals[i];
+      const double x = v - mu;
+      d[i] = v != v ? v : (mu != mu ? mu : x * x);
     }
   }
 }
@@ -1947,7 +1950,7 @@ __global__ void k_var_finish(const double* __restrict__ m2, const long long* __r
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) {
     const double v = count[g] > 0 ? m2[g] / (double)count[g] : 0.0;
     if (var) var[g] = v;
-    if (sd) sd[g] = sqrt(v);
+    if (sd) sd[g] = v != v ? v : sqrt(v);  // a NaN variance passes through unchanged (x86 sqrtsd keeps the operand's NaN bits)
   }
 }
 
