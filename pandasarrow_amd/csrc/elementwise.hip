@@ -62,20 +62,32 @@ struct Conv<int64_t> {
   __device__ static int64_t from(S x) { return (int64_t)x; }
 };
 
+// NaN results carry the bits the reference's x86 host would produce, not CDNA's: SSE hands back the FIRST NaN operand (quieted;
+// the second one if only that is NaN -- not negated by a subtraction), and an invalid operation (inf - inf, 0 * inf, 0 / 0,
+// inf / inf) yields the negative "real indefinite" 0xFFF8000000000000, where v_add/v_mul/v_div_f64 give +qNaN or flip the sign
+// of a negated source.  Three selects on values already in registers: free in an HBM-bound kernel.
+__device__ __forceinline__ double x86_nan(double r, double x, double y) {
+  if (r == r) return r;
+  const unsigned long long quiet = 0x0008000000000000ull;
+  if (x != x) return __longlong_as_double((long long)((unsigned long long)__double_as_longlong(x) | quiet));
+  if (y != y) return __longlong_as_double((long long)((unsigned long long)__double_as_longlong(y) | quiet));
+  return __longlong_as_double((long long)0xFFF8000000000000ull);
+}
+
 template <typename TO, int OP>
 __device__ __forceinline__ TO apply_op(TO x, TO y, bool valid, unsigned long long* err) {
   if constexpr (sizeof(TO) == 8 && OP == PDX_ADD) {
-    if constexpr (__is_same(TO, double)) return x + y;
+    if constexpr (__is_same(TO, double)) return x86_nan(x + y, x, y);
     else return (int64_t)((uint64_t)x + (uint64_t)y);
   } else if constexpr (OP == PDX_SUB) {
-    if constexpr (__is_same(TO, double)) return x - y;
+    if constexpr (__is_same(TO, double)) return x86_nan(x - y, x, y);
     else return (int64_t)((uint64_t)x - (uint64_t)y);
   } else if constexpr (OP == PDX_MUL) {
-    if constexpr (__is_same(TO, double)) return x * y;
+    if constexpr (__is_same(TO, double)) return x86_nan(x * y, x, y);
     else return (int64_t)((uint64_t)x * (uint64_t)y);
   } else {
     if constexpr (__is_same(TO, double)) {
-      return x / y;
+      return x86_nan(x / y, x, y);
     } else {
       // Arrow "divide" (unchecked): truncation toward zero; INT64_MIN / -1 -> 0; zero divisor at a valid slot is an error
       if (!valid) return 0;
