@@ -239,11 +239,15 @@ int pdx_resample_row_labels(pdx_groupby* gb, int64_t* out_labels, void* stream);
  * Binary operators on Series with UNEQUAL indexes go through Series::broadcast (src/series.cpp:212-227):
  * Concatenate(index_a, index_b) -> Unique -> array_sort_indices(ascending) -> Take, then Series::reindex of both operands
  * (src/series.cpp:1255-1309: std::unordered_map label -> LAST position, absent labels -> null).
- * pdx_index_union: the sorted distinct labels of a and b (same dtype: int64 / uint64 / timestamp[ns], no nulls).
- *   out: same dtype, capacity a.length + b.length; out->length is set to the number of labels.
+ * pdx_index_union: the distinct labels of a and b (same dtype: int64 / uint64 / timestamp[ns], no nulls), sorted ascending
+ *   (sort != 0: Series::broadcast) or in first-occurrence order (sort == 0: Series::union_, src/series.cpp:782-798, used by the
+ *   column-wise concat, src/concat.cpp:78-88, 192-244).  out: same dtype, capacity a.length + b.length; out->length is set.
+ * pdx_index_intersection: Series::intersection (src/series.cpp:763-780): the labels of a that occur in b, one per distinct
+ *   label, ordered by their (last) position in a.  out: capacity a.length.
  * pdx_reindex_indices: for every label of new_index its LAST position in old_index as int64 take indices with a validity
  *   bitmap (absent label -> null index); feed it to pdx_take, whose null indices produce null rows (== AppendNull). */
-int pdx_index_union(const pdx_column* a, const pdx_column* b, pdx_mut_column* out, void* stream);
+int pdx_index_union(const pdx_column* a, const pdx_column* b, int sort, pdx_mut_column* out, void* stream);
+int pdx_index_intersection(const pdx_column* a, const pdx_column* b, pdx_mut_column* out, void* stream);
 int pdx_reindex_indices(const pdx_column* old_index, const pdx_column* new_index, pdx_mut_column* out_idx, void* stream);
 
 /* ---------------------------------------------------------------- concat (rows)

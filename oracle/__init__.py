@@ -353,9 +353,26 @@ def concat(parts, valids=None):
 
 
 # ------------------------------------------------------------------ index alignment
-def index_union(a, b):
-    """Series::broadcast's new index (src/series.cpp:212-227): Unique(Concatenate(a, b)) sorted ascending."""
-    return np.unique(np.concatenate([np.asarray(a), np.asarray(b)]))
+def index_union(a, b, sort=True):
+    """Series::broadcast's new index (src/series.cpp:212-227): Unique(Concatenate(a, b)) sorted ascending; sort=False is
+    Series::union_ (src/series.cpp:782-798): the distinct labels in first-occurrence order."""
+    cat = np.concatenate([np.asarray(a), np.asarray(b)])
+    if sort:
+        return np.unique(cat)
+    _, first = np.unique(cat, return_index=True)
+    return cat[np.sort(first)]
+
+
+def index_intersection(a, b):
+    """Series::intersection (src/series.cpp:763-780): for every distinct label of a that occurs in b, its (last) position in a;
+    positions sorted ascending; Take."""
+    a, b = np.asarray(a), np.asarray(b)
+    last = {}
+    for i, v in enumerate(a.tolist()):
+        last[v] = i
+    inb = set(b.tolist())
+    pos = sorted(p for v, p in last.items() if v in inb)
+    return a[np.array(pos, dtype=np.int64)] if pos else a[:0]
 
 
 def reindex_indices(old_index, new_index):

@@ -98,7 +98,8 @@ ABI_SYMBOLS = {
     "pdx_resample_create": (C.c_int, [_COL, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _P, C.POINTER(_P)]),
     "pdx_resample_row_labels": (C.c_int, [_P, _P, _P]),
     "pdx_concat": (C.c_int, [_COL, C.c_int, _MUT, _P]),
-    "pdx_index_union": (C.c_int, [_COL, _COL, _MUT, _P]),
+    "pdx_index_union": (C.c_int, [_COL, _COL, C.c_int, _MUT, _P]),
+    "pdx_index_intersection": (C.c_int, [_COL, _COL, _MUT, _P]),
     "pdx_reindex_indices": (C.c_int, [_COL, _COL, _MUT, _P]),
 }
 

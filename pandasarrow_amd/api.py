@@ -363,13 +363,21 @@ class Resampler(GroupBy):
     def count(self, args=None): return self._all(L.AGG_COUNT) if args is None else super().count(args)
 
 
-def concat(frames, ignore_index=False):
-    """pd::concat(dfs, AxisType::Index) for same-schema frames (src/concat.cpp:116-190): columns are appended, each frame's
-    index is carried along (``[0,1,0,1]``) unless ignore_index."""
+def concat(frames, axis="index", join="outer", ignore_index=False, sort=False):
+    """pd::concat(dfs, axis, join, ignore_index, sort) (src/concat.h:56-64, src/concat.cpp).
+
+    axis="index" (rows, src/concat.cpp:116-190) for same-schema frames: columns are appended, each frame's index is carried
+    along (``[0,1,0,1]``) unless ignore_index.
+    axis="columns" (src/concat.cpp:192-244): the frames' indexes are merged pairwise -- Series::union_ (distinct labels in
+    first-occurrence order) for join="outer", Series::intersection for "inner" -- optionally sorted, every frame whose index
+    differs is reindexed onto the merged index (labels it lacks -> null rows), and the columns are laid side by side
+    (duplicate names are kept; ignore_index renames them "0", "1", ...)."""
+    if axis in ("columns", 1):
+        return _concat_columns(frames, join, ignore_index, sort)
     names = frames[0].names
     for f in frames:
         if f.names != names:
-            raise L.PdxError(L.NOT_IMPLEMENTED, "concat of frames with different schemas (outer/inner join) is a 'next' item")
+            raise L.PdxError(L.NOT_IMPLEMENTED, "row concat of frames with different schemas (outer/inner join on the columns) is not implemented")
     cols = [K.concat([f.cols[i] for f in frames]) for i in range(len(names))]
     index = None
     if not ignore_index:
@@ -377,4 +385,47 @@ def concat(frames, ignore_index=False):
         index = K.concat(idx_parts)
     df = DataFrame.__new__(DataFrame)
     df.names, df.cols, df.index = list(names), cols, index
+    return df
+
+
+def _frame_index(f):
+    return f.index if f.index is not None else Column(L.UINT64, f.num_rows(), torch.arange(max(f.num_rows(), 1), dtype=torch.int64, device=K._device()), None)
+
+
+def _same_labels(a: Column, b: Column):
+    if a.length != b.length or a.dtype != b.dtype:
+        return False
+    if a.length == 0:
+        return True
+    ai, bi = (Column(L.INT64, c.length, c.values, None, c.offset) for c in (a, b))
+    return K.filter_count(K.compare(L.EQ, ai, bi)) == a.length
+
+
+def _concat_columns(frames, join, ignore_index, sort):
+    if join not in ("outer", "inner"):
+        raise L.PdxError(L.INVALID, "join must be 'outer' or 'inner'")
+    if all(f.index is None for f in frames) and len({f.num_rows() for f in frames}) == 1:
+        new_index, explicit = None, False  # equal implicit ranges: nothing to align
+    else:
+        idxs = [_frame_index(f) for f in frames]
+        new_index = idxs[0]
+        for other in idxs[1:]:  # Concatenator::mergeIndexes (src/concat.cpp:78-88)
+            if new_index.dtype != other.dtype:
+                raise L.PdxError(L.INVALID, "type(NewIndex) != type(CurrentIndex).")
+            new_index = K.index_intersection(new_index, other) if join == "inner" else K.index_union(new_index, other, sort=False)
+        if sort:
+            new_index = K.index_union(new_index, new_index.slice(0, 0), sort=True)  # labels are distinct: this only sorts them
+        explicit = True
+    names, cols = [], []
+    for f in frames:
+        fcols = f.cols
+        if explicit and not _same_labels(_frame_index(f), new_index):
+            take_idx = K.reindex_indices(_frame_index(f), new_index)  # DataFrame::reindexAsync: one plan, every column gathered once
+            fcols = K.take(f.cols, take_idx)
+        names += f.names
+        cols += fcols
+    if ignore_index:
+        names = [str(i) for i in range(len(names))]
+    df = DataFrame.__new__(DataFrame)
+    df.names, df.cols, df.index = names, cols, new_index
     return df

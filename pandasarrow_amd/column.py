@@ -258,12 +258,21 @@ def concat(parts) -> Column:
 
 
 # ---------------------------------------------------------------- index alignment (Series::broadcast / reindex)
-def index_union(a: Column, b: Column) -> Column:
-    """sorted distinct labels of both indexes (pdx_index_union)."""
+def index_union(a: Column, b: Column, sort=True) -> Column:
+    """distinct labels of both indexes, sorted ascending or in first-occurrence order (pdx_index_union)."""
     out = Column.empty(a.dtype, a.length + b.length)
     m = out.mut()
     ca, cb = a.c(), b.c()
-    L.check(L.load().pdx_index_union(C.byref(ca), C.byref(cb), C.byref(m), _stream()))
+    L.check(L.load().pdx_index_union(C.byref(ca), C.byref(cb), int(bool(sort)), C.byref(m), _stream()))
+    return out._adopt(m)
+
+
+def index_intersection(a: Column, b: Column) -> Column:
+    """labels of a that occur in b, one per distinct label, in a's (last-)position order (pdx_index_intersection)."""
+    out = Column.empty(a.dtype, a.length)
+    m = out.mut()
+    ca, cb = a.c(), b.c()
+    L.check(L.load().pdx_index_intersection(C.byref(ca), C.byref(cb), C.byref(m), _stream()))
     return out._adopt(m)
 
 

@@ -248,7 +248,7 @@ class Series {
     Array u = Array::Empty(m_index->dtype, m_index->length + o.m_index->length, false);
     auto ca = m_index->c(), cb = o.m_index->c();
     auto mu = u.mut();
-    ThrowOnFailure(pdx_index_union(&ca, &cb, &mu, nullptr));
+    ThrowOnFailure(pdx_index_union(&ca, &cb, /*sort=*/1, &mu, nullptr));
     u.length = mu.length;
     return {reindex(u), o.reindex(u)};
   }

@@ -65,13 +65,35 @@ struct GroupByOwner {  // RAII for the internal dictionary handle
   }
 };
 
+__global__ void k_mark_groups(const uint32_t* __restrict__ gids, int64_t from, int64_t n, uint8_t* __restrict__ flag) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = from + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) flag[gids[i]] = 1;
+}
+// groups are numbered by first occurrence in concat(reverse(a), b): walking them backwards walks a's LAST positions upwards
+struct IntersectPred {
+  const int64_t* first_rows;
+  const uint8_t* in_b;
+  int64_t G, n_a;
+  __device__ bool operator()(int64_t i) const {
+    const int64_t g = G - 1 - i;
+    return first_rows[g] < n_a && in_b[g];
+  }
+};
+struct IntersectEmit {
+  const int64_t* first_rows;
+  const long long* a;
+  int64_t G, n_a;
+  long long* out;
+  __device__ void operator()(int64_t pos, int64_t i) const { out[pos] = a[n_a - 1 - first_rows[G - 1 - i]]; }
+};
+
 }  // namespace pdx
 
 using namespace pdx;
 
 extern "C" {
 
-int pdx_index_union(const pdx_column* a, const pdx_column* b, pdx_mut_column* out, void* stream) {
+int pdx_index_union(const pdx_column* a, const pdx_column* b, int sort, pdx_mut_column* out, void* stream) {
   PDX_TRY(check_index(a, "pdx_index_union"));
   PDX_TRY(check_index(b, "pdx_index_union"));
   if (!out) return fail(PDX_INVALID, "pdx_index_union: null output");
@@ -107,6 +129,13 @@ int pdx_index_union(const pdx_column* a, const pdx_column* b, pdx_mut_column* ou
   um.values = uniq;
   um.validity = uniq_ok;
   PDX_TRY(pdx_groupby_unique_keys(gb.h, &um, stream));
+  if (!sort) {  // Series::union_ (src/series.cpp:782-798): Unique(Concatenate) as is, first-occurrence order
+    PDX_HIP(hipMemcpyAsync(out->values, uniq, (size_t)G * sizeof(long long), hipMemcpyDeviceToDevice, st));
+    if (out->validity) PDX_HIP(hipMemsetAsync(out->validity, 0xFF, (size_t)((G + 7) / 8), st));
+    PDX_HIP(hipStreamSynchronize(st));
+    out->length = G;
+    return PDX_OK;
+  }
   // array_sort_indices ascending + Take: stable LSD sort of the 64-bit labels, three rounds through the 32-bit pair sort
   uint32_t* perm = s.get<uint32_t>((size_t)G);
   uint32_t* chunk = s.get<uint32_t>((size_t)G);
@@ -172,6 +201,49 @@ int pdx_reindex_indices(const pdx_column* old_index, const pdx_column* new_index
   hipLaunchKernelGGL(k_pack_bytes, dim3(grid_for((n_new + 7) / 8, 256)), dim3(256), 0, st, ok, n_new, static_cast<uint8_t*>(out_idx->validity));
   PDX_LAUNCH_CHECK();
   PDX_HIP(hipStreamSynchronize(st));
+  return PDX_OK;
+}
+
+int pdx_index_intersection(const pdx_column* a, const pdx_column* b, pdx_mut_column* out, void* stream) {
+  PDX_TRY(check_index(a, "pdx_index_intersection"));
+  PDX_TRY(check_index(b, "pdx_index_intersection"));
+  if (!out) return fail(PDX_INVALID, "pdx_index_intersection: null output");
+  if (a->dtype != b->dtype) return fail(PDX_INVALID, "type(NewIndex) != type(CurrentIndex).");
+  const int64_t na = a->length, nb = b->length, n = na + nb;
+  if (out->dtype != a->dtype) return fail(PDX_INVALID, "pdx_index_intersection: output dtype must be the index dtype");
+  if (out->length < na || (na && !out->values)) return fail(PDX_INVALID, "pdx_index_intersection: output must hold a.length labels");
+  out->length = 0;
+  out->null_count = 0;
+  if (na == 0 || nb == 0) return PDX_OK;
+  if (n > 0x7FFFFFFFll) return fail(PDX_NOT_IMPLEMENTED, "pdx_index_intersection: more than 2^31-1 labels per call is not supported yet");
+  hipStream_t st = as_stream(stream);
+  Scratch s;
+  long long* cat = s.get<long long>((size_t)n);
+  uint32_t* gids = s.get<uint32_t>((size_t)n);
+  PDX_SCRATCH_CHECK(s);
+  const long long* av = static_cast<const long long*>(a->values) + a->offset;
+  hipLaunchKernelGGL(k_concat2_i64, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, av, na, 1, static_cast<const long long*>(b->values) + b->offset, nb, cat);
+  PDX_LAUNCH_CHECK();
+  pdx_column cc{};
+  cc.dtype = a->dtype;
+  cc.length = n;
+  cc.values = cat;
+  GroupByOwner gb;
+  PDX_TRY(pdx_groupby_create(&cc, stream, &gb.h));
+  const int64_t G = pdx_groupby_num_groups(gb.h);
+  int64_t* first_rows = s.get<int64_t>((size_t)G);
+  uint8_t* in_b = s.get<uint8_t>((size_t)G);
+  PDX_SCRATCH_CHECK(s);
+  PDX_TRY(pdx_groupby_group_ids(gb.h, gids, stream));
+  PDX_TRY(pdx_groupby_first_rows(gb.h, first_rows, stream));
+  PDX_HIP(hipMemsetAsync(in_b, 0, (size_t)G, st));
+  hipLaunchKernelGGL(k_mark_groups, dim3(grid_for(nb, 256, 4)), dim3(256), 0, st, gids, na, n, in_b);
+  PDX_LAUNCH_CHECK();
+  int64_t m = 0;
+  PDX_TRY(compact_indices(G, IntersectPred{first_rows, in_b, G, na}, IntersectEmit{first_rows, av, G, na, static_cast<long long*>(out->values)}, &m, s, st));
+  if (out->validity) PDX_HIP(hipMemsetAsync(out->validity, 0xFF, (size_t)((m + 7) / 8), st));
+  PDX_HIP(hipStreamSynchronize(st));
+  out->length = m;
   return PDX_OK;
 }
 

@@ -129,3 +129,39 @@ def test_series_binary_ops_align_unequal_indexes(px):
     assert same.index is sa.index and np.array_equal(same.values(), va + va * 2)
     with pytest.raises(px.L.PdxError):
         _ = sa + api.Series(vb, index=px.Column.from_numpy(ib.astype(np.uint64), dtype=px.L.UINT64))  # type(NewIndex) != type(CurrentIndex)
+
+
+@pytest.mark.parametrize("na,nb", [(0, 5), (5, 0), (1000, 700), (120_003, 90_001)])
+def test_index_union_unsorted_and_intersection_vs_oracle(px, na, nb):
+    rng = np.random.default_rng(na + 3 * nb)
+    a = rng.integers(-2 * max(na, nb, 1), 2 * max(na, nb, 1), na).astype(np.int64)   # duplicates on both sides
+    b = rng.integers(-2 * max(na, nb, 1), 2 * max(na, nb, 1), nb).astype(np.int64)
+    ca, cb = px.Column.from_numpy(a), px.Column.from_numpy(b)
+    assert np.array_equal(px.K.index_union(ca, cb, sort=False).to_numpy()[0], orc.index_union(a, b, sort=False))
+    assert np.array_equal(px.K.index_intersection(ca, cb).to_numpy()[0], orc.index_intersection(a, b))
+
+
+def test_concat_columns(px):
+    """pd::concat(..., AxisType::Columns): reference vectors (tests/concat_test.cpp:115-270) + frames with different indexes"""
+    api = px.api
+    df1 = api.DataFrame({"a": np.array([1, 2, 3]), "b": np.array([4, 5, 6])})
+    df2 = api.DataFrame({"a": np.array([7.0, 8.0, 9.0]), "c": np.array([10, 11, 12])})
+    r = api.concat([df1, df2], axis="columns")
+    assert r.names == ["a", "b", "a", "c"] and r.index is None
+    assert [list(c.to_numpy()[0]) for c in r.cols] == [[1, 2, 3], [4, 5, 6], [7.0, 8.0, 9.0], [10, 11, 12]]
+    assert api.concat([df1, df2], axis="columns", ignore_index=True).names == ["0", "1", "2", "3"]
+    # different indexes: outer = union in first-occurrence order (sorted on request), inner = intersection; missing labels -> null
+    rng = np.random.default_rng(8)
+    ia, ib = rng.permutation(4000)[:2500].astype(np.int64), rng.permutation(4000)[:3000].astype(np.int64)
+    va, vb = rng.standard_normal(2500), rng.integers(0, 100, 3000).astype(np.int64)
+    fa = api.DataFrame({"x": va}, index=ia)
+    fb = api.DataFrame({"y": vb}, index=ib)
+    for join, sort in (("outer", False), ("outer", True), ("inner", False)):
+        r = api.concat([fa, fb], axis="columns", join=join, sort=sort)
+        exp_idx = orc.index_intersection(ia, ib) if join == "inner" else orc.index_union(ia, ib, sort=sort)
+        assert np.array_equal(r.index.to_numpy()[0], exp_idx), (join, sort)
+        for col, (src_idx, src_vals) in zip(r.cols, ((ia, va), (ib, vb))):
+            pos, present = orc.reindex_indices(src_idx, exp_idx)
+            vals, ok = col.to_numpy()
+            assert np.array_equal(np.ones(len(exp_idx), bool) if ok is None else ok, present)
+            assert np.array_equal(vals[present], src_vals[pos][present])
