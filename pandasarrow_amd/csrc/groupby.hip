@@ -1432,7 +1432,7 @@ __global__ void __launch_bounds__(64) k_seg_combine_big(const uint32_t* __restri
 // partial sum is the sequential sum of the previous window's last rows (one shuffle), and each lane walks its 16 validity bits
 // emitting finished leaves in order.  The emitted leaf sums are merged with a butterfly whose lanes are aligned to the GLOBAL leaf
 // index, so every perfect subtree it extracts is exactly a run of carries of Arrow's binary counter.
-constexpr int kNullLeafCap = 64 * 9 + 8;  // a 16-row window emits at most 9 leaves (8 isolated values + the carried one)
+constexpr int kNullLeafCap = 64 * 9 + 8 + 64;  // a 16-row window emits at most 9 leaves (8 isolated values + the carried one); + the queue's tail
 
 template <typename T>
 __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_nullable(const T* __restrict__ vals, const uint32_t* __restrict__ sorted_keys,
@@ -1459,7 +1459,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_nullable(const T*
     long long nvalid = 0;
     uint64_t cmask = 0;       // binary counter occupancy (wave-uniform)
     int croot = 0;
-    long long nleaves = 0;    // leaves pushed so far (wave-uniform): lane alignment of the merge butterfly
+    int pend = 0;             // finished leaves waiting in the queue for their block of 64 (wave-uniform, < 64 between chunks)
     int carry_pos = 0;        // rows already in the leaf that is open at the chunk start
     double carry_acc = 0.0;   // ... and their sequential sum
     if (lane < 48) csum[lane] = 0.0;
@@ -1515,7 +1515,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_nullable(const T*
       const int total_new = __shfl(inc_n, 63, 64);
       // pass 2: emit the finished leaves in order
       {
-        int p = pos, w = base;
+        int p = pos, w = pend + base;
         double a = pos > 0 ? acc : 0.0;
         for (int q = 0; q < 16; ++q) {
           if ((m >> q) & 1u) {
@@ -1530,31 +1530,40 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_nullable(const T*
       carry_pos = last_inc < 0 ? carry_pos : last_inc;
       carry_acc = last_tail;
       __builtin_amdgcn_wave_barrier();
-      // merge the new leaves: batches of lanes aligned to the global leaf index
-      int consumed = 0;
-      while (consumed < total_new) {
-        const int lo = (int)(nleaves & 63);
-        const int take = (64 - lo) < (total_new - consumed) ? (64 - lo) : (total_new - consumed);
-        const int hi = lo + take;
-        double x0 = (lane >= lo && lane < hi) ? leaves[consumed + lane - lo] : 0.0;
-        double x1 = x0 + __shfl_down(x0, 1, 64);
-        double x2 = x1 + __shfl_down(x1, 2, 64);
-        double x3 = x2 + __shfl_down(x2, 4, 64);
-        double x4 = x3 + __shfl_down(x3, 8, 64);
-        double x5 = x4 + __shfl_down(x4, 16, 64);
-        double x6 = x5 + __shfl_down(x5, 32, 64);
-        for (int sidx = lo; sidx < hi;) {
-          int tz = sidx == 0 ? 6 : __builtin_ctz((unsigned)sidx);
-          int lg = 31 - __builtin_clz((unsigned)(hi - sidx));
-          const int j = tz < lg ? tz : lg;
-          double xs = j == 0 ? x0 : j == 1 ? x1 : j == 2 ? x2 : j == 3 ? x3 : j == 4 ? x4 : j == 5 ? x5 : x6;
-          lds_counter_push(csum, cmask, croot, __shfl(xs, sidx, 64), j, lane);
-          sidx += 1 << j;
+      // merge: the finished leaves queue up behind `pend` leaves left over from earlier chunks (the queue always starts at a
+      // multiple of 64 of the group's leaf sequence); every full block of 64 is one perfect subtree = ONE level-6 push
+      {
+        const int total = pend + total_new;
+        int b = 0;
+        for (; b + 64 <= total; b += 64) {
+          const double node = wave_tree64(leaves[b + lane]);
+          lds_counter_push(csum, cmask, croot, __shfl(node, 0, 64), 6, lane);
         }
-        nleaves += take;
-        consumed += take;
+        const int rem = total - b;
+        double keep = 0.0;
+        if (b > 0 && lane < rem) keep = leaves[b + lane];
+        __builtin_amdgcn_wave_barrier();
+        if (b > 0 && lane < rem) leaves[lane] = keep;
+        pend = rem;
       }
       __builtin_amdgcn_wave_barrier();
+    }
+    // the queue's tail (< 64 leaves, aligned to a multiple of 64): its perfect subtrees, highest first
+    if (pend > 0) {
+      double x0 = lane < pend ? leaves[lane] : 0.0;
+      double x1 = x0 + __shfl_down(x0, 1, 64);
+      double x2 = x1 + __shfl_down(x1, 2, 64);
+      double x3 = x2 + __shfl_down(x2, 4, 64);
+      double x4 = x3 + __shfl_down(x3, 8, 64);
+      double x5 = x4 + __shfl_down(x4, 16, 64);
+      for (int sidx = 0; sidx < pend;) {
+        int lg = 31 - __builtin_clz((unsigned)(pend - sidx));
+        int tz = sidx == 0 ? 6 : __builtin_ctz((unsigned)sidx);
+        const int j = tz < lg ? tz : lg;
+        double xs = j == 0 ? x0 : j == 1 ? x1 : j == 2 ? x2 : j == 3 ? x3 : j == 4 ? x4 : x5;
+        lds_counter_push(csum, cmask, croot, __shfl(xs, sidx, 64), j, lane);
+        sidx += 1 << j;
+      }
     }
     // the leaf still open at the end of the group
     if (carry_pos > 0) lds_counter_push(csum, cmask, croot, carry_acc, 0, lane);
