@@ -1,0 +1,48 @@
+"""GPU: bench.py's output contract on a small workload (one JSON line with roofline + cpu_baseline), and a 2-rank rehearsal of
+its N > 1 path (the sharded partial-tree group-by) with both ranks on the test box's single GPU over gloo."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+        "config", "roofline", "cpu_baseline")
+
+
+def _last_json(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_contract():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "3e6", "--keys", "5e3", "--steps", "2", "--warmup", "1",
+                        "--cpu-sample-rows", "1e6"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _last_json(p.stdout)
+    assert all(k in d for k in KEYS)
+    assert d["n_gpus"] == 1 and d["unit"] == "Grows/s" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["value"] > 0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["gpu_matches_oracle_bit_exact"] is True
+    assert all(v for v in d["check"].values() if isinstance(v, bool))
+
+
+def test_bench_two_rank_rehearsal():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PDX_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "4e6", "--keys", "2e4", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = _last_json(p.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rows_per_gpu"] == 2_000_000 and d["cpu_baseline"] is None
+    assert d["check"]["groups"] == 20_000 and all(v for v in d["check"].values() if isinstance(v, bool))
