@@ -1754,7 +1754,8 @@ static int ilog2(uint64_t x) {
 // scattered with the stored partition offsets (the first LSD pass) and only the remaining slot bits are sorted.
 template <typename Alloc>
 static int sort_values_by_slot(pdx_groupby* gb, const uint64_t* vals, const uint8_t* vvalid, int64_t voff, Alloc&& alloc, Scratch& s, hipStream_t st,
-                               const uint32_t** keys_sorted, const uint64_t** vals_sorted) {
+                               const uint32_t** keys_sorted, const uint64_t** vals_sorted, int skip_top_bits = 0) {
+  // skip_top_bits: leave the rows sorted by the LOW slot_bits - skip_top_bits bits only (the fused last-digit reduce does the rest)
   const int64_t n = gb->n;
   uint32_t* k0 = static_cast<uint32_t*>(alloc((size_t)n * 4));
   uint32_t* k1 = static_cast<uint32_t*>(alloc((size_t)n * 4));
@@ -1784,7 +1785,8 @@ static int sort_values_by_slot(pdx_groupby* gb, const uint64_t* vals, const uint
       hipLaunchKernelGGL(k_flag_keys_part, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, gb->slot_part, gb->rows_part, vvalid, voff, n, fk);
       kin = fk;
     }
-    return radix_sort_pairs<uint64_t>(kin, vals_part, k0, v0, k1, v1, n, gb->slot_bits - gb->part_bits, keys_sorted, vals_sorted, true, s, st, gb->part_bits);
+    return radix_sort_pairs<uint64_t>(kin, vals_part, k0, v0, k1, v1, n, gb->slot_bits - gb->part_bits - skip_top_bits, keys_sorted, vals_sorted, true, s, st,
+                                      gb->part_bits);
   }
   const uint32_t* kin = gb->slot_of_row;
   if (vvalid) {
@@ -1794,7 +1796,7 @@ static int sort_values_by_slot(pdx_groupby* gb, const uint64_t* vals, const uint
     kin = fk;
   }
   // (pass0_off describes the unflagged slots; the digit of a flagged key is the same: the flag lives in bit 31)
-  return radix_sort_pairs<uint64_t>(kin, vals, k0, v0, k1, v1, n, gb->slot_bits, keys_sorted, vals_sorted, true, s, st, 0, gb->pass0_off);
+  return radix_sort_pairs<uint64_t>(kin, vals, k0, v0, k1, v1, n, gb->slot_bits - skip_top_bits, keys_sorted, vals_sorted, true, s, st, 0, gb->pass0_off);
 }
 
 template <typename T>
@@ -1857,6 +1859,297 @@ static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int
 #undef SEG_DISPATCH
   PDX_LAUNCH_CHECK();
   return PDX_OK;
+}
+
+// ---------------------------------------------------------------- fused last digit: the final sort pass and the reduce in one kernel.
+// After the LSD passes over the low L = B - 6 slot bits, the rows of one "run" (equal low bits) hold at most 64 groups -- the
+// values of the top 6 bits -- interleaved in row order.  Instead of one more 24 B/row scatter pass followed by an 8 B/row reduce,
+// one workgroup per run ranks every 4096-row tile stably by the top digit in LDS (the scatter kernel's ballot ranking) and wave 0
+// replays Arrow's leaf / binary-counter recurrence LITERALLY with one lane per group (state in registers + one LDS column per
+// lane); the other waves already hold the next tile's loads.  Reads 12 B/row once.  Value nulls are the key's bit 31: a null row
+// closes the open leaf, exactly Arrow's restart rule -- no separate nullable kernel on this path.
+constexpr int kFlrBits = 6;
+constexpr int kFlrLevels = 28;  // 2^28 leaves of 16 rows: more than the 2^32-row limit needs
+__global__ void k_run_starts(const uint32_t* __restrict__ sorted_keys, int64_t n, int low_bits, int64_t nruns, uint32_t* __restrict__ run_start,
+                             unsigned int* __restrict__ max_len) {
+  const uint32_t lmask = (1u << low_bits) - 1u;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= nruns; r += stride) {
+    int64_t lo = 0, hi = n;
+    if (r < nruns) {
+      while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)(sorted_keys[mid] & lmask) < r) lo = mid + 1;
+        else hi = mid;
+      }
+    } else {
+      lo = n;
+    }
+    run_start[r] = (uint32_t)lo;
+  }
+  (void)max_len;
+}
+__global__ void k_run_max_len(const uint32_t* __restrict__ run_start, int64_t nruns, unsigned int* __restrict__ max_len) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned int m = 0;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nruns; r += stride) {
+    unsigned int len = run_start[r + 1] - run_start[r];
+    m = len > m ? len : m;
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    unsigned int o = __shfl_xor(m, d, 64);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(max_len, m);
+}
+// Arrow's binary counter, one LDS column per lane: push a finished leaf sum
+__device__ __forceinline__ void flr_counter_push(double (*csum)[1 << kFlrBits], int lane, unsigned long long& cmask, int& root, double leaf) {
+  int cur = 0;
+  unsigned long long m = 1;
+  double v = csum[0][lane] + leaf;
+  cmask ^= m;
+  while ((cmask & m) == 0) {
+    csum[cur][lane] = 0.0;
+    ++cur;
+    m <<= 1;
+    v = csum[cur][lane] + v;
+    cmask ^= m;
+  }
+  csum[cur][lane] = v;
+  root = cur > root ? cur : root;
+}
+template <typename T>
+__global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __restrict__ keys, const T* __restrict__ vals,
+                                                           const uint32_t* __restrict__ run_start, int64_t nruns, int low_bits,
+                                                           const uint32_t* __restrict__ gid_of_slot, SegOut out, uint8_t* __restrict__ ok,
+                                                           int want_pw, int want_mm, int want_is, int nullable) {
+  constexpr int R = 1 << kFlrBits;
+  // staged rows of digit d start at dstart[d] + d: the digits' regions are ~64 rows = 512 B apart, so without the skew the 64
+  // lanes of the replay (one digit each) would hit the same LDS bank on every read (measured: 3x slower)
+  __shared__ T svals[kSortTile + R];
+  __shared__ __attribute__((aligned(8))) uint8_t snull[kSortTile + R];
+  __shared__ uint32_t cnt[kSortWaves][R];
+  __shared__ uint32_t dstart[R + 1];
+  __shared__ double csum[kFlrLevels][R];
+  // dense sum/mean/count fast path (no nulls, no min/max/int sum): one THREAD per 16-value leaf, then one lane per group for the
+  // few counter pushes -- the open leaf of every group (rows so far + their sequential sum) lives in LDS between tiles
+  __shared__ int open_pos[R];
+  __shared__ double open_acc[R];
+  __shared__ int lp[R + 1];
+  double* leafsum = reinterpret_cast<double*>(snull);  // (the null flags are unused on this path: (4096 + 64) / 8 = 520 leaf sums)
+  const bool dense_pw = want_pw && !want_mm && !want_is && !nullable;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  for (int64_t run = blockIdx.x; run < nruns; run += gridDim.x) {
+    const int64_t s = run_start[run], e = run_start[run + 1];
+    if (s == e) continue;
+    if (tid < R) {
+      open_pos[tid] = 0;
+      open_acc[tid] = 0.0;
+    }
+    // per-group state (wave 0, lane = top digit)
+    double acc = 0.0;
+    int pos = 0, root = 0;
+    unsigned long long cmask = 0, isum = 0;
+    long long nvalid = 0, nrows = 0;
+    T vmn = T(0), vmx = T(0);
+    bool has = false;
+    if (wave == 0)
+      for (int l = 0; l < kFlrLevels; ++l) csum[l][lane] = 0.0;
+    uint32_t key[kSortItems];
+    T val[kSortItems];
+    auto load_tile = [&](int64_t t0) {
+      const int rows = (int)(e - t0 < kSortTile ? e - t0 : kSortTile);
+#pragma unroll
+      for (int q = 0; q < kSortItems; ++q) {
+        const int r = wave * (64 * kSortItems) + q * 64 + lane;
+        if (r < rows) {
+          key[q] = keys[t0 + r];
+          val[q] = vals[t0 + r];
+        } else {
+          key[q] = 0;
+          val[q] = T(0);
+        }
+      }
+    };
+    load_tile(s);
+    for (int64_t t0 = s; t0 < e; t0 += kSortTile) {
+      const int rows = (int)(e - t0 < kSortTile ? e - t0 : kSortTile);
+      for (int d = tid; d < kSortWaves * R; d += kSortBlock) (&cnt[0][0])[d] = 0;
+      __syncthreads();
+      uint32_t rank[kSortItems];
+#pragma unroll
+      for (int q = 0; q < kSortItems; ++q) {
+        const int r = wave * (64 * kSortItems) + q * 64 + lane;
+        const bool active = r < rows;
+        const uint32_t d = ((key[q] & kSortKeyMask) >> low_bits) & (R - 1);
+        uint64_t peers = __ballot(active);
+#pragma unroll
+        for (int b = 0; b < kFlrBits; ++b) {
+          const bool bit = (d >> b) & 1;
+          const uint64_t m = __ballot(bit);
+          peers &= bit ? m : ~m;
+        }
+        uint32_t base = 0;
+        if (active) {
+          const int leader = __ffsll((unsigned long long)peers) - 1;
+          if (lane == leader) {
+            base = cnt[wave][d];
+            cnt[wave][d] = base + (uint32_t)__popcll(peers);
+          }
+          base = __shfl(base, leader, 64);
+          rank[q] = base + (uint32_t)__popcll(peers & lt_mask);
+        }
+      }
+      __syncthreads();
+      if (tid < R) {  // exclusive prefix over waves per digit, then over digits (64 values: one wave)
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) {
+          const uint32_t c = cnt[w][tid];
+          cnt[w][tid] = tot;
+          tot += c;
+        }
+        const uint32_t inc = wave_inclusive_scan(tot, SumOp());
+        const uint32_t ex = inc - tot;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) cnt[w][tid] += ex;
+        dstart[tid] = ex;
+        if (tid == R - 1) dstart[R] = inc;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < kSortItems; ++q) {
+        const int r = wave * (64 * kSortItems) + q * 64 + lane;
+        if (r < rows) {
+          const uint32_t d = ((key[q] & kSortKeyMask) >> low_bits) & (R - 1);
+          const uint32_t p = cnt[wave][d] + rank[q] + d;
+          svals[p] = val[q];
+          if (nullable) snull[p] = (uint8_t)(key[q] >> 31);
+        }
+      }
+      if (t0 + kSortTile < e) load_tile(t0 + kSortTile);  // in flight while wave 0 replays this tile
+      __syncthreads();
+      if (dense_pw) {
+        // leaves touched by this tile, per group: the first one may continue the open leaf, the last one may stay open
+        if (wave == 0) {
+          const int c = (int)(dstart[lane + 1] - dstart[lane]);
+          const int nl = c > 0 ? (open_pos[lane] + c + 15) >> 4 : 0;
+          const int inc = wave_inclusive_scan(nl, SumOp());
+          lp[lane] = inc - nl;
+          if (lane == R - 1) lp[R] = inc;
+          nrows += c;
+          nvalid += c;
+        }
+        __syncthreads();
+        const int NL = lp[R];
+        for (int Lf = tid; Lf < NL; Lf += kSortBlock) {
+          int lo = 0, hi = R - 1;
+          while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (lp[mid] <= Lf) lo = mid;
+            else hi = mid - 1;
+          }
+          const int d = lo, j = Lf - lp[d];
+          const int p0 = open_pos[d], c = (int)(dstart[d + 1] - dstart[d]);
+          const int r0 = j == 0 ? 0 : 16 * j - p0;
+          int r1 = 16 * (j + 1) - p0;
+          r1 = r1 < c ? r1 : c;
+          double a = (j == 0 && p0 > 0) ? open_acc[d] : 0.0;
+          const T* v = svals + dstart[d] + d;
+          for (int r = r0; r < r1; ++r) a += seg_to_f64(v[r]);
+          leafsum[Lf] = a;
+        }
+        __syncthreads();
+        if (wave == 0) {
+          const int c = (int)(dstart[lane + 1] - dstart[lane]);
+          if (c > 0) {
+            const int p0 = open_pos[lane];
+            const int nl = (p0 + c + 15) >> 4, nfull = (p0 + c) >> 4;
+            for (int j = 0; j < nfull; ++j) flr_counter_push(csum, lane, cmask, root, leafsum[lp[lane] + j]);
+            const int rem = (p0 + c) & 15;
+            open_pos[lane] = rem;
+            if (rem) open_acc[lane] = leafsum[lp[lane] + nl - 1];
+            pos = rem;
+            acc = rem ? leafsum[lp[lane] + nl - 1] : 0.0;
+          }
+        }
+      } else if (wave == 0) {
+        const int i0 = (int)dstart[lane] + lane, i1 = (int)dstart[lane + 1] + lane;
+        nrows += i1 - i0;
+        // Pass A: leaf sums only.  Finished leaves are written back over the rows already consumed (a leaf has >= 1 row, so the
+        // write index never passes the read index).  The counter pushes are NOT done here: lanes finish leaves at different
+        // rows, so a push inside this loop would make the whole wave walk the (long) push path on nearly every row.
+        int nleaf = 0;
+        for (int ib = i0; ib < i1; ib += 8) {
+          T xb[8];
+          uint8_t nb[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = ib + u < i1 ? ib + u : i1 - 1;
+            xb[u] = svals[i];
+            nb[u] = nullable ? snull[i] : (uint8_t)0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (ib + u >= i1) break;
+            const T x = xb[u];
+            const bool isnull = nb[u] != 0;
+            bool close = false;
+            if (!isnull) {
+              ++nvalid;
+              if (want_pw) {
+                acc = (pos == 0 ? 0.0 : acc) + seg_to_f64(x);
+                close = ++pos == 16;
+              }
+              if (want_is) isum += (unsigned long long)x;
+              if (want_mm && x == x) {
+                if (!has) { vmn = vmx = x; has = true; }
+                else {
+                  if (x < vmn) vmn = x;
+                  if (x > vmx) vmx = x;
+                }
+              }
+            } else {
+              close = want_pw && pos > 0;  // a null row closes the open leaf
+            }
+            if (close) {
+              reinterpret_cast<double*>(svals)[i0 + nleaf++] = acc;
+              pos = 0;
+            }
+          }
+        }
+        // Pass B: Arrow's binary counter over this tile's finished leaves (a handful per lane)
+        for (int j = 0; j < nleaf; ++j) flr_counter_push(csum, lane, cmask, root, reinterpret_cast<const double*>(svals)[i0 + j]);
+      }
+      __syncthreads();
+    }
+    if (wave == 0 && nrows > 0) {
+      const uint32_t slot = ((uint32_t)lane << low_bits) | (uint32_t)run;
+      const uint32_t oi = gid_of_slot[slot];
+      if (want_pw) {
+        if (pos > 0) flr_counter_push(csum, lane, cmask, root, acc);
+        double total = 0.0;
+        if (nvalid > 0) {
+          double a = csum[0][lane];
+          for (int i = 1; i <= root; ++i) a = csum[i][lane] + a;
+          total = a;
+        }
+        if (out.sum_f) out.sum_f[oi] = total;
+        if (out.mean) out.mean[oi] = nvalid ? total / (double)nvalid : 0.0;
+      }
+      if (want_is && out.sum_i) out.sum_i[oi] = (long long)isum;
+      if (want_mm) {
+        T nanv = T(0);
+        if constexpr (__is_same(T, double)) nanv = __builtin_nan("");
+        if (out.vmin) static_cast<T*>(out.vmin)[oi] = has ? vmn : nanv;
+        if (out.vmax) static_cast<T*>(out.vmax)[oi] = has ? vmx : nanv;
+      }
+      if (out.count) out.count[oi] = nvalid;
+      if (ok) ok[oi] = nvalid > 0;
+    }
+    __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------- "next" aggregations on the grouped layout
@@ -2528,11 +2821,65 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   const uint32_t* out_index = nullptr;
   const uint8_t* row_valid = nullptr;  // segments mode reads validity in place
   if (gb->mode == 0) {
+    const uint64_t* vin = static_cast<const uint64_t*>(values->values) + values->offset;
+    const uint64_t* vs = nullptr;
+    // ---- fused last digit (the five standard kinds): sort by all but the top 6 slot bits, then rank + reduce in one kernel
+    static const bool flr_env = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT"); return !(e && e[0] == '0'); }();
+    const int part = gb->slot_part ? gb->part_bits : 0;
+    const int low_bits = gb->slot_bits - kFlrBits;
+    const bool std_only = want_std5 && !var_out && !std_out && !prod_out && !first_out && !last_out;
+    static const int64_t flr_min_rows = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_MIN_ROWS"); return e ? atoll(e) : (1ll << 22); }();
+    static const int flr_min_low = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS"); return e ? atoi(e) : 10; }();
+    // (hash-partitioned slots: measured slower -- short runs of ~15 K rows and half-empty top digits -- unless asked for: tests)
+    static const bool flr_hash = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_HASH"); return e && e[0] == '1'; }();
+    bool flr = flr_env && std_only && n >= flr_min_rows && low_bits - part >= 4 && low_bits >= flr_min_low && low_bits <= 26 &&
+               (!gb->slot_part || flr_hash);
+    if (flr && !gb->slot_part && gb->pass0_off)  // the stored pass-0 offsets belong to the first digit of the FULL plan
+      flr = make_sort_plan(gb->slot_bits, sort_max_bits()).bits[0] == make_sort_plan(low_bits, sort_max_bits()).bits[0];
+    if (flr) {
+      PDX_TRY(sort_values_by_slot(gb, vin, vvalid, values->offset, [&](size_t bytes) { return (void*)s.get<uint8_t>(bytes); }, s, st, &keys_sorted, &vs,
+                                  kFlrBits));
+      const int64_t nruns = (int64_t)1 << low_bits;
+      uint32_t* run_start = s.get<uint32_t>((size_t)nruns + 1);
+      unsigned int* dmax = s.get<unsigned int>(1);
+      uint8_t* okb = vvalid ? s.get<uint8_t>((size_t)G) : nullptr;
+      PDX_SCRATCH_CHECK(s);
+      unsigned int hmax = 0;
+      {
+        PDX_PROFILE("run_starts", st);
+        PDX_HIP(hipMemsetAsync(dmax, 0, sizeof(unsigned int), st));
+        hipLaunchKernelGGL(k_run_starts, dim3(grid_for(nruns + 1, 256)), dim3(256), 0, st, keys_sorted, n, low_bits, nruns, run_start, dmax);
+        hipLaunchKernelGGL(k_run_max_len, dim3(grid_for(nruns, 256)), dim3(256), 0, st, run_start, nruns, dmax);
+        PDX_LAUNCH_CHECK();
+        PDX_HIP(hipMemcpyAsync(&hmax, dmax, sizeof(hmax), hipMemcpyDeviceToHost, st));
+        PDX_HIP(hipStreamSynchronize(st));
+      }
+      if (hmax <= (1u << 19)) {  // a run is walked by ONE workgroup: keep the longest one short (skewed keys take the classic path)
+        {
+          PDX_PROFILE("fused_last_digit_reduce", st);
+          const int grid = (int)std::min<int64_t>(nruns, (int64_t)kCUs * 24);
+          if (is_f)
+            hipLaunchKernelGGL((k_flr_reduce<double>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const double*>(vs), run_start, nruns,
+                               low_bits, gb->gid_of_slot, o, okb, (int)want_pw, (int)want_mm, (int)want_is, vvalid ? 1 : 0);
+          else
+            hipLaunchKernelGGL((k_flr_reduce<long long>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const long long*>(vs), run_start,
+                               nruns, low_bits, gb->gid_of_slot, o, okb, (int)want_pw, (int)want_mm, (int)want_is, vvalid ? 1 : 0);
+          PDX_LAUNCH_CHECK();
+        }
+        for (int k = 0; k < nk; ++k) {
+          uint8_t* bits = static_cast<uint8_t*>(outs[k].validity);
+          if (!bits) continue;
+          if (!okb || kinds[k] == PDX_AGG_COUNT) PDX_HIP(hipMemsetAsync(bits, 0xFF, (size_t)((G + 7) / 8), st));
+          else hipLaunchKernelGGL(k_pack_bytes, dim3(grid_for((G + 7) / 8, 256)), dim3(256), 0, st, okb, G, bits);
+        }
+        PDX_LAUNCH_CHECK();
+        PDX_HIP(hipStreamSynchronize(st));
+        return PDX_OK;
+      }
+    }
     // stable sort of (slot, value) by slot: each group's values become contiguous in row order
     uint32_t* ss = s.get<uint32_t>((size_t)G + 1);
     PDX_SCRATCH_CHECK(s);
-    const uint64_t* vin = static_cast<const uint64_t*>(values->values) + values->offset;
-    const uint64_t* vs = nullptr;
     PDX_TRY(sort_values_by_slot(gb, vin, vvalid, values->offset, [&](size_t bytes) { return (void*)s.get<uint8_t>(bytes); }, s, st, &keys_sorted, &vs));
     vals_sorted = vs;
     {

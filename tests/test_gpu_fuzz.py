@@ -59,12 +59,16 @@ def _make_case(seed):
     return keys, kvalid, vals, vvalid, kinds
 
 
-@pytest.mark.parametrize("mode", ["default", "hash", "hash_global"])
+@pytest.mark.parametrize("mode", ["default", "hash", "hash_global", "fused_dense", "fused_hash"])
 @pytest.mark.parametrize("seed", range(80))
 def test_groupby_fuzz(px, monkeypatch, seed, mode):
-    if mode != "default":
+    if mode in ("hash", "hash_global", "fused_hash"):
         monkeypatch.setenv("PDX_GROUPBY_DENSE", "0")
-        monkeypatch.setenv("PDX_HASH_PARTITION", "2" if mode == "hash" else "0")
+        monkeypatch.setenv("PDX_HASH_PARTITION", "0" if mode == "hash_global" else "2")
+    if mode.startswith("fused"):  # the fused last-digit reduce at any size (product default: >= 2^22 rows and >= 2^10 runs)
+        monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_MIN_ROWS", "0")
+        monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS", "4")
+        monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_HASH", "1")
     keys, kvalid, vals, vvalid, kinds = _make_case(seed * 7919 + 13)
     gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys, kvalid, offset=int(seed % 3)))
     ids, uniq, isnull, first = orc.group_ids(keys, kvalid)
