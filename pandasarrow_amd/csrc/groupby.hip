@@ -2880,7 +2880,19 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
     // stable sort of (slot, value) by slot: each group's values become contiguous in row order
     uint32_t* ss = s.get<uint32_t>((size_t)G + 1);
     PDX_SCRATCH_CHECK(s);
-    PDX_TRY(sort_values_by_slot(gb, vin, vvalid, values->offset, [&](size_t bytes) { return (void*)s.get<uint8_t>(bytes); }, s, st, &keys_sorted, &vs));
+    if (flr) {
+      // the fused kernel was skipped (a run longer than 2^19 rows: skewed keys): finish the sort with the one pass that is left
+      uint32_t* k2 = s.get<uint32_t>((size_t)n);
+      uint64_t* v2 = s.get<uint64_t>((size_t)n);
+      PDX_SCRATCH_CHECK(s);
+      const uint32_t* ks2 = nullptr;
+      const uint64_t* vs2 = nullptr;
+      PDX_TRY((radix_sort_pairs<uint64_t>(keys_sorted, vs, k2, v2, k2, v2, n, kFlrBits, &ks2, &vs2, true, s, st, low_bits)));
+      keys_sorted = ks2;
+      vs = vs2;
+    } else {
+      PDX_TRY(sort_values_by_slot(gb, vin, vvalid, values->offset, [&](size_t bytes) { return (void*)s.get<uint8_t>(bytes); }, s, st, &keys_sorted, &vs));
+    }
     vals_sorted = vs;
     {
       PDX_PROFILE("seg_starts", st);

@@ -670,3 +670,28 @@ def test_groupby_split_partition_special_keys(px, monkeypatch):
             assert_f64_bits(got, exp, valid=eok, what=str(kind))
         else:
             assert np.array_equal(got[eok], exp[eok])
+
+
+@pytest.mark.parametrize("nulls", [False, True])
+def test_groupby_fused_last_digit_and_skew_fallback(px, nulls):
+    """>= 2^22 rows with >= 2^16 slots: the fused last-digit reduce; a hot key makes one run longer than 2^19 rows, which takes the
+    fallback (one more sort pass + the classic reducers).  Both must equal the oracle bit for bit."""
+    n = 5_000_011
+    rng = np.random.default_rng(5)
+    vals = orc.synth_vals(0, n) - 0.5
+    vvalid = (rng.random(n) > 0.07) if nulls else None
+    for hot in (False, True):
+        keys = orc.synth_keys(0, n, 300_000)
+        if hot:
+            keys[rng.random(n) < 0.3] = 4242
+        gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys))
+        ids, uniq, _, _ = orc.group_ids(keys)
+        outs = gb.agg(px.Column.from_numpy(vals, vvalid), [0, 1, 4, 2, 3])
+        for kind, out in zip([0, 1, 4, 2, 3], outs):
+            got, ok = out.to_numpy()
+            exp, eok = orc.groupby_agg(kind, ids, len(uniq), vals, vvalid, nthreads=8)
+            assert ok is None or np.array_equal(ok, eok), (hot, kind)
+            if exp.dtype == np.float64:
+                assert_f64_bits(got, exp, valid=eok, what=f"hot={hot} kind={kind}")
+            else:
+                assert np.array_equal(got[eok], exp[eok]), (hot, kind)
