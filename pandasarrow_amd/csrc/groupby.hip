@@ -1701,6 +1701,7 @@ struct pdx_groupby {
   int dense = 0;                    // 1: slots are key - min (dense integer key domain), 0: open-addressing hash table
   // partitioned hash build (slot_of_row == nullptr): rows live in hash-partition order
   int part_bits = 0;                   // hash bits the rows are partitioned by (8, or 8 + digit2_bits after a second level)
+  int special_slots = 0;               // 1: the null key and/or the INT64_MIN key occur (their two slots lie past the table)
   uint8_t* digit2 = nullptr;           // second-level digit of every row in FIRST-LEVEL order (very many groups only)
   uint32_t* part_off2 = nullptr;       // its scatter offsets [tiles][1 << digit2_bits]
   int digit2_bits = 0;
@@ -2633,6 +2634,12 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     }
     gb->part_bits = (int)pb;
     gb->owned.push_back(table);
+    {
+      Slot sp[2];
+      PDX_HIP(hipMemcpyAsync(sp, table + cap, sizeof(sp), hipMemcpyDeviceToHost, st));
+      PDX_HIP(hipStreamSynchronize(st));
+      gb->special_slots = sp[0].first != kNoRow || sp[1].first != kNoRow;
+    }
     null_slot = cap;
     nslots = (int64_t)cap + 2;
   } else {
@@ -2826,19 +2833,25 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
     // ---- fused last digit (the five standard kinds): sort by all but the top 6 slot bits, then rank + reduce in one kernel
     static const bool flr_env = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT"); return !(e && e[0] == '0'); }();
     const int part = gb->slot_part ? gb->part_bits : 0;
-    const int low_bits = gb->slot_bits - kFlrBits;
+    // partitioned hash slots: the table itself is a power of two; only the two special slots (null key, INT64_MIN key) need one
+    // more bit, so without them the top digit is drawn from the table's own bits (all 64 values used)
+    const int eff_bits = (gb->slot_part && !gb->special_slots) ? gb->slot_bits - 1 : gb->slot_bits;
+    const int low_bits = eff_bits - kFlrBits;
     const bool std_only = want_std5 && !var_out && !std_out && !prod_out && !first_out && !last_out;
     static const int64_t flr_min_rows = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_MIN_ROWS"); return e ? atoll(e) : (1ll << 22); }();
+    // a run is one workgroup's sequential work: it has to span a few tiles to amortise its prologue (1e8 groups: 119-row runs)
+    static const int64_t flr_min_run = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_MIN_RUN"); return e ? atoll(e) : 8192ll; }();
     static const int flr_min_low = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS"); return e ? atoi(e) : 10; }();
-    // (hash-partitioned slots: measured slower -- short runs of ~15 K rows and half-empty top digits -- unless asked for: tests)
-    static const bool flr_hash = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_HASH"); return e && e[0] == '1'; }();
+    // (hash-partitioned slots: only without the special slots -- with them the top digit is half empty and the runs half as long,
+    //  measured slower than the classic path)
+    static const bool flr_hash = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_HASH"); return !(e && e[0] == '0'); }();
     bool flr = flr_env && std_only && n >= flr_min_rows && low_bits - part >= 4 && low_bits >= flr_min_low && low_bits <= 26 &&
-               (!gb->slot_part || flr_hash);
+               (!gb->slot_part || (flr_hash && !gb->special_slots)) && (n >> low_bits) >= flr_min_run;
     if (flr && !gb->slot_part && gb->pass0_off)  // the stored pass-0 offsets belong to the first digit of the FULL plan
       flr = make_sort_plan(gb->slot_bits, sort_max_bits()).bits[0] == make_sort_plan(low_bits, sort_max_bits()).bits[0];
     if (flr) {
       PDX_TRY(sort_values_by_slot(gb, vin, vvalid, values->offset, [&](size_t bytes) { return (void*)s.get<uint8_t>(bytes); }, s, st, &keys_sorted, &vs,
-                                  kFlrBits));
+                                  gb->slot_bits - low_bits));
       const int64_t nruns = (int64_t)1 << low_bits;
       uint32_t* run_start = s.get<uint32_t>((size_t)nruns + 1);
       unsigned int* dmax = s.get<unsigned int>(1);

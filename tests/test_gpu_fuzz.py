@@ -68,6 +68,7 @@ def test_groupby_fuzz(px, monkeypatch, seed, mode):
     if mode.startswith("fused"):  # the fused last-digit reduce at any size (product default: >= 2^22 rows and >= 2^10 runs)
         monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_MIN_ROWS", "0")
         monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS", "4")
+        monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_MIN_RUN", "0")
         monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_HASH", "1")
     keys, kvalid, vals, vvalid, kinds = _make_case(seed * 7919 + 13)
     gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys, kvalid, offset=int(seed % 3)))
