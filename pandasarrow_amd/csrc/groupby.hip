@@ -1870,7 +1870,9 @@ static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int
 // lane); the other waves already hold the next tile's loads.  Reads 12 B/row once.  Value nulls are the key's bit 31: a null row
 // closes the open leaf, exactly Arrow's restart rule -- no separate nullable kernel on this path.
 constexpr int kFlrBits = 6;
-constexpr int kFlrLevels = 28;  // 2^28 leaves of 16 rows: more than the 2^32-row limit needs
+constexpr int kFlrLevels = 16;  // a group lies inside one run and a run is <= 2^19 rows (checked by the host) = 2^15 leaves
+constexpr int kFlrItems = 12;   // rows per thread and tile: 3072-row tiles (measured best: 4096 -> 5.6 ms, 3072 -> 4.2 ms, 2048 -> 4.5 ms per 1e9 rows)
+constexpr int kFlrTile = kSortBlock * kFlrItems;
 __global__ void k_run_starts(const uint32_t* __restrict__ sorted_keys, int64_t n, int low_bits, int64_t nruns, uint32_t* __restrict__ run_start,
                              unsigned int* __restrict__ max_len) {
   const uint32_t lmask = (1u << low_bits) - 1u;
@@ -1927,8 +1929,8 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
   constexpr int R = 1 << kFlrBits;
   // staged rows of digit d start at dstart[d] + d: the digits' regions are ~64 rows = 512 B apart, so without the skew the 64
   // lanes of the replay (one digit each) would hit the same LDS bank on every read (measured: 3x slower)
-  __shared__ T svals[kSortTile + R];
-  __shared__ __attribute__((aligned(8))) uint8_t snull[kSortTile + R];
+  __shared__ T svals[kFlrTile + R];
+  __shared__ __attribute__((aligned(8))) uint8_t snull[kFlrTile + R];
   __shared__ uint32_t cnt[kSortWaves][R];
   __shared__ uint32_t dstart[R + 1];
   __shared__ double csum[kFlrLevels][R];
@@ -1937,7 +1939,7 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
   __shared__ int open_pos[R];
   __shared__ double open_acc[R];
   __shared__ int lp[R + 1];
-  double* leafsum = reinterpret_cast<double*>(snull);  // (the null flags are unused on this path: (4096 + 64) / 8 = 520 leaf sums)
+  double* leafsum = reinterpret_cast<double*>(snull);  // (the null flags are unused on this path: room for (tile + 64) / 8 leaf sums)
   const bool dense_pw = want_pw && !want_mm && !want_is && !nullable;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -1957,13 +1959,13 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
     bool has = false;
     if (wave == 0)
       for (int l = 0; l < kFlrLevels; ++l) csum[l][lane] = 0.0;
-    uint32_t key[kSortItems];
-    T val[kSortItems];
+    uint32_t key[kFlrItems];
+    T val[kFlrItems];
     auto load_tile = [&](int64_t t0) {
-      const int rows = (int)(e - t0 < kSortTile ? e - t0 : kSortTile);
+      const int rows = (int)(e - t0 < kFlrTile ? e - t0 : kFlrTile);
 #pragma unroll
-      for (int q = 0; q < kSortItems; ++q) {
-        const int r = wave * (64 * kSortItems) + q * 64 + lane;
+      for (int q = 0; q < kFlrItems; ++q) {
+        const int r = wave * (64 * kFlrItems) + q * 64 + lane;
         if (r < rows) {
           key[q] = keys[t0 + r];
           val[q] = vals[t0 + r];
@@ -1974,14 +1976,14 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
       }
     };
     load_tile(s);
-    for (int64_t t0 = s; t0 < e; t0 += kSortTile) {
-      const int rows = (int)(e - t0 < kSortTile ? e - t0 : kSortTile);
+    for (int64_t t0 = s; t0 < e; t0 += kFlrTile) {
+      const int rows = (int)(e - t0 < kFlrTile ? e - t0 : kFlrTile);
       for (int d = tid; d < kSortWaves * R; d += kSortBlock) (&cnt[0][0])[d] = 0;
       __syncthreads();
-      uint32_t rank[kSortItems];
+      uint32_t rank[kFlrItems];
 #pragma unroll
-      for (int q = 0; q < kSortItems; ++q) {
-        const int r = wave * (64 * kSortItems) + q * 64 + lane;
+      for (int q = 0; q < kFlrItems; ++q) {
+        const int r = wave * (64 * kFlrItems) + q * 64 + lane;
         const bool active = r < rows;
         const uint32_t d = ((key[q] & kSortKeyMask) >> low_bits) & (R - 1);
         uint64_t peers = __ballot(active);
@@ -2020,8 +2022,8 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
       }
       __syncthreads();
 #pragma unroll
-      for (int q = 0; q < kSortItems; ++q) {
-        const int r = wave * (64 * kSortItems) + q * 64 + lane;
+      for (int q = 0; q < kFlrItems; ++q) {
+        const int r = wave * (64 * kFlrItems) + q * 64 + lane;
         if (r < rows) {
           const uint32_t d = ((key[q] & kSortKeyMask) >> low_bits) & (R - 1);
           const uint32_t p = cnt[wave][d] + rank[q] + d;
@@ -2029,7 +2031,7 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
           if (nullable) snull[p] = (uint8_t)(key[q] >> 31);
         }
       }
-      if (t0 + kSortTile < e) load_tile(t0 + kSortTile);  // in flight while wave 0 replays this tile
+      if (t0 + kFlrTile < e) load_tile(t0 + kFlrTile);  // in flight while wave 0 replays this tile
       __syncthreads();
       if (dense_pw) {
         // leaves touched by this tile, per group: the first one may continue the open leaf, the last one may stay open
