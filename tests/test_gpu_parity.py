@@ -695,3 +695,24 @@ def test_groupby_fused_last_digit_and_skew_fallback(px, nulls):
                 assert_f64_bits(got, exp, valid=eok, what=f"hot={hot} kind={kind}")
             else:
                 assert np.array_equal(got[eok], exp[eok]), (hot, kind)
+
+
+def test_groupby_fused_last_digit_many_short_leaves(px):
+    """nullable values that alternate valid / null inside a ~5e5-row group: every valid row is a leaf of its own, so the per-lane
+    binary counter of the fused last-digit kernel climbs to its 19th level (its LDS column holds 20)"""
+    n = 4_500_003
+    keys = orc.synth_keys(0, n, 200_000)
+    keys[:500_000] = 77          # one group of ~5e5 rows: the longest run stays under 2^19 rows, the fused path is taken
+    vals = orc.synth_vals(0, n) - 0.5
+    vvalid = (np.arange(n) % 2 == 0)
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys))
+    ids, uniq, _, _ = orc.group_ids(keys)
+    s, m, c = gb.agg(px.Column.from_numpy(vals, vvalid), [0, 1, 4])
+    for out, kind in ((s, 0), (m, 1), (c, 4)):
+        got, ok = out.to_numpy()
+        exp, eok = orc.groupby_agg(kind, ids, len(uniq), vals, vvalid, nthreads=8)
+        assert ok is None or np.array_equal(ok, eok)
+        if exp.dtype == np.float64:
+            assert_f64_bits(got, exp, valid=eok, what=str(kind))
+        else:
+            assert np.array_equal(got[eok], exp[eok])
