@@ -1906,6 +1906,11 @@ __global__ void k_run_max_len(const uint32_t* __restrict__ run_start, int64_t nr
   }
   if ((threadIdx.x & 63) == 0 && m) atomicMax(max_len, m);
 }
+// (x - mean)^2 with x86 NaN operand propagation (k_seg_sqdev)
+__device__ __forceinline__ double flr_sqdev(double v, double mu) {
+  const double x = v - mu;
+  return v != v ? v : (mu != mu ? mu : x * x);
+}
 // Arrow's binary counter, one LDS column per lane: push a finished leaf sum
 __device__ __forceinline__ void flr_counter_push(double (*csum)[1 << kFlrBits], int lane, unsigned long long& cmask, int& root, double leaf) {
   int cur = 0;
@@ -1926,7 +1931,10 @@ template <typename T>
 __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __restrict__ keys, const T* __restrict__ vals,
                                                            const uint32_t* __restrict__ run_start, int64_t nruns, int low_bits,
                                                            const uint32_t* __restrict__ gid_of_slot, SegOut out, uint8_t* __restrict__ ok,
-                                                           int want_pw, int want_mm, int want_is, int nullable) {
+                                                           int want_pw, int want_mm, int want_is, int nullable,
+                                                           const double* __restrict__ sqdev_mean) {
+  // sqdev_mean != nullptr (second pass of variance): every value x of group g enters the sum as (x - sqdev_mean[g])^2, with the
+  // reference's x86 NaN propagation (see k_seg_sqdev)
   constexpr int R = 1 << kFlrBits;
   // staged rows of digit d start at dstart[d] + d: the digits' regions are ~64 rows = 512 B apart, so without the skew the 64
   // lanes of the replay (one digit each) would hit the same LDS bank on every read (measured: 3x slower)
@@ -1939,6 +1947,7 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
   // few counter pushes -- the open leaf of every group (rows so far + their sequential sum) lives in LDS between tiles
   __shared__ int open_pos[R];
   __shared__ double open_acc[R];
+  __shared__ double mu_s[R];
   __shared__ int lp[R + 1];
   double* leafsum = reinterpret_cast<double*>(snull);  // (the null flags are unused on this path: room for (tile + 64) / 8 leaf sums)
   const bool dense_pw = want_pw && !want_mm && !want_is && !nullable;
@@ -1950,7 +1959,10 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
     if (tid < R) {
       open_pos[tid] = 0;
       open_acc[tid] = 0.0;
+      mu_s[tid] = 0.0;
     }
+    double mu = 0.0;
+    bool mu_known = false;
     // per-group state (wave 0, lane = top digit)
     double acc = 0.0;
     int pos = 0, root = 0;
@@ -2038,6 +2050,11 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
         // leaves touched by this tile, per group: the first one may continue the open leaf, the last one may stay open
         if (wave == 0) {
           const int c = (int)(dstart[lane + 1] - dstart[lane]);
+          if (sqdev_mean && c > 0 && !mu_known) {
+            mu = sqdev_mean[gid_of_slot[((uint32_t)lane << low_bits) | (uint32_t)run]];
+            mu_s[lane] = mu;
+            mu_known = true;
+          }
           const int nl = c > 0 ? (open_pos[lane] + c + 15) >> 4 : 0;
           const int inc = wave_inclusive_scan(nl, SumOp());
           lp[lane] = inc - nl;
@@ -2061,7 +2078,12 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
           r1 = r1 < c ? r1 : c;
           double a = (j == 0 && p0 > 0) ? open_acc[d] : 0.0;
           const T* v = svals + dstart[d] + d;
-          for (int r = r0; r < r1; ++r) a += seg_to_f64(v[r]);
+          if (sqdev_mean) {
+            const double m = mu_s[d];
+            for (int r = r0; r < r1; ++r) a += flr_sqdev(seg_to_f64(v[r]), m);
+          } else {
+            for (int r = r0; r < r1; ++r) a += seg_to_f64(v[r]);
+          }
           leafsum[Lf] = a;
         }
         __syncthreads();
@@ -2081,6 +2103,10 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
       } else if (wave == 0) {
         const int i0 = (int)dstart[lane] + lane, i1 = (int)dstart[lane + 1] + lane;
         nrows += i1 - i0;
+        if (sqdev_mean && i1 > i0 && !mu_known) {
+          mu = sqdev_mean[gid_of_slot[((uint32_t)lane << low_bits) | (uint32_t)run]];
+          mu_known = true;
+        }
         // Pass A: leaf sums only.  Finished leaves are written back over the rows already consumed (a leaf has >= 1 row, so the
         // write index never passes the read index).  The counter pushes are NOT done here: lanes finish leaves at different
         // rows, so a push inside this loop would make the whole wave walk the (long) push path on nearly every row.
@@ -2103,7 +2129,7 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
             if (!isnull) {
               ++nvalid;
               if (want_pw) {
-                acc = (pos == 0 ? 0.0 : acc) + seg_to_f64(x);
+                acc = (pos == 0 ? 0.0 : acc) + (sqdev_mean ? flr_sqdev(seg_to_f64(x), mu) : seg_to_f64(x));
                 close = ++pos == 16;
               }
               if (want_is) isum += (unsigned long long)x;
@@ -2840,7 +2866,7 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
     // more bit, so without them the top digit is drawn from the table's own bits (all 64 values used)
     const int eff_bits = (gb->slot_part && !gb->special_slots) ? gb->slot_bits - 1 : gb->slot_bits;
     const int low_bits = eff_bits - kFlrBits;
-    const bool std_only = want_std5 && !var_out && !std_out && !prod_out && !first_out && !last_out;
+    const bool std_only = (want_std5 || var_out || std_out) && !prod_out && !first_out && !last_out;  // (variance: two more fused passes)
     static const int64_t flr_min_rows = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_MIN_ROWS"); return e ? atoll(e) : (1ll << 22); }();
     // a run is one workgroup's sequential work: it has to span a few tiles to amortise its prologue (1e8 groups: 119-row runs)
     static const int64_t flr_min_run = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_MIN_RUN"); return e ? atoll(e) : 8192ll; }();
@@ -2871,22 +2897,43 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
         PDX_HIP(hipStreamSynchronize(st));
       }
       if (hmax <= (1u << 19)) {  // a run is walked by ONE workgroup: keep the longest one short (skewed keys take the classic path)
-        {
+        auto launch_flr = [&](const SegOut& oo, bool pw, bool mm, bool is, uint8_t* okbytes, const double* sqmean) {
           PDX_PROFILE("fused_last_digit_reduce", st);
           const int grid = (int)std::min<int64_t>(nruns, (int64_t)kCUs * 24);
           if (is_f)
             hipLaunchKernelGGL((k_flr_reduce<double>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const double*>(vs), run_start, nruns,
-                               low_bits, gb->gid_of_slot, o, okb, (int)want_pw, (int)want_mm, (int)want_is, vvalid ? 1 : 0);
+                               low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, vvalid ? 1 : 0, sqmean);
           else
             hipLaunchKernelGGL((k_flr_reduce<long long>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const long long*>(vs), run_start,
-                               nruns, low_bits, gb->gid_of_slot, o, okb, (int)want_pw, (int)want_mm, (int)want_is, vvalid ? 1 : 0);
+                               nruns, low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, vvalid ? 1 : 0, sqmean);
+        };
+        if (want_std5) launch_flr(o, want_pw, want_mm, want_is, okb, nullptr);
+        PDX_LAUNCH_CHECK();
+        uint8_t* ok2 = nullptr;
+        if (var_out || std_out) {
+          // Arrow's two passes on the same partially sorted rows: per-group mean, then the pairwise sum of (x - mean)^2
+          double* mean_g = s.get<double>((size_t)G);
+          double* m2 = s.get<double>((size_t)G);
+          long long* cnt_g = s.get<long long>((size_t)G);
+          uint8_t* ok1 = vvalid ? s.get<uint8_t>((size_t)G) : nullptr;
+          ok2 = vvalid ? s.get<uint8_t>((size_t)G) : nullptr;
+          PDX_SCRATCH_CHECK(s);
+          SegOut o1{};
+          o1.mean = mean_g;
+          launch_flr(o1, true, false, false, ok1, nullptr);
+          SegOut o2{};
+          o2.sum_f = m2;
+          o2.count = cnt_g;
+          launch_flr(o2, true, false, false, ok2, mean_g);
+          hipLaunchKernelGGL(k_var_finish, dim3(grid_for(G, 256)), dim3(256), 0, st, m2, cnt_g, G, var_out, std_out);
           PDX_LAUNCH_CHECK();
         }
         for (int k = 0; k < nk; ++k) {
           uint8_t* bits = static_cast<uint8_t*>(outs[k].validity);
           if (!bits) continue;
-          if (!okb || kinds[k] == PDX_AGG_COUNT) PDX_HIP(hipMemsetAsync(bits, 0xFF, (size_t)((G + 7) / 8), st));
-          else hipLaunchKernelGGL(k_pack_bytes, dim3(grid_for((G + 7) / 8, 256)), dim3(256), 0, st, okb, G, bits);
+          const uint8_t* src = (kinds[k] == PDX_AGG_VARIANCE || kinds[k] == PDX_AGG_STDDEV) ? ok2 : okb;
+          if (!src || kinds[k] == PDX_AGG_COUNT) PDX_HIP(hipMemsetAsync(bits, 0xFF, (size_t)((G + 7) / 8), st));
+          else hipLaunchKernelGGL(k_pack_bytes, dim3(grid_for((G + 7) / 8, 256)), dim3(256), 0, st, src, G, bits);
         }
         PDX_LAUNCH_CHECK();
         PDX_HIP(hipStreamSynchronize(st));
