@@ -1953,6 +1953,11 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
   const bool dense_pw = want_pw && !want_mm && !want_is && !nullable;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
+  // Barriers per tile: after the ranking, after the prefixes, after the staging and (dense path) after the leaf sums.  The digit
+  // counters are re-zeroed right after the staging barrier, and wave 0's replay needs no closing barrier: the next tile's
+  // staging lies behind two barriers that wave 0 itself has to reach.
+  for (int d = tid; d < kSortWaves * R; d += kSortBlock) (&cnt[0][0])[d] = 0;
+  __syncthreads();
   for (int64_t run = blockIdx.x; run < nruns; run += gridDim.x) {
     const int64_t s = run_start[run], e = run_start[run + 1];
     if (s == e) continue;
@@ -1991,8 +1996,6 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
     load_tile(s);
     for (int64_t t0 = s; t0 < e; t0 += kFlrTile) {
       const int rows = (int)(e - t0 < kFlrTile ? e - t0 : kFlrTile);
-      for (int d = tid; d < kSortWaves * R; d += kSortBlock) (&cnt[0][0])[d] = 0;
-      __syncthreads();
       uint32_t rank[kFlrItems];
 #pragma unroll
       for (int q = 0; q < kFlrItems; ++q) {
@@ -2032,6 +2035,21 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
         for (int w = 0; w < kSortWaves; ++w) cnt[w][tid] += ex;
         dstart[tid] = ex;
         if (tid == R - 1) dstart[R] = inc;
+        if (dense_pw) {
+          // leaves touched by this tile, per group: the first one may continue the open leaf, the last one may stay open
+          const int c = (int)tot;
+          if (sqdev_mean && c > 0 && !mu_known) {
+            mu = sqdev_mean[gid_of_slot[((uint32_t)lane << low_bits) | (uint32_t)run]];
+            mu_s[lane] = mu;
+            mu_known = true;
+          }
+          const int nl = c > 0 ? (open_pos[lane] + c + 15) >> 4 : 0;
+          const int incl = wave_inclusive_scan(nl, SumOp());
+          lp[lane] = incl - nl;
+          if (lane == R - 1) lp[R] = incl;
+          nrows += c;
+          nvalid += c;
+        }
       }
       __syncthreads();
 #pragma unroll
@@ -2046,23 +2064,8 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
       }
       if (t0 + kFlrTile < e) load_tile(t0 + kFlrTile);  // in flight while wave 0 replays this tile
       __syncthreads();
+      for (int d = tid; d < kSortWaves * R; d += kSortBlock) (&cnt[0][0])[d] = 0;  // (free again: the bases were consumed above)
       if (dense_pw) {
-        // leaves touched by this tile, per group: the first one may continue the open leaf, the last one may stay open
-        if (wave == 0) {
-          const int c = (int)(dstart[lane + 1] - dstart[lane]);
-          if (sqdev_mean && c > 0 && !mu_known) {
-            mu = sqdev_mean[gid_of_slot[((uint32_t)lane << low_bits) | (uint32_t)run]];
-            mu_s[lane] = mu;
-            mu_known = true;
-          }
-          const int nl = c > 0 ? (open_pos[lane] + c + 15) >> 4 : 0;
-          const int inc = wave_inclusive_scan(nl, SumOp());
-          lp[lane] = inc - nl;
-          if (lane == R - 1) lp[R] = inc;
-          nrows += c;
-          nvalid += c;
-        }
-        __syncthreads();
         const int NL = lp[R];
         for (int Lf = tid; Lf < NL; Lf += kSortBlock) {
           int lo = 0, hi = R - 1;
@@ -2152,7 +2155,6 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
         // Pass B: Arrow's binary counter over this tile's finished leaves (a handful per lane)
         for (int j = 0; j < nleaf; ++j) flr_counter_push(csum, lane, cmask, root, reinterpret_cast<const double*>(svals)[i0 + j]);
       }
-      __syncthreads();
     }
     if (wave == 0 && nrows > 0) {
       const uint32_t slot = ((uint32_t)lane << low_bits) | (uint32_t)run;
