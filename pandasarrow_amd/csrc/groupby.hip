@@ -1927,7 +1927,7 @@ __device__ __forceinline__ void flr_counter_push(double (*csum)[1 << kFlrBits], 
   csum[cur][lane] = v;
   root = cur > root ? cur : root;
 }
-template <typename T>
+template <typename T, bool DENSE_PW>
 __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __restrict__ keys, const T* __restrict__ vals,
                                                            const uint32_t* __restrict__ run_start, int64_t nruns, int low_bits,
                                                            const uint32_t* __restrict__ gid_of_slot, SegOut out, uint8_t* __restrict__ ok,
@@ -1950,7 +1950,7 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
   __shared__ double mu_s[R];
   __shared__ int lp[R + 1];
   double* leafsum = reinterpret_cast<double*>(snull);  // (the null flags are unused on this path: room for (tile + 64) / 8 leaf sums)
-  const bool dense_pw = want_pw && !want_mm && !want_is && !nullable;
+  constexpr bool dense_pw = DENSE_PW;  // host: want_pw && !want_mm && !want_is && !nullable (a separate instantiation: fewer live registers)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   // Barriers per tile: after the ranking, after the prefixes, after the staging and (dense path) after the leaf sums.  The digit
@@ -2103,7 +2103,7 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
             acc = rem ? leafsum[lp[lane] + nl - 1] : 0.0;
           }
         }
-      } else if (wave == 0) {
+      } else if (!dense_pw && wave == 0) {
         const int i0 = (int)dstart[lane] + lane, i1 = (int)dstart[lane + 1] + lane;
         nrows += i1 - i0;
         if (sqdev_mean && i1 > i0 && !mu_known) {
@@ -2902,12 +2902,18 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
         auto launch_flr = [&](const SegOut& oo, bool pw, bool mm, bool is, uint8_t* okbytes, const double* sqmean) {
           PDX_PROFILE("fused_last_digit_reduce", st);
           const int grid = (int)std::min<int64_t>(nruns, (int64_t)kCUs * 24);
-          if (is_f)
-            hipLaunchKernelGGL((k_flr_reduce<double>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const double*>(vs), run_start, nruns,
-                               low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, vvalid ? 1 : 0, sqmean);
-          else
-            hipLaunchKernelGGL((k_flr_reduce<long long>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const long long*>(vs), run_start,
-                               nruns, low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, vvalid ? 1 : 0, sqmean);
+          const bool dense = pw && !mm && !is && !vvalid;
+#define FLR_LAUNCH(TT, DD)                                                                                                                       \
+  hipLaunchKernelGGL((k_flr_reduce<TT, DD>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const TT*>(vs), run_start, nruns, \
+                     low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, vvalid ? 1 : 0, sqmean)
+          if (is_f) {
+            if (dense) FLR_LAUNCH(double, true);
+            else FLR_LAUNCH(double, false);
+          } else {
+            if (dense) FLR_LAUNCH(long long, true);
+            else FLR_LAUNCH(long long, false);
+          }
+#undef FLR_LAUNCH
         };
         if (want_std5) launch_flr(o, want_pw, want_mm, want_is, okb, nullptr);
         PDX_LAUNCH_CHECK();
