@@ -8,15 +8,21 @@
 //   pd::resample / makeGroupInfo / generate_bins_dt64 / GroupInfo::downsample
 //        src/resample.h:19-43,91-122  src/resample.cpp:11-83,85-178,202-295               -> pdx_resample_create
 //
-// Data path for N rows, G groups (all arrays in HBM):
-//   1. k_hash_insert   keys (8 B/row, coalesced) -> open-addressing table of 16-byte slots {key, first_row, gid}
-//                      (lock-free: 64-bit CAS on the key, atomicMin on first_row); writes slot_of_row (4 B/row).
+// Data path for N rows, G groups (all arrays in HBM; DESIGN.md section 3 has the kernel-by-kernel accounting):
+//   1. key -> slot.  Dense integer key domain (span < min(2^26, 4N)): slot = key - min, or its residue form key & (2^b - 1) built
+//      in ONE speculative pass together with the exact min/max, first rows through an LDS-resident "seen" bitmap
+//      (k_dense_slots*, k_sample_key_range).  General keys: hash -> stable partition of (key, row id) by the low 8 hash bits
+//      (k_hash_bucket_hist + radix scatter; a second level for very many groups) -> one workgroup per bucket builds the
+//      bucket's table region in LDS (k_hash_probe_lds; k_hash_probe_part is the memory-side fallback).  Tiny inputs: one
+//      global open-addressing table (k_hash_insert).
 //   2. occupied slots are compacted (slot order) and sorted by first_row -> dense gid in FIRST-OCCURRENCE order.
 //   3. per aggregated column: stable LSD radix sort of (slot, value) by slot (radix_sort.hpp) -> every group's values
-//      contiguous IN ROW ORDER; group offsets by binary search of the G slot values in the sorted keys.
-//   4. k_seg_reduce: one wave per group: coalesced loads staged through LDS, 16-value sequential leaves per lane,
-//      shuffle tree + binary counter == Arrow's pairwise sum bit-for-bit; min/max/count/int-sum from the same pass.
-// Algorithmic bytes: 16 B/row (8 key + 8 value).  Actual traffic is higher (sort passes); see DESIGN.md.
+//      contiguous IN ROW ORDER.  For sum/mean/min/max/count (and variance) the last 6 slot bits are not sorted: k_flr_reduce
+//      ranks each 3072-row tile by them in LDS and replays Arrow's leaf / binary-counter recurrence with one lane per group.
+//   4. classic reducers on fully sorted values (skewed keys, small inputs, resample, product/first/last): k_seg_reduce (one wave
+//      per group, 16-value leaves + shuffle tree + counter), k_seg_reduce_mid (batches of short groups per wave),
+//      k_seg_reduce_sub + k_seg_combine_big (many waves per long group), k_seg_reduce_nullable.
+// All fp64 sums reproduce Arrow's pairwise summation bit for bit.  Algorithmic bytes: 16 B/row (8 key + 8 value).
 #include <stdlib.h>
 #include <algorithm>
 #include <memory>
