@@ -32,6 +32,9 @@ def _worker(rank, world, port, case, q):
         keys, vals, kvalid, vvalid = case
         n = len(keys)
         lo, hi = n * rank // world, n * (rank + 1) // world
+        if n == 31:  # the "empty_middle_rank" case: rank 1 holds no rows at all
+            cuts = [0, 17, 17, 31][: world] + [31]
+            lo, hi = cuts[rank], cuts[rank + 1]
         eng = OracleEngine()
         res = pdist.groupby_agg_sharded(eng, OCol(keys[lo:hi], None if kvalid is None else kvalid[lo:hi]),
                                         OCol(vals[lo:hi], None if vvalid is None else vvalid[lo:hi]), KINDS, row_offset=lo)
@@ -79,14 +82,15 @@ def _cases():
     yield "nulls_i64", (rng.integers(-5, 40, n).astype(np.int64), rng.integers(-10**6, 10**6, n).astype(np.int64), rng.random(n) > 0.05,
                         rng.random(n) > 0.2)
     yield "tiny", (np.array([3, 3, 1], np.int64), np.array([0.5, 0.25, 4.0]), None, None)
+    yield "empty_middle_rank", (rng.integers(0, 5, 31).astype(np.int64), rng.standard_normal(31), None, None)
     # group sizes straddling every leaf / block alignment: 3 keys with ~6000 rows each + tiny groups, cancellation-heavy values
     k = np.concatenate([rng.integers(0, 3, 18000), np.arange(100, 140).repeat(rng.integers(1, 40, 40))]).astype(np.int64)
     rng.shuffle(k)
     yield "aligned_blocks", (k, rng.standard_normal(len(k)) * 10.0 ** rng.integers(-3, 12, len(k)), None, None)
 
 
-@pytest.mark.parametrize("world,name,case", [(2, n, c) for n, c in _cases()] + [(3, n, c) for n, c in _cases() if n in ("tiny", "nulls_i64", "aligned_blocks")],
-                         ids=[f"w2-{n}" for n, _ in _cases()] + ["w3-nulls_i64", "w3-tiny", "w3-aligned_blocks"])
+@pytest.mark.parametrize("world,name,case", [(2, n, c) for n, c in _cases()] + [(3, n, c) for n, c in _cases() if n in ("tiny", "nulls_i64", "aligned_blocks", "empty_middle_rank")],
+                         ids=[f"w2-{n}" for n, _ in _cases()] + ["w3-nulls_i64", "w3-tiny", "w3-empty_middle_rank", "w3-aligned_blocks"])
 def test_sharded_groupby_matches_single_process(world, name, case):
     got = _run(world, case)
     uniq, isnull, first, outs = _expected(*case)
