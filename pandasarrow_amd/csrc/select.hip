@@ -29,6 +29,7 @@ struct GatherCols {
 // A wave owns kGatherU consecutive 64-row output words per iteration and issues the index loads of all of them, then per
 // column the kGatherU gathers, before anything is consumed (memory-level parallelism; the loop is latency bound otherwise).
 constexpr int kGatherU = 4;
+constexpr int kGatherCols = 4;
 template <typename IDX>
 __global__ void __launch_bounds__(256) k_gather(GatherCols c, const IDX* __restrict__ idx, const uint8_t* __restrict__ idx_valid,
                                                 int64_t idx_off, int64_t m, int64_t n_src, int check_bounds, ErrFlag* err,
@@ -57,30 +58,40 @@ __global__ void __launch_bounds__(256) k_gather(GatherCols c, const IDX* __restr
           k[u] = -1;
         }
     }
-    for (int col = 0; col < c.ncols; ++col) {
-      uint64_t v[kGatherU];
-      bool ok[kGatherU];
+    // columns in batches of kGatherCols: kGatherCols x kGatherU independent random loads are issued before any is consumed
+    for (int col0 = 0; col0 < c.ncols; col0 += kGatherCols) {
+      uint64_t v[kGatherCols][kGatherU];
+      bool ok[kGatherCols][kGatherU];
 #pragma unroll
-      for (int u = 0; u < kGatherU; ++u) {
-        ok[u] = k[u] >= 0 && (!c.src_valid[col] || bit_get(c.src_valid[col], c.src_off[col] + k[u]));
-        v[u] = ok[u] ? c.src[col][k[u]] : 0ull;
+      for (int cc = 0; cc < kGatherCols; ++cc) {
+        const int col = col0 + cc;
+#pragma unroll
+        for (int u = 0; u < kGatherU; ++u) {
+          ok[cc][u] = col < c.ncols && k[u] >= 0 && (!c.src_valid[col] || bit_get(c.src_valid[col], c.src_off[col] + k[u]));
+          v[cc][u] = ok[cc][u] ? c.src[col][k[u]] : 0ull;
+        }
       }
 #pragma unroll
-      for (int u = 0; u < kGatherU; ++u) {
-        const int64_t w = g * kGatherU + u;
-        if (in[u]) c.dst[col][(w << 6) + lane] = v[u];
-        if (c.dst_valid[col]) {
-          uint64_t bal = __ballot(ok[u]);
-          if (lane == 0 && w < nwords) {
-            int64_t remain = m - (w << 6);
-            if (remain >= 64) reinterpret_cast<uint64_t*>(c.dst_valid[col])[w] = bal;
-            else {
-              int nbytes = (int)((remain + 7) >> 3);
-              for (int q = 0; q < nbytes; ++q) c.dst_valid[col][(w << 3) + q] = (uint8_t)(bal >> (8 * q));
+      for (int cc = 0; cc < kGatherCols; ++cc) {
+        const int col = col0 + cc;
+        if (col >= c.ncols) break;
+#pragma unroll
+        for (int u = 0; u < kGatherU; ++u) {
+          const int64_t w = g * kGatherU + u;
+          if (in[u]) c.dst[col][(w << 6) + lane] = v[cc][u];
+          if (c.dst_valid[col]) {
+            uint64_t bal = __ballot(ok[cc][u]);
+            if (lane == 0 && w < nwords) {
+              int64_t remain = m - (w << 6);
+              if (remain >= 64) reinterpret_cast<uint64_t*>(c.dst_valid[col])[w] = bal;
+              else {
+                int nbytes = (int)((remain + 7) >> 3);
+                for (int q = 0; q < nbytes; ++q) c.dst_valid[col][(w << 3) + q] = (uint8_t)(bal >> (8 * q));
+              }
+              int valid_rows = (int)(remain >= 64 ? 64 : remain);
+              unsigned long long nulls = (unsigned long long)(valid_rows - __popcll(bal));
+              if (nulls) atomicAdd(&null_counts[col], nulls);
             }
-            int valid_rows = (int)(remain >= 64 ? 64 : remain);
-            unsigned long long nulls = (unsigned long long)(valid_rows - __popcll(bal));
-            if (nulls) atomicAdd(&null_counts[col], nulls);
           }
         }
       }
