@@ -1847,7 +1847,7 @@ static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int
   int grid = (int)std::min<int64_t>(ceil_div(nseg, kSegWaves), (int64_t)kCUs * 8);
   dim3 g(grid), b(kSegWaves * 64);
   // mostly short groups: one kernel that batches the groups of <= kMidLen rows per wave and chunks through the longer ones
-  static const int64_t mid_max = [] { const char* e = getenv("PDX_SEG_MID_MAX"); return e ? atoll(e) : 256ll; }();
+  const int64_t mid_max = [] { const char* e = getenv("PDX_SEG_MID_MAX"); return e ? atoll(e) : 256ll; }();
   const int64_t min_len = -1;
   if (nrows / nseg < mid_max) {
     const int64_t nwaves = (int64_t)kCUs * 8 * kSegWaves;
@@ -2328,7 +2328,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   int64_t nslots = 0;
   const char* denv = getenv("PDX_GROUPBY_DENSE");
   const bool allow_dense = !(denv && denv[0] == '0');
-  static const bool lds_ok = [] { const char* e = getenv("PDX_DENSE_LDS"); return !(e && e[0] == '0'); }();
+  const bool lds_ok = [] { const char* e = getenv("PDX_DENSE_LDS"); return !(e && e[0] == '0'); }();
   const unsigned long long dense_lim = std::min<unsigned long long>(1ull << 26, (unsigned long long)n * 4 + 1024);
 
   // Builds slot_of_row, first[] and (when the first sort digit is 4..8 bits wide) the scanned pass-0 offsets for the dense domain
@@ -2438,7 +2438,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   bool sample_rules_out_dense = !allow_dense;
   // ---- speculative single pass: guess the width of the key window from a sample, build the residue-form dense domain and the
   // exact min/max together (saves the separate 8 B/row min/max pass), accept when the exact span fits the guessed width
-  static const bool spec_ok = [] { const char* e = getenv("PDX_DENSE_SPECULATE"); return !(e && e[0] == '0'); }();
+  const bool spec_ok = [] { const char* e = getenv("PDX_DENSE_SPECULATE"); return !(e && e[0] == '0'); }();
   if (allow_dense && spec_ok && lds_ok && n >= ((int64_t)1 << 23)) {
     KeyRange* dsample = s.get<KeyRange>(64);
     if (s.failed) return PDX_OOM;
@@ -2465,7 +2465,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     // Only windows of <= 20 bits (LDS-resident bitmap).  Wider windows work too (global bitmap, tile min/max in the same pass) but
     // do not pay: the power-of-two residue domain makes the bitmap up to 2x larger than key - min and costs more than the
     // saved min/max pass (measured at 1e7 keys: 42.6 vs 39.7 ms).
-    static const int spec_max_bits = [] { const char* e = getenv("PDX_DENSE_SPECULATE_BITS"); return e ? atoi(e) : 20; }();
+    const int spec_max_bits = [] { const char* e = getenv("PDX_DENSE_SPECULATE_BITS"); return e ? atoi(e) : 20; }();
     if (b <= spec_max_bits && b <= 26 && (1ull << b) <= dense_lim && (int64_t)16 * (((int64_t)1 << b) + 1) + 2 * kSortTile < n) {
       dense_mask = (1u << b) - 1;
       null_slot = 1u << b;
@@ -2615,7 +2615,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
       // rows measured), split the buckets by a second partition level until a bucket's table (<= 8192 slots at <= ~35 % load)
       // fits in LDS again.  The second level is one more stable scatter of (key, row) by the next hash bits; the logical slot id
       // keeps the (index << pb) | bucket form with pb = 8 + extra, so the later sort by slot just sees a longer partitioned prefix.
-      static const bool split_ok = [] { const char* e = getenv("PDX_HASH_SPLIT"); return !(e && e[0] == '0'); }();
+      const bool split_ok = [] { const char* e = getenv("PDX_HASH_SPLIT"); return !(e && e[0] == '0'); }();
       if (split_ok && pb == (unsigned)kPartBits && groups > 0.0 && next > (1u << 21) && !(lenv && lenv[0] == '0')) {
         int extra = 4;
         while (extra < 8 && groups / (double)((uint64_t)1 << (kPartBits + extra)) > 2800.0) ++extra;  // ~35 % load when there is room ...
@@ -2868,20 +2868,21 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
     const uint64_t* vin = static_cast<const uint64_t*>(values->values) + values->offset;
     const uint64_t* vs = nullptr;
     // ---- fused last digit (the five standard kinds): sort by all but the top 6 slot bits, then rank + reduce in one kernel
-    static const bool flr_env = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT"); return !(e && e[0] == '0'); }();
+    // (diagnostic switches are read on every call: tests flip them inside one process)
+    const bool flr_env = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT"); return !(e && e[0] == '0'); }();
     const int part = gb->slot_part ? gb->part_bits : 0;
     // partitioned hash slots: the table itself is a power of two; only the two special slots (null key, INT64_MIN key) need one
     // more bit, so without them the top digit is drawn from the table's own bits (all 64 values used)
     const int eff_bits = (gb->slot_part && !gb->special_slots) ? gb->slot_bits - 1 : gb->slot_bits;
     const int low_bits = eff_bits - kFlrBits;
     const bool std_only = (want_std5 || var_out || std_out) && !prod_out && !first_out && !last_out;  // (variance: two more fused passes)
-    static const int64_t flr_min_rows = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_MIN_ROWS"); return e ? atoll(e) : (1ll << 22); }();
+    const int64_t flr_min_rows = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_MIN_ROWS"); return e ? atoll(e) : (1ll << 22); }();
     // a run is one workgroup's sequential work: it has to span a few tiles to amortise its prologue (1e8 groups: 119-row runs)
-    static const int64_t flr_min_run = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_MIN_RUN"); return e ? atoll(e) : 8192ll; }();
-    static const int flr_min_low = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS"); return e ? atoi(e) : 10; }();
+    const int64_t flr_min_run = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_MIN_RUN"); return e ? atoll(e) : 8192ll; }();
+    const int flr_min_low = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS"); return e ? atoi(e) : 10; }();
     // (hash-partitioned slots: only without the special slots -- with them the top digit is half empty and the runs half as long,
     //  measured slower than the classic path)
-    static const bool flr_hash = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_HASH"); return !(e && e[0] == '0'); }();
+    const bool flr_hash = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_HASH"); return !(e && e[0] == '0'); }();
     bool flr = flr_env && std_only && n >= flr_min_rows && low_bits - part >= 4 && low_bits >= flr_min_low && low_bits <= 26 &&
                (!gb->slot_part || (flr_hash && !gb->special_slots)) && (n >> low_bits) >= flr_min_run;
     if (flr && !gb->slot_part && gb->pass0_off)  // the stored pass-0 offsets belong to the first digit of the FULL plan
