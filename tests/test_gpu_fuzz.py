@@ -60,7 +60,7 @@ def _make_case(seed):
 
 
 @pytest.mark.parametrize("mode", ["default", "hash", "hash_global", "fused_dense", "fused_hash"])
-@pytest.mark.parametrize("seed", range(80))
+@pytest.mark.parametrize("seed", range(160))
 def test_groupby_fuzz(px, monkeypatch, seed, mode):
     if mode in ("hash", "hash_global", "fused_hash"):
         monkeypatch.setenv("PDX_GROUPBY_DENSE", "0")
