@@ -1878,7 +1878,7 @@ static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int
 constexpr int kFlrBits = 6;
 constexpr int kFlrLevels = 20;  // a group lies inside one run, a run is <= 2^19 rows (checked by the host), and with nulls a leaf can
                                 // be a single row: <= 2^19 leaves
-constexpr int kFlrItems = 12;   // rows per thread and tile: 3072-row tiles (measured best: 4096 -> 5.6 ms, 3072 -> 4.2 ms, 2048 -> 4.5 ms per 1e9 rows)
+constexpr int kFlrItems = 10;   // rows per thread and tile: 3072-row tiles (measured best: 4096 -> 5.6 ms, 3072 -> 4.2 ms, 2048 -> 4.5 ms per 1e9 rows)
 constexpr int kFlrTile = kSortBlock * kFlrItems;
 __global__ void k_run_starts(const uint32_t* __restrict__ sorted_keys, int64_t n, int low_bits, int64_t nruns, uint32_t* __restrict__ run_start,
                              unsigned int* __restrict__ max_len) {
