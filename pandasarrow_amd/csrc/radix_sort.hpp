@@ -183,8 +183,11 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const K* __restric
   bool bytes_staged = false;
   if constexpr (sizeof(K) == 1) {
     if (tile_rows == kSortTile && (reinterpret_cast<uintptr_t>(keys_in) & 15) == 0) {
-      const uint4 v = reinterpret_cast<const uint4*>(keys_in + tile_base + wave * (64 * kSortItems))[lane];
-      reinterpret_cast<uint4*>(skeys)[wave * 64 + lane] = v;
+      // a wave's 64 * kSortItems digit bytes = 4 * kSortItems lanes x 16 bytes
+      if (lane < 4 * kSortItems) {
+        const uint4 v = reinterpret_cast<const uint4*>(keys_in + tile_base + wave * (64 * kSortItems))[lane];
+        reinterpret_cast<uint4*>(skeys)[wave * (4 * kSortItems) + lane] = v;
+      }
       __builtin_amdgcn_wave_barrier();
       bytes_staged = true;
     }
@@ -192,7 +195,7 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const K* __restric
 #pragma unroll
   for (int s = 0; s < kSortItems; ++s) {
     int r = wave * (64 * kSortItems) + s * 64 + lane;
-    if (bytes_staged) key[s] = reinterpret_cast<const uint8_t*>(skeys)[r];
+    if (bytes_staged) key[s] = reinterpret_cast<const uint8_t*>(skeys)[r];  // (byte r of the tile: waves are laid out back to back)
     else key[s] = r < tile_rows ? (uint32_t)keys_in[tile_base + r] : 0u;
   }
 #pragma unroll
