@@ -1438,6 +1438,7 @@ __global__ void __launch_bounds__(64) k_seg_combine_big(const uint32_t* __restri
 // partial sum is the sequential sum of the previous window's last rows (one shuffle), and each lane walks its 16 validity bits
 // emitting finished leaves in order.  The emitted leaf sums are merged with a butterfly whose lanes are aligned to the GLOBAL leaf
 // index, so every perfect subtree it extracts is exactly a run of carries of Arrow's binary counter.
+constexpr int64_t kHugeNullable = (int64_t)1 << 22;  // rows: beyond this a nullable group is not left to one wave
 constexpr int kNullLeafCap = 64 * 9 + 8 + 64;  // a 16-row window emits at most 9 leaves (8 isolated values + the carried one); + the queue's tail
 
 template <typename T>
@@ -1458,6 +1459,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_nullable(const T*
   for (int64_t k = gw; k < nseg; k += nw) {
     const int64_t s = seg_start[k], e = seg_start[k + 1];
     const int64_t len = e - s;
+    if (len > kHugeNullable) continue;  // reduced slice by slice with the whole-column kernels (reduce_huge_nullable_groups)
     const uint32_t oi = out_index ? out_index[k] : (uint32_t)k;
     Extreme<T> ext;
     ext.init();
@@ -2294,6 +2296,102 @@ __global__ void k_var_finish(const double* __restrict__ m2, const long long* __r
   }
 }
 
+// ---------------------------------------------------------------- nullable values in very long groups.
+// One wave per group is hopeless for a group of 1e8 rows with nulls (leaves restart at every run of valid rows, so the work cannot
+// be cut into aligned sub-segments the way dense values are).  The grouped values of such a group are one contiguous slice: the
+// whole-column kernels (pdx_aggregate: window scan + pairwise tree levels, all workgroups on one slice) reduce it exactly.
+struct HugePred {
+  const uint32_t* seg_start;
+  __device__ bool operator()(int64_t k) const { return (int64_t)seg_start[k + 1] - (int64_t)seg_start[k] > kHugeNullable; }
+};
+struct HugeEmit {
+  const uint32_t* seg_start;
+  const uint32_t* out_index;
+  int64_t* rec;  // [3 * pos]: start, end, output index
+  __device__ void operator()(int64_t pos, int64_t k) const {
+    rec[3 * pos] = seg_start[k];
+    rec[3 * pos + 1] = seg_start[k + 1];
+    rec[3 * pos + 2] = out_index ? out_index[k] : k;
+  }
+};
+// validity bitmap of the grouped layout from the flag bit that travelled with the slots
+__global__ void k_flags_to_bitmap(const uint32_t* __restrict__ sorted_keys, int64_t n, uint64_t* __restrict__ words) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwords = (n + 63) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nwords; w += nw) {
+    const int64_t i = (w << 6) + lane;
+    const uint64_t bal = __ballot(i < n && !(sorted_keys[i] >> 31));
+    if (lane == 0) words[w] = bal;
+  }
+}
+static int reduce_huge_nullable_groups(const void* vals, int value_dtype, const uint32_t* sorted_flag_keys, const uint8_t* row_valid, int64_t valid_off,
+                                       const uint32_t* seg_start, int64_t nseg, const uint32_t* out_index, int64_t nrows, const SegOut& o, uint8_t* ok,
+                                       Scratch& s, hipStream_t st) {
+  if (nrows <= kHugeNullable) return PDX_OK;
+  const int64_t maxH = nrows / kHugeNullable + 1;
+  int64_t* rec = s.get<int64_t>((size_t)3 * (size_t)std::min<int64_t>(nseg, maxH));
+  PDX_SCRATCH_CHECK(s);
+  int64_t H = 0;
+  PDX_TRY(compact_indices(nseg, HugePred{seg_start}, HugeEmit{seg_start, out_index, rec}, &H, s, st));
+  if (H == 0) return PDX_OK;
+  std::vector<int64_t> hrec((size_t)3 * (size_t)H);
+  PDX_HIP(hipMemcpyAsync(hrec.data(), rec, hrec.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  const uint8_t* bitmap = row_valid;
+  int64_t bitmap_off = valid_off;
+  if (sorted_flag_keys) {
+    uint64_t* words = s.get<uint64_t>((size_t)((nrows + 63) >> 6) + 2);
+    PDX_SCRATCH_CHECK(s);
+    hipLaunchKernelGGL(k_flags_to_bitmap, dim3(grid_for(nrows, 256)), dim3(256), 0, st, sorted_flag_keys, nrows, words);
+    PDX_LAUNCH_CHECK();
+    bitmap = reinterpret_cast<const uint8_t*>(words);
+    bitmap_off = 0;
+  }
+  PDX_HIP(hipStreamSynchronize(st));
+  for (int64_t h = 0; h < H; ++h) {
+    const int64_t start = hrec[3 * h], end = hrec[3 * h + 1], oi = hrec[3 * h + 2];
+    pdx_column col{};
+    col.dtype = value_dtype;
+    col.length = end - start;
+    col.offset = bitmap_off + start;  // values and bitmap share the element offset: rebase the values pointer instead
+    col.null_count = -1;
+    col.validity = bitmap;
+    col.values = static_cast<const uint8_t*>(vals) - (size_t)bitmap_off * 8;
+    auto put = [&](void* dst, const void* src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st); };
+    pdx_scalar sc{};
+    uint8_t valid_group = 0;
+    if (o.sum_f || o.mean || o.sum_i) {
+      if (o.sum_f || o.sum_i) {
+        PDX_TRY(pdx_aggregate(PDX_AGG_SUM, &col, &sc, st));
+        valid_group = (uint8_t)sc.is_valid;
+        if (o.sum_f) PDX_HIP(put(o.sum_f + oi, &sc.v.f64, 8));
+        if (o.sum_i) PDX_HIP(put(o.sum_i + oi, &sc.v.i64, 8));
+      }
+      if (o.mean) {
+        PDX_TRY(pdx_aggregate(PDX_AGG_MEAN, &col, &sc, st));
+        valid_group = (uint8_t)sc.is_valid;
+        PDX_HIP(put(o.mean + oi, &sc.v.f64, 8));
+      }
+    }
+    if (o.vmin) {
+      PDX_TRY(pdx_aggregate(PDX_AGG_MIN, &col, &sc, st));
+      valid_group = (uint8_t)sc.is_valid;
+      PDX_HIP(put(static_cast<uint8_t*>(o.vmin) + 8 * oi, &sc.v, 8));
+    }
+    if (o.vmax) {
+      PDX_TRY(pdx_aggregate(PDX_AGG_MAX, &col, &sc, st));
+      valid_group = (uint8_t)sc.is_valid;
+      PDX_HIP(put(static_cast<uint8_t*>(o.vmax) + 8 * oi, &sc.v, 8));
+    }
+    PDX_TRY(pdx_aggregate(PDX_AGG_COUNT, &col, &sc, st));
+    if (!(o.sum_f || o.mean || o.sum_i || o.vmin || o.vmax)) valid_group = sc.v.i64 > 0;
+    if (o.count) PDX_HIP(put(o.count + oi, &sc.v.i64, 8));
+    if (ok) PDX_HIP(put(ok + oi, &valid_group, 1));
+    PDX_HIP(hipStreamSynchronize(st));  // (the staged host scalars above must outlive their copies)
+  }
+  return PDX_OK;
+}
+
 }  // namespace pdx
 
 extern "C" {
@@ -3000,7 +3098,7 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
       hipLaunchKernelGGL((k_seg_reduce_nullable<long long>), dim3(grid), dim3(kSegWaves * 64), 0, st, static_cast<const long long*>(vals), fk,
                          row_valid, values->offset, seg_start, G, oidx, oo, ok_bytes);
     PDX_LAUNCH_CHECK();
-    return PDX_OK;
+    return reduce_huge_nullable_groups(vals, f64 ? PDX_FLOAT64 : PDX_INT64, fk, row_valid, values->offset, seg_start, G, oidx, n, oo, ok_bytes, s, st);
   };
   auto pack_validity = [&](uint8_t* bits, const uint8_t* ok_bytes) {
     if (!bits) return;

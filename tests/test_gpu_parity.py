@@ -716,3 +716,26 @@ def test_groupby_fused_last_digit_many_short_leaves(px):
             assert_f64_bits(got, exp, valid=eok, what=str(kind))
         else:
             assert np.array_equal(got[eok], exp[eok])
+
+
+@pytest.mark.parametrize("dtype", ["f", "i"])
+def test_groupby_huge_nullable_group(px, dtype):
+    """one group of > 2^22 rows with nullable values (skewed keys): not left to one wave -- its contiguous slice of the grouped
+    values goes through the whole-column kernels; all five aggregates must still match the oracle bit for bit"""
+    n = 9_000_017
+    rng = np.random.default_rng(21)
+    keys = orc.synth_keys(0, n, 50_000)
+    keys[rng.random(n) < 0.6] = 31337
+    vals = (orc.synth_vals(0, n) - 0.5) if dtype == "f" else rng.integers(-1000, 1000, n).astype(np.int64)
+    vvalid = rng.random(n) > 0.08
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys))
+    ids, uniq, _, _ = orc.group_ids(keys)
+    outs = gb.agg(px.Column.from_numpy(vals, vvalid), [0, 1, 2, 3, 4])
+    for kind, out in zip([0, 1, 2, 3, 4], outs):
+        got, ok = out.to_numpy()
+        exp, eok = orc.groupby_agg(kind, ids, len(uniq), vals, vvalid, nthreads=8)
+        assert ok is None or np.array_equal(ok, eok), kind
+        if exp.dtype == np.float64:
+            assert_f64_bits(got, exp, valid=eok, what=f"kind={kind}")
+        else:
+            assert np.array_equal(got[eok], exp[eok]), kind
