@@ -175,7 +175,8 @@ int pdx_scatter(const pdx_column* cols, int ncols, const pdx_column* indices, pd
  * pdx_groupby_create replaces GroupBy::makeGroups (src/dataframe.cpp:1571-1600): Grouper::Make + Consume
  * (dense group ids in FIRST-OCCURRENCE order, a null key is its own group) + GetUniques.  The reference's eager
  * MakeGroupings/ApplyGroupings of every column (src/dataframe.cpp:1539-1569) is deferred to pdx_groupby_agg.
- * key: PDX_INT64 / PDX_TIMESTAMP_NS / PDX_UINT64.  Limit: length < 2^32 rows per call. */
+ * key: PDX_INT64 / PDX_TIMESTAMP_NS / PDX_UINT64.  Limits: length < 2^31 rows per call; keys that do not span a dense integer
+ * range go through a hash table of at most 2^30 slots (about 7e8 distinct keys; the LDS-resident build covers 2.7e8). */
 typedef struct pdx_groupby pdx_groupby;
 int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out);
 int pdx_groupby_destroy(pdx_groupby* gb);
