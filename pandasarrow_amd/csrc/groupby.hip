@@ -289,6 +289,7 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
   __shared__ unsigned long long lkeys[kLdsRegionMax];
   __shared__ unsigned int lfirst[kLdsRegionMax];
   __shared__ unsigned int linserted;
+  __shared__ unsigned int lspecial[2];
   const int tid = threadIdx.x;
   const unsigned int b = blockIdx.x;
   const unsigned int rmask = region - 1;
@@ -298,7 +299,10 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
     lkeys[i] = (unsigned long long)kEmptyKey;
     lfirst[i] = kNoRow;
   }
-  if (tid == 0) linserted = 0;
+  if (tid == 0) {
+    linserted = 0;
+    lspecial[0] = lspecial[1] = kNoRow;
+  }
   __syncthreads();
   constexpr int U = 4;
   const unsigned int dense_limit = region - (region >> 2);  // 75 % full: give up early, the host retries with a larger table
@@ -326,9 +330,11 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
       h[u] = key_hash32(key[u], row[u] >> 31);
       const unsigned int r = row[u] & 0x7FFFFFFFu;
       unsigned int logical;
-      if ((row[u] >> 31) || key[u] == kEmptyKey) {  // null key / INT64_MIN key: dedicated global slots (rare)
+      if ((row[u] >> 31) || key[u] == kEmptyKey) {  // null key / INT64_MIN key: dedicated global slots
+        // (their first row is tracked in LDS and flushed once: a column that is half null would otherwise send 5e8 atomics to
+        //  one address -- measured 7.5 s)
         const unsigned int sp = (row[u] >> 31) ? cap : cap + 1;
-        atomicMin(&table[sp].first, r);
+        if (r < lspecial[sp - cap]) atomicMin(&lspecial[sp - cap], r);
         logical = sp;
       } else {
         unsigned int idx = (h[u] >> pb) & rmask, probes = 0;
@@ -375,6 +381,7 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
     table[(int64_t)b * region + i] = sl;
   }
   if (tid == 0 && linserted) atomicAdd(&ctl->inserted, linserted);
+  if (tid < 2 && lspecial[tid] != kNoRow) atomicMin(&table[cap + tid].first, lspecial[tid]);
 }
 
 __device__ __forceinline__ int64_t phys_slot(int64_t logical, unsigned int region, unsigned int cap) {

@@ -739,3 +739,34 @@ def test_groupby_huge_nullable_group(px, dtype):
             assert_f64_bits(got, exp, valid=eok, what=f"kind={kind}")
         else:
             assert np.array_equal(got[eok], exp[eok]), kind
+
+
+@pytest.mark.parametrize("part", ["default", "2"])
+def test_groupby_hash_half_null_keys(px, monkeypatch, part):
+    """general keys where half of the rows carry a null key and a tenth the INT64_MIN key: their two dedicated slots take their
+    first rows through an LDS minimum per workgroup (not one global atomic per row); ids, first rows, uniques and sums must match"""
+    monkeypatch.setenv("PDX_GROUPBY_DENSE", "0")
+    if part != "default":
+        monkeypatch.setenv("PDX_HASH_PARTITION", part)
+    n = 3_000_017
+    rng = np.random.default_rng(123)
+    keys = orc.synth_keys(0, n, 40_000) * 7_000_003 - 99
+    keys[rng.random(n) < 0.1] = np.iinfo(np.int64).min
+    kvalid = rng.random(n) > 0.5
+    kvalid[:3] = True            # the null group must not come first by construction
+    vals = orc.synth_vals(0, n) - 0.5
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys, kvalid))
+    ids, uniq, isnull, first = orc.group_ids(keys, kvalid)
+    assert gb.num_groups == len(uniq)
+    assert np.array_equal(gb.group_ids().cpu().numpy().astype(np.uint32), ids)
+    uk, uok = gb.unique_keys().to_numpy()
+    assert np.array_equal(uok, ~isnull) and np.array_equal(uk[uok], uniq[~isnull])
+    assert np.array_equal(gb.first_rows().cpu().numpy(), first)
+    s, c = gb.agg(px.Column.from_numpy(vals), [0, 4])
+    for out, kind in ((s, 0), (c, 4)):
+        got, ok = out.to_numpy()
+        exp, eok = orc.groupby_agg(kind, ids, len(uniq), vals, None, nthreads=8)
+        if exp.dtype == np.float64:
+            assert_f64_bits(got, exp, valid=eok, what=str(kind))
+        else:
+            assert np.array_equal(got[eok], exp[eok])
