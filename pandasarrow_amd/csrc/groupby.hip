@@ -285,7 +285,7 @@ constexpr int kProbeBlock = 1024;
 __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long* __restrict__ keys_part, const uint32_t* __restrict__ rows_part,
                                                                 const uint32_t* __restrict__ bucket_off,
                                                                 int64_t n, Slot* table, unsigned int cap, unsigned int region,
-                                                                uint32_t* __restrict__ slot_part, HashCtl* ctl, unsigned int pb) {
+                                                                uint32_t* __restrict__ slot_part, HashCtl* ctl, unsigned int pb, int64_t head_rows) {
   __shared__ unsigned long long lkeys[kLdsRegionMax];
   __shared__ unsigned int lfirst[kLdsRegionMax];
   __shared__ unsigned int linserted;
@@ -294,7 +294,8 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
   const unsigned int b = blockIdx.x;
   const unsigned int rmask = region - 1;
   const int64_t start = bucket_off[b];
-  const int64_t end = (b + 1 < (1u << pb)) ? (int64_t)bucket_off[b + 1] : n;
+  int64_t end = (b + 1 < (1u << pb)) ? (int64_t)bucket_off[b + 1] : n;
+  if (end - start > head_rows) end = start + head_rows;  // an overlong (skewed) bucket: the rest goes to k_hash_probe_lds_tail
   for (int i = tid; i < (int)region; i += kProbeBlock) {
     lkeys[i] = (unsigned long long)kEmptyKey;
     lfirst[i] = kNoRow;
@@ -380,6 +381,96 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
     sl.gid = kNoRow;
     table[(int64_t)b * region + i] = sl;
   }
+  if (tid == 0 && linserted) atomicAdd(&ctl->inserted, linserted);
+  if (tid < 2 && lspecial[tid] != kNoRow) atomicMin(&table[cap + tid].first, lspecial[tid]);
+}
+
+// Skewed buckets (a hot key, or half of the keys null: all of those rows share one bucket): the workgroup above only builds the
+// region from the bucket's first `head_rows` rows; the rest of the bucket is cut into chunks, one workgroup each.  A chunk's
+// workgroup copies the region's keys into LDS (read-only snapshot) and resolves its rows there; a key the snapshot does not hold
+// continues its probe chain in the memory-side region (CAS insert, the snapshot is a subset of it and keys never move), where
+// its first row is also kept.  Keys found in the snapshot were inserted by the head rows, which precede every tail row of the
+// bucket (the partition is stable), so their first row is already final.
+struct TailChunk {
+  uint32_t bucket, begin, end;
+};
+constexpr int kTailChunkRows = 1 << 17;
+__global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds_tail(const long long* __restrict__ keys_part, const uint32_t* __restrict__ rows_part,
+                                                                     const TailChunk* __restrict__ chunks, Slot* table, unsigned int cap,
+                                                                     unsigned int region, uint32_t* __restrict__ slot_part, HashCtl* ctl, unsigned int pb) {
+  __shared__ unsigned long long lkeys[kLdsRegionMax];
+  __shared__ unsigned int linserted;
+  __shared__ unsigned int lspecial[2];
+  const int tid = threadIdx.x;
+  const TailChunk ch = chunks[blockIdx.x];
+  const unsigned int b = ch.bucket, rmask = region - 1;
+  if (__hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // the head attempt already failed
+  Slot* reg = table + (int64_t)b * region;
+  for (int i = tid; i < (int)region; i += kProbeBlock) lkeys[i] = (unsigned long long)reg[i].key;
+  if (tid == 0) {
+    linserted = 0;
+    lspecial[0] = lspecial[1] = kNoRow;
+  }
+  __syncthreads();
+  constexpr int U = 4;
+  for (int64_t base0 = ch.begin; base0 < (int64_t)ch.end; base0 += (int64_t)U * kProbeBlock) {
+    const int64_t p0 = base0 + tid;
+    unsigned int row[U];
+    long long key[U];
+    bool act[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t p = p0 + (int64_t)u * kProbeBlock;
+      act[u] = p < (int64_t)ch.end;
+      row[u] = act[u] ? rows_part[p] : 0u;
+      key[u] = act[u] ? keys_part[p] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!act[u]) continue;
+      const unsigned int r = row[u] & 0x7FFFFFFFu;
+      unsigned int logical;
+      if ((row[u] >> 31) || key[u] == kEmptyKey) {
+        const unsigned int sp = (row[u] >> 31) ? cap : cap + 1;
+        if (r < lspecial[sp - cap]) atomicMin(&lspecial[sp - cap], r);
+        logical = sp;
+      } else {
+        unsigned int idx = (key_hash32(key[u], false) >> pb) & rmask, probes = 0;
+        bool found = false, dead = false;
+        for (;;) {  // the snapshot
+          unsigned long long cur = lkeys[idx];
+          if (cur == (unsigned long long)key[u]) { found = true; break; }
+          if (cur == (unsigned long long)kEmptyKey) break;
+          idx = (idx + 1) & rmask;
+          if (++probes > region) { dead = true; break; }
+        }
+        if (!found && !dead) {  // memory side, from the slot the snapshot had empty
+          for (;;) {
+            unsigned long long cur = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&reg[idx].key), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == (unsigned long long)key[u]) break;
+            if (cur == (unsigned long long)kEmptyKey) {
+              unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&reg[idx].key), (unsigned long long)kEmptyKey, (unsigned long long)key[u]);
+              if (old == (unsigned long long)kEmptyKey) {
+                atomicAdd(&linserted, 1u);
+                break;
+              }
+              if (old == (unsigned long long)key[u]) break;
+            }
+            idx = (idx + 1) & rmask;
+            if (++probes > region) { dead = true; break; }
+          }
+          if (!dead && r < __hip_atomic_load(&reg[idx].first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&reg[idx].first, r);
+        }
+        if (dead) {  // the region is full: the host retries with a larger table
+          atomicExch(&ctl->overflow, 1u);
+          continue;
+        }
+        logical = (idx << pb) | b;
+      }
+      slot_part[p0 + (int64_t)u * kProbeBlock] = logical;
+    }
+  }
+  __syncthreads();
   if (tid == 0 && linserted) atomicAdd(&ctl->inserted, linserted);
   if (tid < 2 && lspecial[tid] != kNoRow) atomicMin(&table[cap + tid].first, lspecial[tid]);
 }
@@ -2672,8 +2763,36 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
       if (use_lds) {
         PDX_PROFILE("hash_probe_lds", st);
         // bucket starts: the offsets row of tile 0 of the partition pass, or the searched starts after a second level
-        hipLaunchKernelGGL(k_hash_probe_lds, dim3(1u << pb), dim3(kProbeBlock), 0, st, keys_part, gb->rows_part, bucket_starts ? bucket_starts : gb->part_off, n,
-                           table, cap, region, gb->slot_part, ctl, pb);
+        // skewed buckets (longer than 1.5x the average and 2^20 rows): head rows here, the rest in chunks (k_hash_probe_lds_tail)
+        const uint32_t* boff = bucket_starts ? bucket_starts : gb->part_off;
+        const size_t nb = (size_t)1 << pb;
+        int64_t head_rows = std::max<int64_t>((int64_t)1 << 20, (n >> pb) + (n >> (pb + 1)));
+        if (const char* e = getenv("PDX_HASH_HEAD_ROWS")) head_rows = std::max<int64_t>(atoll(e), 1);
+        head_rows = (head_rows + 4 * kProbeBlock - 1) / (4 * kProbeBlock) * (4 * kProbeBlock);
+        std::vector<TailChunk> chunks;
+        if (n > head_rows) {
+          std::vector<uint32_t> hoff(nb);
+          PDX_HIP(hipMemcpyAsync(hoff.data(), boff, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+          PDX_HIP(hipStreamSynchronize(st));
+          for (size_t bi = 0; bi < nb; ++bi) {
+            const int64_t bs = hoff[bi], be = bi + 1 < nb ? (int64_t)hoff[bi + 1] : n;
+            for (int64_t c0 = bs + head_rows; c0 < be; c0 += kTailChunkRows)
+              chunks.push_back(TailChunk{(uint32_t)bi, (uint32_t)c0, (uint32_t)std::min<int64_t>(c0 + kTailChunkRows, be)});
+          }
+        }
+        hipLaunchKernelGGL(k_hash_probe_lds, dim3(1u << pb), dim3(kProbeBlock), 0, st, keys_part, gb->rows_part, boff, n,
+                           table, cap, region, gb->slot_part, ctl, pb, head_rows);
+        if (!chunks.empty()) {
+          TailChunk* dchunks = s.get<TailChunk>(chunks.size());
+          if (s.failed) {
+            pool_free(table);
+            return PDX_OOM;
+          }
+          PDX_HIP(hipMemcpyAsync(dchunks, chunks.data(), chunks.size() * sizeof(TailChunk), hipMemcpyHostToDevice, st));
+          hipLaunchKernelGGL(k_hash_probe_lds_tail, dim3((unsigned)chunks.size()), dim3(kProbeBlock), 0, st, keys_part, gb->rows_part, dchunks, table, cap,
+                             region, gb->slot_part, ctl, pb);
+          PDX_HIP(hipStreamSynchronize(st));  // `chunks` (pageable host memory) must outlive the copy
+        }
       } else {
         PDX_PROFILE("hash_probe_part", st);
         constexpr unsigned int kWindowBits = 16;  // 2^16 slots = 1 MB per bucket window; about two buckets are active at a time

@@ -741,16 +741,25 @@ def test_groupby_huge_nullable_group(px, dtype):
             assert np.array_equal(got[eok], exp[eok]), kind
 
 
-@pytest.mark.parametrize("part", ["default", "2"])
-def test_groupby_hash_half_null_keys(px, monkeypatch, part):
+@pytest.mark.parametrize("head", ["default", "4096"])
+@pytest.mark.parametrize("shape", ["random", "late_keys", "hot"])
+def test_groupby_hash_half_null_keys(px, monkeypatch, shape, head):
     """general keys where half of the rows carry a null key and a tenth the INT64_MIN key: their two dedicated slots take their
-    first rows through an LDS minimum per workgroup (not one global atomic per row); ids, first rows, uniques and sums must match"""
+    first rows through an LDS minimum per workgroup (not one global atomic per row).  Such rows share one hash bucket: a bucket
+    much longer than the average is built from its head rows by one workgroup and finished in chunks (k_hash_probe_lds_tail;
+    head = 4096 forces that split on every bucket; `late_keys`: keys grow with the row number, so the chunks meet keys the head
+    never saw and insert them memory-side).  ids, first rows, uniques and sums must match the oracle."""
     monkeypatch.setenv("PDX_GROUPBY_DENSE", "0")
-    if part != "default":
-        monkeypatch.setenv("PDX_HASH_PARTITION", part)
+    if head != "default":
+        monkeypatch.setenv("PDX_HASH_HEAD_ROWS", head)
     n = 3_000_017
     rng = np.random.default_rng(123)
-    keys = orc.synth_keys(0, n, 40_000) * 7_000_003 - 99
+    if shape == "late_keys":
+        keys = (np.arange(n, dtype=np.int64) // 37) * 7_000_003 - 99
+    else:
+        keys = orc.synth_keys(0, n, 40_000) * 7_000_003 - 99
+    if shape == "hot":
+        keys[rng.random(n) < 0.6] = 123456789012345
     keys[rng.random(n) < 0.1] = np.iinfo(np.int64).min
     kvalid = rng.random(n) > 0.5
     kvalid[:3] = True            # the null group must not come first by construction

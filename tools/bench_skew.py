@@ -25,6 +25,15 @@ def run(name, kcol, vcol):
     for _ in range(3): step()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
     print(f"{name}: {dt*1e3:.1f} ms/step  {n/dt/1e9:.2f} Grows/s", flush=True)
+    if os.environ.get("PDX_SKEW_KERNELS"):  # per-kernel device time of one more step (HIP events inside the library)
+        import ctypes as C
+        lib = L.load()
+        lib.pdx_profile_reset(); lib.pdx_profile_enable(1)
+        step(); torch.cuda.synchronize()
+        lib.pdx_profile_enable(0)
+        buf = C.create_string_buffer(1 << 16)
+        L.check(lib.pdx_profile_report(buf, len(buf)))
+        print("   " + "  ".join(f"{t}={float(ms):.1f}" for t, c, ms in (l.split() for l in buf.value.decode().splitlines()) if float(ms) >= 0.5), flush=True)
 
 
 for dense in ("1", "0"):
