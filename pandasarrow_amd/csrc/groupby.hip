@@ -910,6 +910,13 @@ __global__ void k_seg_starts(const uint32_t* __restrict__ sorted_keys, int64_t n
   }
 }
 
+// seg_start[k] = slot_start[occ_slot[k]] (starts of every slot's rows, from k_level_starts); seg_start[G] = n
+__global__ void k_seg_starts_from_slots(const uint32_t* __restrict__ slot_start, int64_t n, const uint32_t* __restrict__ occ_slot, int64_t G,
+                                        uint32_t* __restrict__ seg_start) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= G; k += stride) seg_start[k] = k == G ? (uint32_t)n : slot_start[occ_slot[k]];
+}
+
 // ---------------------------------------------------------------- segmented reduce (dense values: no nulls)
 struct SegOut {
   double* sum_f;     // SUM of float64 values, or nullptr
@@ -2033,8 +2040,9 @@ __device__ __forceinline__ void flr_counter_push(double (*csum)[1 << kFlrBits], 
   csum[cur][lane] = v;
   root = cur > root ? cur : root;
 }
-template <typename T, bool DENSE_PW>
-__global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __restrict__ keys, const T* __restrict__ vals,
+// KT: uint32 slots (top digit at bit low_bits, bit 31 = the value's null flag) or, after a narrowing sort, the top digit alone in a byte
+template <typename T, bool DENSE_PW, typename KT = uint32_t>
+__global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const KT* __restrict__ keys, const T* __restrict__ vals,
                                                            const uint32_t* __restrict__ run_start, int64_t nruns, int low_bits,
                                                            const uint32_t* __restrict__ gid_of_slot, SegOut out, uint8_t* __restrict__ ok,
                                                            int want_pw, int want_mm, int want_is, int nullable,
@@ -2047,6 +2055,7 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
   __shared__ T svals[kFlrTile + R];
   __shared__ __attribute__((aligned(8))) uint8_t snull[kFlrTile + R];
   __shared__ uint32_t cnt[kSortWaves][R];
+  __shared__ unsigned long long match[kSortWaves][R];  // match-any words of the ranking (wave_match_rank)
   __shared__ uint32_t dstart[R + 1];
   __shared__ double csum[kFlrLevels][R];
   // dense sum/mean/count fast path (no nulls, no min/max/int sum): one THREAD per 16-value leaf, then one lane per group for the
@@ -2062,7 +2071,10 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
   // Barriers per tile: after the ranking, after the prefixes, after the staging and (dense path) after the leaf sums.  The digit
   // counters are re-zeroed right after the staging barrier, and wave 0's replay needs no closing barrier: the next tile's
   // staging lies behind two barriers that wave 0 itself has to reach.
-  for (int d = tid; d < kSortWaves * R; d += kSortBlock) (&cnt[0][0])[d] = 0;
+  for (int d = tid; d < kSortWaves * R; d += kSortBlock) {
+    (&cnt[0][0])[d] = 0;
+    (&match[0][0])[d] = 0;
+  }
   __syncthreads();
   for (int64_t run = blockIdx.x; run < nruns; run += gridDim.x) {
     const int64_t s = run_start[run], e = run_start[run + 1];
@@ -2107,24 +2119,8 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
       for (int q = 0; q < kFlrItems; ++q) {
         const int r = wave * (64 * kFlrItems) + q * 64 + lane;
         const bool active = r < rows;
-        const uint32_t d = ((key[q] & kSortKeyMask) >> low_bits) & (R - 1);
-        uint64_t peers = __ballot(active);
-#pragma unroll
-        for (int b = 0; b < kFlrBits; ++b) {
-          const bool bit = (d >> b) & 1;
-          const uint64_t m = __ballot(bit);
-          peers &= bit ? m : ~m;
-        }
-        uint32_t base = 0;
-        if (active) {
-          const int leader = __ffsll((unsigned long long)peers) - 1;
-          if (lane == leader) {
-            base = cnt[wave][d];
-            cnt[wave][d] = base + (uint32_t)__popcll(peers);
-          }
-          base = __shfl(base, leader, 64);
-          rank[q] = base + (uint32_t)__popcll(peers & lt_mask);
-        }
+        const uint32_t d = sizeof(KT) == 4 ? ((key[q] & kSortKeyMask) >> low_bits) & (R - 1) : key[q] & (R - 1);
+        rank[q] = wave_match_rank(match[wave], cnt[wave], d, active, lane, lt_mask);
       }
       __syncthreads();
       if (tid < R) {  // exclusive prefix over waves per digit, then over digits (64 values: one wave)
@@ -2162,7 +2158,7 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const uint32_t* __res
       for (int q = 0; q < kFlrItems; ++q) {
         const int r = wave * (64 * kFlrItems) + q * 64 + lane;
         if (r < rows) {
-          const uint32_t d = ((key[q] & kSortKeyMask) >> low_bits) & (R - 1);
+          const uint32_t d = sizeof(KT) == 4 ? ((key[q] & kSortKeyMask) >> low_bits) & (R - 1) : key[q] & (R - 1);
           const uint32_t p = cnt[wave][d] + rank[q] + d;
           svals[p] = val[q];
           if (nullable) snull[p] = (uint8_t)(key[q] >> 31);
@@ -3111,23 +3107,97 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
                (!gb->slot_part || (flr_hash && !gb->special_slots)) && (n >> low_bits) >= flr_min_run;
     if (flr && !gb->slot_part && gb->pass0_off)  // the stored pass-0 offsets belong to the first digit of the FULL plan
       flr = make_sort_plan(gb->slot_bits, sort_max_bits()).bits[0] == make_sort_plan(low_bits, sort_max_bits()).bits[0];
+    // Narrowing sort (dense slots, values without nulls, two passes below the fused digit): a digit that has been sorted on is
+    // dropped from the key, so pass 0 writes 2-byte keys, pass 1 reads them and writes the top digit alone in a byte, which is all
+    // the fused kernel reads: 12 B/row less traffic than carrying the 4-byte slot through.  Run starts then come from the scatter
+    // offsets (k_level_starts) instead of a search in the sorted slots.
+    const SortPlan low_plan = make_sort_plan(low_bits, sort_max_bits());
+    const bool narrow_env = [] { const char* e = getenv("PDX_SORT_NARROW"); return !(e && e[0] == '0'); }();
+    const bool narrow = flr && narrow_env && !gb->slot_part && !vvalid && gb->pass0_off && low_plan.npasses == 2 &&
+                        gb->slot_bits - low_plan.bits[0] <= 16 && low_plan.bits[0] <= 8 && low_plan.bits[1] <= 8 && eff_bits == gb->slot_bits;
+    const uint8_t* keys8 = nullptr;       // narrowing sort: the top digit of every partially sorted row
+    bool sorted_done = false;             // narrowing sort, skewed keys: the classic path's inputs are already built
+    uint32_t* ss_narrow = nullptr;
     if (flr) {
-      PDX_TRY(sort_values_by_slot(gb, vin, vvalid, values->offset, [&](size_t bytes) { return (void*)s.get<uint8_t>(bytes); }, s, st, &keys_sorted, &vs,
-                                  gb->slot_bits - low_bits));
       const int64_t nruns = (int64_t)1 << low_bits;
       uint32_t* run_start = s.get<uint32_t>((size_t)nruns + 1);
       unsigned int* dmax = s.get<unsigned int>(1);
       uint8_t* okb = vvalid ? s.get<uint8_t>((size_t)G) : nullptr;
       PDX_SCRATCH_CHECK(s);
+      uint64_t *nv0 = nullptr, *nv1 = nullptr;
+      uint32_t *nhist = nullptr, *nchunk = nullptr;
+      uint8_t* k8 = nullptr;
+      if (narrow) {
+        const int b0 = low_plan.bits[0], b1 = low_plan.bits[1];
+        const int64_t ntiles = ceil_div(n, kSortTile), nchunks = ceil_div(ntiles, kColChunk);
+        uint16_t* k16 = s.get<uint16_t>((size_t)n);
+        k8 = s.get<uint8_t>((size_t)n);
+        nv0 = s.get<uint64_t>((size_t)n);
+        nv1 = s.get<uint64_t>((size_t)n);
+        nhist = s.get<uint32_t>((size_t)ntiles << 8);
+        nchunk = s.get<uint32_t>((size_t)(nchunks + 1) << 8);
+        PDX_SCRATCH_CHECK(s);
+        int rcn = PDX_OK;
+#define NARROW_P0(B) rcn = radix_scatter_narrow<B, uint64_t, uint32_t, uint16_t>(gb->slot_of_row, vin, k16, nv0, n, gb->pass0_off, st)
+        switch (b0) {
+          case 4: NARROW_P0(4); break;
+          case 5: NARROW_P0(5); break;
+          case 6: NARROW_P0(6); break;
+          case 7: NARROW_P0(7); break;
+          default: NARROW_P0(8); break;
+        }
+#undef NARROW_P0
+        PDX_TRY(rcn);
+#define NARROW_P1(B)                                                                    \
+  rcn = radix_offsets<B, uint16_t>(k16, n, 0, nhist, nchunk, true, st);                  \
+  if (rcn == PDX_OK) rcn = radix_scatter_narrow<B, uint64_t, uint16_t, uint8_t>(k16, nv0, k8, nv1, n, nhist, st)
+        switch (b1) {
+          case 4: NARROW_P1(4); break;
+          case 5: NARROW_P1(5); break;
+          case 6: NARROW_P1(6); break;
+          case 7: NARROW_P1(7); break;
+          default: NARROW_P1(8); break;
+        }
+#undef NARROW_P1
+        PDX_TRY(rcn);
+        {
+          PDX_PROFILE("run_starts", st);
+          // (row 0 of the pass-0 offsets = where every first digit's rows begin in the input of pass 1)
+          hipLaunchKernelGGL((k_level_starts<uint16_t>), dim3(1u << b0), dim3(256), 0, st, k16, n, gb->pass0_off, (int64_t)1 << b0, b0, b1, nhist, run_start);
+        }
+        keys8 = k8;
+        vs = nv1;
+      } else {
+        PDX_TRY(sort_values_by_slot(gb, vin, vvalid, values->offset, [&](size_t bytes) { return (void*)s.get<uint8_t>(bytes); }, s, st, &keys_sorted, &vs,
+                                    gb->slot_bits - low_bits));
+      }
       unsigned int hmax = 0;
       {
         PDX_PROFILE("run_starts", st);
         PDX_HIP(hipMemsetAsync(dmax, 0, sizeof(unsigned int), st));
-        hipLaunchKernelGGL(k_run_starts, dim3(grid_for(nruns + 1, 256)), dim3(256), 0, st, keys_sorted, n, low_bits, nruns, run_start, dmax);
+        if (!narrow) hipLaunchKernelGGL(k_run_starts, dim3(grid_for(nruns + 1, 256)), dim3(256), 0, st, keys_sorted, n, low_bits, nruns, run_start, dmax);
         hipLaunchKernelGGL(k_run_max_len, dim3(grid_for(nruns, 256)), dim3(256), 0, st, run_start, nruns, dmax);
         PDX_LAUNCH_CHECK();
         PDX_HIP(hipMemcpyAsync(&hmax, dmax, sizeof(hmax), hipMemcpyDeviceToHost, st));
         PDX_HIP(hipStreamSynchronize(st));
+      }
+      if (narrow && hmax > (1u << 19)) {
+        // skewed keys: the fused kernel is skipped.  Finish the sort with the one pass that is left (on the byte digits) and take the
+        // group offsets from its scatter offsets: one more level of k_level_starts gives the start of every slot's rows
+        ss_narrow = s.get<uint32_t>((size_t)G + 1);
+        uint32_t* slot_start = s.get<uint32_t>(((size_t)nruns << kFlrBits) + 1);
+        PDX_SCRATCH_CHECK(s);
+        PDX_TRY((radix_offsets<kFlrBits, uint8_t>(k8, n, 0, nhist, nchunk, true, st)));
+        PDX_TRY((radix_scatter_narrow<kFlrBits, uint64_t, uint8_t, uint8_t>(k8, nv1, (uint8_t*)nullptr, nv0, n, nhist, st)));
+        {
+          PDX_PROFILE("seg_starts", st);
+          hipLaunchKernelGGL((k_level_starts<uint8_t>), dim3((unsigned)std::min<int64_t>(nruns, 65536)), dim3(256), 0, st, k8, n, run_start, nruns, low_bits,
+                             kFlrBits, nhist, slot_start);
+          hipLaunchKernelGGL(k_seg_starts_from_slots, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, slot_start, n, gb->occ_slot, G, ss_narrow);
+        }
+        PDX_LAUNCH_CHECK();
+        vs = nv0;
+        sorted_done = true;
       }
       if (hmax <= (1u << 19)) {  // a run is walked by ONE workgroup: keep the longest one short (skewed keys take the classic path)
         auto launch_flr = [&](const SegOut& oo, bool pw, bool mm, bool is, uint8_t* okbytes, const double* sqmean) {
@@ -3135,14 +3205,18 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
           const int grid = (int)std::min<int64_t>(nruns, (int64_t)kCUs * 24);
           const bool dense = pw && !mm && !is && !vvalid;
 #define FLR_LAUNCH(TT, DD)                                                                                                                       \
-  hipLaunchKernelGGL((k_flr_reduce<TT, DD>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const TT*>(vs), run_start, nruns, \
-                     low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, vvalid ? 1 : 0, sqmean)
+  if (keys8)                                                                                                                                     \
+    hipLaunchKernelGGL((k_flr_reduce<TT, DD, uint8_t>), dim3(grid), dim3(kSortBlock), 0, st, keys8, reinterpret_cast<const TT*>(vs), run_start, nruns, \
+                       low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, 0, sqmean);                                              \
+  else                                                                                                                                           \
+    hipLaunchKernelGGL((k_flr_reduce<TT, DD>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const TT*>(vs), run_start, nruns, \
+                       low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, vvalid ? 1 : 0, sqmean)
           if (is_f) {
-            if (dense) FLR_LAUNCH(double, true);
-            else FLR_LAUNCH(double, false);
+            if (dense) { FLR_LAUNCH(double, true); }
+            else { FLR_LAUNCH(double, false); }
           } else {
-            if (dense) FLR_LAUNCH(long long, true);
-            else FLR_LAUNCH(long long, false);
+            if (dense) { FLR_LAUNCH(long long, true); }
+            else { FLR_LAUNCH(long long, false); }
           }
 #undef FLR_LAUNCH
         };
@@ -3180,9 +3254,11 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
       }
     }
     // stable sort of (slot, value) by slot: each group's values become contiguous in row order
-    uint32_t* ss = s.get<uint32_t>((size_t)G + 1);
+    uint32_t* ss = sorted_done ? ss_narrow : s.get<uint32_t>((size_t)G + 1);
     PDX_SCRATCH_CHECK(s);
-    if (flr) {
+    if (sorted_done) {
+      // (narrowing sort, skewed keys: values and group offsets were built above)
+    } else if (flr) {
       // the fused kernel was skipped (a run longer than 2^19 rows: skewed keys): finish the sort with the one pass that is left
       uint32_t* k2 = s.get<uint32_t>((size_t)n);
       uint64_t* v2 = s.get<uint64_t>((size_t)n);
@@ -3196,7 +3272,7 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
       PDX_TRY(sort_values_by_slot(gb, vin, vvalid, values->offset, [&](size_t bytes) { return (void*)s.get<uint8_t>(bytes); }, s, st, &keys_sorted, &vs));
     }
     vals_sorted = vs;
-    {
+    if (!sorted_done) {
       PDX_PROFILE("seg_starts", st);
       hipLaunchKernelGGL(k_seg_starts, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, keys_sorted, n, gb->occ_slot, G, ss);
     }

@@ -23,32 +23,43 @@ constexpr int kSortTile = kSortBlock * kSortItems;  // 4096 rows
 constexpr int kSortWaves = kSortBlock / 64;
 constexpr uint32_t kSortKeyMask = 0x7FFFFFFFu;      // bit 31 of a key is a caller flag and never sorted on
 
-template <int BITS>
-__global__ void __launch_bounds__(kSortBlock) k_radix_hist(const uint32_t* __restrict__ keys, int64_t n, int shift,
+template <int BITS, typename K = uint32_t>
+__global__ void __launch_bounds__(kSortBlock) k_radix_hist(const K* __restrict__ keys, int64_t n, int shift,
                                                            uint32_t* __restrict__ hist /* [tiles][1<<BITS] */) {
   constexpr int R = 1 << BITS;
+  constexpr int PER = 16 / (int)sizeof(K);                 // keys per 16-byte load
+  constexpr int NV = kSortItems / PER > 0 ? kSortItems / PER : 1;  // 16-byte loads per thread and tile (uint32: 4, uint16: 2, uint8: 1)
   __shared__ uint32_t h[R];
   for (int d = threadIdx.x; d < R; d += kSortBlock) h[d] = 0;
   __syncthreads();
   int64_t base = (int64_t)blockIdx.x * kSortTile;
   if (base + kSortTile <= n && (reinterpret_cast<uintptr_t>(keys) & 15) == 0) {
-    // full tile: 16-byte loads, all four in flight before the LDS atomics
+    // full tile: 16-byte loads, all of them in flight before the LDS atomics
     const uint4* k4 = reinterpret_cast<const uint4*>(keys + base);
-    uint4 v[kSortItems / 4];
+    uint4 v[NV];
 #pragma unroll
-    for (int k = 0; k < kSortItems / 4; ++k) v[k] = k4[k * kSortBlock + threadIdx.x];
+    for (int k = 0; k < NV; ++k) v[k] = k4[k * kSortBlock + threadIdx.x];
 #pragma unroll
-    for (int k = 0; k < kSortItems / 4; ++k) {
-      atomicAdd(&h[(v[k].x >> shift) & (R - 1)], 1u);
-      atomicAdd(&h[(v[k].y >> shift) & (R - 1)], 1u);
-      atomicAdd(&h[(v[k].z >> shift) & (R - 1)], 1u);
-      atomicAdd(&h[(v[k].w >> shift) & (R - 1)], 1u);
+    for (int k = 0; k < NV; ++k) {
+      const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (sizeof(K) == 4) {
+          atomicAdd(&h[(w[j] >> shift) & (R - 1)], 1u);
+        } else if constexpr (sizeof(K) == 2) {
+          atomicAdd(&h[((w[j] & 0xFFFFu) >> shift) & (R - 1)], 1u);
+          atomicAdd(&h[((w[j] >> 16) >> shift) & (R - 1)], 1u);
+        } else {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) atomicAdd(&h[(((w[j] >> (8 * b)) & 0xFFu) >> shift) & (R - 1)], 1u);
+        }
+      }
     }
   } else {
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
       int64_t i = base + k * kSortBlock + threadIdx.x;
-      if (i < n) atomicAdd(&h[(keys[i] >> shift) & (R - 1)], 1u);
+      if (i < n) atomicAdd(&h[((uint32_t)keys[i] >> shift) & (R - 1)], 1u);
     }
   }
   __syncthreads();
@@ -124,6 +135,26 @@ __global__ void __launch_bounds__(256) k_col_apply(uint32_t* __restrict__ hist, 
   }
 }
 
+// Stable rank of a lane's row among the rows of its wave step that carry the same digit, plus the wave's running digit counter.
+// Match-any through LDS: every lane ORs its lane bit into the digit's 64-bit word (ds_or_b64) and reads the word back -- the
+// lanes with the same digit.  The lowest of them clears the word and advances the counter.  A wave's LDS instructions execute in
+// program order, so no barrier is involved.  (The ballot form -- one ballot per digit bit and a per-lane 64-bit select for each --
+// cost ~100 vector instructions per step and made both kernels issue bound: SQ_ACTIVE_INST_ANY x waves per SIMD ~ 100 %.)
+// match: the wave's [R] words, all zero on entry and again on exit; cnt: the wave's [R] running counters.
+__device__ __forceinline__ uint32_t wave_match_rank(unsigned long long* match, uint32_t* cnt, uint32_t d, bool active, int lane, uint64_t lt_mask) {
+  if (active) __hip_atomic_fetch_or(&match[d], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const unsigned long long peers = __hip_atomic_load(&match[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  const uint32_t base = __hip_atomic_load(&cnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (active && (peers & lt_mask) == 0) {  // the lowest lane of the digit
+    __hip_atomic_store(&match[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_store(&cnt[d], base + (uint32_t)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  return base + (uint32_t)__popcll(peers & lt_mask);
+}
+
 // ---- scatter
 // IOTA: the payload is not read from memory: it is the row index (with bit 31 set when the row's validity bit is clear)
 struct IotaSrc {
@@ -131,11 +162,13 @@ struct IotaSrc {
   int64_t off;
 };
 // K: element type of the digit source (uint32 sort keys, or uint8 when the caller kept only the digit itself)
-template <int BITS, typename V, bool WRITE_KEYS, bool IOTA = false, typename K = uint32_t>
+// KO: element type of the keys written; `drop` low key bits are shifted out on the way (narrowing sort: once a digit has been
+// sorted on, the later passes no longer need it, so the key shrinks from 4 to 2 to 1 byte as the sort proceeds)
+template <int BITS, typename V, bool WRITE_KEYS, bool IOTA = false, typename K = uint32_t, typename KO = uint32_t>
 __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const K* __restrict__ keys_in, const V* __restrict__ vals_in,
-                                                              uint32_t* __restrict__ keys_out, V* __restrict__ vals_out, int64_t n,
+                                                              KO* __restrict__ keys_out, V* __restrict__ vals_out, int64_t n,
                                                               int shift, const uint32_t* __restrict__ offsets /* [tiles][R] */,
-                                                              int xcd_swizzle, IotaSrc iota = IotaSrc{nullptr, 0}) {
+                                                              int xcd_swizzle, IotaSrc iota = IotaSrc{nullptr, 0}, int drop = 0) {
   constexpr int R = 1 << BITS;
   constexpr int DPT = (R + kSortBlock - 1) / kSortBlock;
   __shared__ uint32_t cnt[kSortWaves][R];   // per-wave digit counters, later per-(wave,digit) local base
@@ -157,7 +190,15 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const K* __restric
   const int64_t tile_base = tile * kSortTile;
   const int tile_rows = (int)((n - tile_base) < kSortTile ? (n - tile_base) : kSortTile);
 
-  for (int d = tid; d < kSortWaves * R; d += kSortBlock) (&cnt[0][0])[d] = 0;
+  // match-any words of the ranking: they live in the value staging area, which is not used before the barrier after the ranking
+  // (wide digits with a 4-byte payload: own array)
+  constexpr bool kMatchAliased = sizeof(V) * kSortTile >= sizeof(unsigned long long) * kSortWaves * R;
+  __shared__ unsigned long long match_own[kMatchAliased ? 1 : kSortWaves * R];
+  unsigned long long* match = kMatchAliased ? reinterpret_cast<unsigned long long*>(svals) : match_own;
+  for (int d = tid; d < kSortWaves * R; d += kSortBlock) {
+    (&cnt[0][0])[d] = 0;
+    match[d] = 0;
+  }
   __syncthreads();
 
   uint32_t key[kSortItems];
@@ -181,12 +222,13 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const K* __restric
   // byte digits: one 16-byte load per lane, transposed through the (still unused) key staging area -- sixteen 1-byte loads per
   // lane cost as many memory instructions as sixteen 4-byte ones (measured: 4.3 ms per 1e9 rows for 5 GB moved)
   bool bytes_staged = false;
-  if constexpr (sizeof(K) == 1) {
+  if constexpr (sizeof(K) < 4) {
     if (tile_rows == kSortTile && (reinterpret_cast<uintptr_t>(keys_in) & 15) == 0) {
-      // a wave's 64 * kSortItems digit bytes = 4 * kSortItems lanes x 16 bytes
-      if (lane < 4 * kSortItems) {
-        const uint4 v = reinterpret_cast<const uint4*>(keys_in + tile_base + wave * (64 * kSortItems))[lane];
-        reinterpret_cast<uint4*>(skeys)[wave * (4 * kSortItems) + lane] = v;
+      // a wave's 64 * kSortItems narrow keys = 4 * kSortItems * sizeof(K) lanes x 16 bytes
+      constexpr int NV = 4 * kSortItems * (int)sizeof(K);
+      for (int j = lane; j < NV; j += 64) {
+        const uint4 v = reinterpret_cast<const uint4*>(keys_in + tile_base + wave * (64 * kSortItems))[j];
+        reinterpret_cast<uint4*>(skeys)[wave * NV + j] = v;
       }
       __builtin_amdgcn_wave_barrier();
       bytes_staged = true;
@@ -195,7 +237,7 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const K* __restric
 #pragma unroll
   for (int s = 0; s < kSortItems; ++s) {
     int r = wave * (64 * kSortItems) + s * 64 + lane;
-    if (bytes_staged) key[s] = reinterpret_cast<const uint8_t*>(skeys)[r];  // (byte r of the tile: waves are laid out back to back)
+    if (bytes_staged) key[s] = reinterpret_cast<const K*>(skeys)[r];  // (key r of the tile: waves are laid out back to back)
     else key[s] = r < tile_rows ? (uint32_t)keys_in[tile_base + r] : 0u;
   }
 #pragma unroll
@@ -203,23 +245,7 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const K* __restric
     int r = wave * (64 * kSortItems) + s * 64 + lane;
     bool active = r < tile_rows;
     uint32_t d = (key[s] >> shift) & (R - 1);
-    uint64_t peers = __ballot(active);
-#pragma unroll
-    for (int b = 0; b < BITS; ++b) {
-      bool bit = (d >> b) & 1;
-      uint64_t m = __ballot(bit);
-      peers &= bit ? m : ~m;
-    }
-    uint32_t base = 0;
-    if (active) {
-      int leader = __ffsll((unsigned long long)peers) - 1;
-      if (lane == leader) {
-        base = cnt[wave][d];
-        cnt[wave][d] = base + (uint32_t)__popcll(peers);
-      }
-      base = __shfl(base, leader, 64);
-      rank[s] = base + (uint32_t)__popcll(peers & lt_mask);
-    }
+    rank[s] = wave_match_rank(match + wave * R, cnt[wave], d, active, lane, lt_mask);
   }
   __syncthreads();
   // per digit: exclusive prefix over waves, tile totals, exclusive scan over digits
@@ -270,7 +296,7 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const K* __restric
     uint32_t k = skeys[p];
     uint32_t d = (k >> shift) & (R - 1);
     uint32_t g = gbase[d] + (uint32_t)p;
-    if (WRITE_KEYS) keys_out[g] = k;
+    if (WRITE_KEYS) keys_out[g] = (KO)(k >> drop);
     vals_out[g] = svals[p];
   }
 }
@@ -318,12 +344,12 @@ inline int radix_scan_dispatch(int bits, uint32_t* hist, int64_t ntiles, uint32_
   }
 }
 // per-tile digit histogram + column scan
-template <int BITS>
-int radix_offsets(const uint32_t* kin, int64_t n, int shift, uint32_t* hist, uint32_t* chunk_sum, bool big, hipStream_t st) {
+template <int BITS, typename K = uint32_t>
+int radix_offsets(const K* kin, int64_t n, int shift, uint32_t* hist, uint32_t* chunk_sum, bool big, hipStream_t st) {
   int64_t ntiles = ceil_div(n, kSortTile);
   {
     PDX_PROFILE(big ? "radix_hist" : "radix_hist_small", st);
-    hipLaunchKernelGGL((k_radix_hist<BITS>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, n, shift, hist);
+    hipLaunchKernelGGL((k_radix_hist<BITS, K>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, n, shift, hist);
   }
   return radix_scan_only<BITS>(hist, ntiles, chunk_sum, big, st);
 }
@@ -346,6 +372,47 @@ int radix_scatter_only(const K* kin, const V* vin, uint32_t* kout, V* vout, int6
                        swz, IotaSrc{nullptr, 0});
   PDX_LAUNCH_CHECK();
   return PDX_OK;
+}
+// narrowing pass (digit = the key's low BITS): the keys written are (key >> BITS) in the narrower type KO
+template <int BITS, typename V, typename K, typename KO>
+int radix_scatter_narrow(const K* kin, const V* vin, KO* kout, V* vout, int64_t n, const uint32_t* offsets, hipStream_t st) {
+  int64_t ntiles = ceil_div(n, kSortTile);
+  PDX_PROFILE(sizeof(V) == 8 ? "radix_scatter" : "radix_scatter_small", st);
+  if (kout)
+    hipLaunchKernelGGL((k_radix_scatter<BITS, V, true, false, K, KO>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, vin, kout, vout, n, 0, offsets,
+                       sort_xcd_swizzle(), IotaSrc{nullptr, 0}, BITS);
+  else
+    hipLaunchKernelGGL((k_radix_scatter<BITS, V, false, false, K, KO>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, vin, kout, vout, n, 0, offsets,
+                       sort_xcd_swizzle(), IotaSrc{nullptr, 0}, BITS);
+  PDX_LAUNCH_CHECK();
+  return PDX_OK;
+}
+// Starts of the runs of equal (digit, lower digits) after a stable scatter pass, without a pass over the rows.  The pass's INPUT is
+// sorted by the lower digits: combination c of them occupies input rows [prev_start[c], prev_start[c + 1]).  In the output, run
+// (d, c) starts at offsets[T][d] + (rows of tile T in front of the boundary that carry digit d), T = the tile holding input row
+// prev_start[c] -- one workgroup per c reads at most one tile of the pass's input keys.  out[(d << prev_bits) | c], out[last] = n.
+template <typename K>
+__global__ void __launch_bounds__(256) k_level_starts(const K* __restrict__ keys_in, int64_t n, const uint32_t* __restrict__ prev_start, int64_t ncombos,
+                                                      int prev_bits, int bits, const uint32_t* __restrict__ offsets /* [tiles][1 << bits] */,
+                                                      uint32_t* __restrict__ out) {
+  __shared__ uint32_t h[256];
+  const int R = 1 << bits, tid = threadIdx.x;
+  for (int64_t c = blockIdx.x; c < ncombos; c += gridDim.x) {
+    h[tid] = 0;
+    __syncthreads();
+    const int64_t P = prev_start[c];
+    if (P >= n) {  // nothing at or after this combination: its runs are empty and start where the next digit's rows begin
+      for (int d = tid; d < R; d += 256) out[((int64_t)d << prev_bits) | c] = d + 1 < R ? offsets[d + 1] : (uint32_t)n;
+    } else {
+      const int64_t T = P / kSortTile;
+      const int lim = (int)(P - T * kSortTile);
+      for (int i = tid; i < lim; i += 256) atomicAdd(&h[(uint32_t)keys_in[T * kSortTile + i] & (uint32_t)(R - 1)], 1u);
+      __syncthreads();
+      for (int d = tid; d < R; d += 256) out[((int64_t)d << prev_bits) | c] = offsets[T * R + d] + h[d];
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && tid == 0) out[(int64_t)R * ncombos] = (uint32_t)n;
 }
 // payload = row index (| null flag): no payload input stream
 template <int BITS, typename K = uint32_t>

@@ -672,10 +672,14 @@ def test_groupby_split_partition_special_keys(px, monkeypatch):
             assert np.array_equal(got[eok], exp[eok])
 
 
+@pytest.mark.parametrize("narrow", ["default", "0"])
 @pytest.mark.parametrize("nulls", [False, True])
-def test_groupby_fused_last_digit_and_skew_fallback(px, nulls):
+def test_groupby_fused_last_digit_and_skew_fallback(px, monkeypatch, nulls, narrow):
     """>= 2^22 rows with >= 2^16 slots: the fused last-digit reduce; a hot key makes one run longer than 2^19 rows, which takes the
-    fallback (one more sort pass + the classic reducers).  Both must equal the oracle bit for bit."""
+    fallback (one more sort pass + the classic reducers).  Both must equal the oracle bit for bit.  Values without nulls go through
+    the narrowing sort (4 -> 2 -> 1 byte keys, run / group starts from the scatter offsets) unless PDX_SORT_NARROW=0."""
+    if narrow != "default":
+        monkeypatch.setenv("PDX_SORT_NARROW", narrow)
     n = 5_000_011
     rng = np.random.default_rng(5)
     vals = orc.synth_vals(0, n) - 0.5
