@@ -27,8 +27,8 @@ template <int BITS, typename K = uint32_t>
 __global__ void __launch_bounds__(kSortBlock) k_radix_hist(const K* __restrict__ keys, int64_t n, int shift,
                                                            uint32_t* __restrict__ hist /* [tiles][1<<BITS] */) {
   constexpr int R = 1 << BITS;
-  constexpr int PER = 16 / (int)sizeof(K);                 // keys per 16-byte load
-  constexpr int NV = kSortItems / PER > 0 ? kSortItems / PER : 1;  // 16-byte loads per thread and tile (uint32: 4, uint16: 2, uint8: 1)
+  constexpr int NV4 = kSortTile * (int)sizeof(K) / 16;     // 16-byte loads per tile
+  constexpr int NV = (NV4 + kSortBlock - 1) / kSortBlock;  // ... per thread (uint32: 4, uint16: 2, uint8: 1 at 4096-row tiles)
   __shared__ uint32_t h[R];
   for (int d = threadIdx.x; d < R; d += kSortBlock) h[d] = 0;
   __syncthreads();
@@ -38,9 +38,11 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_hist(const K* __restrict__
     const uint4* k4 = reinterpret_cast<const uint4*>(keys + base);
     uint4 v[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = k4[k * kSortBlock + threadIdx.x];
+    for (int k = 0; k < NV; ++k)
+      if (NV4 % kSortBlock == 0 || k * kSortBlock + (int)threadIdx.x < NV4) v[k] = k4[k * kSortBlock + threadIdx.x];
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
+      if (!(NV4 % kSortBlock == 0 || k * kSortBlock + (int)threadIdx.x < NV4)) continue;
       const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
