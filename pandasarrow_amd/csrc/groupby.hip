@@ -13,12 +13,15 @@
 //      in ONE speculative pass together with the exact min/max, first rows through an LDS-resident "seen" bitmap
 //      (k_dense_slots*, k_sample_key_range).  General keys: hash -> stable partition of (key, row id) by the low 8 hash bits
 //      (k_hash_bucket_hist + radix scatter; a second level for very many groups) -> one workgroup per bucket builds the
-//      bucket's table region in LDS (k_hash_probe_lds; k_hash_probe_part is the memory-side fallback).  Tiny inputs: one
-//      global open-addressing table (k_hash_insert).
+//      bucket's table region in LDS (k_hash_probe_lds; skewed buckets: head rows there, the rest in chunks against an LDS
+//      snapshot, k_hash_probe_lds_tail; k_hash_probe_part is the memory-side fallback).  Tiny inputs: one global
+//      open-addressing table (k_hash_insert).
 //   2. occupied slots are compacted (slot order) and sorted by first_row -> dense gid in FIRST-OCCURRENCE order.
 //   3. per aggregated column: stable LSD radix sort of (slot, value) by slot (radix_sort.hpp) -> every group's values
 //      contiguous IN ROW ORDER.  For sum/mean/min/max/count (and variance) the last 6 slot bits are not sorted: k_flr_reduce
-//      ranks each 3072-row tile by them in LDS and replays Arrow's leaf / binary-counter recurrence with one lane per group.
+//      ranks each 2560-row tile by them in LDS and replays Arrow's leaf / binary-counter recurrence with one lane per group.
+//      Dense slots + values without nulls: narrowing sort (the key shrinks 4 -> 2 -> 1 byte as digits are consumed; run and
+//      group starts come from the scatter offsets, k_level_starts).
 //   4. classic reducers on fully sorted values (skewed keys, small inputs, resample, product/first/last): k_seg_reduce (one wave
 //      per group, 16-value leaves + shuffle tree + counter), k_seg_reduce_mid (batches of short groups per wave),
 //      k_seg_reduce_sub + k_seg_combine_big (many waves per long group), k_seg_reduce_nullable.

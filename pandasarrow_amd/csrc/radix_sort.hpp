@@ -7,8 +7,9 @@
 // One pass = three kernels, all HBM-streaming:
 //   k_radix_hist    : per 4096-row tile, LDS-atomic digit histogram                  (reads 4 B/row)
 //   column scan     : hist[tile][digit] -> global output offsets (3 tiny kernels)
-//   k_radix_scatter : per tile, stable rank by wave-wide match-any (ballot per digit bit) + per-wave LDS counters,
-//                     rows staged in LDS in output order, written back as contiguous runs (reads 12 B, writes 12 B/row)
+//   k_radix_scatter : per tile, stable rank by wave-wide match-any through LDS (wave_match_rank) + per-wave LDS counters,
+//                     rows staged in LDS in output order, written back as contiguous runs (reads 12 B, writes 12 B/row;
+//                     narrowing passes write (key >> digit bits) in a narrower type)
 // Wave = 64 lanes; a tile is 4 waves x 16 steps x 64 rows, so row order == (wave, step, lane) order.
 #pragma once
 #include <stdlib.h>

@@ -19,4 +19,13 @@ for name, col in (("no nulls", vals), ("5% nulls", vals_n)):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(3): step()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
-    print(f"{name}: {dt*1e3:.2f} ms/step  {n/dt/1e9:.2f} Grows/s")
+    print(f"{name}: {dt*1e3:.2f} ms/step  {n/dt/1e9:.2f} Grows/s", flush=True)
+    if os.environ.get("PDX_SKEW_KERNELS"):  # per-kernel device time of one more step (HIP events inside the library)
+        import ctypes as C
+        lib = L.load()
+        lib.pdx_profile_reset(); lib.pdx_profile_enable(1)
+        step(); torch.cuda.synchronize()
+        lib.pdx_profile_enable(0)
+        buf = C.create_string_buffer(1 << 16)
+        L.check(lib.pdx_profile_report(buf, len(buf)))
+        print("   " + "  ".join(f"{t}={float(ms):.2f}" for t, c, ms in (l.split() for l in buf.value.decode().splitlines()) if float(ms) >= 0.2), flush=True)
