@@ -22,7 +22,11 @@ constexpr int kSortBlock = 256;
 constexpr int kSortItems = 16;
 constexpr int kSortTile = kSortBlock * kSortItems;  // 4096 rows
 constexpr int kSortWaves = kSortBlock / 64;
-constexpr uint32_t kSortKeyMask = 0x7FFFFFFFu;      // bit 31 of a key is a caller flag and never sorted on
+constexpr uint32_t kSortKeyMask = 0x7FFFFFFFu;
+// the scatter kernel's own workgroup shape over the same 4096-row tile: more waves with fewer rows each hide more latency
+constexpr int kScatBlock = 256;
+constexpr int kScatItems = kSortTile / kScatBlock;
+constexpr int kScatWaves = kScatBlock / 64;      // bit 31 of a key is a caller flag and never sorted on
 
 template <int BITS, typename K = uint32_t>
 __global__ void __launch_bounds__(kSortBlock) k_radix_hist(const K* __restrict__ keys, int64_t n, int shift,
@@ -168,13 +172,13 @@ struct IotaSrc {
 // KO: element type of the keys written; `drop` low key bits are shifted out on the way (narrowing sort: once a digit has been
 // sorted on, the later passes no longer need it, so the key shrinks from 4 to 2 to 1 byte as the sort proceeds)
 template <int BITS, typename V, bool WRITE_KEYS, bool IOTA = false, typename K = uint32_t, typename KO = uint32_t>
-__global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const K* __restrict__ keys_in, const V* __restrict__ vals_in,
+__global__ void __launch_bounds__(kScatBlock) k_radix_scatter(const K* __restrict__ keys_in, const V* __restrict__ vals_in,
                                                               KO* __restrict__ keys_out, V* __restrict__ vals_out, int64_t n,
                                                               int shift, const uint32_t* __restrict__ offsets /* [tiles][R] */,
                                                               int xcd_swizzle, IotaSrc iota = IotaSrc{nullptr, 0}, int drop = 0) {
   constexpr int R = 1 << BITS;
-  constexpr int DPT = (R + kSortBlock - 1) / kSortBlock;
-  __shared__ uint32_t cnt[kSortWaves][R];   // per-wave digit counters, later per-(wave,digit) local base
+  constexpr int DPT = (R + kScatBlock - 1) / kScatBlock;
+  __shared__ uint32_t cnt[kScatWaves][R];   // per-wave digit counters, later per-(wave,digit) local base
   __shared__ uint32_t gbase[R];             // global offset minus local start, per digit
   __shared__ uint32_t skeys[kSortTile];
   __shared__ V svals[kSortTile];
@@ -195,24 +199,24 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const K* __restric
 
   // match-any words of the ranking: they live in the value staging area, which is not used before the barrier after the ranking
   // (wide digits with a 4-byte payload: own array)
-  constexpr bool kMatchAliased = sizeof(V) * kSortTile >= sizeof(unsigned long long) * kSortWaves * R;
-  __shared__ unsigned long long match_own[kMatchAliased ? 1 : kSortWaves * R];
+  constexpr bool kMatchAliased = sizeof(V) * kSortTile >= sizeof(unsigned long long) * kScatWaves * R;
+  __shared__ unsigned long long match_own[kMatchAliased ? 1 : kScatWaves * R];
   unsigned long long* match = kMatchAliased ? reinterpret_cast<unsigned long long*>(svals) : match_own;
-  for (int d = tid; d < kSortWaves * R; d += kSortBlock) {
+  for (int d = tid; d < kScatWaves * R; d += kScatBlock) {
     (&cnt[0][0])[d] = 0;
     match[d] = 0;
   }
   __syncthreads();
 
-  uint32_t key[kSortItems];
-  V val[kSortItems];
-  uint32_t rank[kSortItems];
+  uint32_t key[kScatItems];
+  V val[kScatItems];
+  uint32_t rank[kScatItems];
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   // each wave owns rows [wave*1024, wave*1024+1024) of the tile; step s covers 64 consecutive rows
   // payload loads first (independent of everything below), then the digits
 #pragma unroll
-  for (int s = 0; s < kSortItems; ++s) {
-    int r = wave * (64 * kSortItems) + s * 64 + lane;
+  for (int s = 0; s < kScatItems; ++s) {
+    int r = wave * (64 * kScatItems) + s * 64 + lane;
     if (r < tile_rows) {
       if constexpr (IOTA) {
         int64_t row = tile_base + r;
@@ -227,10 +231,10 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const K* __restric
   bool bytes_staged = false;
   if constexpr (sizeof(K) < 4) {
     if (tile_rows == kSortTile && (reinterpret_cast<uintptr_t>(keys_in) & 15) == 0) {
-      // a wave's 64 * kSortItems narrow keys = 4 * kSortItems * sizeof(K) lanes x 16 bytes
-      constexpr int NV = 4 * kSortItems * (int)sizeof(K);
+      // a wave's 64 * kScatItems narrow keys = 4 * kScatItems * sizeof(K) lanes x 16 bytes
+      constexpr int NV = 4 * kScatItems * (int)sizeof(K);
       for (int j = lane; j < NV; j += 64) {
-        const uint4 v = reinterpret_cast<const uint4*>(keys_in + tile_base + wave * (64 * kSortItems))[j];
+        const uint4 v = reinterpret_cast<const uint4*>(keys_in + tile_base + wave * (64 * kScatItems))[j];
         reinterpret_cast<uint4*>(skeys)[wave * NV + j] = v;
       }
       __builtin_amdgcn_wave_barrier();
@@ -238,14 +242,14 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const K* __restric
     }
   }
 #pragma unroll
-  for (int s = 0; s < kSortItems; ++s) {
-    int r = wave * (64 * kSortItems) + s * 64 + lane;
+  for (int s = 0; s < kScatItems; ++s) {
+    int r = wave * (64 * kScatItems) + s * 64 + lane;
     if (bytes_staged) key[s] = reinterpret_cast<const K*>(skeys)[r];  // (key r of the tile: waves are laid out back to back)
     else key[s] = r < tile_rows ? (uint32_t)keys_in[tile_base + r] : 0u;
   }
 #pragma unroll
-  for (int s = 0; s < kSortItems; ++s) {
-    int r = wave * (64 * kSortItems) + s * 64 + lane;
+  for (int s = 0; s < kScatItems; ++s) {
+    int r = wave * (64 * kScatItems) + s * 64 + lane;
     bool active = r < tile_rows;
     uint32_t d = (key[s] >> shift) & (R - 1);
     rank[s] = wave_match_rank(match + wave * R, cnt[wave], d, active, lane, lt_mask);
@@ -260,7 +264,7 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const K* __restric
     uint32_t acc = 0;
     if (d < R) {
 #pragma unroll
-      for (int w = 0; w < kSortWaves; ++w) {
+      for (int w = 0; w < kScatWaves; ++w) {
         uint32_t c = cnt[w][d];
         cnt[w][d] = acc;
         acc += c;
@@ -276,7 +280,7 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const K* __restric
     int d = tid * DPT + j;
     if (d < R) {
 #pragma unroll
-      for (int w = 0; w < kSortWaves; ++w) cnt[w][d] += pre;
+      for (int w = 0; w < kScatWaves; ++w) cnt[w][d] += pre;
       gbase[d] = offsets[tile * R + d] - pre;
     }
     pre += dsum[j];
@@ -284,8 +288,8 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const K* __restric
   __syncthreads();
   // stage rows in output order
 #pragma unroll
-  for (int s = 0; s < kSortItems; ++s) {
-    int r = wave * (64 * kSortItems) + s * 64 + lane;
+  for (int s = 0; s < kScatItems; ++s) {
+    int r = wave * (64 * kScatItems) + s * 64 + lane;
     if (r < tile_rows) {
       uint32_t d = (key[s] >> shift) & (R - 1);
       uint32_t p = cnt[wave][d] + rank[s];
@@ -295,7 +299,7 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const K* __restric
   }
   __syncthreads();
   // contiguous runs per digit -> coalesced stores
-  for (int p = tid; p < tile_rows; p += kSortBlock) {
+  for (int p = tid; p < tile_rows; p += kScatBlock) {
     uint32_t k = skeys[p];
     uint32_t d = (k >> shift) & (R - 1);
     uint32_t g = gbase[d] + (uint32_t)p;
@@ -368,10 +372,10 @@ int radix_scatter_only(const K* kin, const V* vin, uint32_t* kout, V* vout, int6
   PDX_PROFILE(sizeof(V) == 8 ? "radix_scatter" : "radix_scatter_small", st);
   const int swz = sort_xcd_swizzle();
   if (write_keys)
-    hipLaunchKernelGGL((k_radix_scatter<BITS, V, true, false, K>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, vin, kout, vout, n, shift, hist,
+    hipLaunchKernelGGL((k_radix_scatter<BITS, V, true, false, K>), dim3((unsigned)ntiles), dim3(kScatBlock), 0, st, kin, vin, kout, vout, n, shift, hist,
                        swz, IotaSrc{nullptr, 0});
   else
-    hipLaunchKernelGGL((k_radix_scatter<BITS, V, false, false, K>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, vin, kout, vout, n, shift, hist,
+    hipLaunchKernelGGL((k_radix_scatter<BITS, V, false, false, K>), dim3((unsigned)ntiles), dim3(kScatBlock), 0, st, kin, vin, kout, vout, n, shift, hist,
                        swz, IotaSrc{nullptr, 0});
   PDX_LAUNCH_CHECK();
   return PDX_OK;
@@ -382,10 +386,10 @@ int radix_scatter_narrow(const K* kin, const V* vin, KO* kout, V* vout, int64_t 
   int64_t ntiles = ceil_div(n, kSortTile);
   PDX_PROFILE(sizeof(V) == 8 ? "radix_scatter" : "radix_scatter_small", st);
   if (kout)
-    hipLaunchKernelGGL((k_radix_scatter<BITS, V, true, false, K, KO>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, vin, kout, vout, n, 0, offsets,
+    hipLaunchKernelGGL((k_radix_scatter<BITS, V, true, false, K, KO>), dim3((unsigned)ntiles), dim3(kScatBlock), 0, st, kin, vin, kout, vout, n, 0, offsets,
                        sort_xcd_swizzle(), IotaSrc{nullptr, 0}, BITS);
   else
-    hipLaunchKernelGGL((k_radix_scatter<BITS, V, false, false, K, KO>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, vin, kout, vout, n, 0, offsets,
+    hipLaunchKernelGGL((k_radix_scatter<BITS, V, false, false, K, KO>), dim3((unsigned)ntiles), dim3(kScatBlock), 0, st, kin, vin, kout, vout, n, 0, offsets,
                        sort_xcd_swizzle(), IotaSrc{nullptr, 0}, BITS);
   PDX_LAUNCH_CHECK();
   return PDX_OK;
@@ -425,10 +429,10 @@ int radix_scatter_iota(const K* kin, uint32_t* kout, uint32_t* rows_out, int64_t
   PDX_PROFILE("radix_scatter_rows", st);
   const int swz = sort_xcd_swizzle();
   if (write_keys)
-    hipLaunchKernelGGL((k_radix_scatter<BITS, uint32_t, true, true, K>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, (const uint32_t*)nullptr,
+    hipLaunchKernelGGL((k_radix_scatter<BITS, uint32_t, true, true, K>), dim3((unsigned)ntiles), dim3(kScatBlock), 0, st, kin, (const uint32_t*)nullptr,
                        kout, rows_out, n, shift, hist, swz, IotaSrc{valid, valid_off});
   else
-    hipLaunchKernelGGL((k_radix_scatter<BITS, uint32_t, false, true, K>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, (const uint32_t*)nullptr,
+    hipLaunchKernelGGL((k_radix_scatter<BITS, uint32_t, false, true, K>), dim3((unsigned)ntiles), dim3(kScatBlock), 0, st, kin, (const uint32_t*)nullptr,
                        kout, rows_out, n, shift, hist, swz, IotaSrc{valid, valid_off});
   PDX_LAUNCH_CHECK();
   return PDX_OK;
@@ -452,7 +456,6 @@ int radix_pass_dispatch(int bits, const uint32_t* kin, const V* vin, uint32_t* k
     case 8: return radix_pass<8, V>(kin, vin, kout, vout, n, shift, write_keys, hist, chunk_sum, st);
     case 9: return radix_pass<9, V>(kin, vin, kout, vout, n, shift, write_keys, hist, chunk_sum, st);
     case 10: return radix_pass<10, V>(kin, vin, kout, vout, n, shift, write_keys, hist, chunk_sum, st);
-    case 11: return radix_pass<11, V>(kin, vin, kout, vout, n, shift, write_keys, hist, chunk_sum, st);
     default: return fail(PDX_INVALID, "radix sort: unsupported digit width");
   }
 }
@@ -471,7 +474,7 @@ int radix_scatter_dispatch(int bits, const uint32_t* kin, const V* vin, uint32_t
 }
 inline int sort_max_bits() {
   int max_bits = 8;
-  if (const char* e = getenv("PDX_SORT_MAX_BITS")) max_bits = atoi(e) >= 4 && atoi(e) <= 11 ? atoi(e) : 8;
+  if (const char* e = getenv("PDX_SORT_MAX_BITS")) max_bits = atoi(e) >= 4 && atoi(e) <= 10 ? atoi(e) : 8;
   return max_bits;
 }
 

@@ -142,6 +142,62 @@ struct MaskEmit {
   }
 };
 
+// Streaming filter for columns without validity (and a mask whose null slots are dropped or absent): instead of gathering by
+// the compacted row ids, every column is read ONCE with coalesced 8-byte loads and the selected values are written in order
+// (within a wave step the selected lanes store to consecutive addresses; consecutive steps continue where the last one ended).
+// Same tile / wave layout as k_compact_count, whose scanned block counts give every workgroup its output offset.  A wave owns
+// 1024 consecutive rows: lane s < 16 loads the 64 selection bits of step s, the words are then broadcast (uniform registers).
+constexpr int kFilterCols = 2;  // columns per batch: 2 x 16 independent 8-byte loads per lane in flight
+__global__ void __launch_bounds__(kCompactBlock) k_filter_stream(GatherCols c, const uint8_t* __restrict__ mask, const uint8_t* __restrict__ mvalid,
+                                                                 int64_t off, int64_t n, const int64_t* __restrict__ block_offsets) {
+  __shared__ int wave_tot[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t base = (int64_t)blockIdx.x * kCompactTile + wave * (64 * kCompactItems);
+  uint64_t mine = 0;
+  if (lane < kCompactItems) {
+    const int64_t i0 = base + (int64_t)lane * 64;
+    if (i0 < n) {
+      mine = load_bits64(mask, off + i0, off + n);
+      if (mvalid) mine &= load_bits64(mvalid, off + i0, off + n);  // (DROP: a null mask slot selects nothing)
+    }
+  }
+  uint64_t sel[kCompactItems];
+  int cnt = 0;
+#pragma unroll
+  for (int s = 0; s < kCompactItems; ++s) {
+    sel[s] = __shfl(mine, s, 64);
+    cnt += __popcll(sel[s]);
+  }
+  if (lane == 0) wave_tot[wave] = cnt;
+  __syncthreads();
+  int64_t pos0 = block_offsets[blockIdx.x];
+  for (int w = 0; w < wave; ++w) pos0 += wave_tot[w];
+  const uint64_t lt = (1ull << lane) - 1ull;
+  for (int col0 = 0; col0 < c.ncols; col0 += kFilterCols) {
+    uint64_t v[kFilterCols][kCompactItems];
+#pragma unroll
+    for (int cc = 0; cc < kFilterCols; ++cc) {
+      const int col = col0 + cc;
+#pragma unroll
+      for (int s = 0; s < kCompactItems; ++s) {
+        const bool p = ((sel[s] >> lane) & 1) && col < c.ncols;
+        v[cc][s] = p ? c.src[col][base + s * 64 + lane] : 0ull;
+      }
+    }
+#pragma unroll
+    for (int cc = 0; cc < kFilterCols; ++cc) {
+      const int col = col0 + cc;
+      if (col >= c.ncols) break;
+      int64_t pos = pos0;
+#pragma unroll
+      for (int s = 0; s < kCompactItems; ++s) {
+        if ((sel[s] >> lane) & 1) c.dst[col][pos + __popcll(sel[s] & lt)] = v[cc][s];
+        pos += __popcll(sel[s]);
+      }
+    }
+  }
+}
+
 static int fill_cols(GatherCols& g, const pdx_column* cols, int ncols, pdx_mut_column* outs, int64_t out_len, int64_t src_len,
                      bool forced_nulls, const char* what) {
   if (ncols < 1 || ncols > kMaxCols) return fail(PDX_INVALID, std::string(what) + ": between 1 and 16 columns per call");
@@ -256,14 +312,46 @@ int pdx_filter(const pdx_column* cols, int ncols, const pdx_column* mask, int em
   Scratch s;
   const int64_t n = mask->length;
   const uint8_t* mvalid = validity_or_null(mask);
-  int64_t* sel = s.get<int64_t>((size_t)n);
-  PDX_SCRATCH_CHECK(s);
   MaskPred pred{static_cast<const uint8_t*>(mask->values), mvalid, mask->offset, emit_null};
-  MaskEmit emit{mvalid, mask->offset, sel};
+  // selected rows per tile, scanned: the output offset of every tile (and the output length)
   int64_t m = 0;
-  PDX_TRY(compact_indices(n, pred, emit, &m, s, st));
+  const int64_t nblocks = ceil_div(n, kCompactTile);
+  int64_t* counts = s.get<int64_t>((size_t)std::max<int64_t>(nblocks, 1));
+  int64_t* total = s.get<int64_t>(1);
+  PDX_SCRATCH_CHECK(s);
+  if (n > 0) {
+    hipLaunchKernelGGL((k_compact_count<MaskPred>), dim3((unsigned)nblocks), dim3(kCompactBlock), 0, st, n, pred, counts);
+    PDX_TRY((device_exclusive_scan<int64_t, SumOp>(counts, counts, nblocks, total, s, st)));
+    PDX_HIP(hipMemcpyAsync(&m, total, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    PDX_HIP(hipStreamSynchronize(st));
+  }
   GatherCols g;
   PDX_TRY(fill_cols(g, cols, ncols, outs, m, n, mvalid && emit_null, "pdx_filter"));
+  bool streaming = !(mvalid && emit_null);
+  for (int c = 0; c < ncols; ++c) streaming = streaming && !g.src_valid[c];
+  if (const char* e = getenv("PDX_FILTER_STREAM")) streaming = streaming && e[0] != '0';
+  if (streaming) {
+    // no validity anywhere: stream every column once (k_filter_stream); outputs are all valid
+    if (m > 0) {
+      hipLaunchKernelGGL(k_filter_stream, dim3((unsigned)nblocks), dim3(kCompactBlock), 0, st, g, static_cast<const uint8_t*>(mask->values), mvalid, mask->offset,
+                         n, counts);
+      PDX_LAUNCH_CHECK();
+    }
+    for (int c = 0; c < ncols; ++c) {
+      if (g.dst_valid[c] && m > 0) PDX_HIP(hipMemsetAsync(g.dst_valid[c], 0xFF, (size_t)((m + 7) / 8), st));
+      outs[c].length = m;
+      outs[c].null_count = 0;
+    }
+    PDX_HIP(hipStreamSynchronize(st));
+    return PDX_OK;
+  }
+  int64_t* sel = s.get<int64_t>((size_t)std::max<int64_t>(m, 1));
+  PDX_SCRATCH_CHECK(s);
+  MaskEmit emit{mvalid, mask->offset, sel};
+  if (n > 0) {
+    hipLaunchKernelGGL((k_compact_write<MaskPred, MaskEmit>), dim3((unsigned)nblocks), dim3(kCompactBlock), 0, st, n, pred, emit, counts);
+    PDX_LAUNCH_CHECK();
+  }
   long long bad = 0;
   return run_gather<int64_t>(g, sel, nullptr, 0, m, n, 0, outs, s, st, &bad);
 }

@@ -783,3 +783,29 @@ def test_groupby_hash_half_null_keys(px, monkeypatch, shape, head):
             assert_f64_bits(got, exp, valid=eok, what=str(kind))
         else:
             assert np.array_equal(got[eok], exp[eok])
+
+
+@pytest.mark.parametrize("stream", ["default", "0"])
+@pytest.mark.parametrize("n", [1, 63, 4097, 300_017])
+@pytest.mark.parametrize("sel", [0.0, 0.03, 0.5, 1.0])
+def test_filter_streaming_vs_gather(px, monkeypatch, n, sel, stream):
+    """columns without validity take the streaming filter (every column read once, selected values written in order); the
+    compacted-row-id gather (PDX_FILTER_STREAM=0) must give the same bytes.  Five columns (odd count: the kernel batches two),
+    sliced columns and mask (offsets), a mask with nulls under DROP, and all-false / all-true masks."""
+    if stream != "default":
+        monkeypatch.setenv("PDX_FILTER_STREAM", stream)
+    rng = np.random.default_rng(n + int(sel * 100))
+    cols_np = [rng.integers(-2**62, 2**62, n).astype(np.int64) if c % 2 else rng.standard_normal(n) for c in range(5)]
+    mask = rng.random(n) < sel
+    mvalid = rng.random(n) > 0.2
+    cols = [px.Column.from_numpy(a, offset=c) for c, a in enumerate(cols_np)]
+    for mv, emit in ((None, True), (mvalid, False)):
+        M = px.Column.from_numpy(mask, mv, offset=13)
+        keep = mask if mv is None else (mask & mv)
+        assert px.K.filter_count(M, emit) == int(keep.sum())
+        outs = px.K.filter(cols, M, emit)
+        for a, out in zip(cols_np, outs):
+            got, ok = out.to_numpy()
+            assert ok is None or ok.all()
+            assert out.null_count == 0
+            assert np.array_equal(got.view(np.uint64), a[keep].view(np.uint64))
