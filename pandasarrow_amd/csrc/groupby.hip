@@ -2164,7 +2164,7 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const KT* __restrict_
           const uint32_t d = sizeof(KT) == 4 ? ((key[q] & kSortKeyMask) >> low_bits) & (R - 1) : key[q] & (R - 1);
           const uint32_t p = cnt[wave][d] + rank[q] + d;
           svals[p] = val[q];
-          if (nullable) snull[p] = (uint8_t)(key[q] >> 31);
+          if (nullable) snull[p] = (uint8_t)(key[q] >> (8 * (int)sizeof(KT) - 1));
         }
       }
       if (t0 + kFlrTile < e) load_tile(t0 + kFlrTile);  // in flight while wave 0 replays this tile
@@ -3116,8 +3116,10 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
     // offsets (k_level_starts) instead of a search in the sorted slots.
     const SortPlan low_plan = make_sort_plan(low_bits, sort_max_bits());
     const bool narrow_env = [] { const char* e = getenv("PDX_SORT_NARROW"); return !(e && e[0] == '0'); }();
-    const bool narrow = flr && narrow_env && !gb->slot_part && !vvalid && gb->pass0_off && low_plan.npasses == 2 &&
-                        gb->slot_bits - low_plan.bits[0] <= 16 && low_plan.bits[0] <= 8 && low_plan.bits[1] <= 8 && eff_bits == gb->slot_bits;
+    // (values with nulls: the null flag rides in the narrow key's top bit, read from the validity bitmap by pass 0 itself)
+    const bool narrow = flr && narrow_env && !gb->slot_part && gb->pass0_off && low_plan.npasses == 2 &&
+                        gb->slot_bits - low_plan.bits[0] <= (vvalid ? 15 : 16) && low_plan.bits[0] <= 8 && low_plan.bits[1] <= 8 &&
+                        eff_bits == gb->slot_bits;
     const uint8_t* keys8 = nullptr;       // narrowing sort: the top digit of every partially sorted row
     bool sorted_done = false;             // narrowing sort, skewed keys: the classic path's inputs are already built
     uint32_t* ss_narrow = nullptr;
@@ -3141,7 +3143,9 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
         nchunk = s.get<uint32_t>((size_t)(nchunks + 1) << 8);
         PDX_SCRATCH_CHECK(s);
         int rcn = PDX_OK;
-#define NARROW_P0(B) rcn = radix_scatter_narrow<B, uint64_t, uint32_t, uint16_t>(gb->slot_of_row, vin, k16, nv0, n, gb->pass0_off, st)
+#define NARROW_P0(B)                                                                                                                         \
+  rcn = vvalid ? radix_scatter_narrow<B, uint64_t, uint32_t, uint16_t, true>(gb->slot_of_row, vin, k16, nv0, n, gb->pass0_off, st, vvalid, values->offset) \
+               : radix_scatter_narrow<B, uint64_t, uint32_t, uint16_t>(gb->slot_of_row, vin, k16, nv0, n, gb->pass0_off, st)
         switch (b0) {
           case 4: NARROW_P0(4); break;
           case 5: NARROW_P0(5); break;
@@ -3153,7 +3157,9 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
         PDX_TRY(rcn);
 #define NARROW_P1(B)                                                                    \
   rcn = radix_offsets<B, uint16_t>(k16, n, 0, nhist, nchunk, true, st);                  \
-  if (rcn == PDX_OK) rcn = radix_scatter_narrow<B, uint64_t, uint16_t, uint8_t>(k16, nv0, k8, nv1, n, nhist, st)
+  if (rcn == PDX_OK)                                                                    \
+    rcn = vvalid ? radix_scatter_narrow<B, uint64_t, uint16_t, uint8_t, true>(k16, nv0, k8, nv1, n, nhist, st) \
+                 : radix_scatter_narrow<B, uint64_t, uint16_t, uint8_t>(k16, nv0, k8, nv1, n, nhist, st)
         switch (b1) {
           case 4: NARROW_P1(4); break;
           case 5: NARROW_P1(5); break;
@@ -3191,7 +3197,14 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
         uint32_t* slot_start = s.get<uint32_t>(((size_t)nruns << kFlrBits) + 1);
         PDX_SCRATCH_CHECK(s);
         PDX_TRY((radix_offsets<kFlrBits, uint8_t>(k8, n, 0, nhist, nchunk, true, st)));
-        PDX_TRY((radix_scatter_narrow<kFlrBits, uint64_t, uint8_t, uint8_t>(k8, nv1, (uint8_t*)nullptr, nv0, n, nhist, st)));
+        if (vvalid) {  // the classic nullable reducers read the null flag from bit 31 of a 4-byte key per grouped row: write flags only
+          uint32_t* fkeys = s.get<uint32_t>((size_t)n);
+          PDX_SCRATCH_CHECK(s);
+          PDX_TRY((radix_scatter_narrow<kFlrBits, uint64_t, uint8_t, uint32_t, true>(k8, nv1, fkeys, nv0, n, nhist, st)));
+          keys_sorted = fkeys;
+        } else {
+          PDX_TRY((radix_scatter_narrow<kFlrBits, uint64_t, uint8_t, uint8_t>(k8, nv1, (uint8_t*)nullptr, nv0, n, nhist, st)));
+        }
         {
           PDX_PROFILE("seg_starts", st);
           hipLaunchKernelGGL((k_level_starts<uint8_t>), dim3((unsigned)std::min<int64_t>(nruns, 65536)), dim3(256), 0, st, k8, n, run_start, nruns, low_bits,
@@ -3210,7 +3223,7 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
 #define FLR_LAUNCH(TT, DD)                                                                                                                       \
   if (keys8)                                                                                                                                     \
     hipLaunchKernelGGL((k_flr_reduce<TT, DD, uint8_t>), dim3(grid), dim3(kSortBlock), 0, st, keys8, reinterpret_cast<const TT*>(vs), run_start, nruns, \
-                       low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, 0, sqmean);                                              \
+                       low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, vvalid ? 1 : 0, sqmean);                                 \
   else                                                                                                                                           \
     hipLaunchKernelGGL((k_flr_reduce<TT, DD>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const TT*>(vs), run_start, nruns, \
                        low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, vvalid ? 1 : 0, sqmean)

@@ -171,7 +171,10 @@ struct IotaSrc {
 // K: element type of the digit source (uint32 sort keys, or uint8 when the caller kept only the digit itself)
 // KO: element type of the keys written; `drop` low key bits are shifted out on the way (narrowing sort: once a digit has been
 // sorted on, the later passes no longer need it, so the key shrinks from 4 to 2 to 1 byte as the sort proceeds)
-template <int BITS, typename V, bool WRITE_KEYS, bool IOTA = false, typename K = uint32_t, typename KO = uint32_t>
+// FLAGS: the top bit of a key (of K and of KO alike) is the row's null flag, carried from type to type; in a FLAGS pass over
+// 4-byte keys with iota.valid set, the flag is not in the key yet: it is read from that validity bitmap here (one 64-bit window per
+// wave step, loaded by lane `step` and broadcast), which saves the separate pass that used to OR it into the keys.
+template <int BITS, typename V, bool WRITE_KEYS, bool IOTA = false, typename K = uint32_t, typename KO = uint32_t, bool FLAGS = false>
 __global__ void __launch_bounds__(kScatBlock) k_radix_scatter(const K* __restrict__ keys_in, const V* __restrict__ vals_in,
                                                               KO* __restrict__ keys_out, V* __restrict__ vals_out, int64_t n,
                                                               int shift, const uint32_t* __restrict__ offsets /* [tiles][R] */,
@@ -212,6 +215,21 @@ __global__ void __launch_bounds__(kScatBlock) k_radix_scatter(const K* __restric
   V val[kScatItems];
   uint32_t rank[kScatItems];
   const uint64_t lt_mask = (1ull << lane) - 1ull;
+  // validity window of step `lane` (FLAGS pass over 4-byte keys): issued first, one aligned 8-byte load where the bitmap allows
+  uint64_t vword = ~0ull;
+  if constexpr (FLAGS && !IOTA && sizeof(K) == 4) {
+    static_assert(kScatItems <= 64, "one validity window per lane");
+    if (iota.valid) {
+      const int64_t row0 = tile_base + wave * (64 * kScatItems) + (int64_t)lane * 64;
+      if (lane < kScatItems && row0 < n) {
+        const int64_t bit0 = iota.off + row0;
+        if ((bit0 & 63) == 0 && row0 + 64 <= n && (reinterpret_cast<uintptr_t>(iota.valid) & 7) == 0)
+          vword = reinterpret_cast<const uint64_t*>(iota.valid)[bit0 >> 6];
+        else
+          vword = load_bits64(iota.valid, bit0, iota.off + n);
+      }
+    }
+  }
   // each wave owns rows [wave*1024, wave*1024+1024) of the tile; step s covers 64 consecutive rows
   // payload loads first (independent of everything below), then the digits
 #pragma unroll
@@ -246,6 +264,15 @@ __global__ void __launch_bounds__(kScatBlock) k_radix_scatter(const K* __restric
     int r = wave * (64 * kScatItems) + s * 64 + lane;
     if (bytes_staged) key[s] = reinterpret_cast<const K*>(skeys)[r];  // (key r of the tile: waves are laid out back to back)
     else key[s] = r < tile_rows ? (uint32_t)keys_in[tile_base + r] : 0u;
+  }
+  if constexpr (FLAGS && !IOTA && sizeof(K) == 4) {
+    if (iota.valid) {
+#pragma unroll
+      for (int s = 0; s < kScatItems; ++s) {
+        const uint64_t w = __shfl(vword, s, 64);
+        key[s] = (key[s] & kSortKeyMask) | (((w >> lane) & 1) ? 0u : 0x80000000u);
+      }
+    }
   }
 #pragma unroll
   for (int s = 0; s < kScatItems; ++s) {
@@ -303,7 +330,14 @@ __global__ void __launch_bounds__(kScatBlock) k_radix_scatter(const K* __restric
     uint32_t k = skeys[p];
     uint32_t d = (k >> shift) & (R - 1);
     uint32_t g = gbase[d] + (uint32_t)p;
-    if (WRITE_KEYS) keys_out[g] = (KO)(k >> drop);
+    if (WRITE_KEYS) {
+      if constexpr (FLAGS) {
+        constexpr int FI = 8 * (int)sizeof(K) - 1, FO = 8 * (int)sizeof(KO) - 1;
+        keys_out[g] = (KO)(((k & ((1u << FI) - 1u)) >> drop) | ((k >> FI) << FO));
+      } else {
+        keys_out[g] = (KO)(k >> drop);
+      }
+    }
     vals_out[g] = svals[p];
   }
 }
@@ -381,16 +415,18 @@ int radix_scatter_only(const K* kin, const V* vin, uint32_t* kout, V* vout, int6
   return PDX_OK;
 }
 // narrowing pass (digit = the key's low BITS): the keys written are (key >> BITS) in the narrower type KO
-template <int BITS, typename V, typename K, typename KO>
-int radix_scatter_narrow(const K* kin, const V* vin, KO* kout, V* vout, int64_t n, const uint32_t* offsets, hipStream_t st) {
+// FLAGS: the keys' top bit is the null flag (see k_radix_scatter); `valid`/`valid_off`: where a pass over 4-byte keys reads it
+template <int BITS, typename V, typename K, typename KO, bool FLAGS = false>
+int radix_scatter_narrow(const K* kin, const V* vin, KO* kout, V* vout, int64_t n, const uint32_t* offsets, hipStream_t st,
+                         const uint8_t* valid = nullptr, int64_t valid_off = 0) {
   int64_t ntiles = ceil_div(n, kSortTile);
   PDX_PROFILE(sizeof(V) == 8 ? "radix_scatter" : "radix_scatter_small", st);
   if (kout)
-    hipLaunchKernelGGL((k_radix_scatter<BITS, V, true, false, K, KO>), dim3((unsigned)ntiles), dim3(kScatBlock), 0, st, kin, vin, kout, vout, n, 0, offsets,
-                       sort_xcd_swizzle(), IotaSrc{nullptr, 0}, BITS);
+    hipLaunchKernelGGL((k_radix_scatter<BITS, V, true, false, K, KO, FLAGS>), dim3((unsigned)ntiles), dim3(kScatBlock), 0, st, kin, vin, kout, vout, n, 0,
+                       offsets, sort_xcd_swizzle(), IotaSrc{valid, valid_off}, BITS);
   else
-    hipLaunchKernelGGL((k_radix_scatter<BITS, V, false, false, K, KO>), dim3((unsigned)ntiles), dim3(kScatBlock), 0, st, kin, vin, kout, vout, n, 0, offsets,
-                       sort_xcd_swizzle(), IotaSrc{nullptr, 0}, BITS);
+    hipLaunchKernelGGL((k_radix_scatter<BITS, V, false, false, K, KO, FLAGS>), dim3((unsigned)ntiles), dim3(kScatBlock), 0, st, kin, vin, kout, vout, n, 0,
+                       offsets, sort_xcd_swizzle(), IotaSrc{valid, valid_off}, BITS);
   PDX_LAUNCH_CHECK();
   return PDX_OK;
 }
