@@ -2043,8 +2043,24 @@ __device__ __forceinline__ void flr_counter_push(double (*csum)[1 << kFlrBits], 
   csum[cur][lane] = v;
   root = cur > root ? cur : root;
 }
+// Segmented "run of valid rows" state of a chunk of staged rows, packed in 32 bits, for the nullable leaf phase: bits 0-11 valid rows at
+// the chunk's end since its last break, bit 12 the chunk holds a break (a null row or a group boundary), bits 13-14 the kind of its
+// last break (1 null, 2 group boundary), bits 16-22 group boundaries in the chunk.  Associative, earlier operand first.
+struct RunStateOp {
+  template <typename U>
+  __device__ static U identity() { return U(0); }
+  __device__ uint32_t operator()(uint32_t a, uint32_t b) const {
+    const uint32_t nh = ((a >> 16) + (b >> 16)) << 16;
+    if (b & 0x1000u) return (b & 0xFFFFu) | nh;
+    return (((a & 0xFFFu) + (b & 0xFFFu)) & 0xFFFu) | (a & 0x7000u) | nh;
+  }
+};
 // KT: uint32 slots (top digit at bit low_bits, bit 31 = the value's null flag) or, after a narrowing sort, the top digit alone in a byte
-template <typename T, bool DENSE_PW, typename KT = uint32_t>
+// NULL_PW (host: nullable values, sum / mean / count only): leaves restart at every null, so they are data dependent; a segmented
+// scan over the staged rows finds every leaf's first row, ONE THREAD PER LEAF sums it (<= 16 rows) and leaves the sum and a marker
+// byte in place, then one lane per group walks its leaves in order for the counter pushes (instead of one lane per group adding
+// up all of its rows one by one).  Bit-exact, but not faster yet (11.3 vs 10.7 ms per 1e9 rows at 5 % nulls): opt-in.
+template <typename T, bool DENSE_PW, typename KT = uint32_t, bool NULL_PW = false>
 __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const KT* __restrict__ keys, const T* __restrict__ vals,
                                                            const uint32_t* __restrict__ run_start, int64_t nruns, int low_bits,
                                                            const uint32_t* __restrict__ gid_of_slot, SegOut out, uint8_t* __restrict__ ok,
@@ -2067,6 +2083,7 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const KT* __restrict_
   __shared__ double open_acc[R];
   __shared__ double mu_s[R];
   __shared__ int lp[R + 1];
+  __shared__ uint32_t run_smem[8];
   double* leafsum = reinterpret_cast<double*>(snull);  // (the null flags are unused on this path: room for (tile + 64) / 8 leaf sums)
   constexpr bool dense_pw = DENSE_PW;  // host: want_pw && !want_mm && !want_is && !nullable (a separate instantiation: fewer live registers)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2140,6 +2157,16 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const KT* __restrict_
         for (int w = 0; w < kSortWaves; ++w) cnt[w][tid] += ex;
         dstart[tid] = ex;
         if (tid == R - 1) dstart[R] = inc;
+        if (NULL_PW) {
+          snull[inc + tid] = 2;  // the unused slot behind this group's staged rows: a group boundary for the scan below
+          const int c = (int)tot;
+          if (sqdev_mean && c > 0 && !mu_known) {
+            mu = sqdev_mean[gid_of_slot[((uint32_t)lane << low_bits) | (uint32_t)run]];
+            mu_s[lane] = mu;
+            mu_known = true;
+          }
+          nrows += c;
+        }
         if (dense_pw) {
           // leaves touched by this tile, per group: the first one may continue the open leaf, the last one may stay open
           const int c = (int)tot;
@@ -2207,6 +2234,127 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const KT* __restrict_
             pos = rem;
             acc = rem ? leafsum[lp[lane] + nl - 1] : 0.0;
           }
+        }
+      } else if (NULL_PW) {
+        constexpr int CH = (kFlrTile + R + kSortBlock - 1) / kSortBlock;  // staged slots per thread
+        const int L = rows + R;                                            // staged slots of this tile (rows + one boundary per group)
+        uint8_t f[CH];
+        uint32_t st = 0;
+        {
+          uint32_t tl = 0, hb = 0, lt = 0, nh = 0;
+#pragma unroll
+          for (int k = 0; k < CH; ++k) {
+            const int pp = tid * CH + k;
+            f[k] = pp < L ? snull[pp] : (uint8_t)2;
+            if (f[k]) {
+              tl = 0;
+              hb = 1;
+              lt = f[k];
+              nh += f[k] == 2;
+            } else {
+              ++tl;
+            }
+          }
+          st = tl | (hb << 12) | (lt << 13) | (nh << 16);
+        }
+        uint32_t tot_unused;
+        const uint32_t ex = block_exclusive_scan(st, RunStateOp(), &tot_unused, run_smem);  // (two barriers: every flag byte has been read)
+        {
+          // first rows of leaves in this thread's chunk (bit k of `starts`) and group boundaries (bit k of `holes`): registers only.
+          // The leaves themselves are summed in a second loop over the set bits, so a wave runs the 16-row loop once per leaf of its
+          // busiest lane and not once per chunk slot
+          int run_idx = (int)(ex & 0xFFFu);
+          const int d0 = (int)(ex >> 16);
+          int d = d0;
+          const int type0 = (ex & 0x1000u) ? (int)((ex >> 13) & 3u) : 2;  // nothing in front: slot 0 starts group 0
+          int q_cur = (type0 == 2 && d < R) ? open_pos[d] : 0;
+          uint32_t starts = 0, holes = 0;
+#pragma unroll
+          for (int k = 0; k < CH; ++k) {
+            if (f[k] == 0) {
+              if (run_idx == 0 || ((q_cur + run_idx) & 15) == 0) starts |= 1u << k;
+              ++run_idx;
+            } else {
+              run_idx = 0;
+              if (f[k] == 2) {
+                holes |= 1u << k;
+                ++d;
+                q_cur = d < R ? open_pos[d] : 0;
+              } else {
+                q_cur = 0;
+              }
+            }
+          }
+          while (starts) {
+            const int k = __ffs((int)starts) - 1;
+            starts &= starts - 1;
+            const int pp = tid * CH + k;
+            const int dd = d0 + __popc(holes & ((1u << k) - 1u));
+            // the open leaf of the previous tile continues only on the group's first staged row
+            const int q0 = (dd < R && pp == (int)dstart[dd] + dd) ? open_pos[dd] : 0;
+            double a = q0 > 0 ? open_acc[dd] : 0.0;
+            const double m = sqdev_mean ? mu_s[dd < R ? dd : 0] : 0.0;
+            // all 16 flag bytes and values are requested before any is looked at (a loop that stops at the first null would pay
+            // two dependent LDS round trips per row); slots behind the leaf's end may already hold another leaf's marker or sum:
+            // they are never used (the first nonzero flag inside the leaf's 16 - q0 slots is an untouched null or boundary)
+            uint8_t ffl[16];
+            double xs[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              const int pj = pp + j < L ? pp + j : L - 1;
+              ffl[j] = j == 0 ? (uint8_t)0 : (pp + j < L ? snull[pj] : (uint8_t)2);
+              xs[j] = seg_to_f64(svals[pj]);
+            }
+            int count = 16 - q0;
+            uint8_t term = 0;
+#pragma unroll
+            for (int j = 15; j >= 1; --j)
+              if (j < 16 - q0 && ffl[j]) {
+                count = j;
+                term = ffl[j];
+              }
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+              if (j < count) a += sqdev_mean ? flr_sqdev(xs[j], m) : xs[j];
+            const bool closed = q0 + count == 16 || term == 1;  // full, or cut by a null row
+            reinterpret_cast<double*>(svals)[pp] = a;
+            snull[pp] = (uint8_t)(0x80 | (closed ? 0x40 : 0) | (q0 + count - 1));
+          }
+        }
+        __syncthreads();
+        if (wave == 0) {
+          const int i0 = (int)dstart[lane] + lane, i1 = (int)dstart[lane + 1] + lane;
+          // Pass A: walk the group's leaves in row order; finished leaves are written back compactly over the slots already consumed
+          // (every step consumes at least one slot and emits at most one leaf).  The pushes come afterwards, as in the literal replay.
+          int nleaf = 0;
+          for (int ip = i0; ip < i1;) {
+            const uint8_t b = snull[ip];
+            if (b & 0x80) {
+              const int fill = (b & 15) + 1;
+              const int cnt_rows = fill - (ip == i0 ? pos : 0);
+              const double sum = reinterpret_cast<const double*>(svals)[ip];
+              nvalid += cnt_rows;
+              if (b & 0x40) {
+                reinterpret_cast<double*>(svals)[i0 + nleaf++] = sum;
+                pos = 0;
+              } else {
+                pos = fill;
+                acc = sum;
+              }
+              ip += cnt_rows;
+            } else {  // a null row: it closes the leaf left open by the previous tile (only possible on the group's first row)
+              if (pos > 0) {
+                reinterpret_cast<double*>(svals)[i0 + nleaf++] = acc;
+                pos = 0;
+              }
+              ++ip;
+            }
+          }
+          if (i1 > i0) {
+            open_pos[lane] = pos;
+            open_acc[lane] = acc;
+          }
+          for (int j = 0; j < nleaf; ++j) flr_counter_push(csum, lane, cmask, root, reinterpret_cast<const double*>(svals)[i0 + j]);
         }
       } else if (!dense_pw && wave == 0) {
         const int i0 = (int)dstart[lane] + lane, i1 = (int)dstart[lane + 1] + lane;
@@ -3220,8 +3368,17 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
           PDX_PROFILE("fused_last_digit_reduce", st);
           const int grid = (int)std::min<int64_t>(nruns, (int64_t)kCUs * 24);
           const bool dense = pw && !mm && !is && !vvalid;
+          // (values with nulls, sum / mean / count: the thread-per-leaf form is opt-in, PDX_FLR_NULL_PW=1 -- measured 11.3 ms against
+          //  10.7 ms of the literal per-lane replay at 5 % nulls: its per-group walk over the leaf markers is as serial as the replay)
+          const bool nullpw = pw && !mm && !is && vvalid && [] { const char* e = getenv("PDX_FLR_NULL_PW"); return e && e[0] == '1'; }();
 #define FLR_LAUNCH(TT, DD)                                                                                                                       \
-  if (keys8)                                                                                                                                     \
+  if (keys8 && nullpw)                                                                                                                           \
+    hipLaunchKernelGGL((k_flr_reduce<TT, false, uint8_t, true>), dim3(grid), dim3(kSortBlock), 0, st, keys8, reinterpret_cast<const TT*>(vs), run_start, \
+                       nruns, low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, 1, sqmean);                                       \
+  else if (nullpw)                                                                                                                               \
+    hipLaunchKernelGGL((k_flr_reduce<TT, false, uint32_t, true>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const TT*>(vs),   \
+                       run_start, nruns, low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, 1, sqmean);                            \
+  else if (keys8)                                                                                                                                \
     hipLaunchKernelGGL((k_flr_reduce<TT, DD, uint8_t>), dim3(grid), dim3(kSortBlock), 0, st, keys8, reinterpret_cast<const TT*>(vs), run_start, nruns, \
                        low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, vvalid ? 1 : 0, sqmean);                                 \
   else                                                                                                                                           \

@@ -690,15 +690,63 @@ def test_groupby_fused_last_digit_and_skew_fallback(px, monkeypatch, nulls, narr
             keys[rng.random(n) < 0.3] = 4242
         gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys))
         ids, uniq, _, _ = orc.group_ids(keys)
-        outs = gb.agg(px.Column.from_numpy(vals, vvalid), [0, 1, 4, 2, 3])
-        for kind, out in zip([0, 1, 4, 2, 3], outs):
-            got, ok = out.to_numpy()
-            exp, eok = orc.groupby_agg(kind, ids, len(uniq), vals, vvalid, nthreads=8)
-            assert ok is None or np.array_equal(ok, eok), (hot, kind)
-            if exp.dtype == np.float64:
-                assert_f64_bits(got, exp, valid=eok, what=f"hot={hot} kind={kind}")
-            else:
-                assert np.array_equal(got[eok], exp[eok]), (hot, kind)
+        # all five kinds (min / max force the literal replay), then sum / mean / count alone (dense thread-per-leaf form / literal
+        # replay of nullable values), then the opt-in nullable thread-per-leaf form
+        for kinds, env in (([0, 1, 4, 2, 3], None), ([0, 1, 4], None), ([0, 1, 4], "1")):
+            if env is not None:
+                if not nulls:
+                    continue
+                monkeypatch.setenv("PDX_FLR_NULL_PW", env)
+            outs = gb.agg(px.Column.from_numpy(vals, vvalid), kinds)
+            monkeypatch.delenv("PDX_FLR_NULL_PW", raising=False)
+            for kind, out in zip(kinds, outs):
+                got, ok = out.to_numpy()
+                exp, eok = orc.groupby_agg(kind, ids, len(uniq), vals, vvalid, nthreads=8)
+                assert ok is None or np.array_equal(ok, eok), (hot, kind)
+                if exp.dtype == np.float64:
+                    assert_f64_bits(got, exp, valid=eok, what=f"hot={hot} kind={kind} kinds={kinds}")
+                else:
+                    assert np.array_equal(got[eok], exp[eok]), (hot, kind)
+
+
+@pytest.mark.parametrize("null_pw", ["0", "1"])
+@pytest.mark.parametrize("pattern", ["alternate", "runs", "int_mean", "variance"])
+def test_groupby_fused_last_digit_nullable_leaf_patterns(px, monkeypatch, pattern, null_pw):
+    """null patterns for the thread-per-leaf nullable form of the fused last-digit kernel: runs of valid rows of every length
+    1..40 between nulls (leaves cut by nulls, by the 16-value limit and by tile ends), nulls on a group's first rows, an int64 column
+    (mean = pairwise sum of the values as doubles) and variance (two fused passes, the second on squared deviations)"""
+    monkeypatch.setenv("PDX_FLR_NULL_PW", null_pw)  # 1: thread-per-leaf form (opt-in), 0: literal per-lane replay
+    n = 4_600_007
+    rng = np.random.default_rng(99)
+    keys = orc.synth_keys(0, n, 180_000)
+    ids, uniq, _, _ = orc.group_ids(keys)
+    if pattern == "alternate":
+        vvalid = (np.arange(n) % 3 != 0)
+    else:
+        gaps = rng.integers(1, 41, n // 8)
+        cut = np.cumsum(gaps)
+        vvalid = np.ones(n, dtype=bool)
+        vvalid[cut[cut < n]] = False
+        vvalid[: 200_000] = rng.random(200_000) > 0.7  # mostly null head: groups whose first rows are null
+    if pattern == "int_mean":
+        vals = rng.integers(-10**12, 10**12, n).astype(np.int64)
+        kinds = [1, 4]
+    elif pattern == "variance":
+        vals = orc.synth_vals(0, n) * 1000.0 - 500.0
+        kinds = [5, 1]
+    else:
+        vals = orc.synth_vals(0, n) - 0.5
+        kinds = [0, 1, 4]
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys))
+    outs = gb.agg(px.Column.from_numpy(vals, vvalid), kinds)
+    for kind, out in zip(kinds, outs):
+        got, ok = out.to_numpy()
+        exp, eok = orc.groupby_agg(kind, ids, len(uniq), vals, vvalid, nthreads=8)
+        assert ok is None or np.array_equal(ok, eok), kind
+        if exp.dtype == np.float64:
+            assert_f64_bits(got, exp, valid=eok, what=f"{pattern} kind={kind}")
+        else:
+            assert np.array_equal(got[eok], exp[eok]), kind
 
 
 def test_groupby_fused_last_digit_many_short_leaves(px):
