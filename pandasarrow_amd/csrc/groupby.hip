@@ -1916,6 +1916,64 @@ static int sort_values_by_slot(pdx_groupby* gb, const uint64_t* vals, const uint
   return radix_sort_pairs<uint64_t>(kin, vals, k0, v0, k1, v1, n, gb->slot_bits - skip_top_bits, keys_sorted, vals_sorted, true, s, st, 0, gb->pass0_off);
 }
 
+
+// One pass of the narrowing sort, digit = the low `bits` of K (the digit width is a template parameter of the kernels).  offsets != nullptr:
+// the scanned per-tile offsets of this pass exist already (pass 0: fused into the slot kernel); otherwise they are built in hist.
+template <typename K, typename KO, bool FLAGS = false>
+static int narrow_pass(int bits, const K* kin, const uint64_t* vin, KO* kout, uint64_t* vout, int64_t n, const uint32_t* offsets, uint32_t* hist,
+                       uint32_t* chunk_sum, hipStream_t st, const uint8_t* valid = nullptr, int64_t valid_off = 0) {
+#define NARROW_PASS(B)                                                                                   \
+  {                                                                                                      \
+    if (!offsets) PDX_TRY((radix_offsets<B, K>(kin, n, 0, hist, chunk_sum, true, st)));                    \
+    return radix_scatter_narrow<B, uint64_t, K, KO, FLAGS>(kin, vin, kout, vout, n, offsets ? offsets : hist, st, valid, valid_off); \
+  }
+  switch (bits) {
+    case 4: NARROW_PASS(4)
+    case 5: NARROW_PASS(5)
+    case 6: NARROW_PASS(6)
+    case 7: NARROW_PASS(7)
+    case 8: NARROW_PASS(8)
+    default: return fail(PDX_INVALID, "narrowing sort: unsupported digit width");
+  }
+#undef NARROW_PASS
+}
+// Full stable sort of the values by dense slot with narrowing keys (three passes: 4 -> 2 -> 1 byte keys -> none) and every group's
+// offset from the scatter offsets (two levels of k_level_starts): 22 + 19 + 17 B/row instead of 3 x 24 + 2 x 4 (histograms) and no
+// search in sorted slots.  Returns PDX_OK with *done = false when the handle's layout does not fit (the caller takes the classic sort).
+template <typename Alloc>
+static int sort_values_narrow_full(pdx_groupby* gb, const uint64_t* vin, Alloc&& alloc, Scratch& s, hipStream_t st, const uint64_t** vals_sorted,
+                                   uint32_t* seg_start_out, bool* done) {
+  *done = false;
+  const int64_t n = gb->n, G = gb->G;
+  const SortPlan plan = make_sort_plan(gb->slot_bits, sort_max_bits());
+  const bool env_ok = [] { const char* e = getenv("PDX_SORT_NARROW"); return !(e && e[0] == '0'); }();
+  if (!env_ok || gb->slot_part || !gb->pass0_off || !gb->slot_of_row || plan.npasses != 3 || n < ((int64_t)1 << 22)) return PDX_OK;
+  const int b0 = plan.bits[0], b1 = plan.bits[1], b2 = plan.bits[2];
+  if (b0 > 8 || b1 > 8 || b2 > 8 || gb->slot_bits - b0 > 16 || b2 > 8 || gb->slot_bits != b0 + b1 + b2) return PDX_OK;
+  const int64_t ntiles = ceil_div(n, kSortTile), nchunks = ceil_div(ntiles, kColChunk);
+  uint16_t* k16 = s.get<uint16_t>((size_t)n);
+  uint8_t* k8 = s.get<uint8_t>((size_t)n);
+  uint32_t* hist = s.get<uint32_t>((size_t)ntiles << 8);
+  uint32_t* chunk = s.get<uint32_t>((size_t)(nchunks + 1) << 8);
+  uint32_t* starts1 = s.get<uint32_t>(((size_t)1 << (b0 + b1)) + 1);
+  uint32_t* slot_start = s.get<uint32_t>(((size_t)1 << gb->slot_bits) + 1);
+  PDX_SCRATCH_CHECK(s);
+  uint64_t* v0 = static_cast<uint64_t*>(alloc((size_t)n * 8));
+  uint64_t* v1 = static_cast<uint64_t*>(alloc((size_t)n * 8));
+  if (!v0 || !v1) return PDX_OOM;
+  PDX_TRY((narrow_pass<uint32_t, uint16_t>(b0, gb->slot_of_row, vin, k16, v0, n, gb->pass0_off, hist, chunk, st)));
+  PDX_TRY((narrow_pass<uint16_t, uint8_t>(b1, k16, v0, k8, v1, n, nullptr, hist, chunk, st)));
+  hipLaunchKernelGGL((k_level_starts<uint16_t>), dim3(1u << b0), dim3(256), 0, st, k16, n, gb->pass0_off, (int64_t)1 << b0, b0, b1, hist, starts1);
+  PDX_TRY((narrow_pass<uint8_t, uint8_t>(b2, k8, v1, (uint8_t*)nullptr, v0, n, nullptr, hist, chunk, st)));
+  hipLaunchKernelGGL((k_level_starts<uint8_t>), dim3((unsigned)std::min<int64_t>((int64_t)1 << (b0 + b1), 65536)), dim3(256), 0, st, k8, n, starts1,
+                     (int64_t)1 << (b0 + b1), b0 + b1, b2, hist, slot_start);
+  hipLaunchKernelGGL(k_seg_starts_from_slots, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, slot_start, n, gb->occ_slot, G, seg_start_out);
+  PDX_LAUNCH_CHECK();
+  *vals_sorted = v0;
+  *done = true;
+  return PDX_OK;
+}
+
 template <typename T>
 static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int64_t nseg, const uint32_t* out_index, const SegOut& o,
                                    bool want_pw, bool want_mm, bool want_is, int64_t nrows, Scratch& s, hipStream_t st) {
@@ -3850,11 +3908,17 @@ int pdx_groupby_group_values(pdx_groupby* gb, const pdx_column* values, void* st
     Scratch s;
     const uint32_t* ks = nullptr;
     const uint64_t* vs = nullptr;
-    int rc = sort_values_by_slot(gb, static_cast<const uint64_t*>(values->values) + values->offset, nullptr, 0,
-                                 [&](size_t bytes) { return (void*)g->own<uint8_t>(bytes); }, s, st, &ks, &vs);
+    bool narrow_done = false;
+    int rc = sort_values_narrow_full(gb, static_cast<const uint64_t*>(values->values) + values->offset,
+                                     [&](size_t bytes) { return (void*)g->own<uint8_t>(bytes); }, s, st, &vs, g->seg_start, &narrow_done);
     if (rc != PDX_OK) return rc;
+    if (!narrow_done) {
+      rc = sort_values_by_slot(gb, static_cast<const uint64_t*>(values->values) + values->offset, nullptr, 0,
+                               [&](size_t bytes) { return (void*)g->own<uint8_t>(bytes); }, s, st, &ks, &vs);
+      if (rc != PDX_OK) return rc;
+      hipLaunchKernelGGL(k_seg_starts, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, ks, n, gb->occ_slot, G, g->seg_start);
+    }
     g->vals_sorted = reinterpret_cast<const double*>(vs);
-    hipLaunchKernelGGL(k_seg_starts, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, ks, n, gb->occ_slot, G, g->seg_start);
     hipLaunchKernelGGL(k_occ_of_gid, dim3(grid_for(G, 256)), dim3(256), 0, st, gb->gid_of_occ, G, g->occ_of_gid);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);

@@ -60,6 +60,28 @@ def test_sharded_single_rank():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("narrow", ["default", "0"])
+def test_sharded_single_rank_large_dense(monkeypatch, narrow):
+    """>= 2^22 rows of dense keys with a three-digit sort plan: the grouped values of the partial-tree exchange come from the full
+    narrowing sort (4 -> 2 -> 1 byte keys, group offsets from the scatter offsets) unless PDX_SORT_NARROW=0; a hot key makes one
+    group much longer than a tile.  Bit-identical to the oracle either way."""
+    import torch
+    from pandasarrow_amd import _lib as L
+    from pandasarrow_amd import dist as pdist
+    from pandasarrow_amd.column import Column
+
+    if narrow != "default":
+        monkeypatch.setenv("PDX_SORT_NARROW", narrow)
+    L.check(L.load().pdx_init(0))
+    n = 4_700_021
+    keys = orc.synth_keys(0, n, 300_000) + 1_000_000
+    keys[np.random.default_rng(3).random(n) < 0.05] = 1_000_777
+    vals = orc.synth_vals(0, n) - 0.5
+    fast = pdist.groupby_sum_mean_count_sharded(pdist.HipEngine(), Column.from_numpy(keys), Column.from_numpy(vals))
+    _compare_fast(fast, keys, vals)
+    torch.cuda.synchronize()
+
+
 def _worker(rank, world, port, n, nk, q):
     import torch
     import torch.distributed as dist
