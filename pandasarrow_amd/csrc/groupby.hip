@@ -3499,6 +3499,16 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
       PDX_TRY((radix_sort_pairs<uint64_t>(keys_sorted, vs, k2, v2, k2, v2, n, kFlrBits, &ks2, &vs2, true, s, st, low_bits)));
       keys_sorted = ks2;
       vs = vs2;
+    } else if (G == 1 && gb->slot_of_row) {
+      // one group: the rows are grouped as they stand (no sort); null flags, if any, still go into a key per row
+      keys_sorted = gb->slot_of_row;
+      if (vvalid) {
+        uint32_t* fk1 = s.get<uint32_t>((size_t)n);
+        PDX_SCRATCH_CHECK(s);
+        hipLaunchKernelGGL(k_flag_keys, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, gb->slot_of_row, vvalid, values->offset, n, fk1);
+        keys_sorted = fk1;
+      }
+      vs = vin;
     } else {
       PDX_TRY(sort_values_by_slot(gb, vin, vvalid, values->offset, [&](size_t bytes) { return (void*)s.get<uint8_t>(bytes); }, s, st, &keys_sorted, &vs));
     }
