@@ -2271,11 +2271,23 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const KT* __restrict_
           r1 = r1 < c ? r1 : c;
           double a = (j == 0 && p0 > 0) ? open_acc[d] : 0.0;
           const T* v = svals + dstart[d] + d;
+          // all (<= 16) values of the leaf are requested before the first add: a loop that loads, waits and adds row by row pays
+          // one LDS round trip per row on the critical path of the tile
+          double xs[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int r = r0 + q < r1 ? r0 + q : r1 - 1;
+            xs[q] = seg_to_f64(v[r]);
+          }
           if (sqdev_mean) {
             const double m = mu_s[d];
-            for (int r = r0; r < r1; ++r) a += flr_sqdev(seg_to_f64(v[r]), m);
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              if (r0 + q < r1) a += flr_sqdev(xs[q], m);
           } else {
-            for (int r = r0; r < r1; ++r) a += seg_to_f64(v[r]);
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              if (r0 + q < r1) a += xs[q];
           }
           leafsum[Lf] = a;
         }
