@@ -251,6 +251,14 @@ int pdx_index_union(const pdx_column* a, const pdx_column* b, int sort, pdx_mut_
 int pdx_index_intersection(const pdx_column* a, const pdx_column* b, pdx_mut_column* out, void* stream);
 int pdx_reindex_indices(const pdx_column* old_index, const pdx_column* new_index, pdx_mut_column* out_idx, void* stream);
 
+/* ---------------------------------------------------------------- sort (sort / argsort / n_largest / n_smallest)
+ * Series::argsort (src/series.cpp:864-868) and Series::sort (978-992: Take of values and index by the same indices; n_largest /
+ * n_smallest, 1211-1229, are sort + Slice) call CallFunction("array_sort_indices", ArraySortOptions{order}).  Semantics pinned
+ * against Arrow 25.0.0: STABLE in both orders (equal values keep their row order; -0.0 == 0.0), NaN behind every number and
+ * nulls behind the NaNs in BOTH orders.  col: int64 / uint64 / float64 / timestamp[ns], <= 2^31-1 rows; out_indices: PDX_UINT64,
+ * capacity col.length (the take indices; feed them to pdx_take). */
+int pdx_argsort(const pdx_column* col, int ascending, pdx_mut_column* out_indices, void* stream);
+
 /* ---------------------------------------------------------------- concat (rows)
  * Replaces arrow::ConcatenateTables + CombineChunksToBatch at src/concat.cpp:152-154 for same-dtype parts
  * (the all-gatherv merge of sharded results).  out->length must be >= sum of part lengths. */

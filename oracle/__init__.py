@@ -352,6 +352,30 @@ def concat(parts, valids=None):
     return out.view(dtype), (None if valids is None else unpack_bits(ov, total))
 
 
+# ------------------------------------------------------------------ sort
+def argsort(v, valid=None, ascending=True):
+    """Series::argsort / the indices of Series::sort (src/series.cpp:864-868, 978-992): Arrow's array_sort_indices restated --
+    stable in both orders (equal values keep their row order, -0.0 == 0.0), NaNs behind every number, nulls behind the NaNs, in
+    BOTH orders.  Returns uint64 indices."""
+    v = np.asarray(v)
+    n = len(v)
+    valid = np.ones(n, bool) if valid is None else np.asarray(valid, bool)
+    isnan = (v != v) if v.dtype.kind == "f" else np.zeros(n, bool)
+    cls = np.where(~valid, 2, np.where(isnan, 1, 0))
+    num = np.flatnonzero(cls == 0)
+    vals = v[num]
+    if v.dtype.kind == "f":
+        vals = vals + 0.0  # -0.0 -> 0.0 is not needed for ordering: numpy compares them equal and the sort is stable
+    order = np.argsort(vals, kind="stable")
+    if not ascending:
+        # stable descending: sort ascending on the negated order of values = stable argsort of the reversed ranks; restate via keys
+        # rank = position in the ascending stable order of DISTINCT values, then a stable argsort of (-rank)
+        _, inv = np.unique(vals, return_inverse=True)
+        order = np.argsort(-inv.astype(np.int64), kind="stable")
+    out = np.concatenate([num[order], np.flatnonzero(cls == 1), np.flatnonzero(cls == 2)])
+    return out.astype(np.uint64)
+
+
 # ------------------------------------------------------------------ index alignment (SURVEY 8(f)-1)
 def index_union(a, b, sort=True):
     """Series::broadcast's new index (src/series.cpp:212-227): Unique(Concatenate(a, b)) sorted ascending; sort=False is

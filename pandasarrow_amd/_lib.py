@@ -100,6 +100,7 @@ ABI_SYMBOLS = {
     "pdx_concat": (C.c_int, [_COL, C.c_int, _MUT, _P]),
     "pdx_index_union": (C.c_int, [_COL, _COL, C.c_int, _MUT, _P]),
     "pdx_index_intersection": (C.c_int, [_COL, _COL, _MUT, _P]),
+    "pdx_argsort": (C.c_int, [_COL, C.c_int, _MUT, _P]),
     "pdx_reindex_indices": (C.c_int, [_COL, _COL, _MUT, _P]),
 }
 

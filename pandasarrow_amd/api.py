@@ -208,6 +208,26 @@ class Series:
             return self.where(s) if s.col.dtype == L.BOOL else self.take(s)
         raise TypeError("only Series selectors are on the hot path")
 
+    # ---- sort (src/series.cpp:864-868, 978-992, 1211-1229)
+    def argsort(self, ascending=True):
+        """Series::argsort: CallFunction("array_sort_indices") -> uint64 indices (re-attached index per ReturnSeriesOrThrowOnError)."""
+        return self._wrap(K.argsort(self.col, ascending))
+
+    def sort(self, ascending=True):
+        """Series::sort: values AND index taken by the same sort indices."""
+        idx = K.argsort(self.col, ascending)
+        cols = [self.col, self._explicit_index()]
+        outs = K.take(cols, idx)
+        return Series(outs[0], index=outs[1], name=self.name)
+
+    def n_largest(self, n):
+        s = self.sort(False)
+        return s if s.size() < n else Series(s.col.slice(0, n), index=s.index.slice(0, n), name=self.name)
+
+    def n_smallest(self, n):
+        s = self.sort(True)
+        return s if s.size() < n else Series(s.col.slice(0, n), index=s.index.slice(0, n), name=self.name)
+
     def resample(self, rule, closed_right=False, label_right=False, origin=L.ORIGIN_START_DAY, offset_ns=0, origin_custom_ns=0):
         return DataFrame({self.name or "0": self}, index=self.index).resample(rule, closed_right, label_right, origin, offset_ns, origin_custom_ns)
 

@@ -276,6 +276,15 @@ def index_intersection(a: Column, b: Column) -> Column:
     return out._adopt(m)
 
 
+def argsort(a: Column, ascending=True) -> Column:
+    """uint64 take indices of the stable sort of a (array_sort_indices: NaN behind the numbers, nulls last, in both orders)."""
+    out = Column.empty(L.UINT64, a.length)
+    m = out.mut()
+    ca = a.c()
+    L.check(L.load().pdx_argsort(C.byref(ca), int(bool(ascending)), C.byref(m), _stream()))
+    return out._adopt(m)
+
+
 def reindex_indices(old_index: Column, new_index: Column) -> Column:
     """int64 take indices (LAST position of every new label in old_index, null where absent)."""
     out = Column.empty(L.INT64, new_index.length, with_validity=True)

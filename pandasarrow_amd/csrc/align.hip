@@ -52,6 +52,59 @@ __global__ void k_reindex_emit(const uint32_t* __restrict__ gids, const int64_t*
   }
 }
 
+// ---- sort keys: the order-preserving unsigned image of every value (ascending: as is, descending: complemented) and its class
+// (0 number, 1 NaN, 2 null): numbers first, then NaNs, then nulls in BOTH orders, as Arrow's array_sort_indices places them
+__global__ void k_sort_keys(const unsigned long long* __restrict__ v, const uint8_t* __restrict__ valid, int64_t off, int64_t n, int dtype, int descending,
+                            long long* __restrict__ key, long long* __restrict__ cls) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    unsigned long long u = v[i];
+    long long c = 0;
+    if (valid && !bit_get(valid, off + i)) {
+      c = 2;
+      u = 0;
+    } else if (dtype == PDX_FLOAT64) {
+      const double x = __longlong_as_double((long long)u);
+      if (x != x) {
+        c = 1;
+        u = 0;
+      } else {
+        if (x == 0.0) u = 0;  // -0.0 and 0.0 compare equal: one key, so the stable sort keeps their row order
+        u = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+      }
+    } else if (dtype != PDX_UINT64) {
+      u ^= 0x8000000000000000ull;  // int64 / timestamp
+    }
+    if (descending && c == 0) u = ~u;
+    key[i] = (long long)u;
+    cls[i] = c;
+  }
+}
+__global__ void k_perm_to_u64(const uint32_t* __restrict__ perm, int64_t n, unsigned long long* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = perm[i];
+}
+// Stable LSD sort of `perm` by the 64-bit keys keys64[perm[i]] ^ flip (unsigned order): three rounds of <= 22 bits through the
+// 32-bit pair sort.  perm is updated in place.
+static int argsort_rounds64(const long long* keys64, int64_t n, unsigned long long flip, uint32_t* perm, Scratch& s, hipStream_t st) {
+  uint32_t* chunk = s.get<uint32_t>((size_t)n);
+  uint32_t* k0 = s.get<uint32_t>((size_t)n);
+  uint32_t* k1 = s.get<uint32_t>((size_t)n);
+  uint32_t* v0 = s.get<uint32_t>((size_t)n);
+  uint32_t* v1 = s.get<uint32_t>((size_t)n);
+  PDX_SCRATCH_CHECK(s);
+  const int shifts[3] = {0, 22, 43}, widths[3] = {22, 21, 21};
+  for (int r = 0; r < 3; ++r) {
+    hipLaunchKernelGGL(k_label_chunk, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, keys64, perm, n, shifts[r], (1u << widths[r]) - 1, flip, chunk);
+    PDX_LAUNCH_CHECK();
+    const uint32_t* ks = nullptr;
+    const uint32_t* vs = nullptr;
+    PDX_TRY((radix_sort_pairs<uint32_t>(chunk, perm, k0, v0, k1, v1, n, widths[r], &ks, &vs, false, s, st)));
+    PDX_HIP(hipMemcpyAsync(perm, vs, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  }
+  return PDX_OK;
+}
+
 static int check_index(const pdx_column* c, const char* what) {
   PDX_TRY(check_column(c, what));
   if (!is_int_like(c->dtype)) return fail(PDX_NOT_IMPLEMENTED, std::string(what) + ": index must be int64 / uint64 / timestamp[ns]");
@@ -138,28 +191,61 @@ int pdx_index_union(const pdx_column* a, const pdx_column* b, int sort, pdx_mut_
   }
   // array_sort_indices ascending + Take: stable LSD sort of the 64-bit labels, three rounds through the 32-bit pair sort
   uint32_t* perm = s.get<uint32_t>((size_t)G);
-  uint32_t* chunk = s.get<uint32_t>((size_t)G);
-  uint32_t* k0 = s.get<uint32_t>((size_t)G);
-  uint32_t* k1 = s.get<uint32_t>((size_t)G);
-  uint32_t* v0 = s.get<uint32_t>((size_t)G);
-  uint32_t* v1 = s.get<uint32_t>((size_t)G);
   PDX_SCRATCH_CHECK(s);
   hipLaunchKernelGGL(k_align_iota, dim3(grid_for(G, 256, 4)), dim3(256), 0, st, perm, G);
   const unsigned long long flip = a->dtype == PDX_UINT64 ? 0ull : 0x8000000000000000ull;
-  const int shifts[3] = {0, 22, 43}, widths[3] = {22, 21, 21};
-  for (int r = 0; r < 3; ++r) {
-    hipLaunchKernelGGL(k_label_chunk, dim3(grid_for(G, 256, 4)), dim3(256), 0, st, uniq, perm, G, shifts[r], (1u << widths[r]) - 1, flip, chunk);
-    PDX_LAUNCH_CHECK();
-    const uint32_t* ks = nullptr;
-    const uint32_t* vs = nullptr;
-    PDX_TRY((radix_sort_pairs<uint32_t>(chunk, perm, k0, v0, k1, v1, G, widths[r], &ks, &vs, false, s, st)));
-    PDX_HIP(hipMemcpyAsync(perm, vs, (size_t)G * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-  }
+  PDX_TRY(argsort_rounds64(uniq, G, flip, perm, s, st));
   hipLaunchKernelGGL(k_gather_labels, dim3(grid_for(G, 256, 4)), dim3(256), 0, st, uniq, perm, G, static_cast<long long*>(out->values));
   PDX_LAUNCH_CHECK();
   if (out->validity) PDX_HIP(hipMemsetAsync(out->validity, 0xFF, (size_t)((G + 7) / 8), st));
   PDX_HIP(hipStreamSynchronize(st));
   out->length = G;
+  return PDX_OK;
+}
+
+int pdx_argsort(const pdx_column* col, int ascending, pdx_mut_column* out, void* stream) {
+  PDX_TRY(check_column(col, "pdx_argsort"));
+  if (!out) return fail(PDX_INVALID, "pdx_argsort: null output");
+  if (col->dtype != PDX_INT64 && col->dtype != PDX_UINT64 && col->dtype != PDX_FLOAT64 && col->dtype != PDX_TIMESTAMP_NS)
+    return fail(PDX_NOT_IMPLEMENTED, "pdx_argsort: int64 / uint64 / float64 / timestamp[ns] columns only");
+  const int64_t n = col->length;
+  if (out->dtype != PDX_UINT64) return fail(PDX_INVALID, "pdx_argsort: the indices are uint64");
+  if (out->length < n || (n && !out->values)) return fail(PDX_INVALID, "pdx_argsort: output too small");
+  if (n > 0x7FFFFFFFll) return fail(PDX_NOT_IMPLEMENTED, "pdx_argsort: more than 2^31-1 rows per call is not supported yet");
+  out->length = n;
+  out->null_count = 0;
+  if (n == 0) return PDX_OK;
+  hipStream_t st = as_stream(stream);
+  Scratch s;
+  long long* keys = s.get<long long>((size_t)n);
+  long long* cls = s.get<long long>((size_t)n);
+  uint32_t* perm = s.get<uint32_t>((size_t)n);
+  PDX_SCRATCH_CHECK(s);
+  const uint8_t* valid = validity_or_null(col);
+  hipLaunchKernelGGL(k_sort_keys, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, static_cast<const unsigned long long*>(col->values) + col->offset, valid,
+                     col->offset, n, col->dtype, ascending ? 0 : 1, keys, cls);
+  hipLaunchKernelGGL(k_align_iota, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, perm, n);
+  PDX_LAUNCH_CHECK();
+  PDX_TRY(argsort_rounds64(keys, n, 0ull, perm, s, st));
+  if (valid || col->dtype == PDX_FLOAT64) {
+    // most significant digit: the class (numbers, NaNs, nulls); one more stable round on 2 bits
+    uint32_t* chunk = s.get<uint32_t>((size_t)n);
+    uint32_t* k0 = s.get<uint32_t>((size_t)n);
+    uint32_t* k1 = s.get<uint32_t>((size_t)n);
+    uint32_t* v0 = s.get<uint32_t>((size_t)n);
+    uint32_t* v1 = s.get<uint32_t>((size_t)n);
+    PDX_SCRATCH_CHECK(s);
+    hipLaunchKernelGGL(k_label_chunk, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, cls, perm, n, 0, 3u, 0ull, chunk);
+    PDX_LAUNCH_CHECK();
+    const uint32_t* ks = nullptr;
+    const uint32_t* vs = nullptr;
+    PDX_TRY((radix_sort_pairs<uint32_t>(chunk, perm, k0, v0, k1, v1, n, 2, &ks, &vs, false, s, st)));
+    PDX_HIP(hipMemcpyAsync(perm, vs, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  }
+  hipLaunchKernelGGL(k_perm_to_u64, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, perm, n, static_cast<unsigned long long*>(out->values));
+  PDX_LAUNCH_CHECK();
+  if (out->validity) PDX_HIP(hipMemsetAsync(out->validity, 0xFF, (size_t)((n + 7) / 8), st));
+  PDX_HIP(hipStreamSynchronize(st));
   return PDX_OK;
 }
 

@@ -857,3 +857,51 @@ def test_filter_streaming_vs_gather(px, monkeypatch, n, sel, stream):
             assert ok is None or ok.all()
             assert out.null_count == 0
             assert np.array_equal(got.view(np.uint64), a[keep].view(np.uint64))
+
+
+# ------------------------------------------------------------------ sort / argsort / n_largest
+def _sort_golden():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sort_golden.npz"))
+    return g, sorted({k[:-2] for k in g.files if k.endswith("_v")})
+
+
+@pytest.mark.parametrize("name", _sort_golden()[1])
+def test_argsort_golden(px, name):
+    g, _ = _sort_golden()
+    v, valid = g[name + "_v"], g[name + "_valid"]
+    col = px.Column.from_numpy(v, None if valid.all() else valid, offset=3)
+    for asc, key in ((True, "_asc"), (False, "_desc")):
+        got, ok = px.K.argsort(col, asc).to_numpy()
+        assert ok is None or ok.all()
+        assert np.array_equal(got.astype(np.uint64), g[name + key]), (name, key)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "i64", "ts"])
+def test_argsort_large_vs_oracle_and_series_sort(px, dtype):
+    n = 1_500_011
+    rng = np.random.default_rng(5)
+    if dtype == "f64":
+        v = np.round(rng.standard_normal(n) * 1000.0, 1)  # many duplicates: stability matters
+        v[rng.random(n) < 0.01] = np.nan
+        v[rng.random(n) < 0.01] = -0.0
+    elif dtype == "i64":
+        v = rng.integers(-2**62, 2**62, n).astype(np.int64)
+        v[rng.random(n) < 0.3] = 7
+    else:
+        v = (946_684_800 * 10**9 + rng.integers(0, 10**6, n) * 10**9).astype("datetime64[ns]")
+    valid = rng.random(n) > 0.05
+    col = px.Column.from_numpy(v, valid)
+    vi = v.astype(np.int64) if dtype == "ts" else v
+    for asc in (True, False):
+        got, _ = px.K.argsort(col, asc).to_numpy()
+        assert np.array_equal(got.astype(np.uint64), orc.argsort(vi, valid, asc)), (dtype, asc)
+    # Series::sort = Take of values and index by the sort indices; n_largest = sort(descending) + Slice
+    S = px.api.Series
+    s = S(v if dtype != "ts" else vi, valid=valid, index=px.Column.from_numpy(np.arange(n, dtype=np.uint64)[::-1].copy()), name="x")
+    top = s.n_largest(10)
+    order = orc.argsort(vi, valid, False)[:10]
+    tv, tok = top.col.to_numpy()
+    assert len(tv) == 10 and (tok is None or tok.all() or np.array_equal(tok, valid[order]))
+    assert np.array_equal(tv.view(np.uint64), vi[order].view(np.uint64))
+    assert np.array_equal(top.index.to_numpy()[0], (np.arange(n, dtype=np.uint64)[::-1])[order])

@@ -1,6 +1,7 @@
 """Pins the CPU oracle (oracle/pdx_oracle.c) against (a) Arrow 25.0.0 golden vectors frozen by
 oracle/gen_golden.py and (b) the reference's own known-answer test vectors (kat_reference.json).
 CPU only."""
+import os
 import numpy as np
 import pytest
 
@@ -283,3 +284,17 @@ def test_concat_kat(kat):
         assert list(idx) == k["index"]
         w, ok = orc.concat([np.zeros(2), np.array(k["weight_parts"][1])], [np.zeros(2, bool), None])
         assert list(ok) == [False, False, True, True] and list(w[2:]) == k["weight_out"][2:]
+
+
+# ------------------------------------------------------------------ sort: oracle vs Arrow's array_sort_indices
+def _sort_cases():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sort_golden.npz"))
+    return g, sorted({k[:-2] for k in g.files if k.endswith("_v")})
+
+
+@pytest.mark.parametrize("name", _sort_cases()[1])
+def test_argsort_oracle_vs_golden(name):
+    g, _ = _sort_cases()
+    v, valid = g[name + "_v"], g[name + "_valid"]
+    assert np.array_equal(orc.argsort(v, valid, True), g[name + "_asc"])
+    assert np.array_equal(orc.argsort(v, valid, False), g[name + "_desc"])

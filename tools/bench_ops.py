@@ -77,6 +77,11 @@ def main():
     ts = K.synth_ts(0, n, 946_684_800 * 10**9, 100_000_000)
     ser = api.Series(K.synth_vals(0, n), index=ts, name="v")
     report("resample_1min_mean[1e9]", n, 16.0 * n, timeit(lambda: ser.resample("1min").mean()))
+    # argsort of 1e8 float64 values (algorithmic bytes: 8 read + 8 written per row)
+    m = int(1e8 * sc)
+    sv = K.synth_vals(11, m)
+    report("argsort_f64[1e8]", m, 16.0 * m, timeit(lambda: K.argsort(sv)))
+    del sv
     # concat of 8 shards (the all-gatherv merge)
     parts = [K.synth_vals(i, n // 8, 0) for i in range(8)]
     report("concat_8parts[1e9]", n // 8 * 8, 16.0 * (n // 8 * 8), timeit(lambda: K.concat(parts)))
