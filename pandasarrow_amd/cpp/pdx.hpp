@@ -329,6 +329,31 @@ class Series {
   }
   Series operator[](const Series& s) const { return s.dtype() == PDX_BOOL ? where(s) : take(s); }
 
+  // ---- sort (src/series.cpp:864-868, 978-992, 1211-1229): CallFunction("array_sort_indices") + Take of values and index + Slice
+  Series argsort(bool ascending = true) const {
+    Array idx = Array::Empty(PDX_UINT64, size(), false);
+    auto ca = m_array.c();
+    auto mi = idx.mut();
+    ThrowOnFailure(pdx_argsort(&ca, ascending ? 1 : 0, &mi, nullptr));
+    return wrap(idx);
+  }
+  Series sort(bool ascending = true) const {
+    Array idx = argsort(ascending).m_array;
+    auto outs = run_take(columns_with_index(), idx);
+    // (the implicit 0..n-1 index taken by the sort indices is the sort indices)
+    return Series(outs[0], m_index ? outs[1] : idx, m_name);
+  }
+  Series n_largest(int n) const { return sort(false).head(n); }
+  Series n_smallest(int n) const { return sort(true).head(n); }
+  Series head(int64_t n) const {  // array()->Slice(0, n): zero copy
+    if (size() <= n) return *this;
+    Series s = *this;
+    s.m_array.length = n;
+    if (s.m_array.validity) s.m_array.null_count = -1;
+    if (s.m_index) s.m_index->length = n;
+    return s;
+  }
+
   inline Resampler resample(const std::string& rule, bool closed_right = false, bool label_right = false) const;
 
   // ---- shared kernels-through-ABI helpers (also used by DataFrame)

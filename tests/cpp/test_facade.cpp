@@ -187,6 +187,20 @@ static void test_concat_and_frame_ops() {
   REQUIRE((f["y"].values<long>() == std::vector<long>{5, 6}));
 }
 
+// Series::argsort / sort / n_smallest (src/series.cpp:864-868, 978-992, 1211-1229): stable, index follows the values
+static void test_sort() {
+  Series s(Array::Make(std::vector<double>{3.0, 1.0, 2.0, 1.0}), Array::Make(std::vector<long>{10, 11, 12, 13}), "s");
+  REQUIRE((s.argsort().values<long>() == std::vector<long>{1, 3, 2, 0}));
+  Series d = s.sort(false);
+  REQUIRE((d.values<double>() == std::vector<double>{3.0, 2.0, 1.0, 1.0}));
+  REQUIRE((d.m_index->values_as<long>() == std::vector<long>{10, 12, 11, 13}));
+  Series two = s.n_smallest(2);
+  REQUIRE(two.size() == 2 && (two.values<double>() == std::vector<double>{1.0, 1.0}));
+  REQUIRE((two.m_index->values_as<long>() == std::vector<long>{11, 13}));
+  Series withnull(std::vector<double>{2.0, std::nan(""), 1.0});  // NaN -> null on construction: nulls last in both orders
+  REQUIRE((withnull.argsort(false).values<long>() == std::vector<long>{0, 2, 1}));
+}
+
 int main() {
   ThrowOnFailure(pdx_init(0));
   test_series_math();
@@ -196,6 +210,7 @@ int main() {
   test_groupby();
   test_resample();
   test_concat_and_frame_ops();
+  test_sort();
   std::printf("%d checks, %d failed\n", g_checks, g_failed);
   return g_failed ? 1 : 0;
 }
