@@ -57,8 +57,9 @@ def main():
         vmask = K.compare(L.NE, K.synth_keys(3, n, 20), 0)
         xn = K.Column(L.FLOAT64, n, x.values, vmask.values, 0, -1)
         report(f"sum_f64_5%nulls[{n:.0e}]", n, (8.0 + 0.125) * n, timeit(lambda: K.aggregate(L.AGG_SUM, xn)))
-        report(f"add_f64_5%nulls[{n:.0e}]", n, (24.0 + 0.375) * n, timeit(lambda: K.binary(L.ADD, xn, xn)))
-        del x, y, xn, vmask
+        yn = K.Column(L.FLOAT64, n, y.values, vmask.values, 0, -1)  # (a second value buffer: x + x would read 8 B/row less)
+        report(f"add_f64_5%nulls[{n:.0e}]", n, (24.0 + 0.375) * n, timeit(lambda: K.binary(L.ADD, xn, yn)))
+        del x, y, xn, yn, vmask
     # C2: boolean-mask filter + take, 1e8 rows x 8 fp64 columns (+ uint64 index)
     n = int(1e8 * sc)
     cols = {f"c{j}": K.synth_vals(0, n, 20 + j) for j in range(8)}
