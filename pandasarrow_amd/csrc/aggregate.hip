@@ -200,17 +200,29 @@ __global__ void k_null_window_count(const uint8_t* __restrict__ valid, int64_t o
     count[w] = fin;
   }
 }
+// (smaller workgroups than the dense kernels: two barriers and a serial 16-row loop per workgroup -- more, smaller ones overlap better)
+constexpr int kEmitBlock = 128;
+constexpr int kEmitElems = kEmitBlock * 16;
 template <typename T>
-__global__ void __launch_bounds__(kLeafBlock) k_null_window_emit(const T* __restrict__ v, const uint8_t* __restrict__ valid, int64_t off, int64_t n,
+__global__ void __launch_bounds__(kEmitBlock) k_null_window_emit(const T* __restrict__ v, const uint8_t* __restrict__ valid, int64_t off, int64_t n,
                                                                  int64_t nwin, const int32_t* __restrict__ pos_in,
                                                                  const int64_t* __restrict__ leaf_base, double* __restrict__ leaves) {
-  __shared__ double lds[kLeafBlock * kLeafPad];
+  __shared__ double lds[kEmitBlock * kLeafPad];
   const int tid = threadIdx.x;
-  const int64_t base = (int64_t)blockIdx.x * kLeafElems;
-  const int rows = (int)((n - base) < kLeafElems ? (n - base) : kLeafElems);
+  const int64_t base = (int64_t)blockIdx.x * kEmitElems;
+  const int rows = (int)((n - base) < kEmitElems ? (n - base) : kEmitElems);
+  // the window's own small inputs (validity bits, open-leaf position, first leaf index) are requested together with the values:
+  // asked for only after the barrier they cost a second and third memory round trip per block (SQ_WAIT_ANY was 86 % of wave cycles)
+  const int64_t w = (int64_t)blockIdx.x * kEmitBlock + tid;
+  const bool in = w < nwin;
+  const unsigned m = in ? window_bits(valid, off, n, w) : 0u;
+  const int p_in = in ? pos_in[w] : 0;
+  const int64_t li_in = in ? leaf_base[w] : 0;
+  __shared__ double prev_tail[16];  // first window of the block: the rows of an open leaf live in the previous block
+  if (tid < 16) prev_tail[tid] = base >= 16 ? to_f64(v[base - 16 + tid]) : 0.0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    int idx = k * kLeafBlock + tid;
+    int idx = k * kEmitBlock + tid;
     if (idx < rows) lds[idx + (idx >> 4)] = to_f64(v[base + idx]);
   }
   __syncthreads();
@@ -219,10 +231,7 @@ __global__ void __launch_bounds__(kLeafBlock) k_null_window_emit(const T* __rest
   // (leaf_base is an exclusive scan over windows) and leave in one coalesced copy -- a store per finished leaf straight from the
   // row loop costs up to 16 mostly empty store instructions per wave (4.3 ms per 1e9 rows).
   __shared__ int64_t blk_lo_s, blk_hi_s;
-  const int64_t w = (int64_t)blockIdx.x * kLeafBlock + tid;
-  const bool in = w < nwin;
-  const unsigned m = in ? window_bits(valid, off, n, w) : 0u;
-  int p = in ? (pos_in[w] < 0 ? 0 : pos_in[w]) : 0;
+  int p = p_in < 0 ? 0 : p_in;
   double x[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) x[q] = lds[tid * kLeafPad + q];
@@ -232,10 +241,10 @@ __global__ void __launch_bounds__(kLeafBlock) k_null_window_emit(const T* __rest
     if (tid > 0) {
       for (int q = 16 - p; q < 16; ++q) acc += lds[(tid - 1) * kLeafPad + q];
     } else {
-      for (int q = 16 - p; q < 16; ++q) acc += to_f64(v[base - 16 + q]);  // first window of the block: the rows live in the previous block
+      for (int q = 16 - p; q < 16; ++q) acc += prev_tail[q];
     }
   }
-  int64_t li = in ? leaf_base[w] : 0;
+  int64_t li = li_in;
   if (tid == 0) blk_lo_s = li;
   __syncthreads();
   const int64_t blk_lo = blk_lo_s;
@@ -248,11 +257,11 @@ __global__ void __launch_bounds__(kLeafBlock) k_null_window_emit(const T* __rest
       } else if (p > 0) { lds[li++ - blk_lo] = acc; p = 0; }
     }
     if (w == nwin - 1 && p > 0) lds[li++ - blk_lo] = acc;
-    if (tid == kLeafBlock - 1 || w == nwin - 1) blk_hi_s = li;  // the block's last window
+    if (tid == kEmitBlock - 1 || w == nwin - 1) blk_hi_s = li;  // the block's last window
   }
   __syncthreads();
   const int cnt = (int)(blk_hi_s - blk_lo);
-  for (int i = tid; i < cnt; i += kLeafBlock) leaves[blk_lo + i] = lds[i];
+  for (int i = tid; i < cnt; i += kEmitBlock) leaves[blk_lo + i] = lds[i];
 }
 
 template <typename T>
@@ -273,7 +282,7 @@ static int sum_nullable(const T* v, const uint8_t* valid, int64_t off, int64_t n
   PDX_HIP(hipStreamSynchronize(st));
   double* leaves = s.get<double>((size_t)(m ? m : 1));
   PDX_SCRATCH_CHECK(s);
-  hipLaunchKernelGGL((k_null_window_emit<T>), dim3((unsigned)ceil_div(n, kLeafElems)), dim3(kLeafBlock), 0, st, v, valid, off, n, nwin, z, lc, leaves);
+  hipLaunchKernelGGL((k_null_window_emit<T>), dim3((unsigned)ceil_div(n, kEmitElems)), dim3(kEmitBlock), 0, st, v, valid, off, n, nwin, z, lc, leaves);
   PDX_LAUNCH_CHECK();
   return run_tree(leaves, m, nullptr, 0, nullptr, 0, result_dev, s, st);
 }
