@@ -77,6 +77,44 @@ def all_gather_v(t: torch.Tensor, sizes):
     return torch.cat([o[:s] for o, s in zip(out, sizes)])
 
 
+def all_gather_v_multi(ts, sizes):
+    """all_gather_v of several equally long 8-byte (or bool / uint8) 1-D tensors in ONE collective: the tensors travel as the rows
+    of one padded int64 matrix.  Returns the per-tensor concatenations in rank order, in the input dtypes."""
+    W, _ = _world()
+    if W == 1:
+        return [t.clone() for t in ts]
+    k, n = len(ts), int(ts[0].numel())
+    mx = max(max(sizes), 1)
+    pad = torch.zeros((k, mx), dtype=torch.int64, device=ts[0].device)
+    for i, t in enumerate(ts):
+        pad[i, :n] = t.view(torch.int64) if t.dtype == torch.float64 else t.to(torch.int64)
+    out = [torch.empty_like(pad) for _ in range(W)]
+    dist.all_gather(out, pad)
+    res = []
+    for i, t in enumerate(ts):
+        cat = torch.cat([o[i, :sz] for o, sz in zip(out, sizes)])
+        res.append(cat.view(torch.float64) if t.dtype == torch.float64 else cat.to(t.dtype))
+    return res
+
+
+def all_to_all_v_pairs(chunks_a, chunks_b):
+    """all_to_all_v of two aligned lists (chunks_a[d] and chunks_b[d] have the same length, 8-byte dtypes) in ONE exchange: every
+    destination receives [a | b] of every source.  Returns (recv_a, recv_b), each the concatenation in source order."""
+    W, _ = _world()
+    if W == 1:
+        return chunks_a[0], chunks_b[0]
+    da, db = chunks_a[0].dtype, chunks_b[0].dtype
+    as64 = lambda t: t.view(torch.int64) if t.dtype == torch.float64 else t.to(torch.int64)
+    recv = all_to_all_v([torch.cat([as64(a), as64(b)]) for a, b in zip(chunks_a, chunks_b)])
+    ra, rb = [], []
+    for piece in recv:
+        h = piece.numel() // 2
+        ra.append(piece[:h])
+        rb.append(piece[h:])
+    back = lambda t, dt: t.view(torch.float64) if dt == torch.float64 else t.to(dt)
+    return back(torch.cat(ra), da), back(torch.cat(rb), db)
+
+
 def all_to_all_v(chunks):
     """chunks[d] goes to rank d; returns the list received from every source, in source (rank) order."""
     W, r = _world()
@@ -296,9 +334,7 @@ def groupby_sum_mean_count_sharded(engine, keys, vals, row_offset=0):
         Gl = int(uk.numel())
     with _Stage("2_dictionary"):
         sizes = all_gather_sizes(Gl, dev)
-        cat_keys = all_gather_v(uk, sizes)
-        cat_ok = all_gather_v(uok.to(torch.uint8), sizes).to(torch.bool)
-        cat_first = all_gather_v(fr, sizes)
+        cat_keys, cat_first, cat_ok = all_gather_v_multi([uk, fr, uok], sizes)  # one collective for the three dictionary columns
         if W == 1:
             glob_keys, glob_ok, glob_first, G = uk, uok, fr, Gl
             my_map = torch.arange(Gl, dtype=torch.int64, device=dev)
@@ -334,8 +370,7 @@ def groupby_sum_mean_count_sharded(engine, keys, vals, row_offset=0):
     with _Stage("6_all_to_all"):
         if W > 1:
             cuts = torch.searchsorted(rec_key, torch.tensor([b * 64 for b in bounds], dtype=torch.int64, device=dev)).tolist()
-            rk = torch.cat(all_to_all_v([rec_key[cuts[d]:cuts[d + 1]] for d in range(W)]))
-            rv = torch.cat(all_to_all_v([rec_val[cuts[d]:cuts[d + 1]] for d in range(W)]))
+            rk, rv = all_to_all_v_pairs([rec_key[cuts[d]:cuts[d + 1]] for d in range(W)], [rec_val[cuts[d]:cuts[d + 1]] for d in range(W)])
         else:
             rk, rv = rec_key, rec_val
     with _Stage("7_replay"):
