@@ -407,7 +407,12 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds_tail(const long 
   const int tid = threadIdx.x;
   const TailChunk ch = chunks[blockIdx.x];
   const unsigned int b = ch.bucket, rmask = region - 1;
-  if (__hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // the head attempt already failed
+  // the head attempt already failed: leave (ONE thread reads the flag -- it can change under us, and a workgroup that splits over
+  // it would leave some waves at the barriers below forever)
+  __shared__ unsigned int gave_up;
+  if (tid == 0) gave_up = __hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (gave_up) return;
   Slot* reg = table + (int64_t)b * region;
   for (int i = tid; i < (int)region; i += kProbeBlock) lkeys[i] = (unsigned long long)reg[i].key;
   if (tid == 0) {
