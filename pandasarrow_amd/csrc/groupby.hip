@@ -925,6 +925,22 @@ __global__ void k_seg_starts_from_slots(const uint32_t* __restrict__ slot_start,
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= G; k += stride) seg_start[k] = k == G ? (uint32_t)n : slot_start[occ_slot[k]];
 }
 
+// k_seg_starts on keys that carry extra bits above `mask`
+__global__ void k_seg_starts_masked(const uint32_t* __restrict__ sorted_keys, int64_t n, uint32_t mask, int64_t G, uint32_t* __restrict__ seg_start) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= G; k += stride) {
+    int64_t lo = 0, hi = n;
+    if (k == G) lo = n;
+    else
+      while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((sorted_keys[mid] & mask) < (uint32_t)k) lo = mid + 1;
+        else hi = mid;
+      }
+    seg_start[k] = (uint32_t)lo;
+  }
+}
+
 // ---------------------------------------------------------------- segmented reduce (dense values: no nulls)
 struct SegOut {
   double* sum_f;     // SUM of float64 values, or nullptr
@@ -3841,7 +3857,7 @@ __global__ void __launch_bounds__(256) k_partial_fill(const double* __restrict__
 }
 
 __global__ void k_replay_keys(const int64_t* __restrict__ rec_key, int64_t m, int64_t gid_lo, int64_t n_own, uint32_t* __restrict__ slot,
-                              uint32_t* __restrict__ lvl, unsigned int* __restrict__ bad) {
+                              uint32_t* __restrict__ lvl, unsigned int* __restrict__ bad, int pack_shift) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
     int64_t key = rec_key[i];
@@ -3850,12 +3866,15 @@ __global__ void k_replay_keys(const int64_t* __restrict__ rec_key, int64_t m, in
       atomicExch(bad, 1u);
       g = 0;
     }
-    slot[i] = (uint32_t)g;
+    // (pack_shift >= 0: the level rides above the slot bits of the sort key -- the sort only looks at the low bits)
+    slot[i] = pack_shift >= 0 ? (uint32_t)g | ((uint32_t)(key & 63) << pack_shift) : (uint32_t)g;
     lvl[i] = (uint32_t)(key & 63);
   }
 }
+// lvl_shift >= 0: `lvl` holds the sorted keys with the record's level packed above bit lvl_shift (one sort carries it along)
 __global__ void __launch_bounds__(256) k_replay(const uint32_t* __restrict__ seg_start, int64_t n_own, const double* __restrict__ val,
-                                                const uint32_t* __restrict__ lvl, double* __restrict__ out, unsigned int* __restrict__ bad) {
+                                                const uint32_t* __restrict__ lvl, double* __restrict__ out, unsigned int* __restrict__ bad,
+                                                int lvl_shift) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_own; g += stride) {
     PairwiseCounter cn;
@@ -3864,7 +3883,7 @@ __global__ void __launch_bounds__(256) k_replay(const uint32_t* __restrict__ seg
     int fill = 0;
     bool any = false;
     for (int64_t i = seg_start[g]; i < (int64_t)seg_start[g + 1]; ++i) {
-      uint32_t l = lvl[i];
+      uint32_t l = lvl_shift >= 0 ? (lvl[i] & kSortKeyMask) >> lvl_shift : lvl[i];
       any = true;
       if (l == 0) {  // fragment value: extend the running 16-value leaf
         acc += val[i];
@@ -4015,20 +4034,27 @@ int pdx_replay_partials(const int64_t* rec_key, const double* rec_val, int64_t m
   unsigned int* bad = s.get<unsigned int>(1);
   PDX_SCRATCH_CHECK(s);
   PDX_HIP(hipMemsetAsync(bad, 0, sizeof(unsigned int), st));
-  if (m) hipLaunchKernelGGL(k_replay_keys, dim3(grid_for(m, 256, 4)), dim3(256), 0, st, rec_key, m, gid_lo, n_own, slot, lvl, bad);
   int bits = ilog2((uint64_t)n_own + 1);
   if (bits < 1) bits = 1;
+  // the record's level (6 bits) rides above the slot bits of the 31-bit sort key when there is room: ONE sort instead of two
+  const int pack_shift = bits <= 25 ? 25 : -1;
+  if (m) hipLaunchKernelGGL(k_replay_keys, dim3(grid_for(m, 256, 4)), dim3(256), 0, st, rec_key, m, gid_lo, n_own, slot, lvl, bad, pack_shift);
   const uint32_t *ks = slot, *ks2 = nullptr, *ls = lvl;
   const uint64_t* vs = reinterpret_cast<const uint64_t*>(rec_val);
   if (m) {
     PDX_TRY(radix_sort_pairs<uint64_t>(slot, reinterpret_cast<const uint64_t*>(rec_val), k0, v0, k1, v1, m, bits, &ks, &vs, true, s, st));
-    PDX_TRY(radix_sort_pairs<uint32_t>(slot, lvl, k2, l0, k3, l1, m, bits, &ks2, &ls, true, s, st));
+    if (pack_shift < 0) PDX_TRY(radix_sort_pairs<uint32_t>(slot, lvl, k2, l0, k3, l1, m, bits, &ks2, &ls, true, s, st));
   }
-  hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n_own, 256)), dim3(256), 0, st, ids, n_own);
-  hipLaunchKernelGGL(k_seg_starts, dim3(grid_for(n_own + 1, 256)), dim3(256), 0, st, ks, m, ids, n_own, ss);
+  if (pack_shift >= 0) {
+    hipLaunchKernelGGL(k_seg_starts_masked, dim3(grid_for(n_own + 1, 256)), dim3(256), 0, st, ks, m, (1u << pack_shift) - 1u, n_own, ss);
+  } else {
+    hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n_own, 256)), dim3(256), 0, st, ids, n_own);
+    hipLaunchKernelGGL(k_seg_starts, dim3(grid_for(n_own + 1, 256)), dim3(256), 0, st, ks, m, ids, n_own, ss);
+  }
   {
     PDX_PROFILE("replay_partials", st);
-    hipLaunchKernelGGL(k_replay, dim3(grid_for(n_own, 256)), dim3(256), 0, st, ss, n_own, reinterpret_cast<const double*>(vs), ls, out_sum, bad);
+    hipLaunchKernelGGL(k_replay, dim3(grid_for(n_own, 256)), dim3(256), 0, st, ss, n_own, reinterpret_cast<const double*>(vs), pack_shift >= 0 ? ks : ls, out_sum,
+                       bad, pack_shift);
   }
   PDX_LAUNCH_CHECK();
   unsigned int hbad = 0;
