@@ -3816,7 +3816,7 @@ __global__ void __launch_bounds__(256) k_partial_fill(const double* __restrict__
                                                       const uint32_t* __restrict__ occ_of_gid, const int64_t* __restrict__ order, int64_t G,
                                                       const int64_t* __restrict__ prefix, const int64_t* __restrict__ gid_map,
                                                       const int64_t* __restrict__ rec_off, int64_t* __restrict__ rec_key,
-                                                      double* __restrict__ rec_val) {
+                                                      double* __restrict__ rec_val, int wave_form_too) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < G; j += stride) {
     const int64_t lg = order ? order[j] : j;
@@ -3826,6 +3826,7 @@ __global__ void __launch_bounds__(256) k_partial_fill(const double* __restrict__
     if (c <= 0) continue;
     const int64_t a = prefix[lg], b = a + c;
     const int64_t kf = (a + 15) >> 4, kl = b >> 4;
+    if (wave_form_too && (kf > kl || kl - kf <= 64)) continue;  // k_partial_fill_wave emits this group
     const int64_t gkey = gid_map[lg] * 64;
     int64_t pos = rec_off[j];
     if (kf > kl) {
@@ -3853,6 +3854,73 @@ __global__ void __launch_bounds__(256) k_partial_fill(const double* __restrict__
       sidx += nleaf;
     }
     for (int64_t i = 16 * kl - a; i < c; ++i) { rec_key[pos] = gkey; rec_val[pos] = v[i]; ++pos; }
+  }
+}
+
+// Wave-per-group form of k_partial_fill for groups with at most 64 interior leaves (<= ~1050 rows; longer ones keep the thread form): lane l
+// sums interior leaf l (16 contiguous values), six shuffle steps build every aligned perfect subtree at once (t[k] at lane r = the tree
+// over leaves [r, r + 2^k), left + right as the counter merges them), the boundary-leaf fragments are copied by the lanes.  The thread
+// form walks each group with one thread and a 64-entry counter in scratch memory (2.2 ms per 5e8 rows).
+__global__ void __launch_bounds__(256) k_partial_fill_wave(const double* __restrict__ vals, const uint32_t* __restrict__ seg_start,
+                                                           const uint32_t* __restrict__ occ_of_gid, const int64_t* __restrict__ order, int64_t G,
+                                                           const int64_t* __restrict__ prefix, const int64_t* __restrict__ gid_map,
+                                                           const int64_t* __restrict__ rec_off, int64_t* __restrict__ rec_key,
+                                                           double* __restrict__ rec_val) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); j < G; j += nw) {
+    const int64_t lg = order ? order[j] : j;
+    const uint32_t k = occ_of_gid[lg];
+    const double* v = vals + seg_start[k];
+    const int64_t c = (int64_t)seg_start[k + 1] - (int64_t)seg_start[k];
+    if (c <= 0) continue;
+    const int64_t a = prefix[lg], b = a + c;
+    const int64_t kf = (a + 15) >> 4, kl = b >> 4;
+    const int64_t gkey = gid_map[lg] * 64;
+    const int64_t pos0 = rec_off[j];
+    if (kf > kl) {  // the whole range lies inside one leaf (< 31 rows): fragments only
+      for (int64_t i = lane; i < c; i += 64) {
+        rec_key[pos0 + i] = gkey;
+        rec_val[pos0 + i] = v[i];
+      }
+      continue;
+    }
+    const int nint = (int)(kl - kf);
+    if (kl - kf > 64) continue;  // long group: k_partial_fill
+    const int h = (int)(16 * kf - a);
+    if (lane < h) {
+      rec_key[pos0 + lane] = gkey;
+      rec_val[pos0 + lane] = v[lane];
+    }
+    double t[7];
+    t[0] = 0.0;
+    if (lane < nint) {
+      const double* lv = v + h + 16 * lane;
+      double acc = 0.0;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc += lv[e];
+      t[0] = acc;
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) t[q + 1] = t[q] + __shfl_down(t[q], 1 << q, 64);
+    int64_t pos = pos0 + h;
+    for (int64_t sidx = kf; sidx < kl;) {
+      const int lvl = (int)aligned_block_level(sidx, kl);
+      if (lane == (int)(sidx - kf)) {
+        double val = t[0];
+#pragma unroll
+        for (int q = 1; q < 7; ++q) val = lvl == q ? t[q] : val;
+        rec_key[pos] = gkey + lvl + 1;
+        rec_val[pos] = val;
+      }
+      ++pos;
+      sidx += (int64_t)1 << lvl;
+    }
+    const int ntail = (int)(b - 16 * kl);
+    if (lane < ntail) {
+      rec_key[pos + lane] = gkey;
+      rec_val[pos + lane] = v[16 * kl - a + lane];
+    }
   }
 }
 
@@ -4011,8 +4079,14 @@ int pdx_grouped_partial_fill(pdx_grouped* g, const int64_t* gid_map, int64_t* re
   hipStream_t st = as_stream(stream);
   if (g->G) {
     PDX_PROFILE("partial_fill", st);
-    hipLaunchKernelGGL(k_partial_fill, dim3(grid_for(g->G, 256)), dim3(256), 0, st, g->vals_sorted, g->seg_start, g->occ_of_gid, g->order, g->G, g->prefix,
-                       gid_map, g->rec_off, rec_key, rec_val);
+    {
+      const int wave_form = [] { const char* e = getenv("PDX_PARTIAL_FILL_WAVE"); return !(e && e[0] == '0'); }() ? 1 : 0;
+      if (wave_form)
+        hipLaunchKernelGGL(k_partial_fill_wave, dim3((unsigned)std::min<int64_t>(ceil_div(g->G, 4), (int64_t)kCUs * 32)), dim3(256), 0, st, g->vals_sorted,
+                           g->seg_start, g->occ_of_gid, g->order, g->G, g->prefix, gid_map, g->rec_off, rec_key, rec_val);
+  hipLaunchKernelGGL(k_partial_fill, dim3(grid_for(g->G, 256)), dim3(256), 0, st, g->vals_sorted, g->seg_start, g->occ_of_gid, g->order, g->G, g->prefix,
+                       gid_map, g->rec_off, rec_key, rec_val, wave_form);
+    }
   }
   PDX_LAUNCH_CHECK();
   PDX_HIP(hipStreamSynchronize(st));

@@ -42,8 +42,14 @@ def _data(n, nk):
     return orc.synth_keys(0, n, nk) * 7919 - 12345, orc.synth_vals(0, n) - 0.5
 
 
-def test_sharded_single_rank():
+@pytest.mark.parametrize("wave_fill", ["default", "0"])
+def test_sharded_single_rank(monkeypatch, wave_fill):
+    """(wave_fill = 0: the partial records of every group come from the thread-per-group kernel; default: groups with at most 64
+    interior leaves take the wave-per-group form)"""
     import torch
+
+    if wave_fill != "default":
+        monkeypatch.setenv("PDX_PARTIAL_FILL_WAVE", wave_fill)
     from pandasarrow_amd import _lib as L
     from pandasarrow_amd import dist as pdist
     from pandasarrow_amd.column import Column
