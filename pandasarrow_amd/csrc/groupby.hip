@@ -2036,7 +2036,7 @@ static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int
   int grid = (int)std::min<int64_t>(ceil_div(nseg, kSegWaves), (int64_t)kCUs * 8);
   dim3 g(grid), b(kSegWaves * 64);
   // mostly short groups: one kernel that batches the groups of <= kMidLen rows per wave and chunks through the longer ones
-  const int64_t mid_max = [] { const char* e = getenv("PDX_SEG_MID_MAX"); return e ? atoll(e) : 256ll; }();
+  const int64_t mid_max = [] { const char* e = getenv("PDX_SEG_MID_MAX"); return e ? atoll(e) : 1100ll; }();
   const int64_t min_len = -1;
   if (nrows / nseg < mid_max) {
     const int64_t nwaves = (int64_t)kCUs * 8 * kSegWaves;
