@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""One-off larger differential fuzz of the group-by path (same generator as tests/test_gpu_fuzz.py, other seeds, bigger inputs and a
+bias towards the narrowing-sort / fused-last-digit configurations).  Usage: python tools/fuzz_campaign.py [first_seed] [count]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import oracle as orc
+from pandasarrow_amd import _lib as L, column as K
+import test_gpu_fuzz as F
+
+L.check(L.load().pdx_init(0))
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+MODES = {"default": {}, "fused_dense": {"PDX_FUSED_LAST_DIGIT_MIN_ROWS": "0", "PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS": "4", "PDX_FUSED_LAST_DIGIT_MIN_RUN": "0"},
+         "hash_tail": {"PDX_GROUPBY_DENSE": "0", "PDX_HASH_HEAD_ROWS": "4096"}, "null_pw": {"PDX_FLR_NULL_PW": "1", "PDX_FUSED_LAST_DIGIT_MIN_ROWS": "0",
+         "PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS": "4", "PDX_FUSED_LAST_DIGIT_MIN_RUN": "0"}}
+ALL_ENV = sorted({k for m in MODES.values() for k in m})
+bad = 0
+for i in range(count):
+    seed = first + i
+    rng = np.random.default_rng(seed)
+    keys, kvalid, vals, vvalid, kinds = F._make_case(seed)
+    if rng.random() < 0.5:  # a large high-cardinality case: two sort digits below the fused one
+        n = int(rng.integers(3_000_000, 6_000_000))
+        card = int(rng.choice([200_000, 1_000_000, 3_000_000]))
+        keys = rng.integers(0, card, n).astype(np.int64) + int(rng.integers(-5, 5)) * 1000
+        if rng.random() < 0.3:
+            keys[rng.random(n) < 0.2] = 77
+        kvalid = (rng.random(n) > 0.03) if rng.random() < 0.3 else None
+        vals = rng.standard_normal(n) if rng.random() < 0.6 else rng.integers(-50, 50, n).astype(np.int64)
+        vvalid = (rng.random(n) > rng.choice([0.02, 0.5])) if rng.random() < 0.5 else None
+        if rng.random() < 0.5:
+            kinds = [0, 1, 4]
+    mode = list(MODES)[seed % len(MODES)]
+    for k in ALL_ENV:
+        os.environ.pop(k, None)
+    os.environ.update(MODES[mode])
+    gb = K.GroupByHandle.create(K.Column.from_numpy(keys, kvalid, offset=seed % 3))
+    ids, uniq, isnull, frst = orc.group_ids(keys, kvalid)
+    G = len(uniq)
+    ok_all = gb.num_groups == G and np.array_equal(gb.group_ids().cpu().numpy().astype(np.uint32), ids) and np.array_equal(gb.first_rows().cpu().numpy(), frst)
+    outs = gb.agg(K.Column.from_numpy(vals, vvalid, offset=seed % 5), kinds)
+    for kind, out in zip(kinds, outs):
+        got, ok = out.to_numpy()
+        exp, eok = orc.groupby_agg(kind, ids, G, vals, vvalid, nthreads=8)
+        ok_all = ok_all and ((ok is None and eok.all()) or np.array_equal(ok, eok)) and F._bits_equal(got, exp, eok)
+    if not ok_all:
+        bad += 1
+        print("MISMATCH seed", seed, "mode", mode, "n", len(keys), "G", G, "kinds", kinds, flush=True)
+    if i % 25 == 24:
+        print(f"{i + 1} cases, {bad} mismatches", flush=True)
+print("done:", count, "cases,", bad, "mismatches")
+sys.exit(1 if bad else 0)
