@@ -331,10 +331,24 @@ __global__ void __launch_bounds__(256) k_minmax_partial(const T* __restrict__ v,
   Extreme<T> e;
   e.init();
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // four independent 8-byte streams per thread (the (value, row) reduction is order independent)
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    T x[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      x[k] = v[i + k * stride];
+      ok[k] = !valid || bit_get(valid, off + i + k * stride);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (ok[k] && x[k] == x[k]) e.add(x[k], i + k * stride);  // (NaN skipped; never true for integers)
+  }
+  for (; i < n; i += stride) {
     if (valid && !bit_get(valid, off + i)) continue;
     T x = v[i];
-    if (x != x) continue;  // NaN (never true for integers)
+    if (x != x) continue;
     e.add(x, i);
   }
   block_reduce_extreme(e, smem);
