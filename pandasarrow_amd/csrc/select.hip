@@ -35,6 +35,11 @@ __global__ void __launch_bounds__(256) k_gather(GatherCols c, const IDX* __restr
                                                 int64_t idx_off, int64_t m, int64_t n_src, int check_bounds, ErrFlag* err,
                                                 unsigned long long* __restrict__ null_counts) {
   const int lane = threadIdx.x & 63;
+  // null rows per column: summed per workgroup in LDS, one global add per workgroup and column at the end (an add per 64-row word
+  // on neighbouring global counters serialises in one L2 channel: a nullable 1e8-row filter took 73 ms that way)
+  __shared__ unsigned int snulls[kMaxCols];
+  if (threadIdx.x < kMaxCols) snulls[threadIdx.x] = 0;
+  __syncthreads();
   int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   int64_t nwords = (m + 63) >> 6;
@@ -90,13 +95,15 @@ __global__ void __launch_bounds__(256) k_gather(GatherCols c, const IDX* __restr
               }
               int valid_rows = (int)(remain >= 64 ? 64 : remain);
               unsigned long long nulls = (unsigned long long)(valid_rows - __popcll(bal));
-              if (nulls) atomicAdd(&null_counts[col], nulls);
+              if (nulls) atomicAdd(&snulls[col], (unsigned int)nulls);
             }
           }
         }
       }
     }
   }
+  __syncthreads();
+  if ((int)threadIdx.x < c.ncols && snulls[threadIdx.x]) atomicAdd(&null_counts[threadIdx.x], (unsigned long long)snulls[threadIdx.x]);
 }
 
 // scatter: dst[idx[j]] = src[j]; validity bits are set/cleared with atomics (distinct rows may share a byte)
@@ -147,18 +154,37 @@ struct MaskEmit {
 // (within a wave step the selected lanes store to consecutive addresses; consecutive steps continue where the last one ended).
 // Same tile / wave layout as k_compact_count, whose scanned block counts give every workgroup its output offset.  A wave owns
 // 1024 consecutive rows: lane s < 16 loads the 64 selection bits of step s, the words are then broadcast (uniform registers).
+// NULLS: columns with validity and / or an EMIT_NULL mask with null slots (a null slot selects the row and makes it null in every
+// column).  The output validity bitmaps are preset to all ones by the host; only the selected rows that ARE null clear their
+// bit (one atomicAnd on the 32-bit word each: nulls are the rare case), and the wave adds its null count per column.
 constexpr int kFilterCols = 2;  // columns per batch: 2 x 16 independent 8-byte loads per lane in flight
+template <bool NULLS>
 __global__ void __launch_bounds__(kCompactBlock) k_filter_stream(GatherCols c, const uint8_t* __restrict__ mask, const uint8_t* __restrict__ mvalid,
-                                                                 int64_t off, int64_t n, const int64_t* __restrict__ block_offsets) {
+                                                                 int64_t off, int64_t n, const int64_t* __restrict__ block_offsets, int emit_null,
+                                                                 unsigned int* __restrict__ block_nulls /* [ncols][blocks] */) {
   __shared__ int wave_tot[4];
+  // null rows per column of this workgroup: summed in LDS and written once (an atomicAdd per wave and column on nine neighbouring
+  // global counters serialised in one L2 channel: 8 of the kernel's 10 ms)
+  __shared__ unsigned int snulls[kMaxCols];
+  if (NULLS && threadIdx.x < kMaxCols) snulls[threadIdx.x] = 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t base = (int64_t)blockIdx.x * kCompactTile + wave * (64 * kCompactItems);
-  uint64_t mine = 0;
+  uint64_t mine = 0, mine_forced = 0;
   if (lane < kCompactItems) {
     const int64_t i0 = base + (int64_t)lane * 64;
     if (i0 < n) {
       mine = load_bits64(mask, off + i0, off + n);
-      if (mvalid) mine &= load_bits64(mvalid, off + i0, off + n);  // (DROP: a null mask slot selects nothing)
+      if (mvalid) {
+        const uint64_t mv = load_bits64(mvalid, off + i0, off + n);
+        if (NULLS && emit_null) {
+          const int64_t remain = n - i0;
+          const uint64_t inr = remain >= 64 ? ~0ull : ((1ull << remain) - 1ull);
+          mine_forced = ~mv & inr;            // EMIT_NULL: a null mask slot selects the row and nulls it
+          mine = (mine & mv) | mine_forced;
+        } else {
+          mine &= mv;                          // DROP: a null mask slot selects nothing
+        }
+      }
     }
   }
   uint64_t sel[kCompactItems];
@@ -189,13 +215,63 @@ __global__ void __launch_bounds__(kCompactBlock) k_filter_stream(GatherCols c, c
       const int col = col0 + cc;
       if (col >= c.ncols) break;
       int64_t pos = pos0;
+      if constexpr (NULLS) {
+        // validity window of step `lane` of this column (all ones without a bitmap), minus the rows the mask forces to null
+        uint64_t okw = ~0ull;
+        if (lane < kCompactItems) {
+          const int64_t i0 = base + (int64_t)lane * 64;
+          if (c.src_valid[col] && i0 < n) okw = load_bits64(c.src_valid[col], c.src_off[col] + i0, c.src_off[col] + n);
+          okw &= ~mine_forced;
+        }
+        uint32_t* dstw = reinterpret_cast<uint32_t*>(c.dst_valid[col]);
+        int wave_nulls = 0;
+        // the wave's selected rows occupy <= 1024 consecutive output bits = <= 33 words: lane w keeps the clear mask of word w and
+        // the wave sends ONE atomicAnd per word at the end (an atomic per null row cost 8 ms of 10 at 5 % nulls).  Which rows are null
+        // is wave-uniform knowledge (64-bit words), so the bit positions come from a scalar loop over the null bits.
+        uint32_t myw = 0xFFFFFFFFu;
+        const int64_t wbase = pos0 & ~31ll;
 #pragma unroll
-      for (int s = 0; s < kCompactItems; ++s) {
-        if ((sel[s] >> lane) & 1) c.dst[col][pos + __popcll(sel[s] & lt)] = v[cc][s];
-        pos += __popcll(sel[s]);
+        for (int s = 0; s < kCompactItems; ++s) {
+          const uint64_t ok = __shfl(okw, s, 64);
+          const uint64_t nulls_v = sel[s] & ~ok;
+          const uint64_t nulls = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(nulls_v >> 32)) << 32) |
+                                 (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nulls_v);
+          if ((sel[s] >> lane) & 1) {
+            const int64_t o = pos + __popcll(sel[s] & lt);
+            c.dst[col][o] = ((nulls >> lane) & 1) ? 0ull : v[cc][s];
+          }
+          for (uint64_t rem = nulls; rem; rem &= rem - 1) {
+            const int b = __ffsll((unsigned long long)rem) - 1;
+            const int orel = (int)(pos - wbase) + __popcll(sel[s] & ((1ull << b) - 1ull));
+            if (lane == (orel >> 5)) myw &= ~(1u << (orel & 31));
+          }
+          wave_nulls += __popcll(nulls);
+          pos += __popcll(sel[s]);
+        }
+        if (myw != 0xFFFFFFFFu && dstw) atomicAnd(&dstw[(wbase >> 5) + lane], myw);
+        if (lane == 0 && wave_nulls) atomicAdd(&snulls[col], (unsigned int)wave_nulls);
+      } else {
+#pragma unroll
+        for (int s = 0; s < kCompactItems; ++s) {
+          if ((sel[s] >> lane) & 1) c.dst[col][pos + __popcll(sel[s] & lt)] = v[cc][s];
+          pos += __popcll(sel[s]);
+        }
       }
     }
   }
+  if constexpr (NULLS) {
+    __syncthreads();
+    if ((int)threadIdx.x < c.ncols) block_nulls[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = snulls[threadIdx.x];
+  }
+}
+__global__ void __launch_bounds__(256) k_sum_block_nulls(const unsigned int* __restrict__ block_nulls, int64_t nblocks, unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long part[4];
+  unsigned long long acc = 0;
+  for (int64_t i = threadIdx.x; i < nblocks; i += 256) acc += block_nulls[(int64_t)blockIdx.x * nblocks + i];
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
 
 static int fill_cols(GatherCols& g, const pdx_column* cols, int ncols, pdx_mut_column* outs, int64_t out_len, int64_t src_len,
@@ -327,22 +403,42 @@ int pdx_filter(const pdx_column* cols, int ncols, const pdx_column* mask, int em
   }
   GatherCols g;
   PDX_TRY(fill_cols(g, cols, ncols, outs, m, n, mvalid && emit_null, "pdx_filter"));
-  bool streaming = !(mvalid && emit_null);
-  for (int c = 0; c < ncols; ++c) streaming = streaming && !g.src_valid[c];
+  // Streaming form (every column read once, selected values written in order).  With nulls in play (a column bitmap, or an EMIT_NULL
+  // mask with null slots) the output bitmaps are preset to ones and null rows clear their bit with a 32-bit atomic: the bitmaps
+  // must start on a 4-byte boundary (fresh buffers do); otherwise the compacted-row-id gather below takes over.
+  bool any_nulls = mvalid && emit_null;
+  bool streaming = true;
+  for (int c = 0; c < ncols; ++c) {
+    any_nulls = any_nulls || g.src_valid[c];
+    if (g.dst_valid[c] && (reinterpret_cast<uintptr_t>(g.dst_valid[c]) & 3)) streaming = false;
+  }
   if (const char* e = getenv("PDX_FILTER_STREAM")) streaming = streaming && e[0] != '0';
   if (streaming) {
-    // no validity anywhere: stream every column once (k_filter_stream); outputs are all valid
+    unsigned long long* nulls = s.get<unsigned long long>(kMaxCols);
+    PDX_SCRATCH_CHECK(s);
+    PDX_HIP(hipMemsetAsync(nulls, 0, sizeof(unsigned long long) * kMaxCols, st));
+    for (int c = 0; c < ncols; ++c)
+      if (g.dst_valid[c] && m > 0) PDX_HIP(hipMemsetAsync(g.dst_valid[c], 0xFF, (size_t)((m + 7) / 8), st));
     if (m > 0) {
-      hipLaunchKernelGGL(k_filter_stream, dim3((unsigned)nblocks), dim3(kCompactBlock), 0, st, g, static_cast<const uint8_t*>(mask->values), mvalid, mask->offset,
-                         n, counts);
+      if (any_nulls) {
+        unsigned int* block_nulls = s.get<unsigned int>((size_t)nblocks * ncols);
+        PDX_SCRATCH_CHECK(s);
+        hipLaunchKernelGGL((k_filter_stream<true>), dim3((unsigned)nblocks), dim3(kCompactBlock), 0, st, g, static_cast<const uint8_t*>(mask->values), mvalid,
+                           mask->offset, n, counts, emit_null, block_nulls);
+        hipLaunchKernelGGL(k_sum_block_nulls, dim3(ncols), dim3(256), 0, st, block_nulls, nblocks, nulls);
+      } else {
+        hipLaunchKernelGGL((k_filter_stream<false>), dim3((unsigned)nblocks), dim3(kCompactBlock), 0, st, g, static_cast<const uint8_t*>(mask->values), mvalid,
+                           mask->offset, n, counts, emit_null, (unsigned int*)nullptr);
+      }
       PDX_LAUNCH_CHECK();
     }
-    for (int c = 0; c < ncols; ++c) {
-      if (g.dst_valid[c] && m > 0) PDX_HIP(hipMemsetAsync(g.dst_valid[c], 0xFF, (size_t)((m + 7) / 8), st));
-      outs[c].length = m;
-      outs[c].null_count = 0;
-    }
+    unsigned long long hn[kMaxCols] = {0};
+    if (any_nulls) PDX_HIP(hipMemcpyAsync(hn, nulls, sizeof(hn), hipMemcpyDeviceToHost, st));
     PDX_HIP(hipStreamSynchronize(st));
+    for (int c = 0; c < ncols; ++c) {
+      outs[c].length = m;
+      outs[c].null_count = g.dst_valid[c] ? (int64_t)hn[c] : 0;
+    }
     return PDX_OK;
   }
   int64_t* sel = s.get<int64_t>((size_t)std::max<int64_t>(m, 1));

@@ -905,3 +905,31 @@ def test_argsort_large_vs_oracle_and_series_sort(px, dtype):
     assert len(tv) == 10 and (tok is None or tok.all() or np.array_equal(tok, valid[order]))
     assert np.array_equal(tv.view(np.uint64), vi[order].view(np.uint64))
     assert np.array_equal(top.index.to_numpy()[0], (np.arange(n, dtype=np.uint64)[::-1])[order])
+
+
+@pytest.mark.parametrize("stream", ["default", "0"])
+@pytest.mark.parametrize("n", [1, 65, 4097, 250_013])
+def test_filter_streaming_with_nulls_vs_oracle(px, monkeypatch, n, stream):
+    """columns WITH validity and a mask with null slots, both FilterOptions: EMIT_NULL (a null slot selects the row and nulls it in
+    every column) and DROP.  The streaming form presets the output bitmaps and clears the bits of null rows; the gather form
+    (PDX_FILTER_STREAM=0) assembles them with ballots.  Values of valid rows, validity and null counts must match the oracle."""
+    if stream != "default":
+        monkeypatch.setenv("PDX_FILTER_STREAM", stream)
+    rng = np.random.default_rng(n)
+    cols_np = [rng.standard_normal(n), rng.integers(-2**62, 2**62, n).astype(np.int64), rng.standard_normal(n)]
+    valids = [rng.random(n) > 0.1, None, rng.random(n) > 0.6]
+    mask = rng.random(n) < 0.4
+    mvalid = rng.random(n) > 0.15
+    cols = [px.Column.from_numpy(a, v, offset=i + 1) for i, (a, v) in enumerate(zip(cols_np, valids))]
+    for mv in (None, mvalid):
+        for emit in (True, False):
+            M = px.Column.from_numpy(mask, mv, offset=5)
+            outs = px.K.filter(cols, M, emit)
+            for a, v, out in zip(cols_np, valids, outs):
+                exp, eok = orc.filter(a, mask, v, mv, emit_null=emit)
+                got, ok = out.to_numpy()
+                assert len(got) == len(exp)
+                ev = np.ones(len(exp), bool) if eok is None else eok
+                assert np.array_equal(np.ones(len(exp), bool) if ok is None else ok, ev), (mv is None, emit)
+                assert out.null_count == int((~ev).sum())
+                assert np.array_equal(got.view(np.uint64)[ev], exp.view(np.uint64)[ev])

@@ -69,6 +69,12 @@ def main():
     sel = K.filter_count(mask.col)
     s = sel / n
     report("filter_8cols+index[1e8]", n, (0.125 + 8 * 9 * (1 + s)) * n, timeit(lambda: df.where(mask)), {"selectivity": s})
+    # the same with 5 % nulls in every column (validity bitmaps travel too: + 9 x (1 + s) / 8 B per row)
+    vm = K.compare(L.NE, K.synth_keys(3, n, 20), 0)
+    colsn = {f"c{j}": K.Column(L.FLOAT64, n, cols[f"c{j}"].values, vm.values, 0, -1) for j in range(8)}
+    dfn = api.DataFrame(colsn, index=idx)
+    report("filter_8cols+index_5%nulls[1e8]", n, (0.125 + (8 + 0.125) * 9 * (1 + s)) * n, timeit(lambda: dfn.where(mask)), {"selectivity": s})
+    del dfn, colsn, vm
     m = n // 2
     take_idx = api.Series(K.synth_keys(7, m, n))
     report("take_8cols+index[5e7 of 1e8]", m, (8 + 16 * 9) * m, timeit(lambda: df.take(take_idx)))
