@@ -1747,15 +1747,43 @@ struct BinParams {
   }
 };
 // sparse bins (many rows per bin): bin b starts at the first row whose timestamp is >= (closed-left) / > (closed-right) edge b
-__global__ void k_bin_lower_bounds(BinParams p, int64_t n, int64_t nbins, uint32_t* __restrict__ lb /* nbins + 1 */) {
+// (the search starts from the position a uniformly spaced axis would give and brackets the answer with growing steps before it
+//  bisects: a few probes in neighbouring cache lines instead of ~30 scattered ones per edge on regular timestamps)
+__global__ void k_bin_lower_bounds(BinParams p, int64_t n, int64_t nbins, long long tmin, long long tmax, uint32_t* __restrict__ lb /* nbins + 1 */) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const double scale = tmax > tmin ? (double)(n - 1) / (double)(tmax - tmin) : 0.0;
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b <= nbins; b += stride) {
     if (b == nbins) {
       lb[b] = (uint32_t)n;
       continue;
     }
     long long edge = p.first + b * p.freq;
+    auto before_at = [&](int64_t i) {
+      const long long v = p.ts[i];
+      return p.closed_right ? (v <= edge) : (v < edge);
+    };
+    int64_t g = (int64_t)((double)(edge - tmin) * scale);
+    g = g < 0 ? 0 : (g > n - 1 ? n - 1 : g);
     int64_t lo = 0, hi = n;
+    if (before_at(g)) {  // the answer lies behind g: step forward until a row is not before the edge
+      lo = g + 1;
+      for (int64_t st = 64; lo + st < n; st <<= 2) {
+        if (!before_at(lo + st)) {
+          hi = lo + st;
+          break;
+        }
+        lo = lo + st + 1;
+      }
+    } else {  // the answer is g or in front of it
+      hi = g;
+      for (int64_t st = 64; hi - st > 0; st <<= 2) {
+        if (before_at(hi - st)) {
+          lo = hi - st + 1;
+          break;
+        }
+        hi = hi - st;
+      }
+    }
     while (lo < hi) {
       int64_t mid = (lo + hi) >> 1;
       long long v = p.ts[mid];
@@ -3736,7 +3764,7 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
       // many rows per bin: binary-search every edge (nbins * log n reads) instead of evaluating the bin of every row
       uint32_t* lb = s.get<uint32_t>((size_t)nbins + 1);
       if (s.failed) return PDX_OOM;
-      hipLaunchKernelGGL(k_bin_lower_bounds, dim3(grid_for(nbins + 1, 256)), dim3(256), 0, st, gb->bin, n, (int64_t)nbins, lb);
+      hipLaunchKernelGGL(k_bin_lower_bounds, dim3(grid_for(nbins + 1, 256)), dim3(256), 0, st, gb->bin, n, (int64_t)nbins, mn, mx, lb);
       rc = compact_indices((int64_t)nbins, NonEmptyBinPred{lb}, NonEmptyBinEmit{lb, gb->label_base, freq_ns, gb->seg_start, gb->uniques, gb->first_rows},
                            &G, s, st);
     } else {
