@@ -160,7 +160,10 @@ int pdx_aggregate(int kind, const pdx_column* a, pdx_scalar* out, void* stream);
 /* ---------------------------------------------------------------- filter / take
  * Replaces CallFunction("filter", {RecordBatch, mask}, FilterOptions{EMIT_NULL}) + CallFunction("array_filter",
  * {index, mask}) at src/dataframe.cpp:461-475 and src/series.cpp:130-144.  mask: PDX_BOOL of the same length as
- * every column (else PDX_INVALID).  Two calls: count (host-visible) then fill; the facade hides the pair. */
+ * every column (else PDX_INVALID).  Two calls: count (host-visible) then fill; the facade hides the pair.
+ * Output validity bitmaps: give them a capacity rounded up to a multiple of 4 bytes and a 4-byte aligned start (any device
+ * allocation has both): null rows clear their bit with a 32-bit atomic on the word that holds it.  A bitmap that does not start on
+ * a 4-byte boundary is still served (row-id gather path), only slower. */
 int pdx_filter_count(const pdx_column* mask, int emit_null, int64_t* out_count, void* stream);
 int pdx_filter(const pdx_column* cols, int ncols, const pdx_column* mask, int emit_null, pdx_mut_column* outs, void* stream);
 /* Replaces CallFunction("take", {RecordBatch, indices}) + "array_take" at src/dataframe.cpp:477-492 and
