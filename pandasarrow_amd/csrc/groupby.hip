@@ -4144,6 +4144,7 @@ int pdx_replay_partials(const int64_t* rec_key, const double* rec_val, int64_t m
   const uint32_t *ks = slot, *ks2 = nullptr, *ls = lvl;
   const uint64_t* vs = reinterpret_cast<const uint64_t*>(rec_val);
   if (m) {
+    ProfileTagOverride replay_tag("replay_sort");  // (not the per-row scatter passes the bench prices against the roofline)
     PDX_TRY(radix_sort_pairs<uint64_t>(slot, reinterpret_cast<const uint64_t*>(rec_val), k0, v0, k1, v1, m, bits, &ks, &vs, true, s, st));
     if (pack_shift < 0) PDX_TRY(radix_sort_pairs<uint32_t>(slot, lvl, k2, l0, k3, l1, m, bits, &ks2, &ls, true, s, st));
   }

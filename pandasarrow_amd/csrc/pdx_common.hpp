@@ -68,6 +68,13 @@ struct ProfileScope {
   ProfileScope(const char* tag, hipStream_t s);
   ~ProfileScope();
 };
+// Every scope opened by this thread while the object lives reports under `tag` (e.g. the sort of the received partial records: not
+// the big per-row scatter passes the bench prices against the roofline)
+struct ProfileTagOverride {
+  const char* prev;
+  explicit ProfileTagOverride(const char* tag);
+  ~ProfileTagOverride();
+};
 #define PDX_CONCAT2(a, b) a##b
 #define PDX_CONCAT(a, b) PDX_CONCAT2(a, b)
 #define PDX_PROFILE(tag, st) ::pdx::ProfileScope PDX_CONCAT(_pdx_prof_scope_, __LINE__)(tag, st)

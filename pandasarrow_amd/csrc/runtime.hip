@@ -118,12 +118,15 @@ Profiler& profiler() {
 }
 }  // namespace
 bool profile_enabled() { return profiler().enabled; }
+static thread_local const char* t_profile_tag_override = nullptr;
+ProfileTagOverride::ProfileTagOverride(const char* tag) : prev(t_profile_tag_override) { t_profile_tag_override = tag; }
+ProfileTagOverride::~ProfileTagOverride() { t_profile_tag_override = prev; }
 ProfileScope::ProfileScope(const char* tag, hipStream_t s) : slot(-1), st(s) {
   Profiler& p = profiler();
   if (!p.enabled) return;
   std::lock_guard<std::mutex> lk(p.mu);
   ProfRecord r;
-  r.tag = tag;
+  r.tag = t_profile_tag_override ? t_profile_tag_override : tag;
   if (!p.free_events.empty()) {
     r.start = p.free_events.back().first;
     r.stop = p.free_events.back().second;
