@@ -89,6 +89,8 @@ typedef struct pdx_scalar {
 typedef enum pdx_binary_op { PDX_ADD = 0, PDX_SUB = 1, PDX_MUL = 2, PDX_DIV = 3 } pdx_binary_op;
 typedef enum pdx_compare_op { PDX_EQ = 0, PDX_NE = 1, PDX_LT = 2, PDX_LE = 3, PDX_GT = 4, PDX_GE = 5 } pdx_compare_op;
 typedef enum pdx_logical_op { PDX_AND = 0, PDX_OR = 1 } pdx_logical_op;
+/* which operand of pdx_binary / pdx_compare is a length-1 column that is broadcast (the `b_is_scalar` argument) */
+typedef enum pdx_scalar_side { PDX_SCALAR_NONE = 0, PDX_SCALAR_RHS = 1, PDX_SCALAR_LHS = 2 } pdx_scalar_side;
 typedef enum pdx_agg_kind {
   PDX_AGG_SUM = 0, PDX_AGG_MEAN = 1, PDX_AGG_MIN = 2, PDX_AGG_MAX = 3, PDX_AGG_COUNT = 4,
   /* group-by only (pdx_groupby_agg; SURVEY 8(f)-3, the reference's GROUPBY_NUMERIC_AGG(variance|stddev), GROUPBY_AGG(product),
@@ -139,12 +141,15 @@ int pdx_synth_ts(int64_t start, int64_t n, int64_t t0_ns, int64_t step_ns, int64
  * Replaces CallFunction("add"|"subtract"|"multiply"|"divide", {lhs, rhs}) at src/series.cpp:19-33 (macro
  * BINARY_OPERATOR, instantiated 229-235), src/scalar.cpp:24-36 (Scalar rhs/lhs) and the DataFrame form
  * src/dataframe.cpp:233-275.  a,b: PDX_INT64 or PDX_FLOAT64 (mixed => float64 result, like Arrow's implicit
- * promotion).  b_is_scalar != 0: b has length 1 and is broadcast.  Integer arithmetic wraps; integer divide
- * truncates toward zero, INT64_MIN / -1 == 0, a zero divisor at a valid slot fails the whole call with
- * PDX_INVALID "divide by zero".  out null where either input is null. */
+ * promotion).  b_is_scalar is a pdx_scalar_side: PDX_SCALAR_RHS (1): b has length 1 and is broadcast (`series - 2`,
+ * src/series.cpp:25-28); PDX_SCALAR_LHS (2): a has length 1 and is broadcast (`2 - series`, `2 / series`:
+ * Scalar::operator op(Series) -> BinaryImpl -> CallFunction(name, {scalar, s.array()}), src/scalar.cpp:24-36; the result has
+ * b's length).  Integer arithmetic wraps; integer divide truncates toward zero, INT64_MIN / -1 == 0, a zero divisor at a valid
+ * slot fails the whole call with PDX_INVALID "divide by zero".  out null where either input is null. */
 int pdx_binary(int op, const pdx_column* a, const pdx_column* b, int b_is_scalar, pdx_mut_column* out, void* stream);
 /* Replaces CallFunction("equal"|"not_equal"|"less"|"less_equal"|"greater"|"greater_equal") at
- * src/series.cpp:247-257.  out: PDX_BOOL (bit-packed). */
+ * src/series.cpp:247-257 and, with PDX_SCALAR_LHS, Scalar::operator{>,>=,<,<=,==,!=}(Series) at src/scalar.cpp:48-56.
+ * out: PDX_BOOL (bit-packed). */
 int pdx_compare(int op, const pdx_column* a, const pdx_column* b, int b_is_scalar, pdx_mut_column* out, void* stream);
 /* Replaces CallFunction("and"|"or") (non-Kleene) at src/series.cpp:259-260 and "invert" at src/series.cpp:319. */
 int pdx_logical(int op, const pdx_column* a, const pdx_column* b, pdx_mut_column* out, void* stream);

@@ -154,24 +154,24 @@ def agg(kind, v, valid=None, offset=0):
 
 # ------------------------------------------------------------------ element-wise
 def _binary_like(fn_f64, fn_i64, op, a, b, va, vb, offset, out_dtype, bits):
-    a = np.asarray(a)
-    scalar = np.ndim(b) == 0
+    sa, sb = np.ndim(a) == 0, np.ndim(b) == 0  # a python scalar on either side (never both)
+    a = np.atleast_1d(np.asarray(a))
     b = np.atleast_1d(np.asarray(b))
     isf = a.dtype == np.float64 or b.dtype == np.float64  # implicit promotion int64 (+) double -> double
     dt = np.float64 if isf else np.int64
-    n = len(a)
-    A = _shift(a.astype(dt), offset)
-    B = b.astype(dt) if scalar else _shift(b.astype(dt), offset)
-    VA = pack_bits(va, offset)
-    VB = pack_bits(vb, 0 if scalar else offset)
+    n = len(b) if sa else len(a)
+    A = a.astype(dt) if sa else _shift(a.astype(dt), offset)
+    B = b.astype(dt) if sb else _shift(b.astype(dt), offset)
+    VA = pack_bits(va, 0 if sa else offset)
+    VB = pack_bits(vb, 0 if sb else offset)
     need_valid = va is not None or vb is not None
     out_valid = np.zeros((n + 7) // 8 + 8, np.uint8) if need_valid else None
     if bits:
         out = np.zeros((n + 7) // 8 + 8, np.uint8)
     else:
         out = np.empty(n, dt if out_dtype is None else out_dtype)
-    rc = (fn_f64 if isf else fn_i64)(C.c_int(op), _p(A), _p(VA), _i64(offset), _p(B), _p(VB), _i64(0 if scalar else offset),
-                                     C.c_int(1 if scalar else 0), _i64(n), _p(out), _p(out_valid))
+    rc = (fn_f64 if isf else fn_i64)(C.c_int(op), _p(A), _p(VA), _i64(0 if sa else offset), _p(B), _p(VB), _i64(0 if sb else offset),
+                                     C.c_int(2 if sa else 1 if sb else 0), _i64(n), _p(out), _p(out_valid))
     if rc == INVALID:
         raise OracleError(INVALID, "divide by zero")
     res = unpack_bits(out, n) if bits else out
@@ -179,7 +179,8 @@ def _binary_like(fn_f64, fn_i64, op, a, b, va, vb, offset, out_dtype, bits):
 
 
 def binary(op, a, b, va=None, vb=None, offset=0):
-    """a (op) b; b may be a python scalar.  Returns (values, valid|None)."""
+    """a (op) b; a OR b may be a python scalar (Scalar lhs: src/scalar.cpp:24-36; a null scalar: pass va/vb = [False]).
+    Returns (values, valid|None)."""
     L = lib()
     return _binary_like(L.orc_binary_f64, L.orc_binary_i64, op, a, b, va, vb, offset, None, False)
 

@@ -275,15 +275,17 @@ static void valid_and_scalar(const uint8_t* va, int64_t aoff, const uint8_t* vb,
                              uint8_t* out_valid) {
   if (!out_valid) return;
   memset(out_valid, 0, (size_t)((n + 7) / 8));
+  /* b_is_scalar: 0 = arrays, 1 = b is ONE value (Series op Scalar), 2 = a is ONE value (Scalar op Series, src/scalar.cpp:24-36) */
   for (int64_t i = 0; i < n; ++i)
-    bit_set_to(out_valid, i, is_valid(va, aoff, i) && (b_is_scalar ? is_valid(vb, boff, 0) : is_valid(vb, boff, i)));
+    bit_set_to(out_valid, i, (b_is_scalar == 2 ? is_valid(va, aoff, 0) : is_valid(va, aoff, i)) &&
+                                 (b_is_scalar == 1 ? is_valid(vb, boff, 0) : is_valid(vb, boff, i)));
 }
 
 /* Series::operator+,-,*,/ (src/series.cpp:19-33,229-235): "add/subtract/multiply/divide", null if either side null. */
 int orc_binary_f64(int op, const double* a, const uint8_t* va, int64_t aoff, const double* b, const uint8_t* vb, int64_t boff,
                    int b_is_scalar, int64_t n, double* out, uint8_t* out_valid) {
   for (int64_t i = 0; i < n; ++i) {
-    double x = a[aoff + i], y = b_is_scalar ? b[boff] : b[boff + i];
+    double x = b_is_scalar == 2 ? a[aoff] : a[aoff + i], y = b_is_scalar == 1 ? b[boff] : b[boff + i];
     double r;
     switch (op) {
       case ORC_ADD: r = x + y; break;
@@ -302,8 +304,8 @@ int orc_binary_f64(int op, const double* a, const uint8_t* va, int64_t aoff, con
 int orc_binary_i64(int op, const int64_t* a, const uint8_t* va, int64_t aoff, const int64_t* b, const uint8_t* vb, int64_t boff,
                    int b_is_scalar, int64_t n, int64_t* out, uint8_t* out_valid) {
   for (int64_t i = 0; i < n; ++i) {
-    int64_t x = a[aoff + i], y = b_is_scalar ? b[boff] : b[boff + i];
-    int ok = is_valid(va, aoff, i) && (b_is_scalar ? is_valid(vb, boff, 0) : is_valid(vb, boff, i));
+    int64_t x = b_is_scalar == 2 ? a[aoff] : a[aoff + i], y = b_is_scalar == 1 ? b[boff] : b[boff + i];
+    int ok = (b_is_scalar == 2 ? is_valid(va, aoff, 0) : is_valid(va, aoff, i)) && (b_is_scalar == 1 ? is_valid(vb, boff, 0) : is_valid(vb, boff, i));
     int64_t r;
     switch (op) {
       case ORC_ADD: r = (int64_t)((uint64_t)x + (uint64_t)y); break;
@@ -326,7 +328,7 @@ int orc_binary_i64(int op, const int64_t* a, const uint8_t* va, int64_t aoff, co
 #define CMP_BODY(T)                                                                          \
   memset(out_bits, 0, (size_t)((n + 7) / 8));                                                \
   for (int64_t i = 0; i < n; ++i) {                                                          \
-    T x = a[aoff + i], y = b_is_scalar ? b[boff] : b[boff + i];                              \
+    T x = b_is_scalar == 2 ? a[aoff] : a[aoff + i], y = b_is_scalar == 1 ? b[boff] : b[boff + i]; \
     int r;                                                                                   \
     switch (op) {                                                                            \
       case ORC_EQ: r = x == y; break;                                                        \

@@ -55,7 +55,9 @@ int orc_minmax_i64(const int64_t* v, const uint8_t* valid, int64_t off, int64_t 
 int64_t orc_count(const uint8_t* valid, int64_t off, int64_t n);
 
 /* ---- element-wise: Series::operator{+,-,*,/} (src/series.cpp:19-33,229-235), DataFrame (src/dataframe.cpp:233-275) ---- */
-/* b_is_scalar: b points to ONE value (Scalar rhs, series.cpp:25-28).  out_valid may be NULL when both inputs have no validity. */
+/* b_is_scalar == 1: b points to ONE value (Scalar rhs, series.cpp:25-28); == 2: a points to ONE value (Scalar lhs:
+ * Scalar::operator op(Series) -> CallFunction(name, {scalar, array}), src/scalar.cpp:24-56; n is b's length).
+ * out_valid may be NULL when both inputs have no validity. */
 int orc_binary_f64(int op, const double* a, const uint8_t* va, int64_t aoff, const double* b, const uint8_t* vb, int64_t boff,
                    int b_is_scalar, int64_t n, double* out, uint8_t* out_valid);
 int orc_binary_i64(int op, const int64_t* a, const uint8_t* va, int64_t aoff, const int64_t* b, const uint8_t* vb, int64_t boff,

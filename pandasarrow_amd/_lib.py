@@ -18,6 +18,7 @@ INT64, FLOAT64, BOOL, UINT64, TIMESTAMP_NS = range(5)
 ADD, SUB, MUL, DIV = range(4)
 EQ, NE, LT, LE, GT, GE = range(6)
 AND, OR = range(2)
+SCALAR_NONE, SCALAR_RHS, SCALAR_LHS = range(3)  # pdx_scalar_side: which operand of pdx_binary / pdx_compare is broadcast
 AGG_SUM, AGG_MEAN, AGG_MIN, AGG_MAX, AGG_COUNT = range(5)
 AGG_VARIANCE, AGG_STDDEV, AGG_PRODUCT, AGG_FIRST, AGG_LAST = range(5, 10)  # group-by only (include/pdx/abi.h)
 ORIGIN_EPOCH, ORIGIN_START_DAY, ORIGIN_START, ORIGIN_END, ORIGIN_END_DAY, ORIGIN_CUSTOM = range(6)

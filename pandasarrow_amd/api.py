@@ -52,10 +52,38 @@ class Scalar:
         return self.value
 
     def __eq__(self, other):
+        if isinstance(other, (Series, DataFrame)):
+            return self._cmp(L.EQ, other)
         return self.value == (other.value if isinstance(other, Scalar) else other)
 
     def __repr__(self):
         return f"Scalar({self.value!r})"
+
+    __hash__ = None
+
+    # ---- BINARY_OPERATOR_2 (src/scalar.cpp:12-56): Scalar op Series / DataFrame = CallFunction(name, {scalar, array(s)});
+    # python scalars on the left reach the same kernels through Series.__radd__ etc.
+    def _bin(self, op, other):
+        if isinstance(other, DataFrame):
+            return other._like([K.binary(op, self.value, c) for c in other.cols])
+        if isinstance(other, Series):
+            return other._wrap(K.binary(op, self.value, other.col))
+        return NotImplemented
+
+    def _cmp(self, op, other):
+        if isinstance(other, DataFrame):
+            return other._like([K.compare(op, self.value, c) for c in other.cols])
+        return other._wrap(K.compare(op, self.value, other.col))
+
+    def __add__(self, o): return self._bin(L.ADD, o)
+    def __sub__(self, o): return self._bin(L.SUB, o)
+    def __mul__(self, o): return self._bin(L.MUL, o)
+    def __truediv__(self, o): return self._bin(L.DIV, o)
+    def __lt__(self, o): return self._cmp(L.LT, o)
+    def __le__(self, o): return self._cmp(L.LE, o)
+    def __gt__(self, o): return self._cmp(L.GT, o)
+    def __ge__(self, o): return self._cmp(L.GE, o)
+    def __ne__(self, o): return self._cmp(L.NE, o) if isinstance(o, (Series, DataFrame)) else not self.__eq__(o)
 
 
 class Series:
@@ -157,6 +185,12 @@ class Series:
     def __sub__(self, o): return self._bin(L.SUB, o)
     def __mul__(self, o): return self._bin(L.MUL, o)
     def __truediv__(self, o): return self._bin(L.DIV, o)
+    # ---- Scalar::operator{+,-,*,/}(Series) (src/scalar.cpp:24-41): CallFunction(name, {scalar, array}), index = the Series' own
+    def _rbin(self, op, o): return self._wrap(K.binary(op, o.value if isinstance(o, Scalar) else o, self.col))
+    def __radd__(self, o): return self._rbin(L.ADD, o)
+    def __rsub__(self, o): return self._rbin(L.SUB, o)
+    def __rmul__(self, o): return self._rbin(L.MUL, o)
+    def __rtruediv__(self, o): return self._rbin(L.DIV, o)
     def __neg__(self):  # "negate": x * -1 is bit-identical for int64 (wraps) and float64 (sign flip)
         return self._wrap(K.binary(L.MUL, self.col, -1.0 if self.col.dtype == L.FLOAT64 else -1, True))
     # ---- comparisons (src/series.cpp:247-257)
@@ -280,6 +314,12 @@ class DataFrame:
     def __sub__(self, o): return self._bin(L.SUB, o)
     def __mul__(self, o): return self._bin(L.MUL, o)
     def __truediv__(self, o): return self._bin(L.DIV, o)
+    # Scalar::operator op(DataFrame) (src/scalar.cpp:12-29): the scalar stays the left operand for every column
+    def _rbin(self, op, o): return self._like([K.binary(op, o.value if isinstance(o, Scalar) else o, c) for c in self.cols])
+    def __radd__(self, o): return self._rbin(L.ADD, o)
+    def __rsub__(self, o): return self._rbin(L.SUB, o)
+    def __rmul__(self, o): return self._rbin(L.MUL, o)
+    def __rtruediv__(self, o): return self._rbin(L.DIV, o)
 
     def sum(self):
         """NDFrame::sum on a DataFrame (src/ndframe.h:329-335): each column (chunk) is summed, totals added in column order."""

@@ -149,23 +149,32 @@ def _promoted(a, b):
 
 
 # ---------------------------------------------------------------- element-wise
-def binary(op, a: Column, b, scalar=False) -> Column:
+def _scalar_sides(a, b, scalar):
+    """-> (a column, b column, pdx_scalar_side, result length).  A non-Column operand on either side is a scalar: on the right
+    `series op 2` (src/series.cpp:25-28), on the left `2 op series` (Scalar::operator op(Series), src/scalar.cpp:24-56)."""
+    side = L.SCALAR_RHS if scalar is True else int(scalar)
+    if not isinstance(a, Column):
+        a, side = _scalar_column(a, b.dtype == L.FLOAT64), L.SCALAR_LHS
+    elif not isinstance(b, Column):
+        b, side = _scalar_column(b, a.dtype == L.FLOAT64), L.SCALAR_RHS
+    return a, b, side, (b.length if side == L.SCALAR_LHS else a.length)
+
+
+def binary(op, a, b, scalar=False) -> Column:
     lib = L.load()
-    if not isinstance(b, Column):
-        b, scalar = _scalar_column(b, a.dtype == L.FLOAT64), True
-    out = Column.empty(_promoted(a, b), a.length, with_validity=a.has_nulls() or b.has_nulls())
+    a, b, side, n = _scalar_sides(a, b, scalar)
+    out = Column.empty(_promoted(a, b), n, with_validity=a.has_nulls() or b.has_nulls())
     ca, cb, m = a.c(), b.c(), out.mut()
-    L.check(lib.pdx_binary(op, C.byref(ca), C.byref(cb), int(scalar), C.byref(m), _stream()))
+    L.check(lib.pdx_binary(op, C.byref(ca), C.byref(cb), side, C.byref(m), _stream()))
     return out._adopt(m)
 
 
-def compare(op, a: Column, b, scalar=False) -> Column:
+def compare(op, a, b, scalar=False) -> Column:
     lib = L.load()
-    if not isinstance(b, Column):
-        b, scalar = _scalar_column(b, a.dtype == L.FLOAT64), True
-    out = Column.empty(L.BOOL, a.length, with_validity=a.has_nulls() or b.has_nulls())
+    a, b, side, n = _scalar_sides(a, b, scalar)
+    out = Column.empty(L.BOOL, n, with_validity=a.has_nulls() or b.has_nulls())
     ca, cb, m = a.c(), b.c(), out.mut()
-    L.check(lib.pdx_compare(op, C.byref(ca), C.byref(cb), int(scalar), C.byref(m), _stream()))
+    L.check(lib.pdx_compare(op, C.byref(ca), C.byref(cb), side, C.byref(m), _stream()))
     return out._adopt(m)
 
 

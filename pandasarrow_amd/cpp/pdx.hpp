@@ -424,8 +424,29 @@ class Series {
     return cols;
   }
 };
-inline Series operator+(const Scalar& a, const Series& b) { return b + a; }
-inline Series operator*(const Scalar& a, const Series& b) { return b * a; }
+// BINARY_OPERATOR_2 (src/scalar.cpp:12-56): Scalar op Series = CallFunction(name, {scalar, s.array()}) with the Series' index --
+// the scalar stays the LEFT operand (2 - s, 2 / s), pdx_binary / pdx_compare with PDX_SCALAR_LHS
+inline Series scalar_lhs(int op, const Scalar& a, const Series& b, bool cmp) {
+  Array sa = a.to_array();
+  Array out = cmp ? Array::Empty(PDX_BOOL, b.size(), b.m_array.has_nulls() || sa.has_nulls())
+                  : Array::Empty((sa.dtype == PDX_FLOAT64 || b.m_array.dtype == PDX_FLOAT64) ? PDX_FLOAT64 : PDX_INT64, b.size(),
+                                 b.m_array.has_nulls() || sa.has_nulls());
+  auto ca = sa.c(), cb = b.m_array.c();
+  auto m = out.mut();
+  ThrowOnFailure(cmp ? pdx_compare(op, &ca, &cb, PDX_SCALAR_LHS, &m, nullptr) : pdx_binary(op, &ca, &cb, PDX_SCALAR_LHS, &m, nullptr));
+  out.null_count = m.null_count;
+  return Series(std::move(out), b.m_index, "");
+}
+inline Series operator+(const Scalar& a, const Series& b) { return scalar_lhs(PDX_ADD, a, b, false); }
+inline Series operator-(const Scalar& a, const Series& b) { return scalar_lhs(PDX_SUB, a, b, false); }
+inline Series operator*(const Scalar& a, const Series& b) { return scalar_lhs(PDX_MUL, a, b, false); }
+inline Series operator/(const Scalar& a, const Series& b) { return scalar_lhs(PDX_DIV, a, b, false); }
+inline Series operator<(const Scalar& a, const Series& b) { return scalar_lhs(PDX_LT, a, b, true); }
+inline Series operator<=(const Scalar& a, const Series& b) { return scalar_lhs(PDX_LE, a, b, true); }
+inline Series operator>(const Scalar& a, const Series& b) { return scalar_lhs(PDX_GT, a, b, true); }
+inline Series operator>=(const Scalar& a, const Series& b) { return scalar_lhs(PDX_GE, a, b, true); }
+inline Series operator==(const Scalar& a, const Series& b) { return scalar_lhs(PDX_EQ, a, b, true); }
+inline Series operator!=(const Scalar& a, const Series& b) { return scalar_lhs(PDX_NE, a, b, true); }
 
 // ---------------------------------------------------------------- handle shared by GroupBy / Resampler
 struct GroupHandle {
@@ -538,6 +559,17 @@ class DataFrame {
     return DataFrame(m_names, outs, idx);
   }
 };
+
+// Scalar op DataFrame (BinaryImpl(DataFrame), src/scalar.cpp:24-28): the same scalar-lhs kernel over every column
+inline DataFrame scalar_lhs(int op, const Scalar& a, const DataFrame& df) {
+  std::vector<Array> out;
+  for (auto& c : df.m_columns) out.push_back(scalar_lhs(op, a, Series(c), false).m_array);
+  return DataFrame(df.m_names, out, df.m_index);
+}
+inline DataFrame operator+(const Scalar& a, const DataFrame& b) { return scalar_lhs(PDX_ADD, a, b); }
+inline DataFrame operator-(const Scalar& a, const DataFrame& b) { return scalar_lhs(PDX_SUB, a, b); }
+inline DataFrame operator*(const Scalar& a, const DataFrame& b) { return scalar_lhs(PDX_MUL, a, b); }
+inline DataFrame operator/(const Scalar& a, const DataFrame& b) { return scalar_lhs(PDX_DIV, a, b); }
 
 // ---------------------------------------------------------------- pd::GroupBy (src/group_by.h:22-299)
 struct GroupBy {

@@ -101,18 +101,29 @@ __device__ __forceinline__ TO apply_op(TO x, TO y, bool valid, unsigned long lon
   }
 }
 
-template <typename TA, typename TB, typename TO, int OP, bool SCALAR_B>
+// SCALAR: 0 = two arrays, 1 = b is one broadcast value (Series op Scalar, src/series.cpp:25-28), 2 = a is one broadcast value
+// (Scalar op Series, src/scalar.cpp:24-36: CallFunction(name, {scalar, array}) -- the scalar stays the LEFT operand, which
+// matters for subtract / divide and for which NaN payload survives)
+template <typename TA, typename TB, typename TO, int OP, int SCALAR>
 __global__ void __launch_bounds__(256) k_binary(const TA* __restrict__ a, const TB* __restrict__ b, TO* __restrict__ out, int64_t n,
                                                 const uint8_t* __restrict__ va, int64_t aoff, const uint8_t* __restrict__ vb,
                                                 int64_t boff, unsigned long long* __restrict__ err) {
   constexpr bool kNeedValid = (OP == PDX_DIV) && !__is_same(TO, double);
+  constexpr bool SA = SCALAR == 2, SB = SCALAR == 1;
+  // Arrow's scalar-array loops for the commutative ops keep the ARRAY element as the first machine operand (measured against
+  // Arrow 25.0.0: NaN(scalar) + NaN(array) returns the array's payload in both orders), so add / multiply swap operands
+  constexpr bool kSwap = SA && (OP == PDX_ADD || OP == PDX_MUL);
   int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  TO ys = 0;
-  bool ys_valid = true;
-  if constexpr (SCALAR_B) {
+  TO xs = 0, ys = 0;
+  bool xs_valid = true, ys_valid = true;
+  if constexpr (SB) {
     ys = Conv<TO>::from(b[0]);
     if (kNeedValid && vb) ys_valid = bit_get(vb, boff);
+  }
+  if constexpr (SA) {
+    xs = Conv<TO>::from(a[0]);
+    if (kNeedValid && va) xs_valid = bit_get(va, aoff);
   }
   unsigned long long local_err = 0;
   // 4 independent 8-byte streams per thread
@@ -121,25 +132,25 @@ __global__ void __launch_bounds__(256) k_binary(const TA* __restrict__ a, const 
     TO x[4], y[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      x[k] = Conv<TO>::from(a[i + k * stride]);
-      y[k] = SCALAR_B ? ys : Conv<TO>::from(b[i + k * stride]);
+      x[k] = SA ? xs : Conv<TO>::from(a[i + k * stride]);
+      y[k] = SB ? ys : Conv<TO>::from(b[i + k * stride]);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       bool valid = true;
       if constexpr (kNeedValid) {
         int64_t j = i + k * stride;
-        valid = (!va || bit_get(va, aoff + j)) && (SCALAR_B ? ys_valid : (!vb || bit_get(vb, boff + j)));
+        valid = (SA ? xs_valid : (!va || bit_get(va, aoff + j))) && (SB ? ys_valid : (!vb || bit_get(vb, boff + j)));
       }
-      out[i + k * stride] = apply_op<TO, OP>(x[k], y[k], valid, &local_err);
+      out[i + k * stride] = kSwap ? apply_op<TO, OP>(y[k], x[k], valid, &local_err) : apply_op<TO, OP>(x[k], y[k], valid, &local_err);
     }
   }
   for (; i < n; i += stride) {
-    TO x = Conv<TO>::from(a[i]);
-    TO y = SCALAR_B ? ys : Conv<TO>::from(b[i]);
+    TO x = SA ? xs : Conv<TO>::from(a[i]);
+    TO y = SB ? ys : Conv<TO>::from(b[i]);
     bool valid = true;
-    if constexpr (kNeedValid) valid = (!va || bit_get(va, aoff + i)) && (SCALAR_B ? ys_valid : (!vb || bit_get(vb, boff + i)));
-    out[i] = apply_op<TO, OP>(x, y, valid, &local_err);
+    if constexpr (kNeedValid) valid = (SA ? xs_valid : (!va || bit_get(va, aoff + i))) && (SB ? ys_valid : (!vb || bit_get(vb, boff + i)));
+    out[i] = kSwap ? apply_op<TO, OP>(y, x, valid, &local_err) : apply_op<TO, OP>(x, y, valid, &local_err);
   }
   if constexpr (kNeedValid) {
     if (local_err) atomicMax(err, local_err);
@@ -148,15 +159,18 @@ __global__ void __launch_bounds__(256) k_binary(const TA* __restrict__ a, const 
 
 template <typename TA, typename TB, typename TO, int OP>
 static void launch_binary_sb(const pdx_column* a, const pdx_column* b, int scalar, TO* out, unsigned long long* err, hipStream_t st) {
-  int64_t n = a->length;
+  int64_t n = scalar == 2 ? b->length : a->length;
   const TA* pa = static_cast<const TA*>(a->values) + a->offset;
   const TB* pb = static_cast<const TB*>(b->values) + b->offset;
   dim3 grid(grid_for(n, 256, 4)), block(256);
-  if (scalar)
-    hipLaunchKernelGGL((k_binary<TA, TB, TO, OP, true>), grid, block, 0, st, pa, pb, out, n, validity_or_null(a), a->offset,
+  if (scalar == 1)
+    hipLaunchKernelGGL((k_binary<TA, TB, TO, OP, 1>), grid, block, 0, st, pa, pb, out, n, validity_or_null(a), a->offset,
+                       validity_or_null(b), b->offset, err);
+  else if (scalar == 2)
+    hipLaunchKernelGGL((k_binary<TA, TB, TO, OP, 2>), grid, block, 0, st, pa, pb, out, n, validity_or_null(a), a->offset,
                        validity_or_null(b), b->offset, err);
   else
-    hipLaunchKernelGGL((k_binary<TA, TB, TO, OP, false>), grid, block, 0, st, pa, pb, out, n, validity_or_null(a), a->offset,
+    hipLaunchKernelGGL((k_binary<TA, TB, TO, OP, 0>), grid, block, 0, st, pa, pb, out, n, validity_or_null(a), a->offset,
                        validity_or_null(b), b->offset, err);
 }
 template <typename TA, typename TB, typename TO>
@@ -276,13 +290,14 @@ __global__ void k_logical(const uint8_t* __restrict__ a, int64_t aoff, int64_t a
   }
 }
 
-static int check_numeric_pair(const pdx_column* a, const pdx_column* b, int b_is_scalar, const char* what) {
+static int check_numeric_pair(const pdx_column* a, const pdx_column* b, int scalar_side, const char* what) {
   PDX_TRY(check_column(a, what));
   PDX_TRY(check_column(b, what));
   auto ok = [](int dt) { return dt == PDX_INT64 || dt == PDX_FLOAT64; };
   if (!ok(a->dtype) || !ok(b->dtype)) return fail(PDX_NOT_IMPLEMENTED, std::string(what) + ": only int64/float64 operands are supported");
-  if (b_is_scalar) {
-    if (b->length != 1) return fail(PDX_INVALID, std::string(what) + ": scalar operand must have length 1");
+  if (scalar_side < 0 || scalar_side > PDX_SCALAR_LHS) return fail(PDX_INVALID, std::string(what) + ": scalar side must be 0 (none), 1 (rhs) or 2 (lhs)");
+  if (scalar_side) {
+    if ((scalar_side == PDX_SCALAR_LHS ? a : b)->length != 1) return fail(PDX_INVALID, std::string(what) + ": scalar operand must have length 1");
   } else if (a->length != b->length) {
     return fail(PDX_INVALID, std::string(what) + ": array lengths differ: " + std::to_string(a->length) + " vs " + std::to_string(b->length));
   }
@@ -298,14 +313,15 @@ extern "C" {
 int pdx_binary(int op, const pdx_column* a, const pdx_column* b, int b_is_scalar, pdx_mut_column* out, void* stream) {
   PDX_TRY(check_numeric_pair(a, b, b_is_scalar, "pdx_binary"));
   if (op < PDX_ADD || op > PDX_DIV) return fail(PDX_INVALID, "pdx_binary: unknown op");
-  if (!out || out->length < a->length) return fail(PDX_INVALID, "pdx_binary: output too small");
+  const pdx_column* arr = b_is_scalar == PDX_SCALAR_LHS ? b : a;  // the operand that gives the result its length
+  if (!out || out->length < arr->length) return fail(PDX_INVALID, "pdx_binary: output too small");
   const bool is_f = a->dtype == PDX_FLOAT64 || b->dtype == PDX_FLOAT64;
   const int out_dt = is_f ? PDX_FLOAT64 : PDX_INT64;
   if (out->dtype != out_dt) return fail(PDX_INVALID, "pdx_binary: output dtype must be the promoted input dtype");
   const bool has_nulls = validity_or_null(a) || validity_or_null(b);
   if (has_nulls && !out->validity) return fail(PDX_INVALID, "pdx_binary: inputs carry nulls but output has no validity buffer");
   hipStream_t st = as_stream(stream);
-  int64_t n = a->length;
+  int64_t n = arr->length;
   out->length = n;
   out->null_count = has_nulls ? -1 : 0;
   if (n == 0) return PDX_OK;
@@ -327,7 +343,10 @@ int pdx_binary(int op, const pdx_column* a, const pdx_column* b, int b_is_scalar
     launch_binary_op<int64_t, int64_t, int64_t>(op, a, b, b_is_scalar, static_cast<int64_t*>(out->values), err, st);
   }
   PDX_LAUNCH_CHECK();
-  if (out->validity) PDX_TRY(launch_validity_and(a, b, b_is_scalar, n, static_cast<uint8_t*>(out->validity), st));
+  if (out->validity) {  // AND is symmetric: the array operand goes first, the scalar's one bit is broadcast
+    if (b_is_scalar == PDX_SCALAR_LHS) PDX_TRY(launch_validity_and(b, a, 1, n, static_cast<uint8_t*>(out->validity), st));
+    else PDX_TRY(launch_validity_and(a, b, b_is_scalar, n, static_cast<uint8_t*>(out->validity), st));
+  }
   if (need_err) {
     unsigned long long h = 0;
     PDX_HIP(hipMemcpyAsync(&h, err, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -340,6 +359,15 @@ int pdx_binary(int op, const pdx_column* a, const pdx_column* b, int b_is_scalar
 int pdx_compare(int op, const pdx_column* a, const pdx_column* b, int b_is_scalar, pdx_mut_column* out, void* stream) {
   PDX_TRY(check_numeric_pair(a, b, b_is_scalar, "pdx_compare"));
   if (op < PDX_EQ || op > PDX_GE) return fail(PDX_INVALID, "pdx_compare: unknown op");
+  if (b_is_scalar == PDX_SCALAR_LHS) {
+    // scalar OP array == array OP' scalar with the mirrored relation (booleans carry no NaN payload, so this is exact)
+    static const int mirrored[6] = {PDX_EQ, PDX_NE, PDX_GT, PDX_GE, PDX_LT, PDX_LE};
+    const pdx_column* t = a;
+    a = b;
+    b = t;
+    op = mirrored[op];
+    b_is_scalar = PDX_SCALAR_RHS;
+  }
   if (!out || out->length < a->length || out->dtype != PDX_BOOL) return fail(PDX_INVALID, "pdx_compare: output must be PDX_BOOL of the input length");
   const bool has_nulls = validity_or_null(a) || validity_or_null(b);
   if (has_nulls && !out->validity) return fail(PDX_INVALID, "pdx_compare: inputs carry nulls but output has no validity buffer");

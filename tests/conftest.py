@@ -22,10 +22,10 @@ def pytest_configure(config):
 
 
 class Golden:
-    """Accessor over tests/golden/arrow_golden.npz (cases are 'name/field' keys)."""
+    """Accessor over tests/golden/arrow_golden*.npz (cases are 'name/field' keys)."""
 
-    def __init__(self):
-        self.z = np.load(os.path.join(GOLDEN_DIR, "arrow_golden.npz"))
+    def __init__(self, fname="arrow_golden.npz"):
+        self.z = np.load(os.path.join(GOLDEN_DIR, fname))
         self.manifest = json.loads(str(self.z["manifest"]))
 
     def cases(self, family):
@@ -44,6 +44,17 @@ def golden():
     if _golden is None:
         _golden = Golden()
     return _golden
+
+
+_golden2 = None
+
+
+def golden2():
+    """Round-2 additions (oracle/gen_golden_r2.py): scalar-lhs ops, temporal rounding, the remaining group-by aggregations."""
+    global _golden2
+    if _golden2 is None:
+        _golden2 = Golden("arrow_golden_r2.npz")
+    return _golden2
 
 
 @pytest.fixture(scope="session")

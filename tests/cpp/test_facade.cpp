@@ -55,6 +55,13 @@ static void test_series_math() {
   auto dv = diff.values<double>();
   const double exp[] = {-0.9, -1.8, -2.7, -3.6, -4.5};
   for (int i = 0; i < 5; ++i) REQUIRE(approx(dv[i], exp[i]));
+  // Scalar on the LEFT (src/scalar.cpp:24-41): the scalar stays the first operand of subtract / divide
+  REQUIRE(((Scalar(10) - int_series).values<long>() == std::vector<long>{9, 8, 7, 6, 5}));
+  REQUIRE(((Scalar(10) / int_series).values<long>() == std::vector<long>{10, 5, 3, 2, 2}));
+  REQUIRE(((Scalar(3) + int_series).values<long>() == std::vector<long>{4, 5, 6, 7, 8}));
+  REQUIRE(approx((Scalar(1.0) / double_series).at(1).as<double>(), 1.0 / 2.2));
+  REQUIRE(((Scalar(3) < int_series).values<bool>() == std::vector<bool>{false, false, false, true, true}));
+  REQUIRE_THROWS(Scalar(1) / Series(std::vector<long>{1, 0}));
   Series named(int_vec, "int_series2");
   auto add = int_series + named;
   REQUIRE(add.size() == 5 && add.dtype() == PDX_INT64 && add.name() == "");
