@@ -244,6 +244,22 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
 /* per-row labels (GroupInfo::downsample): device pointer to num_rows int64 */
 int pdx_resample_row_labels(pdx_groupby* gb, int64_t* out_labels, void* stream);
 
+/* ---------------------------------------------------------------- temporal rounding: DataFrame::downsample
+ * Replaces arrow::compute::FloorTemporal / CeilTemporal(m_index, RoundTemporalOptions(freq_value, getCalendarUnit(freq_unit[0]),
+ * weekStartsMonday, ceil_is_strictly_greater = false, calendar_based_origin = startEpoch)) at src/dataframe.cpp:1271-1276
+ * (unit letters: src/core.cpp:135-172).  ts: PDX_TIMESTAMP_NS (no time zone); out: PDX_TIMESTAMP_NS of the same length, null where
+ * ts is null.  ceil_mode != 0: CeilTemporal (closed_label_right), else FloorTemporal.  Semantics follow Arrow C++ 25.0.0:
+ * floors go toward -inf; calendar_based_origin counts the multiples from the floor to the next larger unit (day: the 1st of the
+ * month, week: the first week of the year) instead of from the epoch; month / quarter ceil is always floor + multiple.
+ * The reference then subtracts one day for M / W / Q rules (src/dataframe.cpp:1277-1285: pdx_binary(PDX_SUB) on the int64 view)
+ * and keys a Resampler's GroupBy on the result (pdx_groupby_create; the labels need not be sorted). */
+typedef enum pdx_calendar_unit {
+  PDX_UNIT_NANOSECOND = 0, PDX_UNIT_MICROSECOND = 1, PDX_UNIT_MILLISECOND = 2, PDX_UNIT_SECOND = 3, PDX_UNIT_MINUTE = 4,
+  PDX_UNIT_HOUR = 5, PDX_UNIT_DAY = 6, PDX_UNIT_WEEK = 7, PDX_UNIT_MONTH = 8, PDX_UNIT_QUARTER = 9
+} pdx_calendar_unit;
+int pdx_round_temporal(int ceil_mode, const pdx_column* ts, int64_t multiple, int unit, int week_starts_monday, int calendar_based_origin,
+                       pdx_mut_column* out, void* stream);
+
 /* ---------------------------------------------------------------- index alignment (the callers' slow path)
  * Binary operators on Series with UNEQUAL indexes go through Series::broadcast (src/series.cpp:212-227):
  * Concatenate(index_a, index_b) -> Unique -> array_sort_indices(ascending) -> Take, then Series::reindex of both operands

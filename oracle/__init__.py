@@ -411,3 +411,55 @@ def reindex_indices(old_index, new_index):
     j = np.searchsorted(so, new_index, side="right") - 1
     present = (j >= 0) & (so[np.maximum(j, 0)] == new_index)
     return np.where(present, order[np.maximum(j, 0)], 0).astype(np.int64), present
+
+
+# ------------------------------------------------------------------ temporal rounding / DataFrame::downsample
+UNIT_NANOSECOND, UNIT_MICROSECOND, UNIT_MILLISECOND, UNIT_SECOND, UNIT_MINUTE, UNIT_HOUR, UNIT_DAY, UNIT_WEEK, UNIT_MONTH, UNIT_QUARTER = range(10)
+UNIT_NAMES = ["nanosecond", "microsecond", "millisecond", "second", "minute", "hour", "day", "week", "month", "quarter"]
+NS_PER_DAY = 86400 * 10**9
+
+
+def round_temporal(ts, multiple, unit, ceil=False, week_starts_monday=True, calendar_based_origin=False, valid=None, offset=0):
+    """arrow::compute::FloorTemporal / CeilTemporal on timestamp[ns] (no tz) with RoundTemporalOptions(multiple, unit,
+    week_starts_monday, ceil_is_strictly_greater=false, calendar_based_origin) -- src/dataframe.cpp:1271-1276.
+    Returns (int64 ns, valid|None)."""
+    ts = np.asarray(ts, np.int64)
+    n = len(ts)
+    T = _shift(ts, offset)
+    vb = pack_bits(valid, offset)
+    out = np.empty(n, np.int64)
+    ov = np.zeros((n + 7) // 8 + 8, np.uint8) if valid is not None else None
+    rc = lib().orc_round_temporal(C.c_int(int(bool(ceil))), _p(T), _p(vb), _i64(offset), _i64(n), _i64(multiple), C.c_int(unit),
+                                  C.c_int(int(bool(week_starts_monday))), C.c_int(int(bool(calendar_based_origin))), _p(out), _p(ov))
+    if rc != OK:
+        raise OracleError(rc, "round_temporal: bad multiple / unit")
+    return out, (None if valid is None else unpack_bits(ov, n))
+
+
+_DOWNSAMPLE_UNITS = {"n": UNIT_NANOSECOND, "u": UNIT_MICROSECOND, "m": UNIT_MILLISECOND, "S": UNIT_SECOND, "T": UNIT_MINUTE,
+                     "H": UNIT_HOUR, "D": UNIT_DAY, "Q": UNIT_QUARTER, "W": UNIT_WEEK, "M": UNIT_MONTH}
+
+
+def downsample_labels(ts, rule, closed_label_right=True, week_starts_monday=True, start_epoch=True):
+    """The binned index of DataFrame::downsample (src/dataframe.cpp:1265-1290): splitTimeSpan(rule) (src/core.cpp:110-133),
+    getCalendarUnit(first letter) (src/core.cpp:135-172), Ceil/FloorTemporal, and one day less for rules whose unit ends with
+    "E" or is M / W / Y / Q (the label becomes the period's last day)."""
+    k = 0
+    while k < len(rule) and not rule[k].isalpha():
+        k += 1
+    mult, unit_s = (int(rule[:k]) if k else 1), rule[k:]
+    if not unit_s or unit_s[0] not in _DOWNSAMPLE_UNITS:
+        raise OracleError(INVALID, "invalid unit got " + unit_s[:1])
+    out, _ = round_temporal(ts, mult, _DOWNSAMPLE_UNITS[unit_s[0]], closed_label_right, week_starts_monday, start_epoch)
+    if unit_s.endswith("E") or unit_s in ("M", "W", "Y", "Q"):
+        out = out - NS_PER_DAY
+    return out
+
+
+def downsample_agg(kind, ts, v, valid=None, rule="1T", **kw):
+    """Resampler(DataFrame{values, binned index}) -> GroupBy on the binned labels (first-occurrence order, hash grouping: the
+    index need not be sorted) -> per-group aggregate.  Returns (labels, values, ok)."""
+    labels = downsample_labels(ts, rule, **kw)
+    ids, uniq, _, _ = group_ids(labels)
+    vals, ok = groupby_agg(kind, ids, len(uniq), v, valid)
+    return uniq, vals, ok

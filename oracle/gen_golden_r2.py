@@ -115,7 +115,120 @@ def gen_scalar_lhs():
     manifest["cases"]["scalar_lhs"] = cases
 
 
-SECTIONS = [gen_scalar_lhs]
+# ------------------------------------------------------------------ floor_temporal / ceil_temporal + DataFrame::downsample
+UNIT_NAMES = ["nanosecond", "microsecond", "millisecond", "second", "minute", "hour", "day", "week", "month", "quarter"]
+DAY = 86400 * 10**9
+
+
+def gen_round_temporal():
+    rng = np.random.default_rng(20260202)
+    cases = []
+    edge = [0, -1, 1, DAY, -DAY, DAY - 1, 7 * DAY, 946684800 * 10**9, 951782400 * 10**9 - 1, 951782400 * 10**9,  # 2000-02-29
+            -2208988800 * 10**9, 725753810610691880, -536625883277931502, 1325099338657844886]  # week-origin quirks found by fuzzing
+    ts = np.concatenate([rng.integers(-2 * 10**18, 2 * 10**18, 160), rng.integers(-10**13, 10**13, 60),
+                         946684800 * 10**9 + rng.integers(0, 400 * DAY, 60), np.array(edge)]).astype(np.int64)
+    valid = rng.random(len(ts)) > 0.15
+    T = pa.array(ts).cast(pa.timestamp("ns"))
+    put("rt_input", ts=ts, valid=valid)
+    for ui, unit in enumerate(UNIT_NAMES):
+        for mult in (1, 2, 3, 7, 15, 60):
+            for cbo in (False, True):
+                for wsm in ((True, False) if unit == "week" else (True,)):
+                    name = f"rt_{unit}_{mult}_{int(cbo)}_{int(wsm)}"
+                    f = pc.floor_temporal(T, multiple=mult, unit=unit, week_starts_monday=wsm, calendar_based_origin=cbo)
+                    c = pc.ceil_temporal(T, multiple=mult, unit=unit, week_starts_monday=wsm, calendar_based_origin=cbo,
+                                         ceil_is_strictly_greater=False)
+                    put(name, unit=ui, multiple=mult, cbo=cbo, wsm=wsm, floor=f.cast(pa.int64()).to_numpy(), ceil=c.cast(pa.int64()).to_numpy())
+                    cases.append(name)
+    # nulls pass through
+    Tn = pa.array(ts, mask=~valid).cast(pa.timestamp("ns"))
+    fn = pc.floor_temporal(Tn, multiple=5, unit="minute")
+    vals, ok = out_np(fn.cast(pa.int64()), np.int64)
+    put("rt_nulls_minute_5", floor=vals, floor_valid=ok)
+    # the reference's M / W / Q post-step: Subtract(binned, date32 scalar 1) -> Cast(int64) -> Cast(timestamp[ns])  (src/dataframe.cpp:1277-1285)
+    one_day = pa.scalar(1, pa.date32())
+    b = pc.ceil_temporal(T, multiple=1, unit="month", calendar_based_origin=True)
+    shifted = pc.subtract(b, one_day).cast(pa.int64()).to_numpy()
+    assert np.array_equal(shifted, b.cast(pa.int64()).to_numpy() - DAY)
+    manifest["month_rule_shift_ns"] = DAY
+    manifest["cases"]["round_temporal"] = cases
+
+
+def reference_downsample(ts, cols, unit, mult, closed_label_right, wsm, start_epoch, minus_day):
+    """DataFrame::downsample + Resampler aggregation with Arrow kernels: binned index -> Grouper ids in first-occurrence order
+    (dictionary_encode) -> ApplyGroupings (take of each group's rows in row order) -> one scalar aggregate per group."""
+    T = pa.array(ts).cast(pa.timestamp("ns"))
+    fn = pc.ceil_temporal if closed_label_right else pc.floor_temporal
+    kw = dict(multiple=mult, unit=unit, week_starts_monday=wsm, calendar_based_origin=start_epoch)
+    if closed_label_right:
+        kw["ceil_is_strictly_greater"] = False
+    binned = fn(T, **kw)
+    if minus_day:
+        binned = pc.subtract(binned, pa.scalar(1, pa.date32())).cast(pa.int64()).cast(pa.timestamp("ns"))
+    enc = binned.dictionary_encode()
+    ids = np.asarray(enc.indices.to_numpy(zero_copy_only=False)).astype(np.uint32)
+    labels = enc.dictionary.cast(pa.int64()).to_numpy()
+    G = len(labels)
+    order = np.argsort(ids, kind="stable")
+    offs = np.concatenate([[0], np.cumsum(np.bincount(ids, minlength=G))])
+    res = {}
+    for cname, (v, valid) in cols.items():
+        V = arr(v, valid)
+        isf = np.asarray(v).dtype == np.float64
+        sums, means, cnts, mins, maxs = [], [], [], [], []
+        for g in range(G):
+            grp = V.take(pa.array(order[offs[g]:offs[g + 1]]))
+            sums.append(pc.sum(grp).as_py())
+            means.append(pc.mean(grp).as_py())
+            mins.append(pc.min(grp).as_py())
+            maxs.append(pc.max(grp).as_py())
+            cnts.append(pc.count(grp).as_py())
+        dt = np.float64 if isf else np.int64
+        nz = lambda xs, d: np.array([0 if x is None else x for x in xs], d)  # noqa: E731
+        res[cname] = dict(sum=nz(sums, dt), mean=nz(means, np.float64), min=nz(mins, dt), max=nz(maxs, dt), count=np.array(cnts, np.int64),
+                          ok=np.array([x is not None for x in sums], bool))
+    return binned.cast(pa.int64()).to_numpy(), labels, res
+
+
+def gen_downsample():
+    rng = np.random.default_rng(20260203)
+    cases = []
+    t0 = 946684800 * 10**9 + 37 * 10**9 + 123
+    for n in (1, 9, 700, 2500):
+        for rule, unit, mult, minus_day in (("3T", "minute", 3, False), ("1T", "minute", 1, False), ("250m", "millisecond", 250, False),
+                                            ("2H", "hour", 2, False), ("5D", "day", 5, False), ("M", "month", 1, True),
+                                            ("W", "week", 1, True), ("2Q", "quarter", 2, True), ("7S", "second", 7, False)):
+            for clr in (False, True):
+                for shuffled in (False, True):
+                    if shuffled != (n == 700):  # the 700-row cases are the shuffled ones
+                        continue
+                    name = f"ds_{n}_{rule}_{int(clr)}_{int(shuffled)}"
+                    span = {"minute": 60 * 10**9, "millisecond": 10**6, "hour": 3600 * 10**9, "day": DAY, "month": 30 * DAY, "week": 7 * DAY,
+                            "quarter": 91 * DAY, "second": 10**9}[unit] * mult
+                    ts = t0 + np.cumsum(rng.integers(1, max(2, span // 3), n))
+                    if n > 4:
+                        ts[3] = (ts[3] // span) * span  # exactly on a boundary (for the fixed units)
+                        ts = np.sort(ts)
+                    if shuffled:  # the reference hash-groups the binned index: order of first occurrence, no sortedness needed
+                        ts = ts[rng.permutation(n)]
+                    vf = (rng.standard_normal(n) * 1e3).astype(np.float32).astype(np.float64)  # exactly representable in 4 bytes
+                    vi = rng.integers(-10**6, 10**6, n, dtype=np.int64)
+                    vvalid = rng.random(n) > 0.1
+                    binned, labels, res = reference_downsample(ts, {"f": (vf, vvalid), "i": (vi, None)}, unit, mult, clr, True, True, minus_day)
+                    # inputs are regenerated by the test from (seed material stored here would double the file): store them compactly
+                    rec = dict(ts=ts, vf=vf.astype(np.float32), vi=vi.astype(np.int32), vvalid=vvalid, labels=labels, clr=clr)
+                    if n <= 700:
+                        rec["binned"] = binned
+                    for c in ("f", "i"):
+                        for k, v in res[c].items():
+                            rec[f"{c}_{k}"] = v
+                    put(name, **rec)
+                    manifest.setdefault("downsample_rules", {})[name] = rule
+                    cases.append(name)
+    manifest["cases"]["downsample"] = cases
+
+
+SECTIONS = [gen_scalar_lhs, gen_round_temporal, gen_downsample]
 
 
 def main():

@@ -699,3 +699,111 @@ void orc_concat_64(const uint64_t* const* parts, const uint8_t* const* valids, c
   }
   if (out_nulls) *out_nulls = nulls;
 }
+
+/* ------------------------------------------------------------------ temporal rounding: DataFrame::downsample (src/dataframe.cpp:1265-1290)
+ * arrow::compute::FloorTemporal / CeilTemporal(index, RoundTemporalOptions(multiple, unit, week_starts_monday,
+ * ceil_is_strictly_greater = false, calendar_based_origin)) on timestamp[ns] without a time zone.  Restates Arrow C++ 25.0.0
+ * (scalar_temporal_unary.cc: FloorTimePoint / FloorWeekTimePoint / GetFlooredYmd / Ceil*), pinned by oracle/gen_golden_r2.py:
+ *   - ns..day, multiple == 1                : floor to the unit since the epoch (toward -inf)
+ *   - ns..day, calendar_based_origin        : origin = floor to the next larger unit (day: the 1st of the month), then whole
+ *                                             multiples of the unit since that origin
+ *   - ns..day otherwise                     : whole multiples of (multiple x unit) since the epoch (toward -inf)
+ *   - week                                  : weeks start Monday (or Sunday); with a calendar origin and multiple > 1 the origin is
+ *                                             the Monday (Sunday) after the last Thursday (Wednesday) of the previous December,
+ *                                             the year taken from t + 3 (4) days, and the result is NOT shifted back (Arrow's own
+ *                                             behaviour, so a floor may lie after t)
+ *   - month / quarter                       : first day of the month, multiples counted from 1970-01 (or from January of the year)
+ *   - ceil                                  : floor if floor >= t, else floor + multiple x unit; month / quarter: ALWAYS floor + multiple
+ *                                             (Arrow ignores ceil_is_strictly_greater there) */
+static void civil_from_days(int64_t z, int64_t* y, int* m, int* d) {
+  z += 719468;
+  const int64_t era = (z >= 0 ? z : z - 146096) / 146097;
+  const int64_t doe = z - era * 146097;
+  const int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+  const int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+  const int64_t mp = (5 * doy + 2) / 153;
+  *d = (int)(doy - (153 * mp + 2) / 5 + 1);
+  *m = (int)(mp < 10 ? mp + 3 : mp - 9);
+  *y = yoe + era * 400 + (*m <= 2);
+}
+static int64_t days_from_civil(int64_t y, int m, int d) {
+  y -= m <= 2;
+  const int64_t era = (y >= 0 ? y : y - 399) / 400;
+  const int64_t yoe = y - era * 400;
+  const int64_t doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
+  const int64_t doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+  return era * 146097 + doe - 719468;
+}
+static const int64_t kUnitNs[7] = {1LL, 1000LL, 1000000LL, 1000000000LL, 60000000000LL, 3600000000000LL, 86400000000000LL};
+
+static int64_t floor_temporal_1(int64_t t, int64_t mult, int unit, int wsm, int cbo) {
+  if (unit <= ORC_UNIT_DAY) {
+    const int64_t u = kUnitNs[unit];
+    if (mult == 1) return floor_div(t, u) * u;
+    if (cbo) {
+      int64_t origin;
+      if (unit == ORC_UNIT_DAY) {
+        int64_t y;
+        int m, d;
+        civil_from_days(floor_div(t, NS_PER_DAY), &y, &m, &d);
+        origin = days_from_civil(y, m, 1) * NS_PER_DAY;
+      } else {
+        origin = floor_div(t, kUnitNs[unit + 1]) * kUnitNs[unit + 1];
+      }
+      const int64_t p = mult * u;
+      return (t - origin) / p * p + origin; /* t >= origin */
+    }
+    return floor_div(floor_div(t, u), mult) * mult * u;
+  }
+  if (unit == ORC_UNIT_WEEK) {
+    const int64_t org = (wsm ? 3 : 4) * NS_PER_DAY, W = 7 * NS_PER_DAY, tt = t + org;
+    if (mult == 1) return floor_div(tt, W) * W - org;
+    if (cbo) {
+      int64_t y;
+      int m, d;
+      civil_from_days(floor_div(tt, NS_PER_DAY), &y, &m, &d);
+      const int64_t dec31 = days_from_civil(y - 1, 12, 31);
+      const int64_t wd = ((dec31 + 4) % 7 + 7) % 7; /* 0 = Sunday; 1970-01-01 was a Thursday */
+      const int64_t target = wsm ? 4 : 3;             /* Thursday / Wednesday */
+      const int64_t last = dec31 - (((wd - target) % 7 + 7) % 7);
+      const int64_t start = (last + 4) * NS_PER_DAY;  /* date.h: (mon - thu) is 4 days modulo 7 */
+      const int64_t p = mult * W;
+      return (tt - start) / p * p + start;            /* C++ truncating division: tt may precede start by a few days */
+    }
+    return floor_div(floor_div(tt, W), mult) * mult * W - org;
+  }
+  /* month / quarter */
+  const int64_t mm = mult * (unit == ORC_UNIT_QUARTER ? 3 : 1);
+  int64_t y;
+  int m, d;
+  civil_from_days(floor_div(t, NS_PER_DAY), &y, &m, &d);
+  if (mm == 1) return days_from_civil(y, m, 1) * NS_PER_DAY;
+  if (cbo) return days_from_civil(y, 1 + (int)((m - 1) / mm * mm), 1) * NS_PER_DAY;
+  int64_t tm = floor_div((y - 1970) * 12 + m - 1, mm) * mm;
+  return days_from_civil(1970 + floor_div(tm, 12), (int)(tm - floor_div(tm, 12) * 12) + 1, 1) * NS_PER_DAY;
+}
+static int64_t ceil_temporal_1(int64_t t, int64_t mult, int unit, int wsm, int cbo) {
+  const int64_t f = floor_temporal_1(t, mult, unit, wsm, cbo);
+  if (unit <= ORC_UNIT_DAY) return f >= t ? f : f + mult * kUnitNs[unit];
+  if (unit == ORC_UNIT_WEEK) return f >= t ? f : f + mult * 7 * NS_PER_DAY;
+  const int64_t mm = mult * (unit == ORC_UNIT_QUARTER ? 3 : 1);
+  int64_t y;
+  int m, d;
+  civil_from_days(floor_div(f, NS_PER_DAY), &y, &m, &d);
+  const int64_t tm = y * 12 + m - 1 + mm;
+  return days_from_civil(floor_div(tm, 12), (int)(tm - floor_div(tm, 12) * 12) + 1, 1) * NS_PER_DAY;
+}
+int orc_round_temporal(int ceil_mode, const int64_t* ts, const uint8_t* valid, int64_t off, int64_t n, int64_t multiple, int unit,
+                       int week_starts_monday, int calendar_based_origin, int64_t* out, uint8_t* out_valid) {
+  if (multiple < 1 || unit < ORC_UNIT_NANOSECOND || unit > ORC_UNIT_QUARTER) return ORC_INVALID;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t t = ts[off + i];
+    out[i] = ceil_mode ? ceil_temporal_1(t, multiple, unit, week_starts_monday, calendar_based_origin)
+                       : floor_temporal_1(t, multiple, unit, week_starts_monday, calendar_based_origin);
+  }
+  if (out_valid && n > 0) {
+    memset(out_valid, 0, (size_t)((n + 7) / 8));
+    for (int64_t i = 0; i < n; ++i) bit_set_to(out_valid, i, is_valid(valid, off, i));
+  }
+  return ORC_OK;
+}

@@ -114,6 +114,13 @@ void orc_resample_expand(const int64_t* bins, const int64_t* labels, int64_t nb,
 void orc_concat_64(const uint64_t* const* parts, const uint8_t* const* valids, const int64_t* offs, const int64_t* lens,
                    int nparts, uint64_t* out, uint8_t* out_valid, int64_t* out_nulls);
 
+/* ---- temporal rounding: DataFrame::downsample (src/dataframe.cpp:1265-1290) = Arrow floor_temporal / ceil_temporal ---- */
+enum { ORC_UNIT_NANOSECOND = 0, ORC_UNIT_MICROSECOND = 1, ORC_UNIT_MILLISECOND = 2, ORC_UNIT_SECOND = 3, ORC_UNIT_MINUTE = 4,
+       ORC_UNIT_HOUR = 5, ORC_UNIT_DAY = 6, ORC_UNIT_WEEK = 7, ORC_UNIT_MONTH = 8, ORC_UNIT_QUARTER = 9 };
+/* ceil_mode != 0: CeilTemporal (ceil_is_strictly_greater = false, as the reference passes), else FloorTemporal. timestamp[ns], no tz. */
+int orc_round_temporal(int ceil_mode, const int64_t* ts, const uint8_t* valid, int64_t off, int64_t n, int64_t multiple, int unit,
+                       int week_starts_monday, int calendar_based_origin, int64_t* out, uint8_t* out_valid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,8 @@ SCALAR_NONE, SCALAR_RHS, SCALAR_LHS = range(3)  # pdx_scalar_side: which operand
 AGG_SUM, AGG_MEAN, AGG_MIN, AGG_MAX, AGG_COUNT = range(5)
 AGG_VARIANCE, AGG_STDDEV, AGG_PRODUCT, AGG_FIRST, AGG_LAST = range(5, 10)  # group-by only (include/pdx/abi.h)
 ORIGIN_EPOCH, ORIGIN_START_DAY, ORIGIN_START, ORIGIN_END, ORIGIN_END_DAY, ORIGIN_CUSTOM = range(6)
+(UNIT_NANOSECOND, UNIT_MICROSECOND, UNIT_MILLISECOND, UNIT_SECOND, UNIT_MINUTE, UNIT_HOUR, UNIT_DAY, UNIT_WEEK, UNIT_MONTH,
+ UNIT_QUARTER) = range(10)  # pdx_calendar_unit
 ORIGIN_SHARD = 0x100  # OR-ed into the origin type for a row-range shard of a longer axis (include/pdx/abi.h)
 
 
@@ -98,6 +100,7 @@ ABI_SYMBOLS = {
     "pdx_replay_partials": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "pdx_resample_create": (C.c_int, [_COL, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _P, C.POINTER(_P)]),
     "pdx_resample_row_labels": (C.c_int, [_P, _P, _P]),
+    "pdx_round_temporal": (C.c_int, [C.c_int, _COL, C.c_int64, C.c_int, C.c_int, C.c_int, _MUT, _P]),
     "pdx_concat": (C.c_int, [_COL, C.c_int, _MUT, _P]),
     "pdx_index_union": (C.c_int, [_COL, _COL, C.c_int, _MUT, _P]),
     "pdx_index_intersection": (C.c_int, [_COL, _COL, _MUT, _P]),

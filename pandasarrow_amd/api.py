@@ -38,6 +38,22 @@ def _rule_to_ns(rule):
     return int(m.group(1) or 1) * _RULE_NS[m.group(2)]
 
 
+# getCalendarUnit(freq_unit[0]) of DataFrame::downsample (src/core.cpp:135-172): only the FIRST letter of the unit counts,
+# so "min" / "ms" both mean millisecond there and upper-case N / U / L are rejected -- kept as the reference has it
+_DOWNSAMPLE_UNITS = {"n": L.UNIT_NANOSECOND, "u": L.UNIT_MICROSECOND, "m": L.UNIT_MILLISECOND, "S": L.UNIT_SECOND, "T": L.UNIT_MINUTE,
+                     "H": L.UNIT_HOUR, "D": L.UNIT_DAY, "Q": L.UNIT_QUARTER, "W": L.UNIT_WEEK, "M": L.UNIT_MONTH}
+
+
+def _split_time_span(rule):
+    """splitTimeSpan (src/core.cpp:110-133): leading digits = multiple (default 1), the rest = unit."""
+    k = 0
+    while k < len(rule) and not rule[k].isalpha():
+        k += 1
+    if k == 0 and any(ch.isdigit() for ch in rule):
+        raise L.PdxError(L.INVALID, "Invalid time offset " + rule)
+    return (int(rule[:k]) if k else 1), rule[k:]
+
+
 class Scalar:
     """pd::Scalar (src/scalar.h:62-241): a value or null."""
 
@@ -356,6 +372,25 @@ class DataFrame:
             raise L.PdxError(L.INVALID, "axis must be a TimestampArray but got the implicit range index")
         return Resampler(self, _rule_to_ns(rule), closed_right, label_right, origin, origin_custom_ns, offset_ns)
 
+    def downsample(self, rule, closed_label_right=True, weekStartsMonday=True, startEpoch=True):
+        """DataFrame::downsample (src/dataframe.cpp:1265-1290): bin the index with Arrow's ceil_temporal (closed_label_right) or
+        floor_temporal -- RoundTemporalOptions(multiple, unit, weekStartsMonday, false, calendar_based_origin = startEpoch) --
+        move M / W / Y / Q (and *E) labels back one day to the period's last day, then key a Resampler's GroupBy on the binned
+        index (hash grouping in first-occurrence order: the index need not be sorted)."""
+        if self.index is None or self.index.dtype != L.TIMESTAMP_NS:
+            raise L.PdxError(L.INVALID, "downsample needs a timestamp[ns] index")
+        mult, unit_s = _split_time_span(rule)
+        if not unit_s or unit_s[0] not in _DOWNSAMPLE_UNITS:  # getCalendarUnit (src/core.cpp:135-172)
+            raise L.PdxError(L.INVALID, "invalid unit got " + unit_s[:1])
+        binned = K.round_temporal(self.index, mult, _DOWNSAMPLE_UNITS[unit_s[0]], closed_label_right, weekStartsMonday, startEpoch)
+        if unit_s.endswith("E") or unit_s in ("M", "W", "Y", "Q"):
+            # Subtract(binned, date32 scalar 1) -> Cast(int64) -> Cast(timestamp[ns]): one day less on the int64 view
+            as_i64 = Column(L.INT64, binned.length, binned.values, binned.validity, binned.offset, binned.null_count)
+            shifted = K.binary(L.SUB, as_i64, 86400 * 10**9, True)
+            binned = Column(L.TIMESTAMP_NS, shifted.length, shifted.values, shifted.validity, 0, shifted.null_count)
+        framed = self._like(self.cols, index=binned)
+        return Resampler(framed, _handle=K.GroupByHandle.create(binned))
+
 
 class GroupBy:
     """pd::GroupBy (src/group_by.h:22-299).  Construction hashes the key column (makeGroups)."""
@@ -406,8 +441,10 @@ class Resampler(GroupBy):
     """pd::Resampler (src/group_by.h:255-299): GroupBy keyed on the per-row bin labels; aggregations run over ALL columns
     and the result is indexed by the labels of the non-empty bins."""
 
-    def __init__(self, df, freq_ns, closed_right, label_right, origin, origin_custom_ns, offset_ns):
-        h = K.GroupByHandle.resample(df.index, freq_ns, closed_right, label_right, origin, origin_custom_ns, offset_ns)
+    def __init__(self, df, freq_ns=None, closed_right=False, label_right=False, origin=L.ORIGIN_START_DAY, origin_custom_ns=0, offset_ns=0,
+                 _handle=None):
+        h = _handle if _handle is not None else K.GroupByHandle.resample(df.index, freq_ns, closed_right, label_right, origin,
+                                                                         origin_custom_ns, offset_ns)
         super().__init__("__resampler_idx__", df, _handle=h)
 
     def index(self) -> Column:

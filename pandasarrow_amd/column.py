@@ -266,6 +266,17 @@ def concat(parts) -> Column:
     return out._adopt(m)
 
 
+# ---------------------------------------------------------------- temporal rounding (DataFrame::downsample)
+def round_temporal(ts: Column, multiple, unit, ceil=False, week_starts_monday=True, calendar_based_origin=False) -> Column:
+    """floor_temporal / ceil_temporal of a timestamp[ns] column (pdx_round_temporal)."""
+    out = Column.empty(L.TIMESTAMP_NS, ts.length, with_validity=ts.has_nulls())
+    m = out.mut()
+    ct = ts.c()
+    L.check(L.load().pdx_round_temporal(int(bool(ceil)), C.byref(ct), int(multiple), int(unit), int(bool(week_starts_monday)),
+                                        int(bool(calendar_based_origin)), C.byref(m), _stream()))
+    return out._adopt(m)
+
+
 # ---------------------------------------------------------------- index alignment (Series::broadcast / reindex)
 def index_union(a: Column, b: Column, sort=True) -> Column:
     """distinct labels of both indexes, sorted ascending or in first-occurrence order (pdx_index_union)."""

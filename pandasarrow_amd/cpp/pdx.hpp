@@ -539,6 +539,9 @@ class DataFrame {
 
   inline GroupBy group_by(const std::string& key) const;
   inline Resampler resample(const std::string& rule, bool closed_right = false, bool label_right = false) const;
+  // DataFrame::downsample (src/dataframe.h:575-578, src/dataframe.cpp:1265-1290)
+  inline Resampler downsample(const std::string& rule, bool closed_label_right = true, bool weekStartsMonday = true,
+                              bool startEpoch = true) const;
 
  private:
   void check() const {
@@ -674,6 +677,46 @@ inline Resampler resample(const DataFrame& df, const std::string& rule, bool clo
 }
 inline Resampler resample(const Series& s, int64_t freq_ns, bool closed_right = false, bool label_right = false) {
   return resample(DataFrame({s.name().empty() ? "0" : s.name()}, {s.m_array}, s.m_index), freq_ns, closed_right, label_right);
+}
+// getCalendarUnit (src/core.cpp:135-172): first letter of the rule's unit
+inline int calendar_unit(char c) {
+  switch (c) {
+    case 'n': return PDX_UNIT_NANOSECOND;
+    case 'u': return PDX_UNIT_MICROSECOND;
+    case 'm': return PDX_UNIT_MILLISECOND;
+    case 'S': return PDX_UNIT_SECOND;
+    case 'T': return PDX_UNIT_MINUTE;
+    case 'H': return PDX_UNIT_HOUR;
+    case 'D': return PDX_UNIT_DAY;
+    case 'Q': return PDX_UNIT_QUARTER;
+    case 'W': return PDX_UNIT_WEEK;
+    case 'M': return PDX_UNIT_MONTH;
+    default: throw std::runtime_error(std::string("invalid unit got ") + c);
+  }
+}
+// Ceil/FloorTemporal of the index -> (M / W / Y / Q and *E rules: one day less) -> Resampler keyed on the binned index
+inline Resampler DataFrame::downsample(const std::string& rule, bool closed_label_right, bool weekStartsMonday, bool startEpoch) const {
+  if (!m_index || m_index->dtype != PDX_TIMESTAMP_NS) throw std::runtime_error("downsample needs a timestamp[ns] index");
+  size_t p = 0;
+  while (p < rule.size() && !std::isalpha((unsigned char)rule[p])) ++p;  // splitTimeSpan (src/core.cpp:110-133)
+  const int64_t mult = p ? std::stoll(rule.substr(0, p)) : 1;
+  const std::string unit = rule.substr(p);
+  if (unit.empty()) throw std::runtime_error("invalid unit got ");
+  Array binned = Array::Empty(PDX_TIMESTAMP_NS, m_index->length, m_index->has_nulls());
+  auto ci = m_index->c();
+  auto mb = binned.mut();
+  ThrowOnFailure(pdx_round_temporal(closed_label_right ? 1 : 0, &ci, mult, calendar_unit(unit[0]), weekStartsMonday, startEpoch, &mb, nullptr));
+  binned.null_count = mb.null_count;
+  if (unit.back() == 'E' || unit == "M" || unit == "W" || unit == "Y" || unit == "Q") {
+    Array as_i64 = binned;
+    as_i64.dtype = PDX_INT64;
+    binned = Series::run_binary(PDX_SUB, as_i64, Scalar((int64_t)86400000000000LL).to_array(), true);
+    binned.dtype = PDX_TIMESTAMP_NS;
+  }
+  auto ck = binned.c();
+  pdx_groupby* h = nullptr;
+  ThrowOnFailure(pdx_groupby_create(&ck, nullptr, &h));
+  return Resampler(DataFrame(m_names, m_columns, binned), std::make_shared<GroupHandle>(h), PDX_TIMESTAMP_NS);
 }
 inline GroupBy DataFrame::group_by(const std::string& key) const { return GroupBy(key, *this); }
 inline Resampler DataFrame::resample(const std::string& rule, bool cr, bool lr) const { return pd::resample(*this, rule, cr, lr); }

@@ -173,6 +173,19 @@ static void test_resample() {
     REQUIRE((r.sum()["v"].values<long>() == std::vector<long>{0, 6, 15, 15}));
   }
   REQUIRE((series.resample("3T").sum()["v"].values<long>() == std::vector<long>{3, 12, 21}));
+  // DataFrame::downsample (tests/series_resample_test.cpp:87-129): floor / ceil_temporal bins of the same nine points
+  DataFrame frame({"i"}, {series.m_array}, index);
+  {
+    auto r = frame.downsample("3T", false);
+    REQUIRE((r.index().values_as<int64_t>() == std::vector<int64_t>{t0, t0 + min3, t0 + 2 * min3}));
+    REQUIRE((r.sum()["i"].values<long>() == std::vector<long>{3, 12, 21}));
+  }
+  {
+    auto r = frame.downsample("3T", true);
+    REQUIRE((r.index().values_as<int64_t>() == std::vector<int64_t>{t0, t0 + min3, t0 + 2 * min3, t0 + 3 * min3}));
+    REQUIRE((r.sum()["i"].values<long>() == std::vector<long>{0, 6, 15, 15}));
+  }
+  REQUIRE_THROWS(frame.downsample("3Y"));
 }
 
 // tests/concat_test.cpp:10-50 ; DataFrame element-wise tests/dataframe_arithmetric_test.cpp:49-195

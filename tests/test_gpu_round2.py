@@ -104,3 +104,83 @@ def test_scalar_lhs_large_vs_oracle(px):
         assert_f64_bits(px.K.binary(op, 0.75, B).to_numpy()[0], orc.binary(op, 0.75, b)[0], what=f"op{op}")
     for op in CMPS.values():
         assert np.array_equal(px.K.compare(op, 0.1, B).to_numpy()[0], orc.compare(op, 0.1, b)[0])
+
+
+# ------------------------------------------------------------------ a12: floor/ceil_temporal + DataFrame::downsample (src/dataframe.cpp:1265-1290)
+@pytest.mark.parametrize("name", G2.cases("round_temporal"))
+def test_round_temporal_golden(px, name):
+    c, inp = G2.case(name), G2.case("rt_input")
+    for ceil, key, off in ((False, "floor", 0), (True, "ceil", 3)):
+        T = px.Column.from_numpy(inp["ts"], dtype=px.L.TIMESTAMP_NS, offset=off)
+        vals, valid = px.K.round_temporal(T, int(c["multiple"]), int(c["unit"]), ceil, bool(c["wsm"]), bool(c["cbo"])).to_numpy()
+        assert valid is None and np.array_equal(vals, c[key]), f"{name} {key}"
+
+
+def test_round_temporal_nulls_errors_large(px):
+    inp, c = G2.case("rt_input"), G2.case("rt_nulls_minute_5")
+    T = px.Column.from_numpy(inp["ts"], inp["valid"], dtype=px.L.TIMESTAMP_NS, offset=5)
+    out = px.K.round_temporal(T, 5, px.L.UNIT_MINUTE)
+    vals, valid = out.to_numpy()
+    assert np.array_equal(valid, c["floor_valid"]) and np.array_equal(vals[valid], c["floor"][valid])
+    for bad in (dict(multiple=0, unit=px.L.UNIT_MINUTE), dict(multiple=1, unit=11), dict(multiple=1, unit=-1)):
+        with pytest.raises(RuntimeError):
+            px.K.round_temporal(T, bad["multiple"], bad["unit"])
+    with pytest.raises(RuntimeError, match="PDX_TIMESTAMP_NS"):
+        px.K.round_temporal(px.Column.from_numpy(np.arange(4)), 1, px.L.UNIT_MINUTE)
+    e = px.K.round_temporal(px.Column.from_numpy(np.zeros(0, np.int64), dtype=px.L.TIMESTAMP_NS), 3, px.L.UNIT_HOUR)
+    assert e.length == 0
+    # every unit / mode at 1e6 rows against the oracle (ragged tail of the 4-way unrolled loop included)
+    n = 1_000_003
+    rng = np.random.default_rng(11)
+    ts = rng.integers(-2 * 10**18, 2 * 10**18, n)
+    T = px.Column.from_numpy(ts, dtype=px.L.TIMESTAMP_NS)
+    for unit in range(10):
+        for mult, cbo in ((1, False), (7, False), (7, True)):
+            for ceil in (False, True):
+                got = px.K.round_temporal(T, mult, unit, ceil, unit % 2 == 0, cbo).to_numpy()[0]
+                exp, _ = orc.round_temporal(ts, mult, unit, ceil, unit % 2 == 0, cbo)
+                assert np.array_equal(got, exp), (unit, mult, cbo, ceil)
+
+
+@pytest.mark.parametrize("name", G2.cases("downsample"))
+def test_downsample_golden(px, name):
+    c = G2.case(name)
+    rule = G2.manifest["downsample_rules"][name]
+    vf, vi = c["vf"].astype(np.float64), c["vi"].astype(np.int64)
+    df = px.api.DataFrame({"f": px.api.Series(vf, valid=c["vvalid"]), "i": vi}, index=px.Column.from_numpy(c["ts"], dtype=px.L.TIMESTAMP_NS))
+    r = df.downsample(rule, closed_label_right=bool(c["clr"]))
+    assert np.array_equal(r.index().to_numpy()[0], c["labels"])
+    if "binned" in c:
+        assert np.array_equal(r.df.index.to_numpy()[0], c["binned"])
+    for key, fn in (("sum", r.sum), ("mean", r.mean), ("min", r.min), ("max", r.max), ("count", r.count)):
+        out = fn()
+        fv, fok = out["f"].to_numpy()
+        iv, _ = out["i"].to_numpy()
+        if key == "count":
+            assert np.array_equal(fv, c["f_count"]) and np.array_equal(iv, c["i_count"])
+            continue
+        assert np.array_equal(fok, c["f_ok"])
+        assert_f64_bits(fv, c[f"f_{key}"], valid=c["f_ok"], what=f"{name} f {key}")
+        if key == "mean":
+            assert_f64_bits(iv, c["i_mean"], what=f"{name} i mean")
+        else:
+            assert np.array_equal(iv, c[f"i_{key}"]), f"{name} i {key}"
+
+
+def test_downsample_kat(px, kat):
+    """the reference's own downsample answers (tests/series_resample_test.cpp:87-165)"""
+    for k in kat["downsample"]:
+        cols = {nm: np.array(v, np.int64) for nm, v in k["columns"].items()}
+        df = px.api.DataFrame(cols, index=px.Column.from_numpy(np.array(k["ts"], np.int64), dtype=px.L.TIMESTAMP_NS))
+        r = df.downsample(k["rule"], k["closed_label_right"])
+        assert list(r.index().to_numpy()[0]) == k["labels"], k["src"]
+        for key in ("sum", "mean"):
+            if key in k:
+                out = getattr(r, key)()
+                for nm, exp in k[key].items():
+                    assert list(out[nm].values()) == exp, (k["src"], nm)
+    df = px.api.DataFrame({"x": np.arange(3)}, index=px.Column.from_numpy(np.arange(3), dtype=px.L.TIMESTAMP_NS))
+    with pytest.raises(RuntimeError, match="invalid unit got Y"):
+        df.downsample("3Y")
+    with pytest.raises(RuntimeError, match="timestamp"):
+        px.api.DataFrame({"x": np.arange(3)}).downsample("3T")

@@ -46,3 +46,61 @@ def test_scalar_lhs_divide_by_zero():
     assert str(e.value) == G2.manifest["scalar_lhs_div_by_zero_message"]
     vals, valid = orc.binary(orc.DIV, 7, np.array([2, 0]), None, np.array([True, False]))
     assert vals[0] == 3 and list(valid) == [True, False]
+
+
+# ------------------------------------------------------------------ floor_temporal / ceil_temporal (src/dataframe.cpp:1271-1276)
+@pytest.mark.parametrize("name", G2.cases("round_temporal"))
+def test_round_temporal(name):
+    c, inp = G2.case(name), G2.case("rt_input")
+    for ceil, key in ((False, "floor"), (True, "ceil")):
+        got, _ = orc.round_temporal(inp["ts"], int(c["multiple"]), int(c["unit"]), ceil, bool(c["wsm"]), bool(c["cbo"]), offset=3 if ceil else 0)
+        assert np.array_equal(got, c[key]), f"{name} {key}"
+
+
+def test_round_temporal_nulls_and_errors():
+    inp, c = G2.case("rt_input"), G2.case("rt_nulls_minute_5")
+    got, ok = orc.round_temporal(inp["ts"], 5, orc.UNIT_MINUTE, valid=inp["valid"], offset=5)
+    assert np.array_equal(ok, c["floor_valid"]) and np.array_equal(got[ok], c["floor"][ok])
+    with pytest.raises(orc.OracleError):
+        orc.round_temporal(inp["ts"], 0, orc.UNIT_MINUTE)
+    with pytest.raises(orc.OracleError):
+        orc.round_temporal(inp["ts"], 1, 10)
+
+
+# ------------------------------------------------------------------ DataFrame::downsample (src/dataframe.cpp:1265-1290)
+@pytest.mark.parametrize("name", G2.cases("downsample"))
+def test_downsample(name):
+    c = G2.case(name)
+    rule = G2.manifest["downsample_rules"][name]
+    ts, vf, vi, vvalid = c["ts"], c["vf"].astype(np.float64), c["vi"].astype(np.int64), c["vvalid"]
+    labels = orc.downsample_labels(ts, rule, closed_label_right=bool(c["clr"]))
+    if "binned" in c:
+        assert np.array_equal(labels, c["binned"])
+    for kind, key in ((orc.AGG_SUM, "sum"), (orc.AGG_MEAN, "mean"), (orc.AGG_MIN, "min"), (orc.AGG_MAX, "max"), (orc.AGG_COUNT, "count")):
+        uniq, vals, ok = orc.downsample_agg(kind, ts, vf, vvalid, rule, closed_label_right=bool(c["clr"]))
+        assert np.array_equal(uniq, c["labels"])
+        if kind == orc.AGG_COUNT:
+            assert np.array_equal(vals, c["f_count"])
+        else:
+            assert np.array_equal(ok, c["f_ok"])
+            assert_f64_bits(vals, c[f"f_{key}"], valid=c["f_ok"], what=f"{name} f {key}")
+        uniq, vals, ok = orc.downsample_agg(kind, ts, vi, None, rule, closed_label_right=bool(c["clr"]))
+        if key == "mean":
+            assert_f64_bits(vals, c["i_mean"], what=f"{name} i mean")
+        else:
+            assert np.array_equal(vals, c[f"i_{key}"]), f"{name} i {key}"
+
+
+def test_downsample_kat(kat):
+    """the reference's own downsample answers (tests/series_resample_test.cpp:87-165)"""
+    for k in kat["downsample"]:
+        ts = np.array(k["ts"], np.int64)
+        for col, v in k["columns"].items():
+            for key, kind in (("sum", orc.AGG_SUM), ("mean", orc.AGG_MEAN)):
+                if key not in k:
+                    continue
+                uniq, vals, ok = orc.downsample_agg(kind, ts, np.array(v, np.int64), None, k["rule"], closed_label_right=k["closed_label_right"])
+                assert list(uniq) == k["labels"], k["src"]
+                assert list(vals) == k[key][col], (k["src"], col)
+    with pytest.raises(orc.OracleError, match="invalid unit got"):
+        orc.downsample_labels(np.zeros(1, np.int64), "3Y")
