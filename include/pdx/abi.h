@@ -21,7 +21,13 @@
  *     ReturnOrThrowOnFailure does (src/core.h:181-194).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are ordered on
  *     that stream; entry points that return host-visible results (scalars, counts) synchronise it.
- *   - Re-entrant: no global mutable state besides the per-device scratch pool (mutex protected).
+ *   - Threading (the reference calls this boundary from tbb::parallel_for workers, src/pd_core_macros.h:21,56,94,122): every
+ *     entry point may be called concurrently from several host threads, each on its own stream (or all on the same one).  The
+ *     only shared state is the scratch pool, which is kept per device and is stream ordered: a block freed by a call on stream S
+ *     is reused at once by later calls on S, and by calls on other streams / threads only after the work queued on S at the time
+ *     of the free has completed.  A handle (pdx_groupby, pdx_grouped) must not be used by two threads at the same time, and calls
+ *     that use one handle on different streams must be ordered by the caller (the handle's buffers are not stream-synchronised).
+ *     pdx_last_error is thread local.  Tested by tests/test_gpu_threads.py.
  */
 #ifndef PDX_ABI_H
 #define PDX_ABI_H
@@ -238,7 +244,9 @@ int pdx_replay_partials(const int64_t* rec_key, const double* rec_val, int64_t m
  * src/group_by.h:255-299).  ts: sorted PDX_TIMESTAMP_NS without nulls.  The handle behaves like a pdx_groupby whose
  * unique keys are the labels of the NON-EMPTY bins (empty bins vanish, as in the reference).
  * Errors (PDX_INVALID): "Values falls before first bin", "Values falls after last bin",
- * "upSampling is not implemented.", unsorted input.  Row-range shards of one axis: see PDX_ORIGIN_SHARD. */
+ * "upSampling is not implemented.", unsorted input.  Row-range shards of one axis: see PDX_ORIGIN_SHARD.
+ * Lifetime: the handle keeps the POINTER to ts' values (pdx_resample_row_labels reads them again): the caller's timestamp
+ * buffer must stay alive and unchanged until pdx_groupby_destroy. */
 int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right, int label_right, int origin_type,
                         int64_t origin_custom_ns, int64_t offset_ns, void* stream, pdx_groupby** out);
 /* per-row labels (GroupInfo::downsample): device pointer to num_rows int64 */

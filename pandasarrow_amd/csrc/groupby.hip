@@ -1886,6 +1886,7 @@ struct pdx_groupby {
   uint32_t* seg_start = nullptr;   // G + 1
   BinParams bin{};
   long long label_base = 0;
+  mutable hipStream_t stream = nullptr;  // the stream of the last call that used the handle (pool frees are ordered behind it)
   std::vector<void*> owned;
   template <typename T>
   T* own(size_t count) {
@@ -1894,7 +1895,8 @@ struct pdx_groupby {
     return p;
   }
   ~pdx_groupby() {
-    for (void* p : owned) pool_free(p);
+    StreamNote note(stream);
+    pool_free_many(owned.data(), (int)owned.size());
   }
 };
 
@@ -2768,6 +2770,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   if (n > 0x7FFFFFFFll) return fail(PDX_NOT_IMPLEMENTED, "pdx_groupby_create: more than 2^31-1 rows per call is not supported yet");
   hipStream_t st = as_stream(stream);
   std::unique_ptr<pdx_groupby> owner(new pdx_groupby());  // released into *out on success
+  owner->stream = st;
   pdx_groupby* gb = owner.get();
   gb->n = n;
   gb->key_dtype = key->dtype;
@@ -3251,6 +3254,7 @@ int pdx_groupby_unique_keys(const pdx_groupby* gb, pdx_mut_column* out, void* st
   if (!gb || !out) return fail(PDX_INVALID, "pdx_groupby_unique_keys: null argument");
   if (out->length < gb->G) return fail(PDX_INVALID, "pdx_groupby_unique_keys: output too small");
   hipStream_t st = as_stream(stream);
+  gb->stream = st;  // frees of the handle's blocks are ordered behind this stream
   out->length = gb->G;
   out->null_count = -1;
   if (gb->G == 0) return PDX_OK;
@@ -3267,6 +3271,7 @@ int pdx_groupby_unique_keys(const pdx_groupby* gb, pdx_mut_column* out, void* st
 int pdx_groupby_first_rows(const pdx_groupby* gb, int64_t* out_rows, void* stream) {
   if (!gb || !out_rows) return fail(PDX_INVALID, "pdx_groupby_first_rows: null argument");
   hipStream_t st = as_stream(stream);
+  gb->stream = st;  // frees of the handle's blocks are ordered behind this stream
   if (gb->G) PDX_HIP(hipMemcpyAsync(out_rows, gb->first_rows, (size_t)gb->G * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
   PDX_HIP(hipStreamSynchronize(st));
   return PDX_OK;
@@ -3275,6 +3280,7 @@ int pdx_groupby_first_rows(const pdx_groupby* gb, int64_t* out_rows, void* strea
 int pdx_groupby_group_ids(pdx_groupby* gb, uint32_t* out_ids, void* stream) {
   if (!gb || !out_ids) return fail(PDX_INVALID, "pdx_groupby_group_ids: null argument");
   hipStream_t st = as_stream(stream);
+  gb->stream = st;  // frees of the handle's blocks are ordered behind this stream
   if (gb->n == 0) return PDX_OK;
   if (gb->mode == 0 && gb->slot_part)
     hipLaunchKernelGGL(k_part_row_gids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->gid_of_slot, gb->slot_part, gb->rows_part, gb->n,
@@ -3291,6 +3297,7 @@ int pdx_groupby_group_ids(pdx_groupby* gb, uint32_t* out_ids, void* stream) {
 int pdx_groupby_map_ids(pdx_groupby* gb, const int64_t* map, int64_t* out, void* stream) {
   if (!gb || !map || !out) return fail(PDX_INVALID, "pdx_groupby_map_ids: null argument");
   hipStream_t st = as_stream(stream);
+  gb->stream = st;  // frees of the handle's blocks are ordered behind this stream
   if (gb->n == 0) return PDX_OK;
   if (gb->mode == 0 && gb->slot_part)
     hipLaunchKernelGGL(k_part_row_gids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->gid_of_slot, gb->slot_part, gb->rows_part, gb->n, map,
@@ -3310,6 +3317,7 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   const bool is_f = values->dtype == PDX_FLOAT64;
   if (!is_f && values->dtype != PDX_INT64) return fail(PDX_NOT_IMPLEMENTED, "pdx_groupby_agg: values must be int64 or float64");
   hipStream_t st = as_stream(stream);
+  gb->stream = st;  // frees of the handle's blocks are ordered behind this stream
   const int64_t n = gb->n, G = gb->G;
   const uint8_t* vvalid = validity_or_null(values);
   SegOut o{};
@@ -3687,6 +3695,7 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
   if (n > 0x7FFFFFFFll) return fail(PDX_NOT_IMPLEMENTED, "pdx_resample_create: more than 2^31-1 rows per call is not supported yet");
   hipStream_t st = as_stream(stream);
   std::unique_ptr<pdx_groupby> owner(new pdx_groupby());  // released into *out on success
+  owner->stream = st;
   pdx_groupby* gb = owner.get();
   gb->mode = 1;
   gb->n = n;
@@ -3786,6 +3795,7 @@ int pdx_resample_row_labels(pdx_groupby* gb, int64_t* out_labels, void* stream) 
   if (!gb || !out_labels) return fail(PDX_INVALID, "pdx_resample_row_labels: null argument");
   if (gb->mode != 1) return fail(PDX_INVALID, "pdx_resample_row_labels: handle was not created by pdx_resample_create");
   hipStream_t st = as_stream(stream);
+  gb->stream = st;  // frees of the handle's blocks are ordered behind this stream
   if (gb->n) hipLaunchKernelGGL(k_row_labels, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->bin, gb->label_base, gb->n, out_labels);
   PDX_LAUNCH_CHECK();
   PDX_HIP(hipStreamSynchronize(st));
@@ -4015,6 +4025,7 @@ struct pdx_grouped {
   const int64_t* prefix = nullptr;
   const int64_t* order = nullptr;
   int64_t total = -1;
+  mutable hipStream_t stream = nullptr;
   std::vector<void*> owned;
   template <typename T>
   T* own(size_t count) {
@@ -4023,7 +4034,8 @@ struct pdx_grouped {
     return p;
   }
   ~pdx_grouped() {
-    for (void* p : owned) pool_free(p);
+    StreamNote note(stream);
+    pool_free_many(owned.data(), (int)owned.size());
   }
 };
 
@@ -4036,7 +4048,9 @@ int pdx_groupby_group_values(pdx_groupby* gb, const pdx_column* values, void* st
   if (values->dtype != PDX_FLOAT64 || validity_or_null(values)) return fail(PDX_NOT_IMPLEMENTED, "pdx_groupby_group_values: float64 values without nulls only");
   if (values->length != gb->n) return fail(PDX_INVALID, "pdx_groupby_group_values: values length differs from the grouped key length");
   hipStream_t st = as_stream(stream);
+  gb->stream = st;  // frees of the handle's blocks are ordered behind this stream
   std::unique_ptr<pdx_grouped> gowner(new pdx_grouped());
+  gowner->stream = st;
   pdx_grouped* g = gowner.get();
   g->gb = gb;
   g->n = gb->n;
@@ -4076,6 +4090,7 @@ int pdx_grouped_destroy(pdx_grouped* g) {
 int pdx_grouped_counts(pdx_grouped* g, int64_t* out_counts, void* stream) {
   if (!g || !out_counts) return fail(PDX_INVALID, "pdx_grouped_counts: null argument");
   hipStream_t st = as_stream(stream);
+  g->stream = st;  // frees of the handle's blocks are ordered behind this stream
   if (g->G) hipLaunchKernelGGL(k_grouped_counts, dim3(grid_for(g->G, 256)), dim3(256), 0, st, g->seg_start, g->gb->gid_of_occ, g->G, out_counts);
   PDX_LAUNCH_CHECK();
   PDX_HIP(hipStreamSynchronize(st));
@@ -4084,6 +4099,7 @@ int pdx_grouped_counts(pdx_grouped* g, int64_t* out_counts, void* stream) {
 int pdx_grouped_partial_plan(pdx_grouped* g, const int64_t* prefix, const int64_t* order, int64_t* out_total, void* stream) {
   if (!g || !prefix || !out_total) return fail(PDX_INVALID, "pdx_grouped_partial_plan: null argument");
   hipStream_t st = as_stream(stream);
+  g->stream = st;  // frees of the handle's blocks are ordered behind this stream
   *out_total = 0;
   g->prefix = prefix;
   g->order = order;
@@ -4105,6 +4121,7 @@ int pdx_grouped_partial_fill(pdx_grouped* g, const int64_t* gid_map, int64_t* re
   if (!g || !gid_map || !rec_key || !rec_val) return fail(PDX_INVALID, "pdx_grouped_partial_fill: null argument");
   if (g->total < 0 || !g->prefix) return fail(PDX_INVALID, "pdx_grouped_partial_fill: call pdx_grouped_partial_plan first");
   hipStream_t st = as_stream(stream);
+  g->stream = st;  // frees of the handle's blocks are ordered behind this stream
   if (g->G) {
     PDX_PROFILE("partial_fill", st);
     {

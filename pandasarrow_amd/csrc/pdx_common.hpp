@@ -28,9 +28,15 @@ int hip_fail(hipError_t e, const char* what);
 // ---------------------------------------------------------------- scratch pool
 // Size-bucketed caching allocator over hipMalloc: group-by needs tens of GB of workspace per call and
 // hipMalloc/hipFree of that size costs milliseconds.  Blocks are reused across calls; pdx_trim_pool frees them.
+// The pool is per device and stream ordered: a block is returned together with the calling thread's CURRENT stream (the stream
+// of the ABI call being served, noted by as_stream) and an event recorded on it; it is handed out again at once to that same
+// stream, and to any other stream / thread only once the event has completed.
 void* pool_alloc(size_t bytes);  // nullptr on failure (error set)
 void pool_free(void* p);
+void pool_free_many(void* const* ptrs, int n);  // one event for the whole batch
 void pool_trim();
+void note_stream(hipStream_t s);  // thread-local: the stream whose queued kernels may still use blocks this thread frees
+hipStream_t current_stream();
 
 struct Scratch {  // RAII: everything allocated through it is returned to the pool on scope exit
   static constexpr int kMax = 64;
@@ -39,13 +45,18 @@ struct Scratch {  // RAII: everything allocated through it is returned to the po
   bool failed = false;
   ~Scratch() { release(); }
   void release() {
-    for (int i = 0; i < n; ++i) pool_free(ptrs[i]);
+    pool_free_many(ptrs, n);
     n = 0;
   }
   template <typename T>
   T* get(size_t count) {
+    if (n >= kMax) {
+      fail(PDX_INVALID, "internal: scratch table full");
+      failed = true;
+      return nullptr;
+    }
     void* p = pool_alloc((count ? count : 1) * sizeof(T));
-    if (!p || n >= kMax) {
+    if (!p) {
       failed = true;
       return nullptr;
     }
@@ -56,7 +67,18 @@ struct Scratch {  // RAII: everything allocated through it is returned to the po
 #define PDX_SCRATCH_CHECK(s) \
   if ((s).failed) return PDX_OOM
 
-inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+// every entry point converts its `void* stream` through here first, which also tells the pool which stream this thread is on
+inline hipStream_t as_stream(void* s) {
+  hipStream_t st = static_cast<hipStream_t>(s);
+  note_stream(st);
+  return st;
+}
+// handles (pdx_groupby, pdx_grouped) outlive the call that made them: they remember their stream and restore it around frees
+struct StreamNote {
+  hipStream_t prev;
+  explicit StreamNote(hipStream_t s) : prev(current_stream()) { note_stream(s); }
+  ~StreamNote() { note_stream(prev); }
+};
 
 // ---------------------------------------------------------------- optional per-kernel timing (pdx_profile_*)
 // When enabled, a HIP event pair brackets the launches inside the scope ON THE LAUNCH STREAM; bench.py reads the

@@ -1,6 +1,7 @@
 // runtime.hip -- status/error plumbing, scratch pool, host<->device helpers, synthetic input generators.
 #include <string.h>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -29,15 +30,67 @@ int check_column(const pdx_column* c, const char* what) {
 }
 
 // ---------------------------------------------------------------- pool
+// One pool per device, stream-ordered reuse.  A block goes back with the stream that last used it (the calling thread's
+// current stream, see note_stream) and an event recorded on that stream at the moment of the free: kernels still queued on
+// the stream may be reading the block.  A later pool_alloc hands it out again
+//   - at once when the requesting stream IS that stream (stream order: the new kernels run behind the old ones), or
+//   - when the event has completed (hipEventQuery), i.e. every kernel that could touch the block has drained;
+// otherwise the block is skipped and, if nothing else fits, a fresh one is hipMalloc'ed.  This is what makes the ABI safe to call
+// from several host threads on their own streams (the reference drives this boundary from tbb::parallel_for workers,
+// src/pd_core_macros.h:21,56,94,122) and from one thread that switches devices.
 namespace {
+struct EventCache {
+  std::mutex mu;
+  std::vector<hipEvent_t> free_events;
+  hipEvent_t get() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!free_events.empty()) {
+        hipEvent_t e = free_events.back();
+        free_events.pop_back();
+        return e;
+      }
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    return e;
+  }
+  void put(hipEvent_t e) {
+    std::lock_guard<std::mutex> lk(mu);
+    free_events.push_back(e);
+  }
+};
+EventCache& event_cache() {
+  static EventCache* c = new EventCache;  // never destroyed: blocks released during static destruction may still return events
+  return *c;
+}
+// one event shared by every block released together (a Scratch scope, a handle): refcounted, returned to the cache by the last block
+struct FreeMark {
+  hipEvent_t ev = nullptr;
+  ~FreeMark() {
+    if (ev) event_cache().put(ev);
+  }
+};
+struct FreeBlock {
+  void* ptr;
+  hipStream_t stream;
+  std::shared_ptr<FreeMark> mark;  // null: nothing was ever queued against the block (safe for any stream)
+};
+struct LiveBlock {
+  size_t size;
+  int device;
+};
 struct Pool {
   std::mutex mu;
-  std::multimap<size_t, void*> free_blocks;  // size -> ptr
-  std::map<void*, size_t> live;              // ptr -> size
+  std::map<int, std::multimap<size_t, FreeBlock>> free_blocks;  // device -> size -> block
+  std::map<void*, LiveBlock> live;                              // ptr -> size, device
 };
 Pool& pool() {
-  static Pool p;
-  return p;
+  static Pool* p = new Pool;
+  return *p;
 }
 size_t bucket(size_t bytes) {
   // round up to 256 B below 1 MiB, to 1/8 of the next power of two above (bounded internal fragmentation)
@@ -47,19 +100,37 @@ size_t bucket(size_t bytes) {
   size_t step = p2 >> 3;
   return (bytes + step - 1) / step * step;
 }
+thread_local hipStream_t t_stream = nullptr;  // the stream of the ABI call this thread is serving (note_stream)
+bool block_ready(const FreeBlock& b, hipStream_t want) {
+  if (!b.mark || !b.mark->ev || b.stream == want) return true;
+  hipError_t e = hipEventQuery(b.mark->ev);
+  if (e == hipSuccess) return true;
+  (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure: keep it out of the next PDX_LAUNCH_CHECK
+  return false;
+}
 }  // namespace
+
+void note_stream(hipStream_t s) { t_stream = s; }
+hipStream_t current_stream() { return t_stream; }
 
 void* pool_alloc(size_t bytes) {
   size_t sz = bucket(bytes);
   Pool& p = pool();
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    fail(PDX_DEVICE, "no current HIP device (call pdx_init first)");
+    return nullptr;
+  }
   {
     std::lock_guard<std::mutex> lk(p.mu);
-    auto it = p.free_blocks.lower_bound(sz);
-    if (it != p.free_blocks.end() && it->first <= sz + sz / 4) {
-      void* ptr = it->second;
-      size_t got = it->first;
-      p.free_blocks.erase(it);
-      p.live[ptr] = got;
+    auto& fb = p.free_blocks[dev];
+    int looked = 0;
+    for (auto it = fb.lower_bound(sz); it != fb.end() && it->first <= sz + sz / 4 && looked < 16; ++it, ++looked) {
+      if (!block_ready(it->second, t_stream)) continue;
+      void* ptr = it->second.ptr;
+      p.live[ptr] = LiveBlock{it->first, dev};
+      fb.erase(it);
       return ptr;
     }
   }
@@ -77,27 +148,56 @@ void* pool_alloc(size_t bytes) {
     }
   }
   std::lock_guard<std::mutex> lk(p.mu);
-  p.live[ptr] = sz;
+  p.live[ptr] = LiveBlock{sz, dev};
   return ptr;
 }
-void pool_free(void* ptr) {
-  if (!ptr) return;
+void pool_free_many(void* const* ptrs, int n) {
+  if (n <= 0) return;
+  // one event for the whole batch, recorded behind everything this thread has queued on its stream so far
+  std::shared_ptr<FreeMark> mark;
+  hipEvent_t ev = event_cache().get();
+  if (ev && hipEventRecord(ev, t_stream) == hipSuccess) {
+    mark = std::make_shared<FreeMark>();
+    mark->ev = ev;
+  } else {
+    // no event: fall back to draining the stream so the blocks are safe for everybody
+    (void)hipGetLastError();
+    if (ev) event_cache().put(ev);
+    (void)hipStreamSynchronize(t_stream);
+    (void)hipGetLastError();
+  }
   Pool& p = pool();
   std::lock_guard<std::mutex> lk(p.mu);
-  auto it = p.live.find(ptr);
-  if (it == p.live.end()) return;
-  p.free_blocks.emplace(it->second, ptr);
-  p.live.erase(it);
+  for (int i = 0; i < n; ++i) {
+    if (!ptrs[i]) continue;
+    auto it = p.live.find(ptrs[i]);
+    if (it == p.live.end()) continue;
+    p.free_blocks[it->second.device].emplace(it->second.size, FreeBlock{ptrs[i], t_stream, mark});
+    p.live.erase(it);
+  }
+}
+void pool_free(void* ptr) {
+  if (ptr) pool_free_many(&ptr, 1);
 }
 void pool_trim() {
   Pool& p = pool();
-  std::vector<void*> to_free;
+  std::vector<std::pair<int, void*>> to_free;
   {
     std::lock_guard<std::mutex> lk(p.mu);
-    for (auto& kv : p.free_blocks) to_free.push_back(kv.second);
-    p.free_blocks.clear();
+    for (auto& dv : p.free_blocks) {
+      for (auto& kv : dv.second) to_free.emplace_back(dv.first, kv.second.ptr);
+      dv.second.clear();
+    }
   }
-  for (void* q : to_free) (void)hipFree(q);
+  // hipFree waits for the device to go idle, so blocks whose event has not completed yet are safe to release here
+  int cur = 0;
+  bool have_cur = hipGetDevice(&cur) == hipSuccess;
+  for (auto& q : to_free) {
+    if (have_cur && q.first != cur) (void)hipSetDevice(q.first);
+    (void)hipFree(q.second);
+    if (have_cur && q.first != cur) (void)hipSetDevice(cur);
+  }
+  (void)hipGetLastError();
 }
 
 // ---------------------------------------------------------------- profiling

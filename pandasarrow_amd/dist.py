@@ -54,9 +54,16 @@ def _world():
     return (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
 
 
+def _solo():
+    """True when the collectives may be skipped (one rank).  PDX_DIST_FORCE_COLLECTIVES=1 (tests) keeps every collective on the
+    wire even at world size 1, so a single-GPU box exercises the RCCL branches (all_gather, all_to_all_single with split sizes)."""
+    W, _ = _world()
+    return W == 1 and not (dist.is_initialized() and _os.environ.get("PDX_DIST_FORCE_COLLECTIVES") == "1")
+
+
 def all_gather_sizes(n, device):
     W, _ = _world()
-    if W == 1:
+    if _solo():
         return [int(n)]
     t = torch.tensor([int(n)], dtype=torch.int64, device=device)
     out = [torch.zeros_like(t) for _ in range(W)]
@@ -67,7 +74,7 @@ def all_gather_sizes(n, device):
 def all_gather_v(t: torch.Tensor, sizes):
     """Concatenation of every rank's 1-D tensor in rank order (all-gatherv: pad to the largest, gather, trim)."""
     W, _ = _world()
-    if W == 1:
+    if _solo():
         return t.clone()
     mx = max(max(sizes), 1)
     pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
@@ -81,7 +88,7 @@ def all_gather_v_multi(ts, sizes):
     """all_gather_v of several equally long 8-byte (or bool / uint8) 1-D tensors in ONE collective: the tensors travel as the rows
     of one padded int64 matrix.  Returns the per-tensor concatenations in rank order, in the input dtypes."""
     W, _ = _world()
-    if W == 1:
+    if _solo():
         return [t.clone() for t in ts]
     k, n = len(ts), int(ts[0].numel())
     mx = max(max(sizes), 1)
@@ -97,15 +104,18 @@ def all_gather_v_multi(ts, sizes):
     return res
 
 
-def all_to_all_v_pairs(chunks_a, chunks_b):
+def all_to_all_v_pairs(chunks_a, chunks_b, all_counts=None):
     """all_to_all_v of two aligned lists (chunks_a[d] and chunks_b[d] have the same length, 8-byte dtypes) in ONE exchange: every
-    destination receives [a | b] of every source.  Returns (recv_a, recv_b), each the concatenation in source order."""
+    destination receives [a | b] of every source.  Returns (recv_a, recv_b), each the concatenation in source order.
+    all_counts (optional): [W][W] python ints, all_counts[s][d] = ELEMENTS of a (== of b) that s sends to d, when the caller has
+    already exchanged them -- saves the count exchange and its host sync."""
     W, _ = _world()
-    if W == 1:
+    if _solo():
         return chunks_a[0], chunks_b[0]
     da, db = chunks_a[0].dtype, chunks_b[0].dtype
     as64 = lambda t: t.view(torch.int64) if t.dtype == torch.float64 else t.to(torch.int64)
-    recv = all_to_all_v([torch.cat([as64(a), as64(b)]) for a, b in zip(chunks_a, chunks_b)])
+    doubled = None if all_counts is None else [[2 * c for c in row] for row in all_counts]
+    recv = all_to_all_v([torch.cat([as64(a), as64(b)]) for a, b in zip(chunks_a, chunks_b)], doubled)
     ra, rb = [], []
     for piece in recv:
         h = piece.numel() // 2
@@ -115,13 +125,20 @@ def all_to_all_v_pairs(chunks_a, chunks_b):
     return back(torch.cat(ra), da), back(torch.cat(rb), db)
 
 
-def all_to_all_v(chunks):
-    """chunks[d] goes to rank d; returns the list received from every source, in source (rank) order."""
+def all_to_all_v(chunks, all_counts=None):
+    """chunks[d] goes to rank d; returns the list received from every source, in source (rank) order.
+    all_counts (optional): [W][W] python ints with all_counts[s][d] = elements s sends to d (already known to every rank)."""
     W, r = _world()
-    if W == 1:
+    if _solo():
         return [chunks[0]]
     dev, dt = chunks[0].device, chunks[0].dtype
-    send_counts = torch.tensor([c.numel() for c in chunks], dtype=torch.int64, device=dev)
+    sc = [int(c.numel()) for c in chunks]
+    if all_counts is not None and dist.get_backend() != "gloo":
+        rc = [int(all_counts[s][r]) for s in range(W)]
+        out = torch.empty(sum(rc), dtype=dt, device=dev)
+        dist.all_to_all_single(out, torch.cat(chunks), output_split_sizes=rc, input_split_sizes=sc)
+        return list(torch.split(out, rc))
+    send_counts = torch.tensor(sc, dtype=torch.int64, device=dev)
     recv_counts = torch.empty_like(send_counts)
     if dist.get_backend() == "gloo":  # gloo has no all-to-all: emulate with W all-gathers (CPU tests only)
         all_counts = [torch.empty_like(send_counts) for _ in range(W)]
@@ -135,8 +152,7 @@ def all_to_all_v(chunks):
             recv.append(buf[off:off + sizes[r]].clone())
         return recv
     dist.all_to_all_single(recv_counts, send_counts)
-    rc = [int(x) for x in recv_counts.tolist()]
-    sc = [int(x) for x in send_counts.tolist()]
+    rc = [int(x) for x in recv_counts.tolist()]  # the one host sync of this exchange (send counts are host values already)
     out = torch.empty(sum(rc), dtype=dt, device=dev)
     dist.all_to_all_single(out, torch.cat(chunks), output_split_sizes=rc, input_split_sizes=sc)
     return list(torch.split(out, rc))
@@ -163,8 +179,11 @@ class HipEngine:
         return (pad.view(-1, 8) * w).sum(dim=1, dtype=torch.uint8)
 
     def _unpack_bits(self, bits: torch.Tensor, offset: int, n: int) -> torch.Tensor:
-        i = torch.arange(offset, offset + n, dtype=torch.int64, device=self.device)
-        return ((bits[i >> 3] >> (i & 7).to(torch.uint8)) & 1).to(torch.bool)
+        # one byte of scratch per row (the bytes that hold the window, spread over 8 lanes), not an 8-byte row index
+        b0, b1 = offset >> 3, (offset + n + 7) >> 3
+        sh = torch.arange(8, dtype=torch.uint8, device=self.device)
+        flat = ((bits[b0:b1, None] >> sh) & 1).reshape(-1)
+        return flat[offset - 8 * b0: offset - 8 * b0 + n].to(torch.bool)
 
     def col(self, t: torch.Tensor, dtype, ok: torch.Tensor | None = None):
         K = self.K
@@ -335,7 +354,8 @@ def groupby_sum_mean_count_sharded(engine, keys, vals, row_offset=0):
     with _Stage("2_dictionary"):
         sizes = all_gather_sizes(Gl, dev)
         cat_keys, cat_first, cat_ok = all_gather_v_multi([uk, fr, uok], sizes)  # one collective for the three dictionary columns
-        if W == 1:
+        solo = _solo()
+        if solo:
             glob_keys, glob_ok, glob_first, G = uk, uok, fr, Gl
             my_map = torch.arange(Gl, dtype=torch.int64, device=dev)
         else:
@@ -353,7 +373,7 @@ def groupby_sum_mean_count_sharded(engine, keys, vals, row_offset=0):
     with _Stage("4_counts_exchange"):
         dense = torch.zeros(max(G, 1), dtype=torch.int64, device=dev)
         dense[my_map] = cnt_local
-        if W > 1:
+        if not solo:
             allc = [torch.empty_like(dense) for _ in range(W)]
             dist.all_gather(allc, dense)
             allc = torch.stack(allc)  # [W, G]
@@ -363,14 +383,20 @@ def groupby_sum_mean_count_sharded(engine, keys, vals, row_offset=0):
             prefix_g, count_g = torch.zeros_like(dense), dense
     with _Stage("5_partial_records"):
         # records are emitted group by group in GLOBAL-id order, so they leave the kernel already partitioned by owner rank
-        order = torch.argsort(my_map) if W > 1 else None
+        order = torch.argsort(my_map) if not solo else None
         rec_key, rec_val = engine.partial_records(gv, prefix_g[my_map].contiguous(), my_map, order)
     # owners of contiguous global-id ranges: one all-to-all(v) of contiguous slices
     bounds = [G * d // W for d in range(W + 1)]
     with _Stage("6_all_to_all"):
-        if W > 1:
-            cuts = torch.searchsorted(rec_key, torch.tensor([b * 64 for b in bounds], dtype=torch.int64, device=dev)).tolist()
-            rk, rv = all_to_all_v_pairs([rec_key[cuts[d]:cuts[d + 1]] for d in range(W)], [rec_val[cuts[d]:cuts[d + 1]] for d in range(W)])
+        if not solo:
+            # every rank's cut points travel in ONE small all-gather: a rank learns its own slices and what it will receive from
+            # the others from the same host read (one sync instead of three: cuts, send counts, receive counts)
+            cuts_t = torch.searchsorted(rec_key, torch.tensor([b * 64 for b in bounds], dtype=torch.int64, device=dev))
+            all_cuts = _gather_scalars(cuts_t).tolist()
+            cuts = all_cuts[r]
+            counts = [[row[d + 1] - row[d] for d in range(W)] for row in all_cuts]
+            rk, rv = all_to_all_v_pairs([rec_key[cuts[d]:cuts[d + 1]] for d in range(W)], [rec_val[cuts[d]:cuts[d + 1]] for d in range(W)],
+                                        counts)
         else:
             rk, rv = rec_key, rec_val
     with _Stage("7_replay"):
@@ -405,7 +431,7 @@ def check_result(res, n_total):
 def _gather_scalars(t: torch.Tensor):
     """[W, k] stack of a small per-rank tensor, rank order."""
     W, _ = _world()
-    if W == 1:
+    if _solo():
         return t[None]
     out = [torch.empty_like(t) for _ in range(W)]
     dist.all_gather(out, t)

@@ -49,8 +49,9 @@ def test_scalar_lhs_golden(px, name, offset):
         S = s
     B = px.Column.from_numpy(c["b"], _valid_or_none(c["vb"]), offset=offset)
     nan_exact = name.startswith("ewl_nanbits")
+    side = px.L.SCALAR_LHS if isinstance(S, px.Column) else False  # a python scalar on the left is recognised by itself
     for k, op in OPS.items():
-        vals, valid = px.K.binary(op, S, B).to_numpy()
+        vals, valid = px.K.binary(op, S, B, side).to_numpy()
         ev = c[f"{k}_valid"]
         if valid is not None:
             assert np.array_equal(valid, ev), f"{name} {k} validity"
@@ -65,7 +66,7 @@ def test_scalar_lhs_golden(px, name, offset):
     if "eq" not in c:
         return
     for k, op in CMPS.items():
-        vals, valid = px.K.compare(op, S, B).to_numpy()
+        vals, valid = px.K.compare(op, S, B, side).to_numpy()
         ev = c[f"{k}_valid"]
         assert np.array_equal(vals[ev], c[k][ev]), f"{name} {k}"
         if valid is not None:
