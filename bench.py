@@ -5,16 +5,33 @@ configs[2], "group_by(int64 key).agg(sum,mean,count), 1e9 rows / 1e6 keys, 1 GPU
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one full pass of the hot path over the resident synthetic columns: pdx_groupby_create (hash keys ->
-first-occurrence group ids) + pdx_groupby_agg(sum, mean, count) (stable sort by group + Arrow-order pairwise reduce),
-inputs already in HBM, results left in HBM.  Rank 0 prints ONE JSON line (see README/DESIGN.md for the fields).
+One "step" = one full pass of the hot path over the resident synthetic columns: pdx_groupby_create (keys -> first-occurrence
+group ids) + pdx_groupby_agg(sum, mean, count) (stable sort by group + Arrow-order pairwise reduce), inputs already in HBM,
+results left in HBM.  Rank 0 prints ONE JSON line:
+
+  value / ms_per_step  whole-job rows per second of the timed region (barrier + synchronize on both sides, MAX over ranks)
+  roofline             bound hbm; `achieved` / `frac` = ALGORITHMIC bytes of the step (16 B/row x local rows) / step time
+                       / 8 TB/s -- the whole step, every pass included.  `dominant_kernel` prices the kernel family with the most
+                       device time (HIP events recorded by the library on the launch stream) two ways: `achieved` with the whole
+                       operator's 16 B/row per launch (the contract's definition; it flatters a multi-pass step) and `own_bytes`
+                       with the bytes that kernel itself has to move.  `traffic` = HBM bytes per launch of that kernel from
+                       rocprofv3 PMC counters (profiles/r02_pmc_traffic.json), dropped when the library sources changed since.
+  cpu_baseline         the reference's Arrow call sequence on this box's host cores: Arrow C++ itself when the pyarrow wheel's
+                       libarrow is present (oracle/_build/arrow_seq, kind "port": same kernels the reference calls, without its
+                       unordered_map<ScalarPtr> bookkeeping), else the oracle's C restatement.
+  secondary            (N = 1) the other BASELINE configs and the general-keys (hash table) form of the headline, each with
+                       its own algorithmic-bytes roofline fraction; not part of `value`.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,6 +40,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 ALGO_BYTES_PER_ROW = 16.0  # 8 B int64 key + 8 B fp64 value per row
+# bytes one launch of a kernel family has to move per row of its input (reads + writes)
+OWN_BYTES_PER_ROW = {"radix_scatter": 20.5,   # narrowing passes: (4 + 8 -> 2 + 8) and (2 + 8 -> 1 + 8), mean of the two
+                     "dense_slots": 12.0,     # 8 B key read, 4 B slot written
+                     "fused_last_digit_reduce": 9.0,  # 1 B key + 8 B value read once
+                     "seg_reduce": 8.0, "hash_probe_lds": 12.0, "radix_hist": 2.0}
 
 
 def parse_args():
@@ -32,10 +54,21 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=float, default=1e9, help="total rows (strong scaling: split by row range over the ranks)")
     ap.add_argument("--keys", type=float, default=1e6)
-    ap.add_argument("--cpu-sample-rows", type=float, default=2.5e8, help="rows of the same workload timed on the host cores (rank 0, N=1), ~10-20 s")
+    ap.add_argument("--cpu-sample-rows", type=float, default=3e7,
+                    help="rows of the same workload timed on the host cores (rank 0, N=1): ~25 s of Arrow C++ (its ApplyGroupings is single threaded)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other configs / the general-keys run after the timed region")
     ap.add_argument("--no-check", action="store_true", help="skip the size-independent result checks after the timed region")
     return ap.parse_args()
+
+
+def source_hash():
+    """sha256 over the library sources: ties a PMC traffic file to the build it was measured on."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "pandasarrow_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "pdx", "abi.h")]):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def profile_report(lib):
@@ -51,22 +84,46 @@ def profile_report(lib):
 
 
 def cpu_baseline(sample_rows, nkeys, gpu_check=None):
-    """The oracle's restatement of the reference's Arrow-CPU call sequence, timed on this host ("port").  The same sample is
-    also pushed through the HIP path and compared bit-for-bit (the oracle as checker, outside every timed region)."""
+    """The reference's Arrow-CPU call sequence on this host (Consume -> MakeGroupings -> ApplyGroupings x3 -> per-group
+    sum / mean / count with a thread pool over the groups, src/dataframe.cpp:1539-1600 + src/pd_core_macros.h:5-147), timed on a
+    bounded sample of the same workload.  The same sample also goes through the HIP path and is compared bit-for-bit."""
     import numpy as np
     import oracle as orc
 
-    threads = max(1, min(16, os.cpu_count() or 1))
+    ncpu = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = ncpu
+    threads = max(1, min(usable, 64))
+    out = {"unit": "Grows/s", "cores": ncpu, "threads": threads, "usable_cores": usable, "kind": "port"}
+    arrow = None
+    try:
+        arrow = orc.arrow_seq_run(sample_rows, nkeys, threads)  # Arrow C++ itself (pyarrow wheel's libarrow), if it could be built
+    except Exception as e:  # noqa: BLE001  (no libarrow / headers on this box: the C restatement below is the baseline)
+        out["arrow_seq_unavailable"] = str(e)[:200]
     keys = orc.synth_keys(0, sample_rows, nkeys)
     vals = orc.synth_vals(0, sample_rows)
     t0 = time.perf_counter()
     uk, s, m, c = orc.groupby_sum_mean_count(keys, vals, nthreads=threads)
     dt = time.perf_counter() - t0
-    out = {"value": sample_rows / dt / 1e9, "unit": "Grows/s", "cores": threads, "kind": "port",
-           "sample": f"first {sample_rows:.3g} rows of the same synthetic workload ({len(uk)} groups), "
-                     f"oracle/pdx_oracle.c orc_groupby_sum_mean_count, {dt:.1f} s"}
-    # context only: Arrow's own multi-threaded hash aggregate on a 1e8-row slice (strongest readily available CPU number; its
-    # fp64 sums use a different summation order than the reference's per-group scalar sum, so it is not the parity target)
+    port = {"value": sample_rows / dt / 1e9, "seconds": dt, "what": "oracle/pdx_oracle.c orc_groupby_sum_mean_count (C restatement, OpenMP over groups)"}
+    if arrow is not None:
+        # per-key comparison: Arrow's Grouper hands out ids per 1024-row mini-batch of its swiss table, and keys that collide
+        # inside a mini-batch get their ids after the others, so on large inputs its group ORDER is first-occurrence only
+        # approximately (DESIGN.md section 4); the per-key aggregates are what must be bit-identical
+        oa, oo = np.argsort(arrow["keys"], kind="stable"), np.argsort(uk, kind="stable")
+        same = bool(len(uk) == len(arrow["keys"]) and np.array_equal(arrow["keys"][oa], uk[oo])
+                    and np.array_equal(arrow["sum"][oa].view(np.uint64), s[oo].view(np.uint64))
+                    and np.array_equal(arrow["mean"][oa].view(np.uint64), m[oo].view(np.uint64)) and np.array_equal(arrow["count"][oa], c[oo]))
+        out.update(value=sample_rows / arrow["seconds"] / 1e9, engine=f"Arrow C++ {arrow['arrow_version']} (Grouper::Consume/MakeGroupings/ApplyGroupings + "
+                   "CallFunction(sum|mean|count) per group)", phases_s=arrow["phases"], arrow_matches_oracle_bit_exact=same,
+                   arrow_group_order_is_first_occurrence=bool(len(uk) == len(arrow["keys"]) and np.array_equal(arrow["keys"], uk)), c_restatement=port,
+                   sample=f"first {sample_rows:.3g} rows of the same synthetic workload ({len(uk)} groups), {arrow['seconds']:.1f} s")
+    else:
+        out.update(value=port["value"], engine=port["what"],
+                   sample=f"first {sample_rows:.3g} rows of the same synthetic workload ({len(uk)} groups), {dt:.1f} s")
+    # context only: Arrow's own multi-threaded hash aggregate (different summation order than the reference's per-group sum)
     try:
         import pyarrow as pa
 
@@ -75,8 +132,7 @@ def cpu_baseline(sample_rows, nkeys, gpu_check=None):
         t1 = time.perf_counter()
         tbl.group_by("k").aggregate([("v", "sum"), ("v", "mean"), ("v", "count")])
         out["arrow_hash_aggregate_Grows_per_s"] = rows_pa / (time.perf_counter() - t1) / 1e9
-        out["arrow_version"] = pa.__version__
-    except Exception:  # pyarrow missing on the box: the port above is the baseline
+    except Exception:  # noqa: BLE001
         pass
     if gpu_check is not None:
         gk, gs, gm, gc = gpu_check(sample_rows)
@@ -85,31 +141,108 @@ def cpu_baseline(sample_rows, nkeys, gpu_check=None):
     return out
 
 
-def main():
-    args = parse_args()
-    import torch
-    import torch.distributed as dist
+def secondary_runs(torch, L, K, api, keys, vals, kinds, n_total, nkeys, steps):
+    """The other BASELINE configs + the general-keys form of the headline, N = 1, after the timed region.  Each entry: ms (median
+    of `reps`), Grows/s, algorithmic GB/s (SURVEY 8d bytes) and its fraction of the 8 TB/s roofline."""
+    out = {}
 
+    def timeit(fn, reps=3, warm=1):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2]
+
+    def put(name, rows, algo_bytes, dt, **extra):
+        gbs = algo_bytes / dt / 1e9
+        out[name] = dict(rows=rows, ms=round(dt * 1e3, 3), Grows_per_s=round(rows / dt / 1e9, 3), algo_GBps=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4), **extra)
+
+    def gb_step():
+        gb = K.GroupByHandle.create(keys)
+        return gb, gb.agg(vals, kinds)
+
+    # (a) the same step when the keys may NOT use the dense-integer shortcut: hash partition + LDS-resident open addressing
+    os.environ["PDX_GROUPBY_DENSE"] = "0"
+    try:
+        put("groupby_general_keys_hash_path", n_total, ALGO_BYTES_PER_ROW * n_total, timeit(gb_step, reps=max(2, min(steps, 3))),
+            workload=f"same {n_total:.3g} rows / {nkeys:.3g} keys with PDX_GROUPBY_DENSE=0 (every key through the hash table)")
+    finally:
+        del os.environ["PDX_GROUPBY_DENSE"]
+    # (b) 5 % null values (SURVEY 8d secondary run)
+    vmask = K.compare(L.NE, K.synth_keys(3, n_total, 20), 0)
+    vn = K.Column(L.FLOAT64, n_total, vals.values, vmask.values, 0, -1)
+
+    def gb_nulls():
+        gb = K.GroupByHandle.create(keys)
+        return gb.agg(vn, kinds)
+
+    put("groupby_5pct_null_values", n_total, (ALGO_BYTES_PER_ROW + 0.125) * n_total, timeit(gb_nulls, reps=2))
+    del vn, vmask
+    # (c) C1: Series<double> add + sum at 1e6 rows (plumbing) and at the headline's row count
+    for n in (1_000_000, n_total):
+        x, y = K.synth_vals(0, n, 1), K.synth_vals(0, n, 2)
+        put(f"C1_add_f64[{n:.0e}]", n, 24.0 * n, timeit(lambda: K.binary(L.ADD, x, y)))
+        put(f"C1_sum_f64[{n:.0e}]", n, 8.0 * n, timeit(lambda: K.aggregate(L.AGG_SUM, x)))
+        del x, y
+    # (d) C2: DataFrame boolean-mask filter + take, 1e8 rows x 8 fp64 cols (+ index)
+    n = min(100_000_000, n_total)
+    cols = {f"c{j}": K.synth_vals(0, n, 20 + j) for j in range(8)}
+    df = api.DataFrame(cols, index=K.synth_keys(0, n, 1 << 62))
+    mask = df["c0"] > 0.5
+    s = K.filter_count(mask.col) / n
+    put("C2_filter_8cols+index", n, (0.125 + 8 * 9 * (1 + s)) * n, timeit(lambda: df.where(mask)), selectivity=round(s, 4))
+    m = n // 2
+    take_idx = api.Series(K.synth_keys(7, m, n))
+    put("C2_take_8cols+index", m, (8 + 16 * 9) * m, timeit(lambda: df.take(take_idx)), note="rows = output rows (random 8-B gathers)")
+    del df, cols, mask, take_idx
+    # (e) C5: resample('1min').mean() on a timestamp + fp64 Series (100 ms spacing -> 600 rows per bin)
+    ts = K.synth_ts(0, n_total, 946_684_800 * 10**9, 100_000_000)
+    ser = api.Series(vals, index=ts, name="v")
+    put("C5_resample_1min_mean", n_total, 16.0 * n_total, timeit(lambda: ser.resample("1min").mean()))
+    # (f) a12: DataFrame::downsample('1T') on the same axis = floor/ceil_temporal (16 B/row) + group-by of the binned labels
+    put("a12_round_temporal_minute", n_total, 16.0 * n_total, timeit(lambda: K.round_temporal(ts, 1, L.UNIT_MINUTE, True, True, True)))
+    del ser, ts
+    return out
+
+
+def main():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before anything initialises HIP/HSA (dmabuf IPC for RCCL)
+    args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:  # before any GPU call, so a launcher can still start the ranks cleanly
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks with torch.distributed.run (one per GPU)")
+    import torch
+    import torch.distributed as dist
+
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     # PDX_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, collectives
-    # go through the host) -- never a measurement; the driver's runs use RCCL, one rank per GPU
+    # go through the host) -- never a measurement; the driver's runs use RCCL, one rank per GPU.
+    # PDX_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, sharded step, collectives on the wire) at world size 1.
     backend = os.environ.get("PDX_BENCH_BACKEND", "nccl")
+    sharded = world > 1 or os.environ.get("PDX_BENCH_FORCE_DIST") == "1"
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if sharded:
+        if "MASTER_ADDR" not in os.environ:  # FORCE_DIST outside a launcher
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from pandasarrow_amd import _lib as L
+    from pandasarrow_amd import api
     from pandasarrow_amd import column as K
 
     lib = L.load()
@@ -123,7 +256,7 @@ def main():
     vals = K.synth_vals(lo, n_local)
     kinds = [L.AGG_SUM, L.AGG_MEAN, L.AGG_COUNT]
 
-    if world == 1:
+    if not sharded:
         def step():
             gb = K.GroupByHandle.create(keys)
             outs = gb.agg(vals, kinds)
@@ -139,7 +272,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -162,7 +295,7 @@ def main():
             print(f"step {i}: {(m - prev) * 1e3:.2f} ms", file=sys.stderr)
             prev = m
     lib.pdx_profile_enable(0)
-    if world > 1:
+    if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -171,35 +304,42 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = n_total / (dt / args.steps) / 1e9
 
-    # dominant kernel family (by device time inside the timed region), priced against the HBM roofline with the
-    # ALGORITHMIC bytes of the rows one launch processes (16 B/row x local rows)
-    dom, roof = None, None
+    # roofline: the WHOLE step against the HBM peak with the operator's algorithmic bytes (this rank's shard); the dominant
+    # kernel family (most device time inside the timed region, HIP events on the launch stream) is priced beside it
+    step_gbs = ALGO_BYTES_PER_ROW * n_local / (ms_per_step * 1e-3) / 1e9
+    roof = {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,
+            "scope": "whole step: 16 B/row x local rows / ms_per_step", "traffic": None, "dominant_kernel": None}
     if prof:
-        dom = max(prof.items(), key=lambda kv: kv[1][1])
-        tag, (cnt, ms) = dom
+        tag, (cnt, ms) = max(prof.items(), key=lambda kv: kv[1][1])
         avg_ms = ms / cnt
-        achieved = ALGO_BYTES_PER_ROW * n_local / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": tag, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "launches_per_step": cnt / args.steps, "avg_launch_ms": avg_ms,
-                "whole_step_frac": ALGO_BYTES_PER_ROW * n_local / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items())}}
-
-    # HBM traffic of the dominant kernel: PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate passes) collected on the same
-    # build by tools/collect_profiles.sh and committed under profiles/ -- only valid for the configuration it was measured on
-    if roof is not None:
+        dk = {"kernel": tag, "launches_per_step": cnt / args.steps, "avg_launch_ms": avg_ms,
+              "achieved": ALGO_BYTES_PER_ROW * n_local / (avg_ms * 1e-3) / 1e9, "traffic": None}
+        dk["frac"] = dk["achieved"] / HBM_PEAK_GBS
+        if tag in OWN_BYTES_PER_ROW:
+            own = OWN_BYTES_PER_ROW[tag] * n_local / (avg_ms * 1e-3) / 1e9
+            dk["own_bytes"] = {"bytes_per_row": OWN_BYTES_PER_ROW[tag], "achieved": own, "frac": own / HBM_PEAK_GBS}
+        roof["dominant_kernel"] = dk
+        roof["kernel_ms_per_step"] = {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items())}
+        roof["kernel_ms_sum"] = round(sum(v[1] for v in prof.values()) / args.steps, 3)
+        # HBM traffic per launch from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes, tools/collect_profiles.sh):
+        # only valid for the configuration AND the sources it was measured on
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
                 pmc = json.load(f)
-            if pmc.get("rows") == n_total and pmc.get("n_gpus") == world:
-                roof["traffic"] = pmc["by_bench_tag_hbm_bytes_per_launch"].get(roof["kernel"])
-                roof["traffic_source"] = "profiles/r01_pmc_traffic.json"
+            if pmc.get("rows") == n_total and pmc.get("n_gpus") == world and pmc.get("source_hash") == source_hash():
+                by_tag = pmc["by_bench_tag_hbm_bytes_per_launch"]
+                dk["traffic"] = by_tag.get(tag)
+                roof["traffic"] = pmc.get("step_hbm_bytes")
+                roof["traffic_source"] = "profiles/r02_pmc_traffic.json (source_hash %s)" % pmc["source_hash"]
+            else:
+                roof["traffic_note"] = "profiles/r02_pmc_traffic.json was measured on another configuration or build: dropped"
         except (OSError, ValueError, KeyError):
             pass
 
     # size-independent checks on the last result (outside the timed region)
     check = None
     if not args.no_check:
-        if world == 1:
+        if not sharded:
             gb, outs = res
             G = gb.num_groups
             cnt = outs[2].values[:G]
@@ -213,9 +353,15 @@ def main():
             check = pdist.check_result(res, n_total)
         if rank == 0 and not all(v for k, v in check.items() if isinstance(v, bool)):
             raise SystemExit(f"result check failed: {check}")
+    res = None
+
+    secondary = None
+    if rank == 0 and not sharded and not args.no_secondary:
+        lib.pdx_trim_pool()
+        secondary = secondary_runs(torch, L, K, api, keys, vals, kinds, n_total, nkeys, args.steps)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not sharded and not args.no_cpu_baseline:
         def gpu_on_sample(m):
             gb = K.GroupByHandle.create(keys.slice(0, m))
             o = gb.agg(vals.slice(0, m), kinds)
@@ -232,11 +378,12 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"group_by(int64 key).agg(sum,mean,count), {n_total:.3g} rows / {nkeys:.3g} keys"
                                    + (", 1 GPU" if world == 1 else f", row-range sharded over {world} GPUs (RCCL exchange)"),
-                       "rows": n_total, "keys": nkeys, "rows_per_gpu": n_local, "parity": "bit-exact vs Arrow-order pairwise sum"},
-            "roofline": roof, "cpu_baseline": cpu, "check": check,
+                       "rows": n_total, "keys": nkeys, "rows_per_gpu": n_local, "parity": "bit-exact vs Arrow-order pairwise sum",
+                       "path": "sharded" if sharded else "single"},
+            "roofline": roof, "cpu_baseline": cpu, "check": check, "secondary": secondary,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -104,7 +104,13 @@ typedef enum pdx_agg_kind {
    * null for a group without valid values), two pairwise passes -> float64.  product: one multiply per valid value in row
    * order, int64 wraps, null without valid values -> value dtype.  first/last: the group's first / last ROW (null if that row
    * is null) -> value dtype. */
-  PDX_AGG_VARIANCE = 5, PDX_AGG_STDDEV = 6, PDX_AGG_PRODUCT = 7, PDX_AGG_FIRST = 8, PDX_AGG_LAST = 9
+  PDX_AGG_VARIANCE = 5, PDX_AGG_STDDEV = 6, PDX_AGG_PRODUCT = 7, PDX_AGG_FIRST = 8, PDX_AGG_LAST = 9,
+  /* GROUPBY_NUMERIC_AGG(all | any, bool) and GROUPBY_NUMERIC_AGG(count_distinct, int64_t), src/dataframe.cpp:1520-1526.
+   * all / any: PDX_BOOL values -> PDX_BOOL result (nulls skipped; a group without a valid value is null, so the output needs a
+   * validity buffer).  count_distinct: the number of distinct VALID values per group -> PDX_INT64, never null; float64 values
+   * are distinct when their bit patterns are (0.0 / -0.0 and NaN payloads count separately, like Arrow's memo table).
+   * GroupBy::min_max (src/dataframe.cpp:1602-1696) is {PDX_AGG_MIN, PDX_AGG_MAX} in one call. */
+  PDX_AGG_ALL = 10, PDX_AGG_ANY = 11, PDX_AGG_COUNT_DISTINCT = 12
 } pdx_agg_kind;
 typedef enum pdx_origin {
   PDX_ORIGIN_EPOCH = 0, PDX_ORIGIN_START_DAY = 1, PDX_ORIGIN_START = 2, PDX_ORIGIN_END = 3, PDX_ORIGIN_END_DAY = 4, PDX_ORIGIN_CUSTOM = 5,

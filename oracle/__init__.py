@@ -463,3 +463,53 @@ def downsample_agg(kind, ts, v, valid=None, rule="1T", **kw):
     ids, uniq, _, _ = group_ids(labels)
     vals, ok = groupby_agg(kind, ids, len(uniq), v, valid)
     return uniq, vals, ok
+
+
+# ------------------------------------------------------------------ Arrow C++ itself as the timed CPU baseline (bench.py cpu_baseline)
+_ARROW_SEQ = os.path.join(_HERE, "_build", "arrow_seq")
+
+
+def arrow_seq_build(force: bool = False):
+    """g++ oracle/arrow_seq.cpp against the pyarrow wheel's headers + libarrow / libarrow_compute (third-party library the
+    reference forwards to; nothing of the reference is compiled).  Returns the binary's path, or raises when the wheel (or its
+    headers) is not on this box."""
+    src = os.path.join(_HERE, "arrow_seq.cpp")
+    if not force and os.path.exists(_ARROW_SEQ) and os.path.getmtime(_ARROW_SEQ) >= os.path.getmtime(src):
+        return _ARROW_SEQ
+    import glob
+
+    import pyarrow as pa
+
+    inc, libdirs = pa.get_include(), pa.get_library_dirs()
+    libdir = next(d for d in libdirs if glob.glob(os.path.join(d, "libarrow.so*")))
+
+    def so(name):  # the wheel ships versioned names only (libarrow.so.2500): link them by file name
+        hits = sorted(glob.glob(os.path.join(libdir, name + ".so.*")) or glob.glob(os.path.join(libdir, name + ".so")))
+        if not hits:
+            raise FileNotFoundError(name)
+        return "-l:" + os.path.basename(hits[0])
+
+    os.makedirs(os.path.dirname(_ARROW_SEQ), exist_ok=True)
+    cmd = ["g++", "-std=c++20", "-O2", "-pthread", f"-I{inc}", src, f"-L{libdir}", so("libarrow_compute"), so("libarrow"),
+           f"-Wl,-rpath,{libdir}", "-o", _ARROW_SEQ]
+    subprocess.check_call(cmd)
+    return _ARROW_SEQ
+
+
+def arrow_seq_run(rows, nkeys, threads, timeout=1800):
+    """Run the harness on the first `rows` rows of the synthetic workload; -> dict(seconds, phases, arrow_version, keys, sum, mean, count)."""
+    import json
+    import tempfile
+
+    exe = arrow_seq_build()
+    with tempfile.NamedTemporaryFile(suffix=".bin") as tf:
+        r = subprocess.run([exe, "--rows", str(int(rows)), "--keys", str(int(nkeys)), "--threads", str(int(threads)), "--out", tf.name],
+                           capture_output=True, text=True, timeout=timeout)
+        if r.returncode != 0:
+            raise RuntimeError("arrow_seq failed: " + r.stderr[-500:])
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        G = int(info["groups"])
+        raw = np.fromfile(tf.name, dtype=np.uint8)
+    a = raw.view(np.int64)
+    info.update(keys=a[:G].copy(), sum=raw.view(np.float64)[G:2 * G].copy(), mean=raw.view(np.float64)[2 * G:3 * G].copy(), count=a[3 * G:4 * G].copy())
+    return info

@@ -21,6 +21,7 @@ AND, OR = range(2)
 SCALAR_NONE, SCALAR_RHS, SCALAR_LHS = range(3)  # pdx_scalar_side: which operand of pdx_binary / pdx_compare is broadcast
 AGG_SUM, AGG_MEAN, AGG_MIN, AGG_MAX, AGG_COUNT = range(5)
 AGG_VARIANCE, AGG_STDDEV, AGG_PRODUCT, AGG_FIRST, AGG_LAST = range(5, 10)  # group-by only (include/pdx/abi.h)
+AGG_ALL, AGG_ANY, AGG_COUNT_DISTINCT = range(10, 13)  # group-by only: all / any need BOOL values
 ORIGIN_EPOCH, ORIGIN_START_DAY, ORIGIN_START, ORIGIN_END, ORIGIN_END_DAY, ORIGIN_CUSTOM = range(6)
 (UNIT_NANOSECOND, UNIT_MICROSECOND, UNIT_MILLISECOND, UNIT_SECOND, UNIT_MINUTE, UNIT_HOUR, UNIT_DAY, UNIT_WEEK, UNIT_MONTH,
  UNIT_QUARTER) = range(10)  # pdx_calendar_unit

@@ -317,7 +317,8 @@ def reindex_indices(old_index: Column, new_index: Column) -> Column:
 # ---------------------------------------------------------------- group-by / resample handles
 _AGG_OUT_DT = {L.AGG_MEAN: lambda dt: L.FLOAT64, L.AGG_COUNT: lambda dt: L.INT64, L.AGG_SUM: lambda dt: dt, L.AGG_MIN: lambda dt: dt,
                L.AGG_MAX: lambda dt: dt, L.AGG_VARIANCE: lambda dt: L.FLOAT64, L.AGG_STDDEV: lambda dt: L.FLOAT64,
-               L.AGG_PRODUCT: lambda dt: dt, L.AGG_FIRST: lambda dt: dt, L.AGG_LAST: lambda dt: dt}
+               L.AGG_PRODUCT: lambda dt: dt, L.AGG_FIRST: lambda dt: dt, L.AGG_LAST: lambda dt: dt,
+               L.AGG_ALL: lambda dt: L.BOOL, L.AGG_ANY: lambda dt: L.BOOL, L.AGG_COUNT_DISTINCT: lambda dt: L.INT64}
 
 
 class GroupByHandle:
@@ -395,7 +396,8 @@ class GroupByHandle:
         """All `kinds` from one grouped pass.  -> list of Columns (G rows, group-id order)."""
         kinds = list(kinds)
         G = self.num_groups
-        outs = [Column.empty(_AGG_OUT_DT[k](values.dtype), G, with_validity=values.has_nulls() and k != L.AGG_COUNT) for k in kinds]
+        outs = [Column.empty(_AGG_OUT_DT[k](values.dtype), G, with_validity=k in (L.AGG_ALL, L.AGG_ANY) or (
+            values.has_nulls() and k not in (L.AGG_COUNT, L.AGG_COUNT_DISTINCT))) for k in kinds]
         marr = _mut_array(outs)
         karr = (C.c_int * len(kinds))(*kinds)
         cv = values.c()

@@ -1903,6 +1903,7 @@ struct pdx_groupby {
 namespace pdx {
 
 int minmax_i64_host(const long long* v, int64_t n, long long* mn, long long* mx, Scratch& s, hipStream_t st);  // aggregate.hip
+int groupby_agg_extra(pdx_groupby* gb, const pdx_column* values, const int* kinds, int nk, pdx_mut_column* outs, void* stream);  // groupby_extra.hip
 int minmax_keys_host(const long long* v, const uint8_t* valid, int64_t off, int64_t n, MinMaxPartial<long long>* out, Scratch& s,
                      hipStream_t st);  // aggregate.hip
 
@@ -3314,6 +3315,11 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   if (!gb || !kinds || !outs || nk <= 0) return fail(PDX_INVALID, "pdx_groupby_agg: null argument");
   PDX_TRY(check_column(values, "pdx_groupby_agg"));
   if (values->length != gb->n) return fail(PDX_INVALID, "pdx_groupby_agg: values length differs from the grouped key length");
+  // all / any / count_distinct (and boolean values) are order-free: they live in groupby_extra.hip and come back here for the
+  // standard kinds named in the same request
+  bool extra = values->dtype == PDX_BOOL;
+  for (int k = 0; k < nk; ++k) extra = extra || kinds[k] == PDX_AGG_ALL || kinds[k] == PDX_AGG_ANY || kinds[k] == PDX_AGG_COUNT_DISTINCT;
+  if (extra) return groupby_agg_extra(gb, values, kinds, nk, outs, stream);
   const bool is_f = values->dtype == PDX_FLOAT64;
   if (!is_f && values->dtype != PDX_INT64) return fail(PDX_NOT_IMPLEMENTED, "pdx_groupby_agg: values must be int64 or float64");
   hipStream_t st = as_stream(stream);

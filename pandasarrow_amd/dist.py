@@ -302,7 +302,7 @@ def groupby_agg_sharded(engine, keys, vals, kinds, row_offset=0):
     bounds = [G * d // W for d in range(W + 1)]
     owner_l = torch.bucketize(my_map, torch.tensor(bounds[1:], dtype=torch.int64, device=dev), right=True)
     row_gid = engine.map_ids(gb, my_map)
-    if W == 1:
+    if _solo():
         recv_gid, recv_val = row_gid, vals
     else:
         row_owner = engine.map_ids(gb, owner_l.contiguous())
@@ -450,7 +450,7 @@ def aggregate_sharded(engine, col, kind):
                                         rows, so the rows themselves are routed to one owner (correctness path)."""
     W, r = _world()
     dev = engine.device
-    if W == 1:
+    if _solo():
         return engine.aggregate(kind, col)
     is_f = engine.dtype_of(col) == L.FLOAT64
     if kind == L.AGG_COUNT or kind in (L.AGG_MIN, L.AGG_MAX) or (kind == L.AGG_SUM and not is_f):
@@ -595,7 +595,7 @@ def resample_agg_sharded(engine, ts, vals, kinds, freq_ns, closed_right=False, l
             m = engine.count_below(ts, upper, inclusive=bool(closed_right))
     vok = engine.valid_bools(vals)
     has_nulls = any(all_gather_sizes(0 if vok is None else 1, dev))
-    if W > 1:
+    if not _solo():
         vv = engine.values(vals)
         head = [tv[:m], vv[:m]]
         if has_nulls:

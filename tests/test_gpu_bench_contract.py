@@ -29,9 +29,19 @@ def test_bench_single_gpu_contract():
     assert d["n_gpus"] == 1 and d["unit"] == "Grows/s" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["value"] > 0
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # frac prices the WHOLE step: 16 B/row x rows / ms_per_step / peak
+    assert abs(r["achieved"] - 16.0 * 3e6 / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    dk = r["dominant_kernel"]
+    assert dk["kernel"] and dk["avg_launch_ms"] > 0 and dk["frac"] >= r["frac"] and "traffic" in r
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["gpu_matches_oracle_bit_exact"] is True
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= c["threads"] >= 1 and c["gpu_matches_oracle_bit_exact"] is True
+    if "arrow_matches_oracle_bit_exact" in c:  # Arrow C++ itself timed (the pyarrow wheel's libarrow is on this box)
+        assert c["arrow_matches_oracle_bit_exact"] is True and "Arrow C++" in c["engine"]
     assert all(v for v in d["check"].values() if isinstance(v, bool))
+    sec = d["secondary"]
+    for k in ("groupby_general_keys_hash_path", "groupby_5pct_null_values", "C1_add_f64[1e+06]", "C2_filter_8cols+index", "C2_take_8cols+index",
+              "C5_resample_1min_mean", "a12_round_temporal_minute"):
+        assert sec[k]["ms"] > 0 and 0 < sec[k]["frac"] < 1, k
 
 
 def test_bench_two_rank_rehearsal():
