@@ -302,6 +302,38 @@ int pdx_argsort(const pdx_column* col, int ascending, pdx_mut_column* out_indice
  * (the all-gatherv merge of sharded results).  out->length must be >= sum of part lengths. */
 int pdx_concat(const pdx_column* parts, int nparts, pdx_mut_column* out, void* stream);
 
+/* ---------------------------------------------------------------- Arrow IPC streams <-> device columns
+ * Replaces, for the column types of this path, DataFrame::readBinary (src/dataframe.cpp:754-791: ipc::RecordBatchStreamReader::Open
+ * + ToRecordBatches, exactly ONE record batch) and DataFrame::toBinary (src/dataframe.cpp:726-752: ipc::MakeStreamWriter +
+ * WriteRecordBatch(batch, custom metadata)).  A record batch body is the Arrow layout the kernels read, so reading is a parse of
+ * the two flatbuffer messages on the host plus ONE host->device copy of the body; the columns are pointers into it.
+ *   pdx_ipc_open     parse a stream held in HOST memory (no GPU needed); the blob must stay alive until pdx_ipc_load returns.
+ *                    Column types: bool, (u)int8..64, float32/64, timestamp (any unit, time zone ignored), date64; narrow
+ *                    numerics are widened to int64 / uint64 / float64 and timestamps scaled to nanoseconds on the device.
+ *                    Anything else (strings, nested, dictionaries, compressed bodies): PDX_NOT_IMPLEMENTED naming the field.
+ *   pdx_ipc_load     upload (one copy + the widening kernels); synchronises `stream`.
+ *   pdx_ipc_column   the i-th column (device pointers owned by the frame until pdx_ipc_destroy; before pdx_ipc_load only dtype,
+ *                    length and null_count are filled in).
+ *   pdx_ipc_write    serialise equally long columns as one schema + one record batch (+ custom metadata key/value pairs:
+ *                    metadata_kv holds 2 x nmeta strings) + end-of-stream.  columns_on_host != 0: the pdx_column pointers are
+ *                    host memory.  *out_blob is malloc'ed by the library: release it with pdx_ipc_free_blob.
+ * The index column convention (readBinary's `index` argument: pull the named column out, int64 -> timestamp[ns]) lives in the
+ * facades. */
+typedef struct pdx_ipc_frame pdx_ipc_frame;
+int pdx_ipc_open(const void* blob, size_t size, pdx_ipc_frame** out);
+int pdx_ipc_destroy(pdx_ipc_frame* frame);
+int pdx_ipc_num_columns(const pdx_ipc_frame* frame);
+int64_t pdx_ipc_num_rows(const pdx_ipc_frame* frame);
+const char* pdx_ipc_column_name(const pdx_ipc_frame* frame, int i);
+int pdx_ipc_num_metadata(const pdx_ipc_frame* frame);
+const char* pdx_ipc_metadata_key(const pdx_ipc_frame* frame, int i);
+const char* pdx_ipc_metadata_value(const pdx_ipc_frame* frame, int i);
+int pdx_ipc_load(pdx_ipc_frame* frame, void* stream);
+int pdx_ipc_column(const pdx_ipc_frame* frame, int i, pdx_column* out);
+int pdx_ipc_write(const pdx_column* cols, const char* const* names, int ncols, const char* const* metadata_kv, int nmeta, int columns_on_host,
+                  void* stream, void** out_blob, size_t* out_size);
+int pdx_ipc_free_blob(void* blob);
+
 #ifdef __cplusplus
 }
 #endif

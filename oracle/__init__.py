@@ -513,3 +513,62 @@ def arrow_seq_run(rows, nkeys, threads, timeout=1800):
     a = raw.view(np.int64)
     info.update(keys=a[:G].copy(), sum=raw.view(np.float64)[G:2 * G].copy(), mean=raw.view(np.float64)[2 * G:3 * G].copy(), count=a[3 * G:4 * G].copy())
     return info
+
+
+# ------------------------------------------------------------------ group-by all / any / count_distinct / min_max
+def groupby_all_any(ids, G, b, valid=None, offset=0):
+    """GROUPBY_NUMERIC_AGG(all | any, bool) (src/dataframe.cpp:1520-1522).  b: bool array.  -> (all bool[G], any bool[G], ok bool[G])."""
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    n = len(ids)
+    oa, oy, ok = (np.zeros(max(G, 1), np.uint8) for _ in range(3))
+    lib().orc_groupby_all_any(_p(ids), _i64(n), _i64(G), _p(pack_bits(np.asarray(b, bool), offset)), _p(pack_bits(valid, offset)), _i64(offset),
+                              _p(oa), _p(oy), _p(ok))
+    return oa[:G].astype(bool), oy[:G].astype(bool), ok[:G].astype(bool)
+
+
+def groupby_count_distinct(ids, G, v, valid=None, offset=0):
+    """GROUPBY_NUMERIC_AGG(count_distinct, int64_t) (src/dataframe.cpp:1526): distinct VALID values per group, by bit pattern."""
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    out = np.zeros(max(G, 1), np.int64)
+    vs = _shift(_as_u64(np.ascontiguousarray(v)), offset)
+    lib().orc_groupby_count_distinct(_p(ids), _i64(len(ids)), _i64(G), _p(vs), _p(pack_bits(valid, offset)), _i64(offset), _p(out))
+    return out[:G]
+
+
+def groupby_min_max(ids, G, v, valid=None):
+    """GroupBy::min_max (src/dataframe.cpp:1602-1696): arrow::compute::MinMax per group -> (min, max, ok)."""
+    mn, ok = groupby_agg(AGG_MIN, ids, G, v, valid)
+    mx, _ = groupby_agg(AGG_MAX, ids, G, v, valid)
+    return mn, mx, ok
+
+
+# ------------------------------------------------------------------ frame-level aggregates (NDFrame<DataFrame>, src/ndframe.h:329-335)
+def frame_agg(kind, cols, valids=None):
+    """NDFrame::sum/mean/min/max/count on a DataFrame: GetInternalArray() is ONE ChunkedArray whose chunks are the columns
+    (src/ndframe.h:329-335), so the aggregate runs over every value of the frame (src/ndframe.cpp:119-220).  Arrow sums each chunk
+    with its pairwise tree and adds the chunk totals in chunk (= column) order; mean = that total / total valid count (int64
+    chunks are summed as doubles); min / max keep the first of ties across chunks; count adds up.  -> value | None."""
+    valids = valids or [None] * len(cols)
+    if kind == AGG_COUNT:
+        return sum(agg(AGG_COUNT, c, v)[0] for c, v in zip(cols, valids))
+    isf = any(np.asarray(c).dtype == np.float64 for c in cols)
+    if kind in (AGG_SUM, AGG_MEAN):
+        tot, cnt, wrap = 0.0 if (isf or kind == AGG_MEAN) else 0, 0, not isf and kind == AGG_SUM
+        for c, v in zip(cols, valids):
+            c = np.asarray(c)
+            s, k = agg(AGG_SUM, c.astype(np.float64) if (kind == AGG_MEAN and c.dtype != np.float64) else c, v)
+            if s is None:
+                continue
+            tot = ((tot + s + 2**63) % 2**64 - 2**63) if wrap else tot + s
+            cnt += k
+        if cnt == 0:
+            return None
+        return tot / cnt if kind == AGG_MEAN else tot
+    best = None
+    for c, v in zip(cols, valids):
+        x, _ = agg(kind, c, v)
+        if x is None:
+            continue
+        if best is None or (best != best and x == x) or (x < best if kind == AGG_MIN else x > best):
+            best = x
+    return best

@@ -228,7 +228,94 @@ def gen_downsample():
     manifest["cases"]["downsample"] = cases
 
 
-SECTIONS = [gen_scalar_lhs, gen_round_temporal, gen_downsample]
+# ------------------------------------------------------------------ group-by all / any / count_distinct / min_max
+def gen_groupby_extra():
+    rng = np.random.default_rng(20260204)
+    cases = []
+    for n in (0, 1, 17, 1000, 20000):
+        for card in (1, 7, 1000):
+            for nulls in (False, True):
+                if n == 0 and (card != 1 or nulls):
+                    continue
+                name = f"gbx_{n}_{card}_{int(nulls)}"
+                keys = rng.integers(-card // 2, card - card // 2, n, dtype=np.int64) * 1000003
+                vb = rng.random(n) > (0.3 if card > 7 else 0.02)  # small cards: mostly-true so that `all` is not trivially false
+                vf = np.round(rng.standard_normal(n) * 3) / 2.0        # few distinct doubles per group
+                if n > 10:
+                    vf[rng.integers(0, n, n // 10)] = -0.0
+                    vf[rng.integers(0, n, n // 20)] = 0.0
+                    vf[rng.integers(0, n, max(1, n // 50))] = np.nan
+                    vf[rng.integers(0, n, max(1, n // 50))] = nan_bits(0x77)
+                vi = rng.integers(-3, 4, n, dtype=np.int64) * (2**40 + 1)
+                vvalid = (rng.random(n) > 0.25) if nulls else None
+                K = arr(keys)
+                enc = K.dictionary_encode()
+                ids = np.asarray(enc.indices.to_numpy(zero_copy_only=False)).astype(np.uint32)
+                G = len(enc.dictionary)
+                order = np.argsort(ids, kind="stable")
+                offs = np.concatenate([[0], np.cumsum(np.bincount(ids, minlength=G))])
+                B, F, I = arr(vb, vvalid), arr(vf, vvalid), arr(vi, vvalid)
+                alls, anys, cdf, cdi, mnf, mxf = [], [], [], [], [], []
+                for g in range(G):
+                    rows = pa.array(order[offs[g]:offs[g + 1]])
+                    alls.append(pc.all(B.take(rows)).as_py())        # CallFunction("all", {group}, nullptr)
+                    anys.append(pc.any(B.take(rows)).as_py())
+                    cdf.append(pc.count_distinct(F.take(rows)).as_py())
+                    cdi.append(pc.count_distinct(I.take(rows)).as_py())
+                    mm = pc.min_max(F.take(rows)).as_py()             # GroupBy::min_max: arrow::compute::MinMax(group)
+                    mnf.append(mm["min"])
+                    mxf.append(mm["max"])
+                nz = lambda xs, d: np.array([0 if x is None else x for x in xs], d)  # noqa: E731
+                put(name, keys=keys, vb=vb, vf=vf, vi=vi, vvalid=np.ones(n, bool) if vvalid is None else vvalid, ids=ids,
+                    uniq=enc.dictionary.to_numpy(zero_copy_only=False).astype(np.int64),
+                    all=nz(alls, bool), any=nz(anys, bool), ok=np.array([x is not None for x in alls], bool),
+                    cd_f=np.array(cdf, np.int64), cd_i=np.array(cdi, np.int64), min_f=nz(mnf, np.float64), max_f=nz(mxf, np.float64),
+                    ok_mm=np.array([x is not None for x in mnf], bool))
+                cases.append(name)
+    manifest["cases"]["groupby_extra"] = cases
+
+
+# ------------------------------------------------------------------ frame-level aggregates: ChunkedArray of all columns
+def gen_frame_aggs():
+    rng = np.random.default_rng(20260205)
+    cases = []
+    for ncols in (1, 3, 8):
+        for n in (0, 1, 17, 1000):
+            for dt in ("f64", "i64"):
+                for nulls in (False, True):
+                    name = f"fr_{dt}_{ncols}_{n}_{int(nulls)}"
+                    if dt == "f64":
+                        cols = [rng.standard_normal(n) * 10.0 ** rng.integers(-3, 6, n) if n else np.zeros(0) for _ in range(ncols)]
+                        if n > 3:
+                            cols[-1][1], cols[0][2] = -0.0, 0.0
+                    else:
+                        cols = [rng.integers(-2**61, 2**61, n, dtype=np.int64) for _ in range(ncols)]
+                    valids = [(rng.random(n) > 0.2) if nulls else np.ones(n, bool) for _ in range(ncols)]
+                    if nulls and ncols > 1:
+                        valids[1][:] = False  # an all-null column (chunk): contributes nothing
+                    ch = pa.chunked_array([arr(c, v) for c, v in zip(cols, valids)], type=pa.float64() if dt == "f64" else pa.int64())
+                    res = dict(sum=pc.sum(ch).as_py(), mean=pc.mean(ch).as_py(), min=pc.min(ch).as_py(), max=pc.max(ch).as_py(), count=pc.count(ch).as_py())
+                    rec = dict(count=res["count"], isnull=np.array([res[k] is None for k in ("sum", "mean", "min", "max")]),
+                               mean=np.float64(np.nan if res["mean"] is None else res["mean"]))
+                    odt = np.float64 if dt == "f64" else np.int64
+                    for k in ("sum", "min", "max"):
+                        rec[k] = np.array(0 if res[k] is None else res[k], odt)
+                    for j, (c, v) in enumerate(zip(cols, valids)):
+                        rec[f"c{j}"], rec[f"v{j}"] = c, v
+                    rec["ncols"] = ncols
+                    put(name, **rec)
+                    cases.append(name)
+    # ties across chunks keep the first: (0.0 | -0.0) and (-0.0 | 0.0)
+    for j, (a, b) in enumerate(((0.0, -0.0), (-0.0, 0.0))):
+        ch = pa.chunked_array([pa.array([a, 1.0]), pa.array([b, 1.0])])
+        put(f"fr_tie_{j}", c0=np.array([a, 1.0]), c1=np.array([b, 1.0]), v0=np.ones(2, bool), v1=np.ones(2, bool), ncols=2,
+            min=np.array(pc.min(ch).as_py()), max=np.array(pc.max(ch).as_py()), sum=np.array(pc.sum(ch).as_py()),
+            mean=np.float64(pc.mean(ch).as_py()), count=4, isnull=np.zeros(4, bool))
+        cases.append(f"fr_tie_{j}")
+    manifest["cases"]["frame_aggs"] = cases
+
+
+SECTIONS = [gen_scalar_lhs, gen_round_temporal, gen_downsample, gen_groupby_extra, gen_frame_aggs]
 
 
 def main():

@@ -222,6 +222,11 @@ int orc_minmax_f64(const double* v, const uint8_t* valid, int64_t off, int64_t n
   int64_t cnt = 0;
   int have = 0;
   double lo = 0, hi = 0;
+  /* Ties between values that compare equal but differ in bits (0.0 / -0.0), pinned against Arrow 25.0.0: min keeps the FIRST;
+   * max keeps the FIRST when the array has no nulls and the LAST when it has at least one (Arrow's null-aware loop is a different
+   * instantiation of the same fmax step, compiled with the operands the other way round). */
+  int has_nulls = 0;
+  for (int64_t i = 0; i < n && !has_nulls; ++i) has_nulls = !is_valid(valid, off, i);
   for (int64_t i = 0; i < n; ++i) {
     if (!is_valid(valid, off, i)) continue;
     ++cnt;
@@ -232,7 +237,7 @@ int orc_minmax_f64(const double* v, const uint8_t* valid, int64_t off, int64_t n
       have = 1;
     } else {
       if (x < lo) lo = x;
-      if (x > hi) hi = x;
+      if (x > hi || (has_nulls && x == hi)) hi = x;
     }
   }
   *count = cnt;
@@ -805,5 +810,53 @@ int orc_round_temporal(int ceil_mode, const int64_t* ts, const uint8_t* valid, i
     memset(out_valid, 0, (size_t)((n + 7) / 8));
     for (int64_t i = 0; i < n; ++i) bit_set_to(out_valid, i, is_valid(valid, off, i));
   }
+  return ORC_OK;
+}
+
+/* ------------------------------------------------------------------ group-by all / any / count_distinct
+ * GROUPBY_NUMERIC_AGG(all | any, bool), GROUPBY_NUMERIC_AGG(count_distinct, int64_t) (src/dataframe.cpp:1520-1526): one
+ * CallFunction(name, {group}, nullptr) per group -> Arrow defaults: all / any skip nulls and are null without a valid value
+ * (ScalarAggregateOptions{skip_nulls = true, min_count = 1}); count_distinct counts distinct VALID values (CountOptions
+ * ONLY_VALID), two doubles being the same value iff their bit patterns are (memo table hashed on the bytes). */
+int orc_groupby_all_any(const uint32_t* ids, int64_t n, int64_t G, const uint8_t* bits, const uint8_t* valid, int64_t off,
+                        uint8_t* out_all, uint8_t* out_any, uint8_t* out_valid) {
+  for (int64_t g = 0; g < G; ++g) {
+    out_all[g] = 1;
+    out_any[g] = 0;
+    out_valid[g] = 0;
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    if (!is_valid(valid, off, i)) continue;
+    const uint32_t g = ids[i];
+    const int b = bit_get(bits, off + i);
+    out_valid[g] = 1;
+    if (b) out_any[g] = 1;
+    else out_all[g] = 0;
+  }
+  return ORC_OK;
+}
+typedef struct { uint32_t g; uint64_t v; } gv_pair;
+static int gv_cmp(const void* a, const void* b) {
+  const gv_pair *x = (const gv_pair*)a, *y = (const gv_pair*)b;
+  if (x->g != y->g) return x->g < y->g ? -1 : 1;
+  if (x->v != y->v) return x->v < y->v ? -1 : 1;
+  return 0;
+}
+int orc_groupby_count_distinct(const uint32_t* ids, int64_t n, int64_t G, const uint64_t* v, const uint8_t* valid, int64_t off,
+                               int64_t* out) {
+  for (int64_t g = 0; g < G; ++g) out[g] = 0;
+  gv_pair* p = (gv_pair*)malloc((size_t)(n > 0 ? n : 1) * sizeof(gv_pair));
+  if (!p) return ORC_INVALID;
+  int64_t m = 0;
+  for (int64_t i = 0; i < n; ++i)
+    if (is_valid(valid, off, i)) {
+      p[m].g = ids[i];
+      p[m].v = v[off + i];
+      ++m;
+    }
+  qsort(p, (size_t)m, sizeof(gv_pair), gv_cmp);
+  for (int64_t i = 0; i < m; ++i)
+    if (i == 0 || p[i].g != p[i - 1].g || p[i].v != p[i - 1].v) out[p[i].g] += 1;
+  free(p);
   return ORC_OK;
 }

@@ -114,6 +114,13 @@ void orc_resample_expand(const int64_t* bins, const int64_t* labels, int64_t nb,
 void orc_concat_64(const uint64_t* const* parts, const uint8_t* const* valids, const int64_t* offs, const int64_t* lens,
                    int nparts, uint64_t* out, uint8_t* out_valid, int64_t* out_nulls);
 
+/* ---- group-by all / any (bit-packed bool values) and count_distinct (8-byte values as bit patterns): src/dataframe.cpp:1520-1526.
+ * outputs: one byte per group; out_valid[g] == 0 <=> the group has no valid value (all / any are null there). */
+int orc_groupby_all_any(const uint32_t* ids, int64_t n, int64_t G, const uint8_t* bits, const uint8_t* valid, int64_t off,
+                        uint8_t* out_all, uint8_t* out_any, uint8_t* out_valid);
+int orc_groupby_count_distinct(const uint32_t* ids, int64_t n, int64_t G, const uint64_t* v, const uint8_t* valid, int64_t off,
+                               int64_t* out);
+
 /* ---- temporal rounding: DataFrame::downsample (src/dataframe.cpp:1265-1290) = Arrow floor_temporal / ceil_temporal ---- */
 enum { ORC_UNIT_NANOSECOND = 0, ORC_UNIT_MICROSECOND = 1, ORC_UNIT_MILLISECOND = 2, ORC_UNIT_SECOND = 3, ORC_UNIT_MINUTE = 4,
        ORC_UNIT_HOUR = 5, ORC_UNIT_DAY = 6, ORC_UNIT_WEEK = 7, ORC_UNIT_MONTH = 8, ORC_UNIT_QUARTER = 9 };

@@ -337,16 +337,56 @@ class DataFrame:
     def __rmul__(self, o): return self._rbin(L.MUL, o)
     def __rtruediv__(self, o): return self._rbin(L.DIV, o)
 
+    # ---- NDFrame::sum/mean/min/max/count on a DataFrame (src/ndframe.cpp:119-220): GetInternalArray() is ONE ChunkedArray whose
+    # chunks are the columns (src/ndframe.h:329-335), so the aggregate runs over every value of the frame.  Arrow reduces a
+    # chunked array chunk by chunk (each chunk with its own pairwise tree) and folds the chunk results in chunk = column order.
+    def _check_one_dtype(self):
+        if len({c.dtype for c in self.cols}) > 1:  # arrow::ChunkedArray needs one type for all its chunks
+            raise L.PdxError(L.INVALID, "frame-level aggregates need all columns to have the same dtype")
+
     def sum(self):
-        """NDFrame::sum on a DataFrame (src/ndframe.h:329-335): each column (chunk) is summed, totals added in column order."""
+        self._check_one_dtype()
         tot, first = None, True
         for c in self.cols:
             v, _ = K.aggregate(L.AGG_SUM, c)
             if v is None:
                 continue
-            tot = v if first else tot + v
+            if first:
+                tot = v
+            elif isinstance(v, float):
+                tot = tot + v
+            else:
+                tot = (tot + v + 2**63) % 2**64 - 2**63  # int64 wraps
             first = False
         return Scalar(tot)
+
+    def count(self):
+        return Scalar(sum(K.aggregate(L.AGG_COUNT, c)[0] for c in self.cols))
+
+    def mean(self):
+        """total of the per-chunk pairwise sums (int64 chunks are summed as doubles, like Arrow's mean) / total valid count"""
+        self._check_one_dtype()
+        tot, cnt = 0.0, 0
+        for c in self.cols:
+            v, k = K.aggregate(L.AGG_SUM, c if c.dtype == L.FLOAT64 else K.binary(L.MUL, c, 1.0))
+            if v is None:
+                continue
+            tot, cnt = tot + v, cnt + k
+        return Scalar(tot / cnt if cnt else None, cnt)
+
+    def _extreme(self, kind):
+        self._check_one_dtype()
+        best = None
+        for c in self.cols:  # the first of ties across chunks wins; a NaN chunk result never replaces a number
+            x, _ = K.aggregate(kind, c)
+            if x is None:
+                continue
+            if best is None or (best != best and x == x) or (x < best if kind == L.AGG_MIN else x > best):
+                best = x
+        return Scalar(best)
+
+    def min(self): return self._extreme(L.AGG_MIN)
+    def max(self): return self._extreme(L.AGG_MAX)
 
     # ---- where / take (src/dataframe.cpp:461-492)
     def where(self, mask: Series):
@@ -429,6 +469,20 @@ class GroupBy:
     def product(self, args): return self._agg_frame(L.AGG_PRODUCT, args)
     def first(self, args): return self._agg_frame(L.AGG_FIRST, args)
     def last(self, args): return self._agg_frame(L.AGG_LAST, args)
+    # GROUPBY_NUMERIC_AGG(all | any, bool), GROUPBY_NUMERIC_AGG(count_distinct, int64_t) (src/dataframe.cpp:1520-1526)
+    def all(self, args): return self._agg_frame(L.AGG_ALL, args)
+    def any(self, args): return self._agg_frame(L.AGG_ANY, args)
+    def count_distinct(self, args): return self._agg_frame(L.AGG_COUNT_DISTINCT, args)
+
+    def min_max(self, args):
+        """GroupBy::min_max (src/dataframe.cpp:1602-1696): arrow::compute::MinMax per group.  One column name -> frame with
+        columns "min", "max"; a list -> "<name>_min", "<name>_max" per column.  Both extremes come from ONE grouped pass."""
+        single = isinstance(args, str)
+        cols = {}
+        for nm in ([args] if single else list(args)):
+            mn, mx = self._h.agg(self.df.cols[self.df.names.index(nm)], [L.AGG_MIN, L.AGG_MAX])
+            cols["min" if single else nm + "_min"], cols["max" if single else nm + "_max"] = mn, mx
+        return DataFrame(cols, index=None)
 
     def agg(self, name, kinds):
         """sum/mean/count of one column from a single grouped pass (the headline query)."""

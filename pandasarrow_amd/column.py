@@ -474,3 +474,81 @@ def synth_ts(start, n, t0_ns, step_ns) -> Column:
     out = Column.empty(L.TIMESTAMP_NS, n)
     L.check(L.load().pdx_synth_ts(int(start), int(n), int(t0_ns), int(step_ns), out.values.data_ptr(), _stream()))
     return out
+
+
+# ---------------------------------------------------------------- Arrow IPC streams <-> device columns (pdx_ipc_*)
+class _FrameMemory:
+    """A window of device memory owned by a pdx_ipc_frame, exposed through the CUDA array interface so that a torch tensor can
+    alias it without a copy (the tensor keeps this object, and through it the frame, alive)."""
+
+    def __init__(self, frame, ptr, count, typestr):
+        self._frame = frame
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class IpcFrame:
+    """Owner of a pdx_ipc_frame*: the parsed schema / record batch of ONE Arrow IPC stream and, after load(), its device copy."""
+
+    def __init__(self, blob):
+        lib = L.load()
+        self._blob = bytes(blob) if not isinstance(blob, (bytes, bytearray, memoryview)) else blob  # must outlive load()
+        self._h = C.c_void_p()
+        buf = (C.c_char * len(self._blob)).from_buffer_copy(self._blob) if not isinstance(self._blob, bytes) else self._blob
+        self._buf = buf
+        L.check(lib.pdx_ipc_open(buf, len(self._blob), C.byref(self._h)))
+        self.names = [lib.pdx_ipc_column_name(self._h, i).decode() for i in range(lib.pdx_ipc_num_columns(self._h))]
+        self.num_rows = int(lib.pdx_ipc_num_rows(self._h))
+        self.metadata = {lib.pdx_ipc_metadata_key(self._h, i).decode(): lib.pdx_ipc_metadata_value(self._h, i).decode()
+                         for i in range(lib.pdx_ipc_num_metadata(self._h))}
+
+    def __del__(self):
+        try:
+            if self._h is not None and self._h.value:
+                L.load().pdx_ipc_destroy(self._h)
+            self._h = None
+        except Exception:
+            pass
+
+    def schema(self):
+        """[(name, pdx dtype, null_count)] without touching the GPU."""
+        out = []
+        for i, nm in enumerate(self.names):
+            c = L.PdxColumn()
+            L.check(L.load().pdx_ipc_column(self._h, i, C.byref(c)))
+            out.append((nm, int(c.dtype), int(c.null_count)))
+        return out
+
+    def load(self):
+        """One host->device copy of the record batch body (+ widening kernels for narrow types) -> {name: Column} aliasing it."""
+        _device()
+        L.check(L.load().pdx_ipc_load(self._h, _stream()))
+        self._blob = self._buf = None
+        cols = []
+        n = self.num_rows
+        for i, nm in enumerate(self.names):
+            c = L.PdxColumn()
+            L.check(L.load().pdx_ipc_column(self._h, i, C.byref(c)))
+            if c.dtype == L.BOOL:
+                vals = torch.as_tensor(_FrameMemory(self, c.values, (n + 7) // 8 + 8, "|u1"), device=_device())
+            else:
+                vals = torch.as_tensor(_FrameMemory(self, c.values, max(n, 1), "<f8" if c.dtype == L.FLOAT64 else "<i8"), device=_device())
+            vb = None
+            if c.validity:
+                vb = torch.as_tensor(_FrameMemory(self, c.validity, (n + 7) // 8 + 8, "|u1"), device=_device())
+            cols.append((nm, Column(int(c.dtype), n, vals, vb, 0, int(c.null_count))))
+        return cols
+
+
+def ipc_write(cols, names, metadata=None) -> bytes:
+    """One schema + one record batch (+ custom metadata) + end-of-stream, the layout DataFrame::toBinary produces."""
+    lib = L.load()
+    arr = _col_array(cols)
+    cn = (C.c_char_p * max(len(names), 1))(*[nm.encode() for nm in names])
+    kv = [x.encode() for k, v in (metadata or {}).items() for x in (k, v)]
+    ckv = (C.c_char_p * max(len(kv), 1))(*kv)
+    out, size = C.c_void_p(), C.c_size_t()
+    L.check(lib.pdx_ipc_write(arr, cn, len(cols), ckv, len(kv) // 2, 0, _stream(), C.byref(out), C.byref(size)))
+    try:
+        return C.string_at(out, size.value)
+    finally:
+        lib.pdx_ipc_free_blob(out)

@@ -525,6 +525,42 @@ class DataFrame {
     if (first) return Scalar();
     return is_f ? Scalar(f) : Scalar(i);
   }
+  // NDFrame::count/mean/min/max on a frame (src/ndframe.cpp:119-220 over GetInternalArray() = one ChunkedArray of all columns,
+  // src/ndframe.h:329-335): chunk results folded in column order; mean = total of the per-chunk double sums / total valid count
+  Scalar count() const {
+    int64_t n = 0;
+    for (auto& c : m_columns) n += Series(c).count().as<int64_t>();
+    return Scalar(n);
+  }
+  Scalar mean() const {
+    double tot = 0.0;
+    int64_t cnt = 0;
+    for (auto& c : m_columns) {
+      Series col(c.dtype == PDX_FLOAT64 ? c : Series::run_binary(PDX_MUL, c, Scalar(1.0).to_array(), true));  // int64 chunks sum as doubles
+      Scalar s = col.sum();
+      if (!s.isValid()) continue;
+      tot += s.s.v.f64;
+      cnt += s.s.count;
+    }
+    return cnt ? Scalar(tot / (double)cnt) : Scalar();
+  }
+  Scalar extreme(int kind) const {
+    Scalar best;
+    for (auto& c : m_columns) {  // the first of ties across chunks wins; a NaN chunk result never replaces a number
+      Scalar x = Series(c).agg(kind);
+      if (!x.isValid()) continue;
+      if (!best.isValid()) { best = x; continue; }
+      if (x.s.dtype == PDX_FLOAT64) {
+        const double b = best.s.v.f64, v = x.s.v.f64;
+        if ((b != b && v == v) || (kind == PDX_AGG_MIN ? v < b : v > b)) best = x;
+      } else if (kind == PDX_AGG_MIN ? x.s.v.i64 < best.s.v.i64 : x.s.v.i64 > best.s.v.i64) {
+        best = x;
+      }
+    }
+    return best;
+  }
+  Scalar min() const { return extreme(PDX_AGG_MIN); }
+  Scalar max() const { return extreme(PDX_AGG_MAX); }
 
   DataFrame where(const Series& mask) const {
     if (mask.dtype() != PDX_BOOL) throw std::runtime_error("filter mask must be boolean");
@@ -599,8 +635,9 @@ struct GroupBy {
   }
   Array agg_array(const std::string& arg, int kind) const {
     const Array& v = df.m_columns[(size_t)df.column_index(arg)];
-    int out_dt = (kind == PDX_AGG_MEAN || kind == PDX_AGG_VARIANCE || kind == PDX_AGG_STDDEV) ? PDX_FLOAT64 : kind == PDX_AGG_COUNT ? PDX_INT64 : v.dtype;
-    Array out = Array::Empty(out_dt, (int64_t)groupSize(), v.has_nulls() && kind != PDX_AGG_COUNT);
+    const bool boolean = kind == PDX_AGG_ALL || kind == PDX_AGG_ANY, counting = kind == PDX_AGG_COUNT || kind == PDX_AGG_COUNT_DISTINCT;
+    int out_dt = (kind == PDX_AGG_MEAN || kind == PDX_AGG_VARIANCE || kind == PDX_AGG_STDDEV) ? PDX_FLOAT64 : counting ? PDX_INT64 : boolean ? PDX_BOOL : v.dtype;
+    Array out = Array::Empty(out_dt, (int64_t)groupSize(), boolean || (v.has_nulls() && !counting));
     auto c = v.c();
     auto m = out.mut();
     ThrowOnFailure(pdx_groupby_agg(handle->h, &c, &kind, 1, &m, nullptr));
@@ -626,6 +663,11 @@ struct GroupBy {
   Series product(const std::string& a) const { return agg(a, PDX_AGG_PRODUCT); }
   Series first(const std::string& a) const { return agg(a, PDX_AGG_FIRST); }
   Series last(const std::string& a) const { return agg(a, PDX_AGG_LAST); }
+  // GROUPBY_NUMERIC_AGG(all | any | count_distinct) (src/dataframe.cpp:1520-1526) and GroupBy::min_max (1602-1696)
+  Series all(const std::string& a) const { return agg(a, PDX_AGG_ALL); }
+  Series any(const std::string& a) const { return agg(a, PDX_AGG_ANY); }
+  Series count_distinct(const std::string& a) const { return agg(a, PDX_AGG_COUNT_DISTINCT); }
+  DataFrame min_max(const std::string& a) const { return DataFrame({"min", "max"}, {agg_array(a, PDX_AGG_MIN), agg_array(a, PDX_AGG_MAX)}); }
   DataFrame sum(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_SUM); }
   DataFrame mean(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_MEAN); }
   DataFrame min(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_MIN); }

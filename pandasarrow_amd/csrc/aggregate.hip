@@ -308,8 +308,8 @@ __global__ void __launch_bounds__(256) k_sum_i64(const int64_t* __restrict__ v, 
   if ((threadIdx.x & 63) == 0) atomicAdd(total, acc);  // wrap-around add is order independent
 }
 
-template <typename T>
-__device__ __forceinline__ void block_reduce_extreme(Extreme<T>& e, MinMaxPartial<T>* smem) {
+template <typename T, bool ML>
+__device__ __forceinline__ void block_reduce_extreme(Extreme<T, ML>& e, MinMaxPartial<T>* smem) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int d = 32; d > 0; d >>= 1) {
     T omin = __shfl_down(e.vmin, d, 64), omax = __shfl_down(e.vmax, d, 64);
@@ -324,11 +324,11 @@ __device__ __forceinline__ void block_reduce_extreme(Extreme<T>& e, MinMaxPartia
 }
 
 // pass 1: grid-stride over rows -> one partial per block.  NaN rows are skipped (counted separately through `valid` only).
-template <typename T>
+template <typename T, bool ML>
 __global__ void __launch_bounds__(256) k_minmax_partial(const T* __restrict__ v, const uint8_t* __restrict__ valid, int64_t off,
                                                         int64_t n, MinMaxPartial<T>* __restrict__ partials) {
   __shared__ MinMaxPartial<T> smem[4];
-  Extreme<T> e;
+  Extreme<T, ML> e;
   e.init();
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -354,24 +354,31 @@ __global__ void __launch_bounds__(256) k_minmax_partial(const T* __restrict__ v,
   block_reduce_extreme(e, smem);
   if (threadIdx.x == 0) partials[blockIdx.x] = {e.vmin, e.vmax, e.rmin, e.rmax};
 }
-template <typename T>
+template <typename T, bool ML>
 __global__ void __launch_bounds__(256) k_minmax_final(const MinMaxPartial<T>* __restrict__ partials, int np,
                                                       MinMaxPartial<T>* __restrict__ out) {
   __shared__ MinMaxPartial<T> smem[4];
-  Extreme<T> e;
+  Extreme<T, ML> e;
   e.init();
   for (int i = threadIdx.x; i < np; i += blockDim.x) e.merge(partials[i].vmin, partials[i].rmin, partials[i].vmax, partials[i].rmax);
   block_reduce_extreme(e, smem);
   if (threadIdx.x == 0) *out = {e.vmin, e.vmax, e.rmin, e.rmax};
 }
 
+// max_last: the array holds at least one null, so the LAST of tied maxima (0.0 / -0.0) wins (minmax.hpp)
 template <typename T>
-static int minmax_impl(const T* v, const uint8_t* valid, int64_t off, int64_t n, MinMaxPartial<T>* host_out, Scratch& s, hipStream_t st) {
+static int minmax_impl(const T* v, const uint8_t* valid, int64_t off, int64_t n, MinMaxPartial<T>* host_out, Scratch& s, hipStream_t st,
+                       bool max_last = false) {
   int grid = grid_for(n, 256, 8);
   MinMaxPartial<T>* partials = s.get<MinMaxPartial<T>>((size_t)grid + 1);
   PDX_SCRATCH_CHECK(s);
-  hipLaunchKernelGGL((k_minmax_partial<T>), dim3(grid), dim3(256), 0, st, v, valid, off, n, partials);
-  hipLaunchKernelGGL((k_minmax_final<T>), dim3(1), dim3(256), 0, st, partials, grid, partials + grid);
+  if (max_last) {
+    hipLaunchKernelGGL((k_minmax_partial<T, true>), dim3(grid), dim3(256), 0, st, v, valid, off, n, partials);
+    hipLaunchKernelGGL((k_minmax_final<T, true>), dim3(1), dim3(256), 0, st, partials, grid, partials + grid);
+  } else {
+    hipLaunchKernelGGL((k_minmax_partial<T, false>), dim3(grid), dim3(256), 0, st, v, valid, off, n, partials);
+    hipLaunchKernelGGL((k_minmax_final<T, false>), dim3(1), dim3(256), 0, st, partials, grid, partials + grid);
+  }
   PDX_LAUNCH_CHECK();
   PDX_HIP(hipMemcpyAsync(host_out, partials + grid, sizeof(*host_out), hipMemcpyDeviceToHost, st));
   PDX_HIP(hipStreamSynchronize(st));
@@ -507,7 +514,8 @@ extern "C" int pdx_aggregate(int kind, const pdx_column* a, pdx_scalar* out, voi
   if (cnt == 0) return PDX_OK;  // null
   if (is_f) {
     MinMaxPartial<double> r;
-    PDX_TRY(minmax_impl<double>(static_cast<const double*>(a->values) + a->offset, validity_or_null(a), a->offset, n, &r, s, st));
+    PDX_TRY(minmax_impl<double>(static_cast<const double*>(a->values) + a->offset, validity_or_null(a), a->offset, n, &r, s, st,
+                                /*max_last=*/cnt < n));
     out->is_valid = 1;
     if (r.rmin < 0) out->v.f64 = __builtin_nan("");  // every valid value is NaN
     else out->v.f64 = kind == PDX_AGG_MIN ? r.vmin : r.vmax;

@@ -1592,6 +1592,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_nullable(const T*
     const uint32_t oi = out_index ? out_index[k] : (uint32_t)k;
     Extreme<T> ext;
     ext.init();
+    long long zlast = -1;     // last valid zero-valued row of the group and its sign: the max tie rule of a group WITH nulls (minmax.hpp)
     unsigned long long isum = 0;
     long long nvalid = 0;
     uint64_t cmask = 0;       // binary counter occupancy (wave-uniform)
@@ -1616,6 +1617,12 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_nullable(const T*
           if (v) {
             isum += (unsigned long long)x;
             if (x == x) ext.add(x, (long long)(c0 + idx));
+            if constexpr (__is_same(T, double)) {
+              if (x == 0.0) {
+                const long long zm = zero_mark(x, (long long)(c0 + idx));
+                zlast = zm > zlast ? zm : zlast;
+              }
+            }
           }
         }
         const uint64_t bal = __ballot(v);
@@ -1715,6 +1722,8 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_nullable(const T*
       long long ormin = __shfl_down(ext.rmin, d, 64), ormax = __shfl_down(ext.rmax, d, 64);
       ext.merge(omin, ormin, omax, ormax);
       isum += __shfl_down(isum, d, 64);
+      const long long oz = __shfl_down(zlast, d, 64);
+      zlast = oz > zlast ? oz : zlast;
     }
     if (lane == 0) {
       if (out.sum_f) out.sum_f[oi] = total;
@@ -1723,6 +1732,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_nullable(const T*
       T nanv = T(0);
       if constexpr (__is_same(T, double)) nanv = __builtin_nan("");
       if (out.vmin) static_cast<T*>(out.vmin)[oi] = ext.rmin < 0 ? nanv : ext.vmin;
+      if constexpr (__is_same(T, double)) ext.vmax = zero_tie_fix(ext.vmax, zlast, nvalid < len);
       if (out.vmax) static_cast<T*>(out.vmax)[oi] = ext.rmax < 0 ? nanv : ext.vmax;
       if (out.count) out.count[oi] = nvalid;
       ok[oi] = nvalid > 0;
@@ -2222,6 +2232,7 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const KT* __restrict_
     unsigned long long cmask = 0, isum = 0;
     long long nvalid = 0, nrows = 0;
     T vmn = T(0), vmx = T(0);
+    int zneg = -1;  // sign of the last zero-valued valid row (-1: none)
     bool has = false;
     if (wave == 0)
       for (int l = 0; l < kFlrLevels; ++l) csum[l][lane] = 0.0;
@@ -2517,6 +2528,9 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const KT* __restrict_
                   if (x < vmn) vmn = x;
                   if (x > vmx) vmx = x;
                 }
+                if constexpr (__is_same(T, double)) {
+                  if (x == 0.0) zneg = __double_as_longlong(x) < 0 ? 1 : 0;  // the LAST zero of the group (rows are replayed in order)
+                }
               }
             } else {
               close = want_pw && pos > 0;  // a null row closes the open leaf
@@ -2550,6 +2564,9 @@ __global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const KT* __restrict_
         T nanv = T(0);
         if constexpr (__is_same(T, double)) nanv = __builtin_nan("");
         if (out.vmin) static_cast<T*>(out.vmin)[oi] = has ? vmn : nanv;
+        if constexpr (__is_same(T, double)) {  // a group WITH nulls keeps the last of tied zero maxima (minmax.hpp)
+          if (has && zneg >= 0 && vmx == 0.0 && nvalid < nrows) vmx = zneg ? -0.0 : 0.0;
+        }
         if (out.vmax) static_cast<T*>(out.vmax)[oi] = has ? vmx : nanv;
       }
       if (out.count) out.count[oi] = nvalid;

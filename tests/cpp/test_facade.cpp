@@ -148,6 +148,23 @@ static void test_groupby() {
   REQUIRE((g.product("age").values<int64_t>() == std::vector<int64_t>{3024000000LL, 7500}));
   REQUIRE((g.first("age").values<int>() == std::vector<int>{16, 10}));
   REQUIRE((g.last("age").values<int>() == std::vector<int>{45, 25}));
+  // the remaining aggregations of src/dataframe.cpp:1520-1526, 1602-1696 on a small frame of our own
+  DataFrame f2({"k", "b", "v"}, {Array::Make(std::vector<long>{1, 1, 3, 1, 3, 8}), Array::Make(std::vector<bool>{true, true, false, true, true, true}),
+                                 Array::Make(std::vector<double>{1.0, 1.0, 2.0, 3.0, 2.0, 7.0})});
+  auto g2 = f2.group_by("k");
+  REQUIRE((g2.all("b").values<bool>() == std::vector<bool>{true, false, true}));
+  REQUIRE((g2.any("b").values<bool>() == std::vector<bool>{true, true, true}));
+  REQUIRE((g2.count_distinct("v").values<long>() == std::vector<long>{2, 1, 1}));
+  auto mm = g2.min_max("v");
+  REQUIRE((mm["min"].values<double>() == std::vector<double>{1.0, 2.0, 7.0}));
+  REQUIRE((mm["max"].values<double>() == std::vector<double>{3.0, 2.0, 7.0}));
+  // frame-level aggregates over all columns as chunks (src/ndframe.h:329-335)
+  DataFrame f3({"x", "y"}, {Array::Make(std::vector<double>{1.0, 2.0}), Array::Make(std::vector<double>{3.0, 6.0})});
+  REQUIRE(f3.sum().as<double>() == 12.0);
+  REQUIRE(f3.mean().as<double>() == 3.0);
+  REQUIRE(f3.min().as<double>() == 1.0);
+  REQUIRE(f3.max().as<double>() == 6.0);
+  REQUIRE(f3.count().as<long>() == 4);
 }
 
 // tests/series_resample_test.cpp:12-85

@@ -185,3 +185,109 @@ def test_downsample_kat(px, kat):
         df.downsample("3Y")
     with pytest.raises(RuntimeError, match="timestamp"):
         px.api.DataFrame({"x": np.arange(3)}).downsample("3T")
+
+
+# ------------------------------------------------------------------ 8(f)-3: all / any / count_distinct / min_max on the grouped layout
+@pytest.mark.parametrize("name", G2.cases("groupby_extra"))
+@pytest.mark.parametrize("offset", [0, 3])
+def test_groupby_extra_golden(px, name, offset):
+    c = G2.case(name)
+    valid = _valid_or_none(c["vvalid"])
+    L = px.L
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(c["keys"]))
+    G = gb.num_groups
+    assert np.array_equal(gb.unique_keys().to_numpy()[0], c["uniq"])
+    B = px.Column.from_numpy(c["vb"], valid, offset=offset)
+    a, y = gb.agg(B, [L.AGG_ALL, L.AGG_ANY])
+    (av, aok), (yv, yok) = a.to_numpy(), y.to_numpy()
+    assert a.dtype == L.BOOL and a.length == G
+    assert np.array_equal(aok, c["ok"]) and np.array_equal(yok, c["ok"])
+    assert np.array_equal(av[c["ok"]], c["all"][c["ok"]]) and np.array_equal(yv[c["ok"]], c["any"][c["ok"]])
+    assert a.null_count == int((~c["ok"]).sum())
+    F = px.Column.from_numpy(c["vf"], valid, offset=offset)
+    I = px.Column.from_numpy(c["vi"], valid, offset=offset)
+    # count_distinct together with standard kinds of the same request (one call, the standard kinds share one grouped pass)
+    cd, mn, mx = gb.agg(F, [L.AGG_COUNT_DISTINCT, L.AGG_MIN, L.AGG_MAX])
+    assert cd.dtype == L.INT64 and np.array_equal(cd.to_numpy()[0], c["cd_f"])
+    assert np.array_equal(gb.agg(I, [L.AGG_COUNT_DISTINCT])[0].to_numpy()[0], c["cd_i"])
+    (mnv, mnok), (mxv, _) = mn.to_numpy(), mx.to_numpy()
+    okm = c["ok_mm"]
+    assert (mnok is None and okm.all()) or np.array_equal(mnok, okm)
+    # bit-exact including the sign of tied zeros: a group WITH nulls keeps the LAST of tied maxima, one without the first
+    assert np.array_equal(mnv.view(np.uint64)[okm & ~np.isnan(c["min_f"])], c["min_f"].view(np.uint64)[okm & ~np.isnan(c["min_f"])])
+    assert np.array_equal(mxv.view(np.uint64)[okm & ~np.isnan(c["max_f"])], c["max_f"].view(np.uint64)[okm & ~np.isnan(c["max_f"])])
+    assert np.array_equal(np.isnan(mnv[okm]), np.isnan(c["min_f"][okm]))
+
+
+def test_groupby_extra_api_errors_large(px):
+    L = px.L
+    df = px.api.DataFrame({"k": np.array([1, 1, 3, 1, 3, 8]), "b": np.array([True, True, False, True, True, True]),
+                           "v": np.array([1.0, 1.0, 2.0, 3.0, 2.0, 7.0])})
+    g = df.group_by("k")
+    assert list(g.all("b").values()) == [True, False, True] and list(g.any("b").values()) == [True, True, True]
+    assert list(g.count_distinct("v").values()) == [2, 1, 1]
+    mm = g.min_max("v")
+    assert mm.names == ["min", "max"] and list(mm["min"].values()) == [1.0, 2.0, 7.0] and list(mm["max"].values()) == [3.0, 2.0, 7.0]
+    mm2 = g.min_max(["v"])
+    assert mm2.names == ["v_min", "v_max"]
+    with pytest.raises(RuntimeError, match="all / any need PDX_BOOL"):
+        g.all("v")
+    with pytest.raises(RuntimeError, match="boolean values support all / any only"):
+        g.sum("b")
+    # large: hash-path keys, 2e6 rows, values with few distinct levels and nulls
+    n = 2_000_003
+    keys = orc.synth_keys(0, n, 40_000) * 7919 - 5
+    rng = np.random.default_rng(9)
+    vf = np.round(orc.synth_vals(0, n, 4) * 6) / 3.0
+    vb = orc.synth_vals(0, n, 5) > 0.0005
+    valid = rng.random(n) > 0.1
+    ids, uniq, _, _ = orc.group_ids(keys)
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys))
+    cd, = gb.agg(px.Column.from_numpy(vf, valid), [L.AGG_COUNT_DISTINCT])
+    assert np.array_equal(cd.to_numpy()[0], orc.groupby_count_distinct(ids, len(uniq), vf, valid))
+    a, y = gb.agg(px.Column.from_numpy(vb, valid), [L.AGG_ALL, L.AGG_ANY])
+    ea, ey, eok = orc.groupby_all_any(ids, len(uniq), vb, valid)
+    (av, aok), (yv, _) = a.to_numpy(), y.to_numpy()
+    assert np.array_equal(aok, eok) and np.array_equal(av[eok], ea[eok]) and np.array_equal(yv[eok], ey[eok])
+
+
+def test_nullable_max_zero_tie_rule(px):
+    """max of tied zeros: FIRST without nulls, LAST with at least one null (Arrow 25.0.0; minmax.hpp) -- whole array, grouped
+    (classic nullable reducer and the fused last-digit replay), and a group without nulls inside a nullable column."""
+    L = px.L
+    for vals, valid, emax, emin in (([-0.0, 0.0, -5.0], None, -0.0, -5.0), ([-0.0, 0.0, -5.0], [True, True, False], 0.0, -0.0),
+                                    ([0.0, -0.0, -5.0], [True, True, False], -0.0, 0.0), ([0.0, -5.0, -0.0], [True, False, True], -0.0, 0.0)):
+        col = px.Column.from_numpy(np.array(vals), None if valid is None else np.array(valid))
+        mx, _ = px.K.aggregate(L.AGG_MAX, col)
+        mn, _ = px.K.aggregate(L.AGG_MIN, col)
+        assert np.signbit(mx) == np.signbit(emax) and mx == emax and np.signbit(mn) == np.signbit(emin), (vals, valid, mx, mn)
+    # grouped, sizes that take the classic path and (>= 2^22 rows, >= 2^10 slots) the fused last digit
+    for n, nk in ((50_000, 300), (4_500_000, 3000)):
+        rng = np.random.default_rng(n)
+        keys = orc.synth_keys(0, n, nk)
+        v = np.where(rng.random(n) < 0.5, -0.0, 0.0) - (rng.random(n) < 0.3) * 2.5
+        valid = rng.random(n) > 0.0005  # most groups have no null at all, some have one or two
+        ids, uniq, _, _ = orc.group_ids(keys)
+        emx, eok = orc.groupby_agg(orc.AGG_MAX, ids, len(uniq), v, valid)
+        emn, _ = orc.groupby_agg(orc.AGG_MIN, ids, len(uniq), v, valid)
+        gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys))
+        mx, mn = gb.agg(px.Column.from_numpy(v, valid), [L.AGG_MAX, L.AGG_MIN])
+        assert np.array_equal(mx.to_numpy()[0].view(np.uint64)[eok], emx.view(np.uint64)[eok]), n
+        assert np.array_equal(mn.to_numpy()[0].view(np.uint64)[eok], emn.view(np.uint64)[eok]), n
+
+
+# ------------------------------------------------------------------ frame-level aggregates (src/ndframe.h:329-335, src/ndframe.cpp:119-220)
+@pytest.mark.parametrize("name", G2.cases("frame_aggs"))
+def test_frame_aggs_golden(px, name):
+    c = G2.case(name)
+    k = int(c["ncols"])
+    df = px.api.DataFrame({f"c{j}": px.Column.from_numpy(c[f"c{j}"], _valid_or_none(c[f"v{j}"])) for j in range(k)})
+    assert df.count().value == int(c["count"])
+    for j, key in enumerate(("sum", "mean", "min", "max")):
+        got = getattr(df, key)().value
+        if c["isnull"][j]:
+            assert got is None, (name, key)
+        elif c[key].dtype == np.float64:
+            assert np.float64(got).view(np.uint64) == np.float64(c[key]).view(np.uint64), (name, key, got, c[key])
+        else:
+            assert got == int(c[key]), (name, key)

@@ -126,3 +126,40 @@ def test_arrow_seq_harness_matches_oracle_per_key():
         assert np.array_equal(r["count"][oa], c[oo])
         if expect_same_order:
             assert np.array_equal(r["keys"], uk)
+
+
+# ------------------------------------------------------------------ group-by all / any / count_distinct / min_max (src/dataframe.cpp:1520-1526, 1602-1696)
+@pytest.mark.parametrize("name", G2.cases("groupby_extra"))
+@pytest.mark.parametrize("offset", [0, 3])
+def test_groupby_extra(name, offset):
+    c = G2.case(name)
+    valid = None if c["vvalid"].all() else c["vvalid"]
+    ids, uniq, _, _ = orc.group_ids(c["keys"])
+    assert np.array_equal(ids, c["ids"]) and np.array_equal(uniq, c["uniq"])
+    G = len(uniq)
+    a, y, ok = orc.groupby_all_any(ids, G, c["vb"], valid, offset)
+    assert np.array_equal(ok, c["ok"]) and np.array_equal(a[ok], c["all"][ok]) and np.array_equal(y[ok], c["any"][ok])
+    assert np.array_equal(orc.groupby_count_distinct(ids, G, c["vf"], valid, offset), c["cd_f"])
+    assert np.array_equal(orc.groupby_count_distinct(ids, G, c["vi"], valid, offset), c["cd_i"])
+    mn, mx, okm = orc.groupby_min_max(ids, G, c["vf"], valid)
+    assert np.array_equal(okm, c["ok_mm"])
+    assert_f64_bits(mn, c["min_f"], valid=c["ok_mm"], what=f"{name} min")
+    assert_f64_bits(mx, c["max_f"], valid=c["ok_mm"], what=f"{name} max")
+
+
+# ------------------------------------------------------------------ frame-level aggregates (src/ndframe.h:329-335, src/ndframe.cpp:119-220)
+@pytest.mark.parametrize("name", G2.cases("frame_aggs"))
+def test_frame_aggs(name):
+    c = G2.case(name)
+    k = int(c["ncols"])
+    cols = [c[f"c{j}"] for j in range(k)]
+    valids = [None if c[f"v{j}"].all() else c[f"v{j}"] for j in range(k)]
+    assert orc.frame_agg(orc.AGG_COUNT, cols, valids) == int(c["count"])
+    for j, (kind, key) in enumerate(((orc.AGG_SUM, "sum"), (orc.AGG_MEAN, "mean"), (orc.AGG_MIN, "min"), (orc.AGG_MAX, "max"))):
+        got = orc.frame_agg(kind, cols, valids)
+        if c["isnull"][j]:
+            assert got is None, (name, key)
+        elif c[key].dtype == np.float64:
+            assert np.float64(got).view(np.uint64) == np.float64(c[key]).view(np.uint64), (name, key, got, c[key])
+        else:
+            assert got == int(c[key]), (name, key)
