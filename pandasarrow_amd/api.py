@@ -403,6 +403,36 @@ class DataFrame:
         outs = K.take(cols, idx.col)
         return self._like(outs[: len(self.cols)], index=outs[-1] if self.index is not None else None)
 
+    # ---- Arrow IPC (src/dataframe.cpp:726-791)
+    def toBinary(self, columns=None, index=None, metadata=None) -> bytes:
+        """DataFrame::toBinary: one IPC stream (schema + ONE record batch + custom metadata).  Like the reference, every column
+        is written whatever `columns` says (it computes the list and then serialises m_array whole); with `index` the index is
+        cast to int64 and appended as the LAST column under that name."""
+        cols, names = list(self.cols), list(self.names)
+        if index is not None:
+            ix = _frame_index(self)
+            cols.append(Column(L.INT64, ix.length, ix.values, ix.validity, ix.offset, ix.null_count))
+            names.append(index)
+        return K.ipc_write(cols, names, metadata)
+
+    @staticmethod
+    def readBinary(blob, index=None):
+        """DataFrame::readBinary: exactly one record batch; the body goes to the device in ONE copy and the columns alias it.
+        `index`: that column is taken out of the frame and becomes the index (int64 -> timestamp[ns], as the reference casts)."""
+        frame = K.IpcFrame(blob)
+        pairs = frame.load()
+        idx = None
+        if index is not None:
+            hit = [i for i, (nm, _) in enumerate(pairs) if nm == index]
+            if hit:
+                _, c = pairs.pop(hit[0])
+                idx = Column(L.TIMESTAMP_NS, c.length, c.values, c.validity, c.offset, c.null_count) if c.dtype == L.INT64 else c
+            # (absent: the reference logs `no field "<index>" exist` and carries on without an index)
+        df = DataFrame.__new__(DataFrame)
+        df.names, df.cols, df.index = [nm for nm, _ in pairs], [c for _, c in pairs], idx
+        df.metadata = frame.metadata
+        return df
+
     # ---- group_by / resample (src/dataframe.cpp:1227-1262)
     def group_by(self, key):
         return GroupBy(key, self)

@@ -37,8 +37,12 @@ inline void ThrowOnFailure(int status) {
 struct DeviceBuffer {
   void* ptr = nullptr;
   size_t bytes = 0;
+  std::shared_ptr<void> keep;  // set: `ptr` aliases memory owned by `keep` (an IPC frame's device copy) and is not freed here
   explicit DeviceBuffer(size_t n) : bytes(n) { ThrowOnFailure(pdx_malloc(&ptr, n ? n : 1)); }
-  ~DeviceBuffer() { pdx_free(ptr); }
+  DeviceBuffer(const void* borrowed, size_t n, std::shared_ptr<void> owner) : ptr(const_cast<void*>(borrowed)), bytes(n), keep(std::move(owner)) {}
+  ~DeviceBuffer() {
+    if (!keep) pdx_free(ptr);
+  }
   DeviceBuffer(const DeviceBuffer&) = delete;
   DeviceBuffer& operator=(const DeviceBuffer&) = delete;
 };
@@ -571,6 +575,66 @@ class DataFrame {
     if (idx.dtype() == PDX_BOOL) throw std::runtime_error("take indices must be integers, not boolean");
     auto outs = Series::run_take(columns_with_index(), idx.m_array);
     return rebuild(outs);
+  }
+
+  // ---- Arrow IPC (src/dataframe.cpp:726-791).  toBinary: schema + ONE record batch + custom metadata; every column is written
+  // (the reference computes `columns` and then serialises m_array whole); `index`: the index as a last int64 column of that name.
+  std::vector<uint8_t> toBinary(const std::optional<std::string>& index = std::nullopt,
+                                const std::map<std::string, std::string>& metadata = {}) const {
+    std::vector<Array> cols = m_columns;
+    std::vector<std::string> names = m_names;
+    if (index) {
+      Array ix;
+      if (m_index) ix = *m_index;
+      else {
+        std::vector<int64_t> r((size_t)num_rows());
+        for (size_t i = 0; i < r.size(); ++i) r[i] = (int64_t)i;
+        ix = Array::Make(r);
+      }
+      ix.dtype = PDX_INT64;
+      cols.push_back(ix);
+      names.push_back(*index);
+    }
+    std::vector<pdx_column> in;
+    std::vector<const char*> cn, kv;
+    for (auto& c : cols) in.push_back(c.c());
+    for (auto& n : names) cn.push_back(n.c_str());
+    for (auto& m : metadata) { kv.push_back(m.first.c_str()); kv.push_back(m.second.c_str()); }
+    void* blob = nullptr;
+    size_t size = 0;
+    ThrowOnFailure(pdx_ipc_write(in.data(), cn.data(), (int)in.size(), kv.data(), (int)kv.size() / 2, 0, nullptr, &blob, &size));
+    std::vector<uint8_t> out(static_cast<uint8_t*>(blob), static_cast<uint8_t*>(blob) + size);
+    pdx_ipc_free_blob(blob);
+    return out;
+  }
+  // readBinary: exactly one record batch; ONE host->device copy of its body, the columns alias it (kept alive by their buffers)
+  static DataFrame readBinary(const uint8_t* blob, size_t size, const std::optional<std::string>& index = std::nullopt) {
+    pdx_ipc_frame* raw = nullptr;
+    ThrowOnFailure(pdx_ipc_open(blob, size, &raw));
+    std::shared_ptr<void> frame(raw, [](void* p) { pdx_ipc_destroy(static_cast<pdx_ipc_frame*>(p)); });
+    ThrowOnFailure(pdx_ipc_load(raw, nullptr));
+    std::vector<std::string> names;
+    std::vector<Array> cols;
+    std::optional<Array> idx;
+    for (int i = 0; i < pdx_ipc_num_columns(raw); ++i) {
+      pdx_column c{};
+      ThrowOnFailure(pdx_ipc_column(raw, i, &c));
+      Array a;
+      a.dtype = c.dtype;
+      a.length = c.length;
+      a.null_count = c.null_count;
+      a.values = std::make_shared<DeviceBuffer>(c.values, (size_t)c.length * 8, frame);
+      if (c.validity) a.validity = std::make_shared<DeviceBuffer>(c.validity, bitmap_bytes(c.length), frame);
+      const std::string nm = pdx_ipc_column_name(raw, i);
+      if (index && nm == *index && !idx) {
+        if (a.dtype == PDX_INT64) a.dtype = PDX_TIMESTAMP_NS;  // Cast(int64 -> timestamp[ns]) of the index column
+        idx = a;
+      } else {
+        names.push_back(nm);
+        cols.push_back(a);
+      }
+    }
+    return DataFrame(names, cols, idx);
   }
 
   inline GroupBy group_by(const std::string& key) const;

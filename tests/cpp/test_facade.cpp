@@ -165,6 +165,16 @@ static void test_groupby() {
   REQUIRE(f3.min().as<double>() == 1.0);
   REQUIRE(f3.max().as<double>() == 6.0);
   REQUIRE(f3.count().as<long>() == 4);
+  // Arrow IPC round trip (src/dataframe.cpp:726-791): toBinary with the index as a last int64 column, readBinary pulls it back out
+  DataFrame f4({"x", "y"}, {Array::Make(std::vector<double>{1.5, 2.5, 3.5}), Array::Make(std::vector<long>{7, 8, 9})}, date_range(946684800000000000LL, 3));
+  auto blob = f4.toBinary(std::string("__index__"), {{"origin", "facade"}});
+  auto f5 = DataFrame::readBinary(blob.data(), blob.size(), std::string("__index__"));
+  REQUIRE(f5.m_names == (std::vector<std::string>{"x", "y"}));
+  REQUIRE((f5["x"].values<double>() == std::vector<double>{1.5, 2.5, 3.5}));
+  REQUIRE((f5["y"].values<long>() == std::vector<long>{7, 8, 9}));
+  REQUIRE(f5.m_index && f5.m_index->dtype == PDX_TIMESTAMP_NS);
+  REQUIRE((f5.m_index->values_as<int64_t>() == f4.m_index->values_as<int64_t>()));
+  REQUIRE((f5["x"] + f5["y"]).sum().as<double>() == 31.5);
 }
 
 // tests/series_resample_test.cpp:12-85
