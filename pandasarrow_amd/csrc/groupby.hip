@@ -2163,6 +2163,9 @@ __device__ __forceinline__ void flr_counter_push(double (*csum)[1 << kFlrBits], 
   csum[cur][lane] = v;
   root = cur > root ? cur : root;
 }
+}  // namespace pdx
+#include "flr_wave.hpp"
+namespace pdx {
 // Segmented "run of valid rows" state of a chunk of staged rows, packed in 32 bits, for the nullable leaf phase: bits 0-11 valid rows at
 // the chunk's end since its last break, bit 12 the chunk holds a break (a null row or a group boundary), bits 13-14 the kind of its
 // last break (1 null, 2 group boundary), bits 16-22 group boundaries in the chunk.  Associative, earlier operand first.
@@ -3534,7 +3537,33 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   else                                                                                                                                           \
     hipLaunchKernelGGL((k_flr_reduce<TT, DD>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const TT*>(vs), run_start, nruns, \
                        low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, vvalid ? 1 : 0, sqmean)
-          if (is_f) {
+          // one WAVE per run (flr_wave.hpp) for everything but the dense sum / mean / count: nullable values, min / max and int64 sums
+          // were a per-lane replay by wave 0 alone in the workgroup-per-run kernel (5 % nulls: 10.7 -> 4.9 ms per 1e9 rows); the dense
+          // fast path of k_flr_reduce (thread per leaf) is still ahead of the wave form (3.0 vs 3.3 ms).  PDX_FLR_WAVE=1 / 0 force either.
+          const char* fw_env = getenv("PDX_FLR_WAVE");
+          const bool wave_form = !nullpw && (fw_env ? fw_env[0] != '0' : !dense);
+          if (wave_form) {
+            const int wgrid = (int)std::min<int64_t>(nruns, (int64_t)kCUs * 12 * 4);
+            const bool pw_only = pw && !mm && !is;
+            // counter levels: a group cannot outgrow its run, and a leaf holds 16 rows unless nulls cut it short
+            const uint64_t max_leaves = vvalid ? (uint64_t)hmax + 1 : (uint64_t)hmax / 16 + 2;
+            const int fw_levels = std::max(2, ilog2(max_leaves + 1));  // 2^levels > leaves: level index <= levels - 1
+            const size_t fw_lds = (size_t)fw_lds_bytes(vvalid != nullptr, fw_levels);
+#define FW_LAUNCH(TT, KK, KPTR, NN, PP)                                                                                                  \
+  hipLaunchKernelGGL((k_flr_wave<TT, KK, NN, PP>), dim3(wgrid), dim3(64), fw_lds, st, KPTR, reinterpret_cast<const TT*>(vs), n, run_start, nruns, low_bits, \
+                     gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, sqmean, fw_levels)
+#define FW_DISPATCH(TT)                                                                        \
+  if (keys8) {                                                                                 \
+    if (vvalid) { if (pw_only) FW_LAUNCH(TT, uint8_t, keys8, true, true); else FW_LAUNCH(TT, uint8_t, keys8, true, false); }          \
+    else { if (pw_only) FW_LAUNCH(TT, uint8_t, keys8, false, true); else FW_LAUNCH(TT, uint8_t, keys8, false, false); }              \
+  } else {                                                                                     \
+    if (vvalid) { if (pw_only) FW_LAUNCH(TT, uint32_t, keys_sorted, true, true); else FW_LAUNCH(TT, uint32_t, keys_sorted, true, false); } \
+    else { if (pw_only) FW_LAUNCH(TT, uint32_t, keys_sorted, false, true); else FW_LAUNCH(TT, uint32_t, keys_sorted, false, false); } \
+  }
+            if (is_f) { FW_DISPATCH(double) } else { FW_DISPATCH(long long) }
+#undef FW_DISPATCH
+#undef FW_LAUNCH
+          } else if (is_f) {
             if (dense) { FLR_LAUNCH(double, true); }
             else { FLR_LAUNCH(double, false); }
           } else {
