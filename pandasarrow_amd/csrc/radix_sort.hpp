@@ -174,11 +174,18 @@ struct IotaSrc {
 // FLAGS: the top bit of a key (of K and of KO alike) is the row's null flag, carried from type to type; in a FLAGS pass over
 // 4-byte keys with iota.valid set, the flag is not in the key yet: it is read from that validity bitmap here (one 64-bit window per
 // wave step, loaded by lane `step` and broadcast), which saves the separate pass that used to OR it into the keys.
-template <int BITS, typename V, bool WRITE_KEYS, bool IOTA = false, typename K = uint32_t, typename KO = uint32_t, bool FLAGS = false>
+// EMIT_ROWS (the hash build's partition of the keys by their bucket byte: K = uint8, BITS = 8, shift = 0): beside the payload, every
+// row's ORIGINAL index (| bit 31 when its validity bit in iota.valid is clear) is written to rows_out at the same position -- the
+// row-id partition that used to be a second scatter kernel with the same ranking and the same digit reads.  The local row (12 bits)
+// and the null flag ride in the unused upper bits of the staged digit word, so the kernel needs no extra LDS.
+template <int BITS, typename V, bool WRITE_KEYS, bool IOTA = false, typename K = uint32_t, typename KO = uint32_t, bool FLAGS = false,
+          bool EMIT_ROWS = false>
 __global__ void __launch_bounds__(kScatBlock) k_radix_scatter(const K* __restrict__ keys_in, const V* __restrict__ vals_in,
                                                               KO* __restrict__ keys_out, V* __restrict__ vals_out, int64_t n,
                                                               int shift, const uint32_t* __restrict__ offsets /* [tiles][R] */,
-                                                              int xcd_swizzle, IotaSrc iota = IotaSrc{nullptr, 0}, int drop = 0) {
+                                                              int xcd_swizzle, IotaSrc iota = IotaSrc{nullptr, 0}, int drop = 0,
+                                                              uint32_t* __restrict__ rows_out = nullptr) {
+  static_assert(!EMIT_ROWS || (sizeof(K) == 1 && BITS <= 8 && !WRITE_KEYS && !IOTA && !FLAGS), "EMIT_ROWS: byte digits, payload + row ids only");
   constexpr int R = 1 << BITS;
   constexpr int DPT = (R + kScatBlock - 1) / kScatBlock;
   __shared__ uint32_t cnt[kScatWaves][R];   // per-wave digit counters, later per-(wave,digit) local base
@@ -274,6 +281,14 @@ __global__ void __launch_bounds__(kScatBlock) k_radix_scatter(const K* __restric
       }
     }
   }
+  if constexpr (EMIT_ROWS) {
+#pragma unroll
+    for (int s = 0; s < kScatItems; ++s) {
+      const int r = wave * (64 * kScatItems) + s * 64 + lane;
+      const bool isnull = iota.valid && r < tile_rows && !bit_get(iota.valid, iota.off + tile_base + r);
+      key[s] = (key[s] & 0xFFu) | ((uint32_t)r << 8) | (isnull ? 0x80000000u : 0u);
+    }
+  }
 #pragma unroll
   for (int s = 0; s < kScatItems; ++s) {
     int r = wave * (64 * kScatItems) + s * 64 + lane;
@@ -339,6 +354,7 @@ __global__ void __launch_bounds__(kScatBlock) k_radix_scatter(const K* __restric
       }
     }
     vals_out[g] = svals[p];
+    if constexpr (EMIT_ROWS) rows_out[g] = (uint32_t)(tile_base + ((k >> 8) & 0xFFFu)) | (k & 0x80000000u);
   }
 }
 
@@ -456,6 +472,18 @@ __global__ void __launch_bounds__(256) k_level_starts(const K* __restrict__ keys
     __syncthreads();
   }
   if (blockIdx.x == 0 && tid == 0) out[(int64_t)R * ncombos] = (uint32_t)n;
+}
+// the hash build's partition: 8-byte payload (the keys) + the rows' original indexes (| null flag) in one launch
+template <int BITS>
+int radix_scatter_with_rows(const uint8_t* digits, const uint64_t* vin, uint64_t* vout, uint32_t* rows_out, int64_t n, const uint32_t* hist,
+                            const uint8_t* valid, int64_t valid_off, hipStream_t st) {
+  static_assert(kSortTile <= 4096, "the local row rides in 12 bits");
+  int64_t ntiles = ceil_div(n, kSortTile);
+  PDX_PROFILE("radix_scatter", st);
+  hipLaunchKernelGGL((k_radix_scatter<BITS, uint64_t, false, false, uint8_t, uint32_t, false, true>), dim3((unsigned)ntiles), dim3(kScatBlock), 0, st,
+                     digits, vin, (uint32_t*)nullptr, vout, n, 0, hist, sort_xcd_swizzle(), IotaSrc{valid, valid_off}, 0, rows_out);
+  PDX_LAUNCH_CHECK();
+  return PDX_OK;
 }
 // payload = row index (| null flag): no payload input stream
 template <int BITS, typename K = uint32_t>
