@@ -1,0 +1,484 @@
+// gb_flr_reduce.hpp -- part of groupby.hip (textually included there, in its namespace context; split by stage, kernels unchanged):
+// fused last digit (workgroup per run) -- the wave-per-run form lives in flr_wave.hpp.
+#pragma once
+
+// ---------------------------------------------------------------- fused last digit: the final sort pass and the reduce in one kernel.
+// After the LSD passes over the low L = B - 6 slot bits, the rows of one "run" (equal low bits) hold at most 64 groups -- the
+// values of the top 6 bits -- interleaved in row order.  Instead of one more 24 B/row scatter pass followed by an 8 B/row reduce,
+// one workgroup per run ranks every 4096-row tile stably by the top digit in LDS (the scatter kernel's ballot ranking) and wave 0
+// replays Arrow's leaf / binary-counter recurrence LITERALLY with one lane per group (state in registers + one LDS column per
+// lane); the other waves already hold the next tile's loads.  Reads 12 B/row once.  Value nulls are the key's bit 31: a null row
+// closes the open leaf, exactly Arrow's restart rule -- no separate nullable kernel on this path.
+constexpr int kFlrBits = 6;
+constexpr int kFlrLevels = 20;  // a group lies inside one run, a run is <= 2^19 rows (checked by the host), and with nulls a leaf can
+                                // be a single row: <= 2^19 leaves
+constexpr int kFlrItems = 10;   // rows per thread and tile: 3072-row tiles (measured best: 4096 -> 5.6 ms, 3072 -> 4.2 ms, 2048 -> 4.5 ms per 1e9 rows)
+constexpr int kFlrTile = kSortBlock * kFlrItems;
+__global__ void k_run_starts(const uint32_t* __restrict__ sorted_keys, int64_t n, int low_bits, int64_t nruns, uint32_t* __restrict__ run_start,
+                             unsigned int* __restrict__ max_len) {
+  const uint32_t lmask = (1u << low_bits) - 1u;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= nruns; r += stride) {
+    int64_t lo = 0, hi = n;
+    if (r < nruns) {
+      while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)(sorted_keys[mid] & lmask) < r) lo = mid + 1;
+        else hi = mid;
+      }
+    } else {
+      lo = n;
+    }
+    run_start[r] = (uint32_t)lo;
+  }
+  (void)max_len;
+}
+__global__ void k_run_max_len(const uint32_t* __restrict__ run_start, int64_t nruns, unsigned int* __restrict__ max_len) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned int m = 0;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nruns; r += stride) {
+    unsigned int len = run_start[r + 1] - run_start[r];
+    m = len > m ? len : m;
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    unsigned int o = __shfl_xor(m, d, 64);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(max_len, m);
+}
+// (x - mean)^2 with x86 NaN operand propagation (k_seg_sqdev)
+__device__ __forceinline__ double flr_sqdev(double v, double mu) {
+  const double x = v - mu;
+  return v != v ? v : (mu != mu ? mu : x * x);
+}
+// Arrow's binary counter, one LDS column per lane: push a finished leaf sum
+__device__ __forceinline__ void flr_counter_push(double (*csum)[1 << kFlrBits], int lane, unsigned long long& cmask, int& root, double leaf) {
+  int cur = 0;
+  unsigned long long m = 1;
+  double v = csum[0][lane] + leaf;
+  cmask ^= m;
+  while ((cmask & m) == 0) {
+    csum[cur][lane] = 0.0;
+    ++cur;
+    m <<= 1;
+    v = csum[cur][lane] + v;
+    cmask ^= m;
+  }
+  csum[cur][lane] = v;
+  root = cur > root ? cur : root;
+}
+}  // namespace pdx
+#include "flr_wave.hpp"
+namespace pdx {
+// Segmented "run of valid rows" state of a chunk of staged rows, packed in 32 bits, for the nullable leaf phase: bits 0-11 valid rows at
+// the chunk's end since its last break, bit 12 the chunk holds a break (a null row or a group boundary), bits 13-14 the kind of its
+// last break (1 null, 2 group boundary), bits 16-22 group boundaries in the chunk.  Associative, earlier operand first.
+struct RunStateOp {
+  template <typename U>
+  __device__ static U identity() { return U(0); }
+  __device__ uint32_t operator()(uint32_t a, uint32_t b) const {
+    const uint32_t nh = ((a >> 16) + (b >> 16)) << 16;
+    if (b & 0x1000u) return (b & 0xFFFFu) | nh;
+    return (((a & 0xFFFu) + (b & 0xFFFu)) & 0xFFFu) | (a & 0x7000u) | nh;
+  }
+};
+// KT: uint32 slots (top digit at bit low_bits, bit 31 = the value's null flag) or, after a narrowing sort, the top digit alone in a byte
+// NULL_PW (host: nullable values, sum / mean / count only): leaves restart at every null, so they are data dependent; a segmented
+// scan over the staged rows finds every leaf's first row, ONE THREAD PER LEAF sums it (<= 16 rows) and leaves the sum and a marker
+// byte in place, then one lane per group walks its leaves in order for the counter pushes (instead of one lane per group adding
+// up all of its rows one by one).  Bit-exact, but not faster yet (11.3 vs 10.7 ms per 1e9 rows at 5 % nulls): opt-in.
+template <typename T, bool DENSE_PW, typename KT = uint32_t, bool NULL_PW = false>
+__global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const KT* __restrict__ keys, const T* __restrict__ vals,
+                                                           const uint32_t* __restrict__ run_start, int64_t nruns, int low_bits,
+                                                           const uint32_t* __restrict__ gid_of_slot, SegOut out, uint8_t* __restrict__ ok,
+                                                           int want_pw, int want_mm, int want_is, int nullable,
+                                                           const double* __restrict__ sqdev_mean) {
+  // sqdev_mean != nullptr (second pass of variance): every value x of group g enters the sum as (x - sqdev_mean[g])^2, with the
+  // reference's x86 NaN propagation (see k_seg_sqdev)
+  constexpr int R = 1 << kFlrBits;
+  // staged rows of digit d start at dstart[d] + d: the digits' regions are ~64 rows = 512 B apart, so without the skew the 64
+  // lanes of the replay (one digit each) would hit the same LDS bank on every read (measured: 3x slower)
+  __shared__ T svals[kFlrTile + R];
+  __shared__ __attribute__((aligned(8))) uint8_t snull[kFlrTile + R];
+  __shared__ uint32_t cnt[kSortWaves][R];
+  __shared__ unsigned long long match[kSortWaves][R];  // match-any words of the ranking (wave_match_rank)
+  __shared__ uint32_t dstart[R + 1];
+  __shared__ double csum[kFlrLevels][R];
+  // dense sum/mean/count fast path (no nulls, no min/max/int sum): one THREAD per 16-value leaf, then one lane per group for the
+  // few counter pushes -- the open leaf of every group (rows so far + their sequential sum) lives in LDS between tiles
+  __shared__ int open_pos[R];
+  __shared__ double open_acc[R];
+  __shared__ double mu_s[R];
+  __shared__ int lp[R + 1];
+  __shared__ uint32_t run_smem[8];
+  double* leafsum = reinterpret_cast<double*>(snull);  // (the null flags are unused on this path: room for (tile + 64) / 8 leaf sums)
+  constexpr bool dense_pw = DENSE_PW;  // host: want_pw && !want_mm && !want_is && !nullable (a separate instantiation: fewer live registers)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  // Barriers per tile: after the ranking, after the prefixes, after the staging and (dense path) after the leaf sums.  The digit
+  // counters are re-zeroed right after the staging barrier, and wave 0's replay needs no closing barrier: the next tile's
+  // staging lies behind two barriers that wave 0 itself has to reach.
+  for (int d = tid; d < kSortWaves * R; d += kSortBlock) {
+    (&cnt[0][0])[d] = 0;
+    (&match[0][0])[d] = 0;
+  }
+  __syncthreads();
+  for (int64_t run = blockIdx.x; run < nruns; run += gridDim.x) {
+    const int64_t s = run_start[run], e = run_start[run + 1];
+    if (s == e) continue;
+    if (tid < R) {
+      open_pos[tid] = 0;
+      open_acc[tid] = 0.0;
+      mu_s[tid] = 0.0;
+    }
+    double mu = 0.0;
+    bool mu_known = false;
+    // per-group state (wave 0, lane = top digit)
+    double acc = 0.0;
+    int pos = 0, root = 0;
+    unsigned long long cmask = 0, isum = 0;
+    long long nvalid = 0, nrows = 0;
+    T vmn = T(0), vmx = T(0);
+    int zneg = -1;  // sign of the last zero-valued valid row (-1: none)
+    bool has = false;
+    if (wave == 0)
+      for (int l = 0; l < kFlrLevels; ++l) csum[l][lane] = 0.0;
+    uint32_t key[kFlrItems];
+    T val[kFlrItems];
+    auto load_tile = [&](int64_t t0) {
+      const int rows = (int)(e - t0 < kFlrTile ? e - t0 : kFlrTile);
+#pragma unroll
+      for (int q = 0; q < kFlrItems; ++q) {
+        const int r = wave * (64 * kFlrItems) + q * 64 + lane;
+        if (r < rows) {
+          key[q] = keys[t0 + r];
+          val[q] = vals[t0 + r];
+        } else {
+          key[q] = 0;
+          val[q] = T(0);
+        }
+      }
+    };
+    load_tile(s);
+    for (int64_t t0 = s; t0 < e; t0 += kFlrTile) {
+      const int rows = (int)(e - t0 < kFlrTile ? e - t0 : kFlrTile);
+      uint32_t rank[kFlrItems];
+#pragma unroll
+      for (int q = 0; q < kFlrItems; ++q) {
+        const int r = wave * (64 * kFlrItems) + q * 64 + lane;
+        const bool active = r < rows;
+        const uint32_t d = sizeof(KT) == 4 ? ((key[q] & kSortKeyMask) >> low_bits) & (R - 1) : key[q] & (R - 1);
+        rank[q] = wave_match_rank(match[wave], cnt[wave], d, active, lane, lt_mask);
+      }
+      __syncthreads();
+      if (tid < R) {  // exclusive prefix over waves per digit, then over digits (64 values: one wave)
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) {
+          const uint32_t c = cnt[w][tid];
+          cnt[w][tid] = tot;
+          tot += c;
+        }
+        const uint32_t inc = wave_inclusive_scan(tot, SumOp());
+        const uint32_t ex = inc - tot;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) cnt[w][tid] += ex;
+        dstart[tid] = ex;
+        if (tid == R - 1) dstart[R] = inc;
+        if (NULL_PW) {
+          snull[inc + tid] = 2;  // the unused slot behind this group's staged rows: a group boundary for the scan below
+          const int c = (int)tot;
+          if (sqdev_mean && c > 0 && !mu_known) {
+            mu = sqdev_mean[gid_of_slot[((uint32_t)lane << low_bits) | (uint32_t)run]];
+            mu_s[lane] = mu;
+            mu_known = true;
+          }
+          nrows += c;
+        }
+        if (dense_pw) {
+          // leaves touched by this tile, per group: the first one may continue the open leaf, the last one may stay open
+          const int c = (int)tot;
+          if (sqdev_mean && c > 0 && !mu_known) {
+            mu = sqdev_mean[gid_of_slot[((uint32_t)lane << low_bits) | (uint32_t)run]];
+            mu_s[lane] = mu;
+            mu_known = true;
+          }
+          const int nl = c > 0 ? (open_pos[lane] + c + 15) >> 4 : 0;
+          const int incl = wave_inclusive_scan(nl, SumOp());
+          lp[lane] = incl - nl;
+          if (lane == R - 1) lp[R] = incl;
+          nrows += c;
+          nvalid += c;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < kFlrItems; ++q) {
+        const int r = wave * (64 * kFlrItems) + q * 64 + lane;
+        if (r < rows) {
+          const uint32_t d = sizeof(KT) == 4 ? ((key[q] & kSortKeyMask) >> low_bits) & (R - 1) : key[q] & (R - 1);
+          const uint32_t p = cnt[wave][d] + rank[q] + d;
+          svals[p] = val[q];
+          if (nullable) snull[p] = (uint8_t)(key[q] >> (8 * (int)sizeof(KT) - 1));
+        }
+      }
+      if (t0 + kFlrTile < e) load_tile(t0 + kFlrTile);  // in flight while wave 0 replays this tile
+      __syncthreads();
+      for (int d = tid; d < kSortWaves * R; d += kSortBlock) (&cnt[0][0])[d] = 0;  // (free again: the bases were consumed above)
+      if (dense_pw) {
+        const int NL = lp[R];
+        for (int Lf = tid; Lf < NL; Lf += kSortBlock) {
+          int lo = 0, hi = R - 1;
+          while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (lp[mid] <= Lf) lo = mid;
+            else hi = mid - 1;
+          }
+          const int d = lo, j = Lf - lp[d];
+          const int p0 = open_pos[d], c = (int)(dstart[d + 1] - dstart[d]);
+          const int r0 = j == 0 ? 0 : 16 * j - p0;
+          int r1 = 16 * (j + 1) - p0;
+          r1 = r1 < c ? r1 : c;
+          double a = (j == 0 && p0 > 0) ? open_acc[d] : 0.0;
+          const T* v = svals + dstart[d] + d;
+          // all (<= 16) values of the leaf are requested before the first add: a loop that loads, waits and adds row by row pays
+          // one LDS round trip per row on the critical path of the tile
+          double xs[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int r = r0 + q < r1 ? r0 + q : r1 - 1;
+            xs[q] = seg_to_f64(v[r]);
+          }
+          if (sqdev_mean) {
+            const double m = mu_s[d];
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              if (r0 + q < r1) a += flr_sqdev(xs[q], m);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              if (r0 + q < r1) a += xs[q];
+          }
+          leafsum[Lf] = a;
+        }
+        __syncthreads();
+        if (wave == 0) {
+          const int c = (int)(dstart[lane + 1] - dstart[lane]);
+          if (c > 0) {
+            const int p0 = open_pos[lane];
+            const int nl = (p0 + c + 15) >> 4, nfull = (p0 + c) >> 4;
+            for (int j = 0; j < nfull; ++j) flr_counter_push(csum, lane, cmask, root, leafsum[lp[lane] + j]);
+            const int rem = (p0 + c) & 15;
+            open_pos[lane] = rem;
+            if (rem) open_acc[lane] = leafsum[lp[lane] + nl - 1];
+            pos = rem;
+            acc = rem ? leafsum[lp[lane] + nl - 1] : 0.0;
+          }
+        }
+      } else if (NULL_PW) {
+        constexpr int CH = (kFlrTile + R + kSortBlock - 1) / kSortBlock;  // staged slots per thread
+        const int L = rows + R;                                            // staged slots of this tile (rows + one boundary per group)
+        uint8_t f[CH];
+        uint32_t st = 0;
+        {
+          uint32_t tl = 0, hb = 0, lt = 0, nh = 0;
+#pragma unroll
+          for (int k = 0; k < CH; ++k) {
+            const int pp = tid * CH + k;
+            f[k] = pp < L ? snull[pp] : (uint8_t)2;
+            if (f[k]) {
+              tl = 0;
+              hb = 1;
+              lt = f[k];
+              nh += f[k] == 2;
+            } else {
+              ++tl;
+            }
+          }
+          st = tl | (hb << 12) | (lt << 13) | (nh << 16);
+        }
+        uint32_t tot_unused;
+        const uint32_t ex = block_exclusive_scan(st, RunStateOp(), &tot_unused, run_smem);  // (two barriers: every flag byte has been read)
+        {
+          // first rows of leaves in this thread's chunk (bit k of `starts`) and group boundaries (bit k of `holes`): registers only.
+          // The leaves themselves are summed in a second loop over the set bits, so a wave runs the 16-row loop once per leaf of its
+          // busiest lane and not once per chunk slot
+          int run_idx = (int)(ex & 0xFFFu);
+          const int d0 = (int)(ex >> 16);
+          int d = d0;
+          const int type0 = (ex & 0x1000u) ? (int)((ex >> 13) & 3u) : 2;  // nothing in front: slot 0 starts group 0
+          int q_cur = (type0 == 2 && d < R) ? open_pos[d] : 0;
+          uint32_t starts = 0, holes = 0;
+#pragma unroll
+          for (int k = 0; k < CH; ++k) {
+            if (f[k] == 0) {
+              if (run_idx == 0 || ((q_cur + run_idx) & 15) == 0) starts |= 1u << k;
+              ++run_idx;
+            } else {
+              run_idx = 0;
+              if (f[k] == 2) {
+                holes |= 1u << k;
+                ++d;
+                q_cur = d < R ? open_pos[d] : 0;
+              } else {
+                q_cur = 0;
+              }
+            }
+          }
+          while (starts) {
+            const int k = __ffs((int)starts) - 1;
+            starts &= starts - 1;
+            const int pp = tid * CH + k;
+            const int dd = d0 + __popc(holes & ((1u << k) - 1u));
+            // the open leaf of the previous tile continues only on the group's first staged row
+            const int q0 = (dd < R && pp == (int)dstart[dd] + dd) ? open_pos[dd] : 0;
+            double a = q0 > 0 ? open_acc[dd] : 0.0;
+            const double m = sqdev_mean ? mu_s[dd < R ? dd : 0] : 0.0;
+            // all 16 flag bytes and values are requested before any is looked at (a loop that stops at the first null would pay
+            // two dependent LDS round trips per row); slots behind the leaf's end may already hold another leaf's marker or sum:
+            // they are never used (the first nonzero flag inside the leaf's 16 - q0 slots is an untouched null or boundary)
+            uint8_t ffl[16];
+            double xs[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              const int pj = pp + j < L ? pp + j : L - 1;
+              ffl[j] = j == 0 ? (uint8_t)0 : (pp + j < L ? snull[pj] : (uint8_t)2);
+              xs[j] = seg_to_f64(svals[pj]);
+            }
+            int count = 16 - q0;
+            uint8_t term = 0;
+#pragma unroll
+            for (int j = 15; j >= 1; --j)
+              if (j < 16 - q0 && ffl[j]) {
+                count = j;
+                term = ffl[j];
+              }
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+              if (j < count) a += sqdev_mean ? flr_sqdev(xs[j], m) : xs[j];
+            const bool closed = q0 + count == 16 || term == 1;  // full, or cut by a null row
+            reinterpret_cast<double*>(svals)[pp] = a;
+            snull[pp] = (uint8_t)(0x80 | (closed ? 0x40 : 0) | (q0 + count - 1));
+          }
+        }
+        __syncthreads();
+        if (wave == 0) {
+          const int i0 = (int)dstart[lane] + lane, i1 = (int)dstart[lane + 1] + lane;
+          // Pass A: walk the group's leaves in row order; finished leaves are written back compactly over the slots already consumed
+          // (every step consumes at least one slot and emits at most one leaf).  The pushes come afterwards, as in the literal replay.
+          int nleaf = 0;
+          for (int ip = i0; ip < i1;) {
+            const uint8_t b = snull[ip];
+            if (b & 0x80) {
+              const int fill = (b & 15) + 1;
+              const int cnt_rows = fill - (ip == i0 ? pos : 0);
+              const double sum = reinterpret_cast<const double*>(svals)[ip];
+              nvalid += cnt_rows;
+              if (b & 0x40) {
+                reinterpret_cast<double*>(svals)[i0 + nleaf++] = sum;
+                pos = 0;
+              } else {
+                pos = fill;
+                acc = sum;
+              }
+              ip += cnt_rows;
+            } else {  // a null row: it closes the leaf left open by the previous tile (only possible on the group's first row)
+              if (pos > 0) {
+                reinterpret_cast<double*>(svals)[i0 + nleaf++] = acc;
+                pos = 0;
+              }
+              ++ip;
+            }
+          }
+          if (i1 > i0) {
+            open_pos[lane] = pos;
+            open_acc[lane] = acc;
+          }
+          for (int j = 0; j < nleaf; ++j) flr_counter_push(csum, lane, cmask, root, reinterpret_cast<const double*>(svals)[i0 + j]);
+        }
+      } else if (!dense_pw && wave == 0) {
+        const int i0 = (int)dstart[lane] + lane, i1 = (int)dstart[lane + 1] + lane;
+        nrows += i1 - i0;
+        if (sqdev_mean && i1 > i0 && !mu_known) {
+          mu = sqdev_mean[gid_of_slot[((uint32_t)lane << low_bits) | (uint32_t)run]];
+          mu_known = true;
+        }
+        // Pass A: leaf sums only.  Finished leaves are written back over the rows already consumed (a leaf has >= 1 row, so the
+        // write index never passes the read index).  The counter pushes are NOT done here: lanes finish leaves at different
+        // rows, so a push inside this loop would make the whole wave walk the (long) push path on nearly every row.
+        int nleaf = 0;
+        for (int ib = i0; ib < i1; ib += 8) {
+          T xb[8];
+          uint8_t nb[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = ib + u < i1 ? ib + u : i1 - 1;
+            xb[u] = svals[i];
+            nb[u] = nullable ? snull[i] : (uint8_t)0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (ib + u >= i1) break;
+            const T x = xb[u];
+            const bool isnull = nb[u] != 0;
+            bool close = false;
+            if (!isnull) {
+              ++nvalid;
+              if (want_pw) {
+                acc = (pos == 0 ? 0.0 : acc) + (sqdev_mean ? flr_sqdev(seg_to_f64(x), mu) : seg_to_f64(x));
+                close = ++pos == 16;
+              }
+              if (want_is) isum += (unsigned long long)x;
+              if (want_mm && x == x) {
+                if (!has) { vmn = vmx = x; has = true; }
+                else {
+                  if (x < vmn) vmn = x;
+                  if (x > vmx) vmx = x;
+                }
+                if constexpr (__is_same(T, double)) {
+                  if (x == 0.0) zneg = __double_as_longlong(x) < 0 ? 1 : 0;  // the LAST zero of the group (rows are replayed in order)
+                }
+              }
+            } else {
+              close = want_pw && pos > 0;  // a null row closes the open leaf
+            }
+            if (close) {
+              reinterpret_cast<double*>(svals)[i0 + nleaf++] = acc;
+              pos = 0;
+            }
+          }
+        }
+        // Pass B: Arrow's binary counter over this tile's finished leaves (a handful per lane)
+        for (int j = 0; j < nleaf; ++j) flr_counter_push(csum, lane, cmask, root, reinterpret_cast<const double*>(svals)[i0 + j]);
+      }
+    }
+    if (wave == 0 && nrows > 0) {
+      const uint32_t slot = ((uint32_t)lane << low_bits) | (uint32_t)run;
+      const uint32_t oi = gid_of_slot[slot];
+      if (want_pw) {
+        if (pos > 0) flr_counter_push(csum, lane, cmask, root, acc);
+        double total = 0.0;
+        if (nvalid > 0) {
+          double a = csum[0][lane];
+          for (int i = 1; i <= root; ++i) a = csum[i][lane] + a;
+          total = a;
+        }
+        if (out.sum_f) out.sum_f[oi] = total;
+        if (out.mean) out.mean[oi] = nvalid ? total / (double)nvalid : 0.0;
+      }
+      if (want_is && out.sum_i) out.sum_i[oi] = (long long)isum;
+      if (want_mm) {
+        T nanv = T(0);
+        if constexpr (__is_same(T, double)) nanv = __builtin_nan("");
+        if (out.vmin) static_cast<T*>(out.vmin)[oi] = has ? vmn : nanv;
+        if constexpr (__is_same(T, double)) {  // a group WITH nulls keeps the last of tied zero maxima (minmax.hpp)
+          if (has && zneg >= 0 && vmx == 0.0 && nvalid < nrows) vmx = zneg ? -0.0 : 0.0;
+        }
+        if (out.vmax) static_cast<T*>(out.vmax)[oi] = has ? vmx : nanv;
+      }
+      if (out.count) out.count[oi] = nvalid;
+      if (ok) ok[oi] = nvalid > 0;
+    }
+    __syncthreads();
+  }
+}

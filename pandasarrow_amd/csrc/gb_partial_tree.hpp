@@ -1,0 +1,387 @@
+// gb_partial_tree.hpp -- part of groupby.hip (textually included there, in its namespace context; split by stage, kernels unchanged):
+// exact multi-GPU fp64 sum: partial-tree exchange (pdx_grouped_*, pdx_replay_partials).
+#pragma once
+
+// =====================================================================================================================
+// Exact multi-GPU fp64 sum: partial-tree exchange (see include/pdx/abi.h).  Thread-per-group kernels: every group's values
+// are contiguous (grouped), a thread walks its group once.  Uncoalesced but short: c ~ rows/group/rank.
+// =====================================================================================================================
+namespace pdx {
+
+__device__ __forceinline__ int64_t aligned_block_level(int64_t s, int64_t kl) {
+  // largest j with s % 2^j == 0 and s + 2^j <= kl
+  int tz = s == 0 ? 62 : __ffsll((unsigned long long)s) - 1;
+  int64_t room = kl - s;
+  int lg = 63 - __clzll((unsigned long long)room);
+  return tz < lg ? tz : lg;
+}
+__device__ __forceinline__ int64_t partial_record_count(int64_t a, int64_t c) {
+  if (c <= 0) return 0;
+  int64_t b = a + c, kf = (a + 15) >> 4, kl = b >> 4;
+  if (kf > kl) return c;  // the whole range lies inside one leaf
+  int64_t cnt = (16 * kf - a) + (b - 16 * kl);
+  for (int64_t s = kf; s < kl;) {
+    s += (int64_t)1 << aligned_block_level(s, kl);
+    ++cnt;
+  }
+  return cnt;
+}
+
+__global__ void k_grouped_counts(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ gid_of_occ, int64_t G,
+                                 int64_t* __restrict__ out) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < G; k += stride)
+    out[gid_of_occ[k]] = (int64_t)seg_start[k + 1] - (int64_t)seg_start[k];
+}
+// emission order: record block j belongs to local group order[j] (order == nullptr: group j); occ_of_gid maps a local group id to
+// its position in slot order (where its values live)
+__global__ void k_occ_of_gid(const uint32_t* __restrict__ gid_of_occ, int64_t G, uint32_t* __restrict__ occ_of_gid) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < G; k += stride) occ_of_gid[gid_of_occ[k]] = (uint32_t)k;
+}
+__global__ void k_partial_plan(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ occ_of_gid, const int64_t* __restrict__ order,
+                               int64_t G, const int64_t* __restrict__ prefix, int64_t* __restrict__ rec_cnt) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < G; j += stride) {
+    const int64_t lg = order ? order[j] : j;
+    const uint32_t k = occ_of_gid[lg];
+    rec_cnt[j] = partial_record_count(prefix[lg], (int64_t)seg_start[k + 1] - (int64_t)seg_start[k]);
+  }
+}
+__global__ void __launch_bounds__(256) k_partial_fill(const double* __restrict__ vals, const uint32_t* __restrict__ seg_start,
+                                                      const uint32_t* __restrict__ occ_of_gid, const int64_t* __restrict__ order, int64_t G,
+                                                      const int64_t* __restrict__ prefix, const int64_t* __restrict__ gid_map,
+                                                      const int64_t* __restrict__ rec_off, int64_t* __restrict__ rec_key,
+                                                      double* __restrict__ rec_val, int wave_form_too) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < G; j += stride) {
+    const int64_t lg = order ? order[j] : j;
+    const uint32_t k = occ_of_gid[lg];
+    const double* v = vals + seg_start[k];
+    const int64_t c = (int64_t)seg_start[k + 1] - (int64_t)seg_start[k];
+    if (c <= 0) continue;
+    const int64_t a = prefix[lg], b = a + c;
+    const int64_t kf = (a + 15) >> 4, kl = b >> 4;
+    if (wave_form_too && (kf > kl || kl - kf <= 64)) continue;  // k_partial_fill_wave emits this group
+    const int64_t gkey = gid_map[lg] * 64;
+    int64_t pos = rec_off[j];
+    if (kf > kl) {
+      for (int64_t i = 0; i < c; ++i) { rec_key[pos] = gkey; rec_val[pos] = v[i]; ++pos; }
+      continue;
+    }
+    const int64_t h = 16 * kf - a;
+    for (int64_t i = 0; i < h; ++i) { rec_key[pos] = gkey; rec_val[pos] = v[i]; ++pos; }
+    for (int64_t sidx = kf; sidx < kl;) {
+      const int lvl = (int)aligned_block_level(sidx, kl);
+      const int64_t nleaf = (int64_t)1 << lvl;
+      // perfect tree over leaves [sidx, sidx + nleaf): replay the counter, all merges happen inside the block
+      PairwiseCounter cn;
+      cn.init();
+      const double* lv = v + (16 * sidx - a);
+      for (int64_t q = 0; q < nleaf; ++q) {
+        double acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc += lv[q * 16 + e];
+        cn.push(acc, 0);
+      }
+      rec_key[pos] = gkey + lvl + 1;
+      rec_val[pos] = cn.sum[lvl];
+      ++pos;
+      sidx += nleaf;
+    }
+    for (int64_t i = 16 * kl - a; i < c; ++i) { rec_key[pos] = gkey; rec_val[pos] = v[i]; ++pos; }
+  }
+}
+
+// Wave-per-group form of k_partial_fill for groups with at most 64 interior leaves (<= ~1050 rows; longer ones keep the thread form): lane l
+// sums interior leaf l (16 contiguous values), six shuffle steps build every aligned perfect subtree at once (t[k] at lane r = the tree
+// over leaves [r, r + 2^k), left + right as the counter merges them), the boundary-leaf fragments are copied by the lanes.  The thread
+// form walks each group with one thread and a 64-entry counter in scratch memory (2.2 ms per 5e8 rows).
+__global__ void __launch_bounds__(256) k_partial_fill_wave(const double* __restrict__ vals, const uint32_t* __restrict__ seg_start,
+                                                           const uint32_t* __restrict__ occ_of_gid, const int64_t* __restrict__ order, int64_t G,
+                                                           const int64_t* __restrict__ prefix, const int64_t* __restrict__ gid_map,
+                                                           const int64_t* __restrict__ rec_off, int64_t* __restrict__ rec_key,
+                                                           double* __restrict__ rec_val) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); j < G; j += nw) {
+    const int64_t lg = order ? order[j] : j;
+    const uint32_t k = occ_of_gid[lg];
+    const double* v = vals + seg_start[k];
+    const int64_t c = (int64_t)seg_start[k + 1] - (int64_t)seg_start[k];
+    if (c <= 0) continue;
+    const int64_t a = prefix[lg], b = a + c;
+    const int64_t kf = (a + 15) >> 4, kl = b >> 4;
+    const int64_t gkey = gid_map[lg] * 64;
+    const int64_t pos0 = rec_off[j];
+    if (kf > kl) {  // the whole range lies inside one leaf (< 31 rows): fragments only
+      for (int64_t i = lane; i < c; i += 64) {
+        rec_key[pos0 + i] = gkey;
+        rec_val[pos0 + i] = v[i];
+      }
+      continue;
+    }
+    const int nint = (int)(kl - kf);
+    if (kl - kf > 64) continue;  // long group: k_partial_fill
+    const int h = (int)(16 * kf - a);
+    if (lane < h) {
+      rec_key[pos0 + lane] = gkey;
+      rec_val[pos0 + lane] = v[lane];
+    }
+    double t[7];
+    t[0] = 0.0;
+    if (lane < nint) {
+      const double* lv = v + h + 16 * lane;
+      double acc = 0.0;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc += lv[e];
+      t[0] = acc;
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) t[q + 1] = t[q] + __shfl_down(t[q], 1 << q, 64);
+    int64_t pos = pos0 + h;
+    for (int64_t sidx = kf; sidx < kl;) {
+      const int lvl = (int)aligned_block_level(sidx, kl);
+      if (lane == (int)(sidx - kf)) {
+        double val = t[0];
+#pragma unroll
+        for (int q = 1; q < 7; ++q) val = lvl == q ? t[q] : val;
+        rec_key[pos] = gkey + lvl + 1;
+        rec_val[pos] = val;
+      }
+      ++pos;
+      sidx += (int64_t)1 << lvl;
+    }
+    const int ntail = (int)(b - 16 * kl);
+    if (lane < ntail) {
+      rec_key[pos + lane] = gkey;
+      rec_val[pos + lane] = v[16 * kl - a + lane];
+    }
+  }
+}
+
+__global__ void k_replay_keys(const int64_t* __restrict__ rec_key, int64_t m, int64_t gid_lo, int64_t n_own, uint32_t* __restrict__ slot,
+                              uint32_t* __restrict__ lvl, unsigned int* __restrict__ bad, int pack_shift) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+    int64_t key = rec_key[i];
+    int64_t g = (key >> 6) - gid_lo;
+    if (g < 0 || g >= n_own) {
+      atomicExch(bad, 1u);
+      g = 0;
+    }
+    // (pack_shift >= 0: the level rides above the slot bits of the sort key -- the sort only looks at the low bits)
+    slot[i] = pack_shift >= 0 ? (uint32_t)g | ((uint32_t)(key & 63) << pack_shift) : (uint32_t)g;
+    lvl[i] = (uint32_t)(key & 63);
+  }
+}
+// lvl_shift >= 0: `lvl` holds the sorted keys with the record's level packed above bit lvl_shift (one sort carries it along)
+__global__ void __launch_bounds__(256) k_replay(const uint32_t* __restrict__ seg_start, int64_t n_own, const double* __restrict__ val,
+                                                const uint32_t* __restrict__ lvl, double* __restrict__ out, unsigned int* __restrict__ bad,
+                                                int lvl_shift) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_own; g += stride) {
+    PairwiseCounter cn;
+    cn.init();
+    double acc = 0.0;
+    int fill = 0;
+    bool any = false;
+    for (int64_t i = seg_start[g]; i < (int64_t)seg_start[g + 1]; ++i) {
+      uint32_t l = lvl_shift >= 0 ? (lvl[i] & kSortKeyMask) >> lvl_shift : lvl[i];
+      any = true;
+      if (l == 0) {  // fragment value: extend the running 16-value leaf
+        acc += val[i];
+        if (++fill == 16) {
+          cn.push(acc, 0);
+          acc = 0.0;
+          fill = 0;
+        }
+      } else {
+        if (fill != 0) atomicExch(bad, 2u);  // a node must start on a leaf boundary
+        cn.push(val[i], (int)l - 1);
+      }
+    }
+    if (fill) cn.push(acc, 0);
+    if (!any) atomicExch(bad, 3u);
+    out[g] = any ? cn.finish() : 0.0;
+  }
+}
+__global__ void k_iota_u32(uint32_t* p, int64_t n) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = (uint32_t)i;
+}
+
+}  // namespace pdx
+
+struct pdx_grouped {
+  pdx_groupby* gb = nullptr;
+  int64_t n = 0, G = 0;
+  const double* vals_sorted = nullptr;
+  uint32_t* seg_start = nullptr;  // G + 1, slot (occ) order
+  uint32_t* occ_of_gid = nullptr; // G: local group id -> position in slot order
+  int64_t* rec_off = nullptr;     // G + 1 after plan (emission order)
+  const int64_t* prefix = nullptr;
+  const int64_t* order = nullptr;
+  int64_t total = -1;
+  mutable hipStream_t stream = nullptr;
+  std::vector<void*> owned;
+  template <typename T>
+  T* own(size_t count) {
+    T* p = static_cast<T*>(pool_alloc((count ? count : 1) * sizeof(T)));
+    if (p) owned.push_back(p);
+    return p;
+  }
+  ~pdx_grouped() {
+    StreamNote note(stream);
+    pool_free_many(owned.data(), (int)owned.size());
+  }
+};
+
+extern "C" {
+
+int pdx_groupby_group_values(pdx_groupby* gb, const pdx_column* values, void* stream, pdx_grouped** out) {
+  if (!gb || !out) return fail(PDX_INVALID, "pdx_groupby_group_values: null argument");
+  PDX_TRY(check_column(values, "pdx_groupby_group_values"));
+  if (gb->mode != 0) return fail(PDX_INVALID, "pdx_groupby_group_values: needs a hash group-by handle");
+  if (values->dtype != PDX_FLOAT64 || validity_or_null(values)) return fail(PDX_NOT_IMPLEMENTED, "pdx_groupby_group_values: float64 values without nulls only");
+  if (values->length != gb->n) return fail(PDX_INVALID, "pdx_groupby_group_values: values length differs from the grouped key length");
+  hipStream_t st = as_stream(stream);
+  gb->stream = st;  // frees of the handle's blocks are ordered behind this stream
+  std::unique_ptr<pdx_grouped> gowner(new pdx_grouped());
+  gowner->stream = st;
+  pdx_grouped* g = gowner.get();
+  g->gb = gb;
+  g->n = gb->n;
+  g->G = gb->G;
+  *out = nullptr;
+  const int64_t n = gb->n, G = gb->G;
+  g->seg_start = g->own<uint32_t>((size_t)G + 1);
+  g->occ_of_gid = g->own<uint32_t>((size_t)G);
+  if (!g->seg_start || !g->occ_of_gid) return PDX_OOM;
+  if (n > 0) {
+    Scratch s;
+    const uint32_t* ks = nullptr;
+    const uint64_t* vs = nullptr;
+    bool narrow_done = false;
+    int rc = sort_values_narrow_full(gb, static_cast<const uint64_t*>(values->values) + values->offset,
+                                     [&](size_t bytes) { return (void*)g->own<uint8_t>(bytes); }, s, st, &vs, g->seg_start, &narrow_done);
+    if (rc != PDX_OK) return rc;
+    if (!narrow_done) {
+      rc = sort_values_by_slot(gb, static_cast<const uint64_t*>(values->values) + values->offset, nullptr, 0,
+                               [&](size_t bytes) { return (void*)g->own<uint8_t>(bytes); }, s, st, &ks, &vs);
+      if (rc != PDX_OK) return rc;
+      hipLaunchKernelGGL(k_seg_starts, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, ks, n, gb->occ_slot, G, g->seg_start);
+    }
+    g->vals_sorted = reinterpret_cast<const double*>(vs);
+    hipLaunchKernelGGL(k_occ_of_gid, dim3(grid_for(G, 256)), dim3(256), 0, st, gb->gid_of_occ, G, g->occ_of_gid);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return hip_fail(e, "pdx_groupby_group_values");
+  }
+  *out = gowner.release();
+  return PDX_OK;
+}
+int pdx_grouped_destroy(pdx_grouped* g) {
+  delete g;
+  return PDX_OK;
+}
+int pdx_grouped_counts(pdx_grouped* g, int64_t* out_counts, void* stream) {
+  if (!g || !out_counts) return fail(PDX_INVALID, "pdx_grouped_counts: null argument");
+  hipStream_t st = as_stream(stream);
+  g->stream = st;  // frees of the handle's blocks are ordered behind this stream
+  if (g->G) hipLaunchKernelGGL(k_grouped_counts, dim3(grid_for(g->G, 256)), dim3(256), 0, st, g->seg_start, g->gb->gid_of_occ, g->G, out_counts);
+  PDX_LAUNCH_CHECK();
+  PDX_HIP(hipStreamSynchronize(st));
+  return PDX_OK;
+}
+int pdx_grouped_partial_plan(pdx_grouped* g, const int64_t* prefix, const int64_t* order, int64_t* out_total, void* stream) {
+  if (!g || !prefix || !out_total) return fail(PDX_INVALID, "pdx_grouped_partial_plan: null argument");
+  hipStream_t st = as_stream(stream);
+  g->stream = st;  // frees of the handle's blocks are ordered behind this stream
+  *out_total = 0;
+  g->prefix = prefix;
+  g->order = order;
+  g->total = 0;
+  if (g->G == 0) return PDX_OK;
+  if (!g->rec_off) g->rec_off = g->own<int64_t>((size_t)g->G + 1);
+  if (!g->rec_off) return PDX_OOM;
+  Scratch s;
+  int64_t* total = s.get<int64_t>(1);
+  PDX_SCRATCH_CHECK(s);
+  hipLaunchKernelGGL(k_partial_plan, dim3(grid_for(g->G, 256)), dim3(256), 0, st, g->seg_start, g->occ_of_gid, order, g->G, prefix, g->rec_off);
+  PDX_TRY((device_exclusive_scan<int64_t, SumOp>(g->rec_off, g->rec_off, g->G, total, s, st)));
+  PDX_HIP(hipMemcpyAsync(&g->total, total, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  PDX_HIP(hipStreamSynchronize(st));
+  *out_total = g->total;
+  return PDX_OK;
+}
+int pdx_grouped_partial_fill(pdx_grouped* g, const int64_t* gid_map, int64_t* rec_key, double* rec_val, void* stream) {
+  if (!g || !gid_map || !rec_key || !rec_val) return fail(PDX_INVALID, "pdx_grouped_partial_fill: null argument");
+  if (g->total < 0 || !g->prefix) return fail(PDX_INVALID, "pdx_grouped_partial_fill: call pdx_grouped_partial_plan first");
+  hipStream_t st = as_stream(stream);
+  g->stream = st;  // frees of the handle's blocks are ordered behind this stream
+  if (g->G) {
+    PDX_PROFILE("partial_fill", st);
+    {
+      const int wave_form = [] { const char* e = getenv("PDX_PARTIAL_FILL_WAVE"); return !(e && e[0] == '0'); }() ? 1 : 0;
+      if (wave_form)
+        hipLaunchKernelGGL(k_partial_fill_wave, dim3((unsigned)std::min<int64_t>(ceil_div(g->G, 4), (int64_t)kCUs * 32)), dim3(256), 0, st, g->vals_sorted,
+                           g->seg_start, g->occ_of_gid, g->order, g->G, g->prefix, gid_map, g->rec_off, rec_key, rec_val);
+  hipLaunchKernelGGL(k_partial_fill, dim3(grid_for(g->G, 256)), dim3(256), 0, st, g->vals_sorted, g->seg_start, g->occ_of_gid, g->order, g->G, g->prefix,
+                       gid_map, g->rec_off, rec_key, rec_val, wave_form);
+    }
+  }
+  PDX_LAUNCH_CHECK();
+  PDX_HIP(hipStreamSynchronize(st));
+  return PDX_OK;
+}
+int pdx_replay_partials(const int64_t* rec_key, const double* rec_val, int64_t m, int64_t gid_lo, int64_t n_own, double* out_sum, void* stream) {
+  if (m < 0 || n_own < 0 || (m && (!rec_key || !rec_val)) || (n_own && !out_sum)) return fail(PDX_INVALID, "pdx_replay_partials: bad argument");
+  if (m > 0x7FFFFFFFll || n_own > 0x3FFFFFFFll) return fail(PDX_NOT_IMPLEMENTED, "pdx_replay_partials: too many records / groups for one call");
+  hipStream_t st = as_stream(stream);
+  if (n_own == 0) return PDX_OK;
+  Scratch s;
+  uint32_t* slot = s.get<uint32_t>((size_t)m);
+  uint32_t* lvl = s.get<uint32_t>((size_t)m);
+  uint32_t *k0 = s.get<uint32_t>((size_t)m), *k1 = s.get<uint32_t>((size_t)m), *k2 = s.get<uint32_t>((size_t)m), *k3 = s.get<uint32_t>((size_t)m);
+  uint64_t *v0 = s.get<uint64_t>((size_t)m), *v1 = s.get<uint64_t>((size_t)m);
+  uint32_t *l0 = s.get<uint32_t>((size_t)m), *l1 = s.get<uint32_t>((size_t)m);
+  uint32_t* ids = s.get<uint32_t>((size_t)n_own);
+  uint32_t* ss = s.get<uint32_t>((size_t)n_own + 1);
+  unsigned int* bad = s.get<unsigned int>(1);
+  PDX_SCRATCH_CHECK(s);
+  PDX_HIP(hipMemsetAsync(bad, 0, sizeof(unsigned int), st));
+  int bits = ilog2((uint64_t)n_own + 1);
+  if (bits < 1) bits = 1;
+  // the record's level (6 bits) rides above the slot bits of the 31-bit sort key when there is room: ONE sort instead of two
+  const int pack_shift = bits <= 25 ? 25 : -1;
+  if (m) hipLaunchKernelGGL(k_replay_keys, dim3(grid_for(m, 256, 4)), dim3(256), 0, st, rec_key, m, gid_lo, n_own, slot, lvl, bad, pack_shift);
+  const uint32_t *ks = slot, *ks2 = nullptr, *ls = lvl;
+  const uint64_t* vs = reinterpret_cast<const uint64_t*>(rec_val);
+  if (m) {
+    ProfileTagOverride replay_tag("replay_sort");  // (not the per-row scatter passes the bench prices against the roofline)
+    PDX_TRY(radix_sort_pairs<uint64_t>(slot, reinterpret_cast<const uint64_t*>(rec_val), k0, v0, k1, v1, m, bits, &ks, &vs, true, s, st));
+    if (pack_shift < 0) PDX_TRY(radix_sort_pairs<uint32_t>(slot, lvl, k2, l0, k3, l1, m, bits, &ks2, &ls, true, s, st));
+  }
+  if (pack_shift >= 0) {
+    hipLaunchKernelGGL(k_seg_starts_masked, dim3(grid_for(n_own + 1, 256)), dim3(256), 0, st, ks, m, (1u << pack_shift) - 1u, n_own, ss);
+  } else {
+    hipLaunchKernelGGL(k_iota_u32, dim3(grid_for(n_own, 256)), dim3(256), 0, st, ids, n_own);
+    hipLaunchKernelGGL(k_seg_starts, dim3(grid_for(n_own + 1, 256)), dim3(256), 0, st, ks, m, ids, n_own, ss);
+  }
+  {
+    PDX_PROFILE("replay_partials", st);
+    hipLaunchKernelGGL(k_replay, dim3(grid_for(n_own, 256)), dim3(256), 0, st, ss, n_own, reinterpret_cast<const double*>(vs), pack_shift >= 0 ? ks : ls, out_sum,
+                       bad, pack_shift);
+  }
+  PDX_LAUNCH_CHECK();
+  unsigned int hbad = 0;
+  PDX_HIP(hipMemcpyAsync(&hbad, bad, sizeof(hbad), hipMemcpyDeviceToHost, st));
+  PDX_HIP(hipStreamSynchronize(st));
+  if (hbad == 1) return fail(PDX_INVALID, "pdx_replay_partials: record for a group outside [gid_lo, gid_lo + n_own)");
+  if (hbad == 2) return fail(PDX_INVALID, "pdx_replay_partials: node record inside an unfinished leaf (records out of order)");
+  if (hbad == 3) return fail(PDX_INVALID, "pdx_replay_partials: an owned group received no record");
+  return PDX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+// gb_resample_kernels.hpp -- part of groupby.hip (textually included there, in its namespace context; split by stage, kernels unchanged):
+// resample: bin arithmetic on sorted timestamps, non-empty bins, row labels.
+#pragma once
+
+// ---------------------------------------------------------------- resample helpers
+struct BinParams {
+  const long long* ts;
+  long long first, freq;
+  double inv_freq;  // 1.0 / freq: quotient estimate, corrected exactly below (int64 division is ~100 instructions on CDNA)
+  int closed_right;
+  __device__ long long bin(int64_t i) const {
+    long long x = ts[i] - first - (closed_right ? 1 : 0);  // >= 0: every timestamp is >= first (checked on the host)
+    long long q = (long long)((double)x * inv_freq);
+    long long r = x - q * freq;
+    while (r < 0) { --q; r += freq; }
+    while (r >= freq) { ++q; r -= freq; }
+    return q;
+  }
+};
+// sparse bins (many rows per bin): bin b starts at the first row whose timestamp is >= (closed-left) / > (closed-right) edge b
+// (the search starts from the position a uniformly spaced axis would give and brackets the answer with growing steps before it
+//  bisects: a few probes in neighbouring cache lines instead of ~30 scattered ones per edge on regular timestamps)
+__global__ void k_bin_lower_bounds(BinParams p, int64_t n, int64_t nbins, long long tmin, long long tmax, uint32_t* __restrict__ lb /* nbins + 1 */) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const double scale = tmax > tmin ? (double)(n - 1) / (double)(tmax - tmin) : 0.0;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b <= nbins; b += stride) {
+    if (b == nbins) {
+      lb[b] = (uint32_t)n;
+      continue;
+    }
+    long long edge = p.first + b * p.freq;
+    auto before_at = [&](int64_t i) {
+      const long long v = p.ts[i];
+      return p.closed_right ? (v <= edge) : (v < edge);
+    };
+    int64_t g = (int64_t)((double)(edge - tmin) * scale);
+    g = g < 0 ? 0 : (g > n - 1 ? n - 1 : g);
+    int64_t lo = 0, hi = n;
+    if (before_at(g)) {  // the answer lies behind g: step forward until a row is not before the edge
+      lo = g + 1;
+      for (int64_t st = 64; lo + st < n; st <<= 2) {
+        if (!before_at(lo + st)) {
+          hi = lo + st;
+          break;
+        }
+        lo = lo + st + 1;
+      }
+    } else {  // the answer is g or in front of it
+      hi = g;
+      for (int64_t st = 64; hi - st > 0; st <<= 2) {
+        if (before_at(hi - st)) {
+          lo = hi - st + 1;
+          break;
+        }
+        hi = hi - st;
+      }
+    }
+    while (lo < hi) {
+      int64_t mid = (lo + hi) >> 1;
+      long long v = p.ts[mid];
+      bool before = p.closed_right ? (v <= edge) : (v < edge);
+      if (before) lo = mid + 1;
+      else hi = mid;
+    }
+    lb[b] = (uint32_t)lo;
+  }
+}
+struct NonEmptyBinPred {
+  const uint32_t* lb;
+  __device__ bool operator()(int64_t b) const { return lb[b] < lb[b + 1]; }
+};
+struct NonEmptyBinEmit {
+  const uint32_t* lb;
+  long long label_base, freq;
+  uint32_t* seg_start;
+  int64_t* labels;
+  int64_t* first_rows;
+  __device__ void operator()(int64_t pos, int64_t b) const {
+    seg_start[pos] = lb[b];
+    labels[pos] = label_base + b * freq;
+    first_rows[pos] = (int64_t)lb[b];
+  }
+};
+struct BinStartPred {
+  BinParams p;
+  __device__ bool operator()(int64_t i) const { return i == 0 || p.bin(i) != p.bin(i - 1); }
+};
+struct BinStartEmit {
+  BinParams p;
+  long long label_base;  // first + label_right * freq
+  uint32_t* seg_start;
+  int64_t* labels;
+  int64_t* first_rows;
+  __device__ void operator()(int64_t pos, int64_t i) const {
+    seg_start[pos] = (uint32_t)i;
+    labels[pos] = label_base + p.bin(i) * p.freq;
+    first_rows[pos] = i;
+  }
+};
+__global__ void k_check_sorted(const long long* __restrict__ ts, int64_t n, unsigned int* __restrict__ bad) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; i < n; i += stride)
+    if (ts[i] < ts[i - 1]) atomicExch(bad, 1u);
+}
+__global__ void k_row_labels(BinParams p, long long label_base, int64_t n, int64_t* __restrict__ out) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = label_base + p.bin(i) * p.freq;
+}
+__global__ void k_seg_row_ids(const uint32_t* __restrict__ seg_start, int64_t G, int64_t n, uint32_t* __restrict__ out) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int64_t lo = 0, hi = G;  // last segment with start <= i
+    while (hi - lo > 1) {
+      int64_t mid = (lo + hi) >> 1;
+      if (seg_start[mid] <= (uint32_t)i) lo = mid;
+      else hi = mid;
+    }
+    out[i] = (uint32_t)lo;
+  }
+}
+__global__ void k_set_last(uint32_t* p, int64_t idx, uint32_t v) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) p[idx] = v;
+}
