@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpdx_hip.so")
+# PDX_LIB_PATH: load another build of the same library (tools/sanitize_cpu.sh: the host side under ASan / UBSan)
+LIB_PATH = os.environ.get("PDX_LIB_PATH") or os.path.join(_HERE, "csrc", "libpdx_hip.so")
 
 # enums (include/pdx/abi.h)
 OK, INVALID, INDEX_ERROR, OOM, DEVICE, NOT_IMPLEMENTED = range(6)
