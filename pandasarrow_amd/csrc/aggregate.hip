@@ -72,18 +72,42 @@ struct FinishArgs {
   int counts[9];
   int nlevels;
 };
-// single thread: replay the counter over the ragged tails, top level first, then fold
-__global__ void k_sum_finish(FinishArgs a, double* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// replay the counter over the ragged tails, top level first, then fold.  A level's tail (< 256 nodes, pushed when every lower
+// counter level is empty) is what the counter turns into one perfect subtree per set bit of its length -- 128, 64, ... nodes,
+// front to back -- so the wave builds those subtrees with shuffle trees and lane 0 pushes <= 8 finished nodes per level at their
+// own levels, instead of replaying up to 255 single pushes through the private (scratch) counter array: ~100 us -> a few us per
+// call, 7 % of a 1e9-row dense sum.
+__global__ void __launch_bounds__(64) k_sum_finish(FinishArgs a, double* __restrict__ out) {
+  __shared__ double t[9][256];
+  const int lane = threadIdx.x;
+  for (int r = 0; r < a.nlevels; ++r)
+    for (int i = lane; i < a.counts[r]; i += 64) t[r][i] = a.tails[r][i];
+  __syncthreads();
   PairwiseCounter c;
   c.init();
   bool any = false;
-  for (int r = a.nlevels - 1; r >= 0; --r)
-    for (int i = 0; i < a.counts[r]; ++i) {
-      c.push(a.tails[r][i], 8 * r);
+  for (int r = a.nlevels - 1; r >= 0; --r) {
+    const int cnt = a.counts[r];
+    int pos = 0;
+    for (int b = 8; b >= 0; --b) {  // (a level-0 tail can hold exactly 256 leaves: 4081..4095 ragged rows)
+      if (!((cnt >> b) & 1)) continue;
+      double node;
+      if (b == 8) {
+        const double q0 = wave_tree64(t[r][lane]), q1 = wave_tree64(t[r][64 + lane]), q2 = wave_tree64(t[r][128 + lane]),
+                     q3 = wave_tree64(t[r][192 + lane]);
+        node = (q0 + q1) + (q2 + q3);
+      } else if (b == 7) {
+        const double lo = wave_tree64(t[r][pos + lane]), hi = wave_tree64(t[r][pos + 64 + lane]);
+        node = lo + hi;
+      } else {
+        node = wave_tree_levels(lane < (1 << b) ? t[r][pos + lane] : 0.0, b);
+      }
+      if (lane == 0) c.push(node, 8 * r + b);
       any = true;
+      pos += 1 << b;
     }
-  *out = any ? c.finish() : 0.0;
+  }
+  if (lane == 0) *out = any ? c.finish() : 0.0;
 }
 
 // runs the tree over level arrays; level0_nodes = number of level-8 nodes already produced (dense) or, when
@@ -147,14 +171,19 @@ static int sum_dense(const T* v, int64_t n, double* result_dev, Scratch& s, hipS
 }
 
 // ---------------------------------------------------------------- nullable path
-// Arrow restarts its 16-value leaves at every run of valid rows.  One thread owns a 16-row window (= one leaf length):
-//   k_null_window_state : rows at the END of the window that stay in an open leaf if the window has an invalid row, else "pass"
-//   "latest" device scan: rows already in the open leaf at every window START (a full window passes the value through: 16 | 16)
-//   k_null_window_count : leaves FINISHED inside the window (+ the leaf still open at the end of the array)  -> device sum scan
-//   k_null_window_emit  : 4096 rows per block staged through LDS (coalesced loads); the open leaf's partial sum at a window
-//                         start is the sequential sum of the previous window's last rows; every window walks its 16 bits once
-//                         and writes the leaves it finishes, in order, into the compact leaf array
-// then the ordinary merge tree (run_tree) over the leaf array.
+// Arrow restarts its 16-value leaves at every run of valid rows.  All bookkeeping is per 1024-ROW SEGMENT (16 words of the
+// validity bitmap = the 64 sixteen-row windows one wave owns); what used to be per 16-row window in global arrays (12 B per
+// window, two device scans over n / 16 elements, workgroup barriers in the emit kernel: 4.7 ms per 1e9 rows) now stays inside a wave:
+//   k_null_seg_state : one wave per 4096 rows (lane = bitmap word, 16 lanes = one segment): rows of the leaf still OPEN at every
+//                      segment's end if the segment holds an invalid row, else "pass" (a full segment hands its input on:
+//                      1024 % 16 == 0); also the valid-row count (one atomic per wave, not per tile)
+//   "latest" device scan over segments -> rows already in the open leaf at every segment START
+//   k_null_seg_count : same shape: leaves FINISHED inside every segment (+ the leaf still open at the end of the array) -> sum scan
+//   k_null_seg_emit  : one WAVE per segment, lane = 16-row window, no workgroup barrier: values staged through the wave's own LDS
+//                      region (coalesced loads), open-leaf position and first leaf index of every window from two wave scans
+//                      seeded with the segment's carry-ins, ONE walk over the window's bits that sums and counts its leaves,
+//                      leaf sums written straight to their places in the compact leaf array
+// then the ordinary merge tree (run_tree) over the leaf array.  Traffic: the values once + ~3 x the bitmap + the leaf array.
 __device__ __forceinline__ unsigned window_bits(const uint8_t* valid, int64_t off, int64_t n, int64_t w) {
   // 16 validity bits of window w (rows [16w, 16w+16)), zero beyond n
   const int64_t row = w << 4;
@@ -171,118 +200,213 @@ __device__ __forceinline__ unsigned window_bits(const uint8_t* valid, int64_t of
   if (remain < 16) v &= (1u << remain) - 1u;
   return v;
 }
-__global__ void k_null_window_state(const uint8_t* __restrict__ valid, int64_t off, int64_t n, int64_t nwin, int32_t* __restrict__ z,
-                                    unsigned long long* __restrict__ valid_total) {
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+// rows of the open leaf after a 16-row window with bits m, entered with p rows open; *fin += leaves finished inside
+__device__ __forceinline__ int window_walk(unsigned m, int p, int* fin) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    if ((m >> q) & 1u) {
+      if (++p == 16) { ++*fin; p = 0; }
+    } else if (p > 0) { ++*fin; p = 0; }
+  }
+  return p;
+}
+constexpr int kSegRows = 1024;       // rows per segment = 64 windows of 16 = one wave of the emit kernel
+constexpr int kNullTileWaves = 4;    // 4096-row tiles (one wave each, lane = bitmap word) per workgroup of the two bitmap-only kernels
+// lane l holds the tile's validity word l (rows [64 l, 64 l + 64) of the tile, zero beyond n)
+__device__ __forceinline__ uint64_t tile_word(const uint8_t* valid, int64_t off, int64_t n, int64_t tile, int lane) {
+  const int64_t row = tile * kLeafElems + (int64_t)lane * 64;
+  if (row >= n) return 0ull;
+  if (((off + row) & 63) == 0 && row + 64 <= n && (reinterpret_cast<uintptr_t>(valid) & 7) == 0)
+    return reinterpret_cast<const uint64_t*>(valid)[(off + row) >> 6];  // the common case: one aligned 8-byte load instead of nine bytes
+  return load_bits64(valid, off + row, off + n);
+}
+// leaves finished inside a 64-row word entered with p rows open, run by run (a 5 %-null word has ~4 runs; bit by bit it was 64 steps)
+__device__ __forceinline__ int word_leaf_count(uint64_t w, int p) {
+  int fin = 0, pos = 0;
+  while (pos < 64) {
+    const uint64_t x = w >> pos;
+    const uint64_t nx = ~x;
+    int ones = nx ? __builtin_ctzll(nx) : 64;
+    ones = ones < 64 - pos ? ones : 64 - pos;
+    if (ones > 0) {
+      const int tot = p + ones;
+      fin += tot >> 4;
+      p = tot & 15;
+      pos += ones;
+    }
+    if (pos >= 64) break;
+    if (p > 0) {  // an invalid row closes the open leaf
+      ++fin;
+      p = 0;
+    }
+    const uint64_t y = w >> pos;
+    const int zeros = y ? __builtin_ctzll(y) : 64 - pos;
+    pos += zeros;
+  }
+  return fin | (p << 16);
+}
+__global__ void __launch_bounds__(kNullTileWaves * 64) k_null_seg_state(const uint8_t* __restrict__ valid, int64_t off, int64_t n, int64_t ntiles,
+                                                                        int32_t* __restrict__ z /* [4 * ntiles] */,
+                                                                        unsigned long long* __restrict__ valid_total) {
+  const int lane = threadIdx.x & 63;
   unsigned long long vc = 0;
-  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwin; w += stride) {
-    const unsigned m = window_bits(valid, off, n, w);
-    z[w] = m == 0xFFFFu ? -1 : (int32_t)__builtin_clz(~(m << 16));  // valid rows at the end of the window
-    vc += __popc(m);
+  // (grid-stride over tiles and ONE atomic per wave at the end: an atomic per tile on the single counter serialised the kernel --
+  //  2.9 ms for the 244 k tiles of 1e9 rows)
+  for (int64_t tile = (int64_t)blockIdx.x * kNullTileWaves + (threadIdx.x >> 6); tile < ntiles; tile += (int64_t)gridDim.x * kNullTileWaves) {
+    const uint64_t w = tile_word(valid, off, n, tile, lane);
+    const uint64_t nonfull = __ballot(w != ~0ull);
+    vc += (unsigned long long)__popcll(w);
+    // per segment (16 lanes): the valid rows behind the segment's last invalid row, modulo 16 (whole words behind it add 64 each)
+    const int g = lane >> 4;
+    const unsigned nf = (unsigned)(nonfull >> (16 * g)) & 0xFFFFu;
+    const int hl = nf ? 16 * g + (31 - __builtin_clz(nf)) : -1;
+    const uint64_t wl = __shfl(w, hl < 0 ? 0 : hl, 64);
+    if ((lane & 15) == 0) z[tile * 4 + g] = hl < 0 ? -1 : (int32_t)(__builtin_clzll(~wl) & 15);
   }
   for (int d = 32; d > 0; d >>= 1) vc += __shfl_down(vc, d, 64);
-  if ((threadIdx.x & 63) == 0 && vc) atomicAdd(valid_total, vc);
+  if (lane == 0 && vc) atomicAdd(valid_total, vc);
 }
-__global__ void k_null_window_count(const uint8_t* __restrict__ valid, int64_t off, int64_t n, int64_t nwin, const int32_t* __restrict__ pos_in,
-                                    int64_t* __restrict__ count) {
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwin; w += stride) {
-    const unsigned m = window_bits(valid, off, n, w);
-    int p = pos_in[w] < 0 ? 0 : pos_in[w];
-    int fin = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      if ((m >> q) & 1u) {
-        if (++p == 16) { ++fin; p = 0; }
-      } else if (p > 0) { ++fin; p = 0; }
-    }
-    if (w == nwin - 1 && p > 0) ++fin;  // the leaf still open at the end of the array
-    count[w] = fin;
-  }
+__global__ void __launch_bounds__(kNullTileWaves * 64) k_null_seg_count(const uint8_t* __restrict__ valid, int64_t off, int64_t n, int64_t ntiles,
+                                                                        const int32_t* __restrict__ pos_in /* scanned z */,
+                                                                        int64_t* __restrict__ count /* [4 * ntiles] */) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tile = (int64_t)blockIdx.x * kNullTileWaves + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  const uint64_t w = tile_word(valid, off, n, tile, lane);
+  // open-leaf rows at the start of every word: "latest" scan over the words of the tile, seeded with the tile's carry-in
+  const int zw = w == ~0ull ? -1 : (int)(__builtin_clzll(~w) & 15);
+  const int inc = wave_inclusive_scan(zw, LatestOp());
+  const int exc = __shfl_up(inc, 1, 64);
+  const int carry = pos_in[tile * 4] < 0 ? 0 : pos_in[tile * 4];
+  int p = (lane == 0 || exc < 0) ? carry : exc;  // exc < 0: every earlier word of the tile is full (64 % 16 == 0: the carry passes through)
+  const int fp = word_leaf_count(w, p);
+  int fin = fp & 0xFFFF;
+  p = fp >> 16;
+  // the leaf still open at the end of the ARRAY: the last word that holds a row
+  const int64_t row0 = tile * kLeafElems + (int64_t)lane * 64;
+  if (row0 >= n) fin = 0;  // (a word past the end of the array: its zero bits are not rows)
+  else if (row0 + 64 >= n && p > 0) ++fin;
+  for (int d = 8; d > 0; d >>= 1) fin += __shfl_down(fin, d, 16);
+  if ((lane & 15) == 0) count[tile * 4 + (lane >> 4)] = fin;
 }
-// (smaller workgroups than the dense kernels: two barriers and a serial 16-row loop per workgroup -- more, smaller ones overlap better)
-constexpr int kEmitBlock = 128;
-constexpr int kEmitElems = kEmitBlock * 16;
+constexpr int kEmitWaves = 2;  // waves per workgroup of the emit kernel (waves are independent: the size only packs the LDS)
+// Persistent waves: a wave takes segments seg, seg + stride, ... and requests the NEXT segment's rows (and its small inputs) before
+// it works on the current one, so the ~2 us of memory latency per segment overlap with the staging / scan / walk of the previous
+// one (one segment per short-lived wave: 2.8 ms per 1e9 rows, mostly waiting).
 template <typename T>
-__global__ void __launch_bounds__(kEmitBlock) k_null_window_emit(const T* __restrict__ v, const uint8_t* __restrict__ valid, int64_t off, int64_t n,
-                                                                 int64_t nwin, const int32_t* __restrict__ pos_in,
-                                                                 const int64_t* __restrict__ leaf_base, double* __restrict__ leaves) {
-  __shared__ double lds[kEmitBlock * kLeafPad];
-  const int tid = threadIdx.x;
-  const int64_t base = (int64_t)blockIdx.x * kEmitElems;
-  const int rows = (int)((n - base) < kEmitElems ? (n - base) : kEmitElems);
-  // the window's own small inputs (validity bits, open-leaf position, first leaf index) are requested together with the values:
-  // asked for only after the barrier they cost a second and third memory round trip per block (SQ_WAIT_ANY was 86 % of wave cycles)
-  const int64_t w = (int64_t)blockIdx.x * kEmitBlock + tid;
-  const bool in = w < nwin;
-  const unsigned m = in ? window_bits(valid, off, n, w) : 0u;
-  const int p_in = in ? pos_in[w] : 0;
-  const int64_t li_in = in ? leaf_base[w] : 0;
-  __shared__ double prev_tail[16];  // first window of the block: the rows of an open leaf live in the previous block
-  if (tid < 16) prev_tail[tid] = base >= 16 ? to_f64(v[base - 16 + tid]) : 0.0;
+__global__ void __launch_bounds__(kEmitWaves * 64) k_null_seg_emit(const T* __restrict__ v, const uint8_t* __restrict__ valid, int64_t off, int64_t n,
+                                                                   const int32_t* __restrict__ seg_pos, const int64_t* __restrict__ seg_leaf_base,
+                                                                   double* __restrict__ leaves) {
+  __shared__ double lds_all[kEmitWaves][64 * kLeafPad];
+  const int lane = threadIdx.x & 63;
+  double* const lds = lds_all[threadIdx.x >> 6];
+  const int64_t nsegs = (n + kSegRows - 1) / kSegRows, nwin = (n + 15) >> 4;
+  const int64_t stride = (int64_t)gridDim.x * kEmitWaves;
+  int64_t seg = (int64_t)blockIdx.x * kEmitWaves + (threadIdx.x >> 6);
+  if (seg >= nsegs) return;  // (whole waves leave: nothing below is a workgroup barrier)
+  T nv[16];
+  T npt = T(0);
+  unsigned nm = 0;
+  int ncarry = 0;
+  int64_t nleaf0 = 0;
+  auto request = [&](int64_t sg) {
+    const int64_t base = sg * kSegRows;
+    const int rows = (int)((n - base) < kSegRows ? (n - base) : kSegRows);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    int idx = k * kEmitBlock + tid;
-    if (idx < rows) lds[idx + (idx >> 4)] = to_f64(v[base + idx]);
-  }
-  __syncthreads();
-  // Every thread takes its window's 16 values (and the tail of the previous window, if a leaf is open) into registers; after a
-  // barrier the staging area is reused for the block's finished leaf sums, which land at consecutive positions of `leaves`
-  // (leaf_base is an exclusive scan over windows) and leave in one coalesced copy -- a store per finished leaf straight from the
-  // row loop costs up to 16 mostly empty store instructions per wave (4.3 ms per 1e9 rows).
-  __shared__ int64_t blk_lo_s, blk_hi_s;
-  int p = p_in < 0 ? 0 : p_in;
-  double x[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) x[q] = lds[tid * kLeafPad + q];
-  // partial sum of the leaf that is open at the window start: its p rows are the LAST p rows of the previous window (all valid)
-  double acc = 0.0;
-  if (in && p > 0) {
-    if (tid > 0) {
-      for (int q = 16 - p; q < 16; ++q) acc += lds[(tid - 1) * kLeafPad + q];
-    } else {
-      for (int q = 16 - p; q < 16; ++q) acc += prev_tail[q];
+    for (int k = 0; k < 16; ++k) {
+      const int idx = k * 64 + lane;  // coalesced 8-byte lanes
+      nv[k] = idx < rows ? v[base + idx] : T(0);
     }
-  }
-  int64_t li = li_in;
-  if (tid == 0) blk_lo_s = li;
-  __syncthreads();
-  const int64_t blk_lo = blk_lo_s;
-  if (in) {
+    const int64_t w = sg * 64 + lane;
+    nm = w < nwin ? window_bits(valid, off, n, w) : 0u;
+    ncarry = seg_pos[sg];
+    nleaf0 = seg_leaf_base[sg];
+    npt = (lane < 16 && base >= 16) ? v[base - 16 + lane] : T(0);  // the 16 rows in front of the segment (lane 0's open leaf)
+  };
+  request(seg);
+  for (; seg < nsegs; seg += stride) {
+    const int64_t w = seg * 64 + lane;
+    const bool in = w < nwin;
+    const unsigned m = nm;
+    const int carry_in = ncarry;
+    const int64_t leaf0 = nleaf0;
+    const double pt = to_f64(npt);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      if ((m >> q) & 1u) {
-        acc = (p == 0 ? 0.0 : acc) + x[q];
-        if (++p == 16) { lds[li++ - blk_lo] = acc; p = 0; }
-      } else if (p > 0) { lds[li++ - blk_lo] = acc; p = 0; }
+    for (int k = 0; k < 16; ++k) {
+      const int idx = k * 64 + lane;
+      lds[idx + (idx >> 4)] = to_f64(nv[k]);
     }
-    if (w == nwin - 1 && p > 0) lds[li++ - blk_lo] = acc;
-    if (tid == kEmitBlock - 1 || w == nwin - 1) blk_hi_s = li;  // the block's last window
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    double x[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) x[q] = lds[lane * kLeafPad + q];
+    if (seg + stride < nsegs) request(seg + stride);  // in flight while this segment is reduced
+    // open-leaf rows at every window start: "latest" wave scan of the windows' end states, seeded with the segment's carry-in
+    const int zw = m == 0xFFFFu ? -1 : (int)__builtin_clz(~(m << 16));
+    const int inc = wave_inclusive_scan(zw, LatestOp());
+    const int exc = __shfl_up(inc, 1, 64);
+    int p = (lane == 0 || exc < 0) ? (carry_in < 0 ? 0 : carry_in) : exc;
+    // Partial sum of the leaf that is open at the window start = the previous window's sequential sum over its LAST p rows.  That
+    // leaf always STARTS inside the previous window (a window of 16 rows closes at least one leaf unless it ends exactly on one), so
+    // every lane can sum its own tail from its own registers -- no dependency on its incoming leaf -- and hand it to the next lane
+    // with one shuffle (sixteen 8-byte shuffles per window before: ~64 LDS-crossbar instructions per segment).
+    const int pend = m == 0xFFFFu ? p : zw;  // rows of the leaf open at MY window's end (all valid: what came in comes out)
+    double tail = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (q >= 16 - pend) tail += x[q];
+    double acc = __shfl_up(tail, 1, 64);
+    {  // lane 0: the rows in front of the segment sit one per lane in pt (lanes 0..15): scalar reads, sequential adds
+      double a0 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(pt) & 0xFFFFFFFFll), q);
+        const int hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(pt) >> 32), q);
+        const double t0 = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        if (q >= 16 - p) a0 += t0;
+      }
+      if (lane == 0) acc = a0;
+    }
+    if (!in || p == 0) acc = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // every lane holds its values: its LDS row now collects its leaf sums
+    int j = 0;
+    if (in) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        if ((m >> q) & 1u) {
+          acc = (p == 0 ? 0.0 : acc) + x[q];
+          if (++p == 16) { lds[lane * kLeafPad + j++] = acc; p = 0; }
+        } else if (p > 0) { lds[lane * kLeafPad + j++] = acc; p = 0; }
+      }
+      if (w == nwin - 1 && p > 0) lds[lane * kLeafPad + j++] = acc;
+    }
+    const int incj = wave_inclusive_scan(j, SumOp());
+    double* const dst = leaves + leaf0 + (incj - j);
+    for (int t = 0; t < j; ++t) dst[t] = lds[lane * kLeafPad + t];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the row is read out before the next segment is staged
   }
-  __syncthreads();
-  const int cnt = (int)(blk_hi_s - blk_lo);
-  for (int i = tid; i < cnt; i += kEmitBlock) leaves[blk_lo + i] = lds[i];
 }
 
 template <typename T>
 static int sum_nullable(const T* v, const uint8_t* valid, int64_t off, int64_t n, double* result_dev, unsigned long long* valid_total,
                         Scratch& s, hipStream_t st) {
-  const int64_t nwin = (n + 15) >> 4;
-  int32_t* z = s.get<int32_t>((size_t)nwin);
-  int64_t* lc = s.get<int64_t>((size_t)nwin);
+  const int64_t ntiles = ceil_div(n, kLeafElems), nseg = ntiles * 4;
+  int32_t* z = s.get<int32_t>((size_t)nseg);
+  int64_t* lc = s.get<int64_t>((size_t)nseg);
   int64_t* total = s.get<int64_t>(1);
   PDX_SCRATCH_CHECK(s);
-  int grid = grid_for(nwin, 256, 4);
-  hipLaunchKernelGGL(k_null_window_state, dim3(grid), dim3(256), 0, st, valid, off, n, nwin, z, valid_total);
-  PDX_TRY((device_exclusive_scan<int32_t, LatestOp>(z, z, nwin, nullptr, s, st)));
-  hipLaunchKernelGGL(k_null_window_count, dim3(grid), dim3(256), 0, st, valid, off, n, nwin, z, lc);
-  PDX_TRY((device_exclusive_scan<int64_t, SumOp>(lc, lc, nwin, total, s, st)));
+  const unsigned grid = (unsigned)ceil_div(ntiles, kNullTileWaves);
+  hipLaunchKernelGGL(k_null_seg_state, dim3(std::min<unsigned>(grid, kCUs * 8)), dim3(kNullTileWaves * 64), 0, st, valid, off, n, ntiles, z, valid_total);
+  PDX_TRY((device_exclusive_scan<int32_t, LatestOp>(z, z, nseg, nullptr, s, st)));
+  hipLaunchKernelGGL(k_null_seg_count, dim3(grid), dim3(kNullTileWaves * 64), 0, st, valid, off, n, ntiles, z, lc);
+  PDX_TRY((device_exclusive_scan<int64_t, SumOp>(lc, lc, nseg, total, s, st)));
   int64_t m = 0;
   PDX_HIP(hipMemcpyAsync(&m, total, sizeof(m), hipMemcpyDeviceToHost, st));
   PDX_HIP(hipStreamSynchronize(st));
   double* leaves = s.get<double>((size_t)(m ? m : 1));
   PDX_SCRATCH_CHECK(s);
-  hipLaunchKernelGGL((k_null_window_emit<T>), dim3((unsigned)ceil_div(n, kEmitElems)), dim3(kEmitBlock), 0, st, v, valid, off, n, nwin, z, lc, leaves);
+  const unsigned egrid = (unsigned)std::min<int64_t>(ceil_div(ceil_div(n, kSegRows), kEmitWaves), (int64_t)kCUs * 9);  // 9 workgroups fit a CU's LDS
+  hipLaunchKernelGGL((k_null_seg_emit<T>), dim3(egrid), dim3(kEmitWaves * 64), 0, st, v, valid, off, n, z, lc, leaves);
   PDX_LAUNCH_CHECK();
   return run_tree(leaves, m, nullptr, 0, nullptr, 0, result_dev, s, st);
 }

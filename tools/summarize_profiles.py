@@ -14,7 +14,7 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -26,6 +26,8 @@ def newest(pattern):
 
 stats = [newest(os.path.join(src, "kt", "*", "*kernel_stats.csv"))]
 shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+if glob.glob(os.path.join(src, "kt_secondary", "*", "*kernel_stats.csv")):  # the default run: headline + the secondary configs
+    shutil.copy(newest(os.path.join(src, "kt_secondary", "*", "*kernel_stats.csv")), os.path.join(dst, f"{tag}_kernel_stats_with_secondary.csv"))
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
 if os.path.exists(os.path.join(src, "bench_general_keys.json")):
     shutil.copy(os.path.join(src, "bench_general_keys.json"), os.path.join(dst, f"{tag}_bench_general_keys.json"))
@@ -57,14 +59,21 @@ for k, t in traffic.items():
     out[k] = {"launches_in_profiled_run": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
 # bench.py tags -> kernels (large-payload instantiations only)
 TAGS = {"radix_scatter": r"k_radix_scatter<\d+, unsigned long", "radix_hist": r"k_radix_hist<", "dense_slots": r"k_dense_slots_tail", "hash_insert": r"k_hash_insert",
-        "seg_reduce": r"k_seg_reduce<", "key_minmax": r"k_minmax_partial<long long>", "fused_last_digit_reduce": r"k_flr_reduce<"}
+        "seg_reduce": r"k_seg_reduce<", "key_minmax": r"k_minmax_partial<long long>", "fused_last_digit_reduce": r"k_flr_(reduce|wave)<",
+        "hash_probe_lds": r"k_hash_probe_lds", "hash_bucket_hist": r"k_hash_bucket_hist"}
 by_tag = {}
 for tg, pat in TAGS.items():
     ks = [(k, v) for k, v in out.items() if re.search(pat, k)]
     if ks:
         n = sum(v["launches_in_profiled_run"] for _, v in ks)
         by_tag[tg] = sum(v["hbm_bytes_per_launch"] * v["launches_in_profiled_run"] for _, v in ks) / n
-json.dump({"by_bench_tag_hbm_bytes_per_launch": by_tag, "rows": 1000000000, "n_gpus": 1, "note": "bytes per launch at 1e9 rows / 1e6 keys, 1 GPU; read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB",
+sys.path.insert(0, root)
+import bench  # noqa: E402  (source_hash: ties these counters to the library sources they were measured on)
+
+# one step's HBM traffic: every kernel of the profiled run except the input generators, over its (warmup + timed) steps
+steps_in_run = 2
+step_bytes = sum(v["hbm_bytes_per_launch"] * v["launches_in_profiled_run"] for k, v in out.items() if "synth" not in k) / steps_in_run
+json.dump({"by_bench_tag_hbm_bytes_per_launch": by_tag, "step_hbm_bytes": step_bytes, "source_hash": bench.source_hash(), "rows": 1000000000, "n_gpus": 1, "note": "bytes per launch at 1e9 rows / 1e6 keys, 1 GPU; read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB",
            "kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]))},
           open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_bench.json")).read()[:600])
