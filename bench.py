@@ -207,7 +207,10 @@ def secondary_runs(torch, L, K, api, keys, vals, kinds, n_total, nkeys, steps):
     put("C5_resample_1min_mean", n_total, 16.0 * n_total, timeit(lambda: ser.resample("1min").mean()))
     # (f) a12: DataFrame::downsample('1T') on the same axis = floor/ceil_temporal (16 B/row) + group-by of the binned labels
     put("a12_round_temporal_minute", n_total, 16.0 * n_total, timeit(lambda: K.round_temporal(ts, 1, L.UNIT_MINUTE, True, True, True)))
-    del ser, ts
+    df12 = api.DataFrame({"v": vals}, index=ts)
+    put("a12_downsample_1T_mean", n_total, 16.0 * n_total, timeit(lambda: df12.downsample("1T").mean(), reps=2),
+        note="end to end: ceil_temporal + group-by of the rounded labels (sorted axis: runs of equal labels, no value sort) + mean")
+    del ser, ts, df12
     return out
 
 

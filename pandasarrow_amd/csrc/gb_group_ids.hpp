@@ -45,6 +45,59 @@ __global__ void k_assign_gids(const Slot* __restrict__ table, long long dense_mi
     first_rows[r] = (int64_t)sorted_first[r];
   }
 }
+// ---- first-occurrence rank without a sort: every group's first row sets one bit of an n-bit map; a group's id is the number of
+// set bits in front of its own (the first rows are distinct).  n / 8 bytes of traffic and a handful of launches, where sorting the
+// (first row, slot) pairs took four LSD passes = twenty dependent small kernels (~0.45 ms of a 16 ms step at 1e6 groups, and a
+// full-size sort when almost every row is its own group).
+constexpr int kRankWords = 16;  // 64-bit words per counted block (1024 rows)
+__global__ void k_mark_first_rows(const uint32_t* __restrict__ occ_first, int64_t G, unsigned long long* __restrict__ bits) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < G; j += stride) {
+    const uint32_t fr = occ_first[j];
+    atomicOr(&bits[fr >> 6], 1ull << (fr & 63));
+  }
+}
+__global__ void k_rank_block_counts(const unsigned long long* __restrict__ bits, int64_t nwords, int64_t nblocks, int64_t* __restrict__ counts) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += stride) {
+    int c = 0;
+    const int64_t w0 = b * kRankWords;
+#pragma unroll
+    for (int q = 0; q < kRankWords; ++q)
+      if (w0 + q < nwords) c += __popcll(bits[w0 + q]);
+    counts[b] = c;
+  }
+}
+// k_assign_gids with the rank computed from the bit map (block_pre = exclusive prefix of k_rank_block_counts)
+__global__ void k_assign_gids_ranked(const Slot* __restrict__ table, long long dense_min, unsigned int dense_mask, uint32_t* __restrict__ gid_of_slot,
+                                     const uint32_t* __restrict__ occ_first, const uint32_t* __restrict__ occ_slot, int64_t G,
+                                     const unsigned long long* __restrict__ bits, const int64_t* __restrict__ block_pre, unsigned int null_slot,
+                                     int64_t* __restrict__ uniques, uint8_t* __restrict__ unique_ok, int64_t* __restrict__ first_rows,
+                                     unsigned int region, uint32_t* __restrict__ gid_of_occ) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < G; j += stride) {
+    const unsigned int s = occ_slot[j];
+    const uint32_t fr = occ_first[j];
+    const int64_t w = fr >> 6, b = w / kRankWords;
+    int64_t r = block_pre[b];
+    for (int64_t q = b * kRankWords; q < w; ++q) r += __popcll(bits[q]);
+    r += __popcll(bits[w] & ((1ull << (fr & 63)) - 1ull));
+    gid_of_slot[s] = (unsigned int)r;
+    gid_of_occ[j] = (unsigned int)r;
+    long long k;
+    if (table) {
+      k = table[phys_slot(s, region, null_slot)].key;
+      if (s == null_slot + 1) k = kEmptyKey;
+    } else {
+      k = dense_mask ? (long long)((unsigned long long)dense_min + (((unsigned long long)s - (unsigned long long)dense_min) & dense_mask))
+                     : (long long)((unsigned long long)dense_min + (unsigned long long)s);
+    }
+    if (s == null_slot) k = 0;
+    uniques[r] = k;
+    unique_ok[r] = s != null_slot;
+    first_rows[r] = (int64_t)fr;
+  }
+}
 __global__ void k_gid_of_occ(const uint32_t* __restrict__ gid_of_slot, const uint32_t* __restrict__ occ_slot, int64_t G, uint32_t* __restrict__ out) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < G; k += stride) out[k] = gid_of_slot[occ_slot[k]];

@@ -2,7 +2,8 @@
 #pragma once
 
 struct pdx_groupby {
-  int mode = 0;  // 0 = hash group-by, 1 = contiguous segments (resample)
+  int mode = 0;  // 0 = hash group-by, 1 = contiguous segments (resample bins; runs of equal keys when the keys arrive sorted)
+  bool resample = false;  // segments are time bins (pdx_resample_create): `bin` / `label_base` are set
   int64_t n = 0, G = 0;
   int key_dtype = PDX_INT64;
   // hash mode

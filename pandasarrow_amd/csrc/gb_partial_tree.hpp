@@ -242,7 +242,7 @@ extern "C" {
 int pdx_groupby_group_values(pdx_groupby* gb, const pdx_column* values, void* stream, pdx_grouped** out) {
   if (!gb || !out) return fail(PDX_INVALID, "pdx_groupby_group_values: null argument");
   PDX_TRY(check_column(values, "pdx_groupby_group_values"));
-  if (gb->mode != 0) return fail(PDX_INVALID, "pdx_groupby_group_values: needs a hash group-by handle");
+  if (gb->resample) return fail(PDX_INVALID, "pdx_groupby_group_values: needs a group-by handle");
   if (values->dtype != PDX_FLOAT64 || validity_or_null(values)) return fail(PDX_NOT_IMPLEMENTED, "pdx_groupby_group_values: float64 values without nulls only");
   if (values->length != gb->n) return fail(PDX_INVALID, "pdx_groupby_group_values: values length differs from the grouped key length");
   hipStream_t st = as_stream(stream);
@@ -258,7 +258,18 @@ int pdx_groupby_group_values(pdx_groupby* gb, const pdx_column* values, void* st
   g->seg_start = g->own<uint32_t>((size_t)G + 1);
   g->occ_of_gid = g->own<uint32_t>((size_t)G);
   if (!g->seg_start || !g->occ_of_gid) return PDX_OOM;
-  if (n > 0) {
+  if (n > 0 && gb->mode == 1) {
+    // keys that arrived sorted: the rows are grouped as they stand (a private copy, so the handle does not borrow the caller's column)
+    double* vc = g->own<double>((size_t)n);
+    if (!vc) return PDX_OOM;
+    PDX_HIP(hipMemcpyAsync(vc, static_cast<const double*>(values->values) + values->offset, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    PDX_HIP(hipMemcpyAsync(g->seg_start, gb->seg_start, ((size_t)G + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    g->vals_sorted = vc;
+    hipLaunchKernelGGL(k_occ_of_gid, dim3(grid_for(G, 256)), dim3(256), 0, st, gb->gid_of_occ, G, g->occ_of_gid);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return hip_fail(e, "pdx_groupby_group_values");
+  } else if (n > 0) {
     Scratch s;
     const uint32_t* ks = nullptr;
     const uint64_t* vs = nullptr;

@@ -121,3 +121,54 @@ __global__ void k_seg_row_ids(const uint32_t* __restrict__ seg_start, int64_t G,
 __global__ void k_set_last(uint32_t* p, int64_t idx, uint32_t v) {
   if (threadIdx.x == 0 && blockIdx.x == 0) p[idx] = v;
 }
+
+// ---- keys that arrive grouped already (non-decreasing): the groups are the runs of equal keys, in place
+// Sampled test (64 x 1024 evenly spaced adjacent pairs): bit 0 = a pair descends in signed order, bit 1 = in unsigned order, bit 2 = a
+// null row.  Either order proves that equal keys are neighbours, so a clean bit 0 OR bit 1 (and no null) makes the input a candidate.
+__global__ void __launch_bounds__(1024) k_sample_descents(const long long* __restrict__ keys, const uint8_t* __restrict__ valid, int64_t off, int64_t n,
+                                                          unsigned int* __restrict__ flags) {
+  const int64_t npairs = n - 1;
+  const int64_t nsamp = npairs < 65536 ? npairs : 65536;
+  const int64_t j = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  if (j >= nsamp) return;
+  const int64_t i = (int64_t)((unsigned __int128)j * (unsigned __int128)npairs / (unsigned __int128)nsamp);
+  unsigned int f = 0;
+  if (valid && (!bit_get(valid, off + i) || !bit_get(valid, off + i + 1))) f |= 4u;
+  const long long a = keys[i], b = keys[i + 1];
+  if (b < a) f |= 1u;
+  if ((unsigned long long)b < (unsigned long long)a) f |= 2u;
+  if (f) atomicOr(flags, f);
+}
+// Run starts of the keys.  CHECK: the counting pass also proves the order (flags as above, plain stores of a constant).
+template <bool CHECK>
+struct KeyRunStartPred {
+  const long long* keys;
+  const uint8_t* valid;
+  int64_t off;
+  unsigned int* flags;  // [0] signed descents, [1] unsigned descents, [2] null rows
+  __device__ bool operator()(int64_t i) const {
+    if constexpr (CHECK) {
+      if (valid && !bit_get(valid, off + i)) flags[2] = 1u;
+    }
+    if (i == 0) return true;
+    const long long a = keys[i - 1], b = keys[i];
+    if constexpr (CHECK) {
+      if (b < a) flags[0] = 1u;
+      if ((unsigned long long)b < (unsigned long long)a) flags[1] = 1u;
+    }
+    return a != b;
+  }
+};
+struct KeyRunStartEmit {
+  const long long* keys;
+  uint32_t* seg_start;
+  int64_t* uniques;
+  int64_t* first_rows;
+  uint32_t* gid_of_occ;  // identity: the runs are the groups, in first-occurrence order
+  __device__ void operator()(int64_t pos, int64_t i) const {
+    seg_start[pos] = (uint32_t)i;
+    uniques[pos] = keys[i];
+    first_rows[pos] = i;
+    gid_of_occ[pos] = (uint32_t)pos;
+  }
+};

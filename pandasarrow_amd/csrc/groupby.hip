@@ -56,6 +56,21 @@ namespace pdx {
 
 }  // namespace pdx
 
+// one pinned word per host thread: the target of small device-to-host reads that must not block the launches queued behind them
+// (a copy into pageable memory is staged and waits; pinned memory makes hipMemcpyAsync + an event a real overlap)
+static unsigned int* hmax_pinned() {
+  static thread_local unsigned int* p = nullptr;
+  if (!p) {
+    void* q = nullptr;
+    if (hipHostMalloc(&q, 64, hipHostMallocPortable) != hipSuccess) {
+      (void)hipGetLastError();
+      q = new unsigned int[16];
+    }
+    p = static_cast<unsigned int*>(q);
+  }
+  return p;
+}
+
 extern "C" {
 
 int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
@@ -80,6 +95,73 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   const uint8_t* valid = validity_or_null(key);
   HashCtl* ctl = s.get<HashCtl>(1);
   if (s.failed) return PDX_OOM;
+  // ---- keys that arrive grouped (non-decreasing, no nulls: a sorted id column, a time index rounded to calendar bins): the groups
+  // are the runs of equal keys where they stand -- no dictionary, and no value sort in pdx_groupby_agg (segments mode, as resample).
+  // 65536 sampled neighbour pairs rule the path out for anything else at the price of one small kernel; the counting pass of the
+  // run-start compaction then proves the order over all rows (a sample that lied costs that one pass: the build below takes over).
+  const bool sorted_env = [] { const char* e = getenv("PDX_GROUPBY_SORTED"); return !(e && e[0] == '0'); }();
+  const char* denv = getenv("PDX_GROUPBY_DENSE");
+  const bool allow_dense = !(denv && denv[0] == '0');
+  const bool lds_ok = [] { const char* e = getenv("PDX_DENSE_LDS"); return !(e && e[0] == '0'); }();
+  const bool spec_ok = [] { const char* e = getenv("PDX_DENSE_SPECULATE"); return !(e && e[0] == '0'); }();
+  const bool want_sorted_sample = sorted_env && n >= 2 && !valid;
+  const bool want_range_sample = allow_dense && spec_ok && lds_ok && n >= ((int64_t)1 << 23);  // (the speculative dense build below)
+  KeyRange hsv[64];
+  unsigned int hflags[4] = {0, 0, 0, 4u};
+  unsigned int* flags = nullptr;
+  if (want_sorted_sample || want_range_sample) {  // both samples, one host round trip
+    flags = s.get<unsigned int>(4);
+    KeyRange* dsample = s.get<KeyRange>(64);
+    if (s.failed) return PDX_OOM;
+    if (want_sorted_sample) {
+      PDX_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(unsigned int), st));
+      hipLaunchKernelGGL(k_sample_descents, dim3(64), dim3(1024), 0, st, keys, valid, key->offset, n, flags + 3);
+      PDX_HIP(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, st));
+    }
+    if (want_range_sample) {
+      hipLaunchKernelGGL(k_sample_key_range, dim3(64), dim3(1024), 0, st, keys, valid, key->offset, n, dsample);
+      PDX_HIP(hipMemcpyAsync(hsv, dsample, sizeof(hsv), hipMemcpyDeviceToHost, st));
+    }
+    PDX_LAUNCH_CHECK();
+    PDX_HIP(hipStreamSynchronize(st));
+  }
+  if (want_sorted_sample) {
+    const int64_t nblocks = ceil_div(n, kCompactTile);
+    if (!(hflags[3] & 4u) && (hflags[3] & 3u) != 3u) {
+      int64_t* offsets = s.get<int64_t>((size_t)nblocks);
+      int64_t* total = s.get<int64_t>(1);
+      if (s.failed) return PDX_OOM;
+      int64_t G = 0;
+      {
+        PDX_PROFILE("sorted_key_runs", st);
+        PDX_TRY(compact_count(n, KeyRunStartPred<true>{keys, valid, key->offset, flags}, offsets, total, s, st));
+      }
+      PDX_HIP(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, st));
+      PDX_HIP(hipMemcpyAsync(&G, total, sizeof(G), hipMemcpyDeviceToHost, st));
+      PDX_HIP(hipStreamSynchronize(st));
+      if (!hflags[2] && !(hflags[0] && hflags[1])) {
+        gb->mode = 1;
+        gb->G = G;
+        gb->seg_start = gb->own<uint32_t>((size_t)G + 1);
+        gb->uniques = gb->own<int64_t>((size_t)G);
+        gb->first_rows = gb->own<int64_t>((size_t)G);
+        gb->unique_ok = gb->own<uint8_t>((size_t)G);
+        gb->gid_of_occ = gb->own<uint32_t>((size_t)G);
+        if (!gb->seg_start || !gb->uniques || !gb->first_rows || !gb->unique_ok || !gb->gid_of_occ) return PDX_OOM;
+        {
+          PDX_PROFILE("sorted_key_runs", st);
+          PDX_TRY(compact_write(n, KeyRunStartPred<false>{keys, nullptr, 0, nullptr},
+                                KeyRunStartEmit{keys, gb->seg_start, gb->uniques, gb->first_rows, gb->gid_of_occ}, offsets, total, st));
+        }
+        hipLaunchKernelGGL(k_set_last, dim3(1), dim3(64), 0, st, gb->seg_start, G, (uint32_t)n);
+        PDX_HIP(hipMemsetAsync(gb->unique_ok, 1, (size_t)G, st));
+        PDX_LAUNCH_CHECK();
+        PDX_HIP(hipStreamSynchronize(st));
+        *out = owner.release();
+        return PDX_OK;
+      }
+    }
+  }
   // ---- dense-domain fast path: valid keys span a small integer range -> slot = key - min (or its residue form), no table
   Slot* table = nullptr;
   unsigned int* dense_first = nullptr;
@@ -87,9 +169,6 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   unsigned int dense_mask = 0;
   unsigned int null_slot = 0;
   int64_t nslots = 0;
-  const char* denv = getenv("PDX_GROUPBY_DENSE");
-  const bool allow_dense = !(denv && denv[0] == '0');
-  const bool lds_ok = [] { const char* e = getenv("PDX_DENSE_LDS"); return !(e && e[0] == '0'); }();
   const unsigned long long dense_lim = std::min<unsigned long long>(1ull << 26, (unsigned long long)n * 4 + 1024);
 
   // Builds slot_of_row, first[] and (when the first sort digit is 4..8 bits wide) the scanned pass-0 offsets for the dense domain
@@ -199,14 +278,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   bool sample_rules_out_dense = !allow_dense;
   // ---- speculative single pass: guess the width of the key window from a sample, build the residue-form dense domain and the
   // exact min/max together (saves the separate 8 B/row min/max pass), accept when the exact span fits the guessed width
-  const bool spec_ok = [] { const char* e = getenv("PDX_DENSE_SPECULATE"); return !(e && e[0] == '0'); }();
-  if (allow_dense && spec_ok && lds_ok && n >= ((int64_t)1 << 23)) {
-    KeyRange* dsample = s.get<KeyRange>(64);
-    if (s.failed) return PDX_OOM;
-    hipLaunchKernelGGL(k_sample_key_range, dim3(64), dim3(1024), 0, st, keys, valid, key->offset, n, dsample);
-    KeyRange hsv[64];
-    PDX_HIP(hipMemcpyAsync(hsv, dsample, sizeof(hsv), hipMemcpyDeviceToHost, st));
-    PDX_HIP(hipStreamSynchronize(st));
+  if (want_range_sample) {
     KeyRange hs{0x7FFFFFFFFFFFFFFFll, (long long)0x8000000000000000ull, 0, 0};
     for (const KeyRange& w : hsv)
       if (w.any) {
@@ -515,21 +587,22 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   gb->uniques = gb->own<int64_t>((size_t)G);
   gb->unique_ok = gb->own<uint8_t>((size_t)G);
   gb->first_rows = gb->own<int64_t>((size_t)G);
-  uint32_t* k0 = s.get<uint32_t>((size_t)G);
-  uint32_t* v0 = s.get<uint32_t>((size_t)G);
-  uint32_t* k1 = s.get<uint32_t>((size_t)G);
-  uint32_t* v1 = s.get<uint32_t>((size_t)G);
   if (s.failed || !gb->occ_slot || !gb->gid_of_occ || !gb->uniques || !gb->unique_ok || !gb->first_rows) return PDX_OOM;
   hipMemcpyAsync(gb->occ_slot, occ_slot_tmp, (size_t)G * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
-  // order groups by first occurrence: sort (first_row -> slot); first rows are distinct so any order of ties is moot
-  const uint32_t *ks = nullptr, *vs = nullptr;
-  rc = radix_sort_pairs<uint32_t>(occ_first_tmp, occ_slot_tmp, k0, v0, k1, v1, G, ilog2((uint64_t)n + 1) < 31 ? ilog2((uint64_t)n + 1) : 31,
-                                  &ks, &vs, true, s, st);
-  if (rc != PDX_OK) return rc;
-  int g = grid_for(G, 256);
-  hipLaunchKernelGGL(k_assign_gids, dim3(g), dim3(256), 0, st, table, dense_min, dense_mask, gb->gid_of_slot, ks, vs, G, null_slot, gb->uniques,
-                     gb->unique_ok, gb->first_rows, region);
-  hipLaunchKernelGGL(k_gid_of_occ, dim3(g), dim3(256), 0, st, gb->gid_of_slot, gb->occ_slot, G, gb->gid_of_occ);
+  // order groups by first occurrence: gid = rank of the group's first row among all first rows (bit map + block prefix, no sort)
+  {
+    const int64_t nwords = (n + 63) >> 6, nrb = ceil_div(nwords, (int64_t)kRankWords);
+    unsigned long long* bits = s.get<unsigned long long>((size_t)nwords);
+    int64_t* block_pre = s.get<int64_t>((size_t)nrb);
+    PDX_SCRATCH_CHECK(s);
+    PDX_HIP(hipMemsetAsync(bits, 0, (size_t)nwords * sizeof(unsigned long long), st));
+    const int g = grid_for(G, 256);
+    hipLaunchKernelGGL(k_mark_first_rows, dim3(g), dim3(256), 0, st, occ_first_tmp, G, bits);
+    hipLaunchKernelGGL(k_rank_block_counts, dim3(grid_for(nrb, 256)), dim3(256), 0, st, bits, nwords, nrb, block_pre);
+    PDX_TRY((device_exclusive_scan<int64_t, SumOp>(block_pre, block_pre, nrb, (int64_t*)nullptr, s, st)));
+    hipLaunchKernelGGL(k_assign_gids_ranked, dim3(g), dim3(256), 0, st, table, dense_min, dense_mask, gb->gid_of_slot, occ_first_tmp, occ_slot_tmp, G, bits,
+                       block_pre, null_slot, gb->uniques, gb->unique_ok, gb->first_rows, region, gb->gid_of_occ);
+  }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) return hip_fail(e, "pdx_groupby_create");
@@ -706,6 +779,7 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
       uint64_t *nv0 = nullptr, *nv1 = nullptr;
       uint32_t *nhist = nullptr, *nchunk = nullptr;
       uint8_t* k8 = nullptr;
+      hipEvent_t hmax_ready = nullptr;
       if (narrow) {
         const int b0 = low_plan.bits[0], b1 = low_plan.bits[1];
         const int64_t ntiles = ceil_div(n, kSortTile), nchunks = ceil_div(ntiles, kColChunk);
@@ -729,9 +803,30 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
         }
 #undef NARROW_P0
         PDX_TRY(rcn);
+        // pass 1 in two halves: its offsets first -- the run starts and the longest run (the host needs that number to choose the
+        // reducer) follow from them alone -- then the scatter, which runs while the host reads the number back
+#define NARROW_P1_OFFSETS(B) rcn = radix_offsets<B, uint16_t>(k16, n, 0, nhist, nchunk, true, st)
+        switch (b1) {
+          case 4: NARROW_P1_OFFSETS(4); break;
+          case 5: NARROW_P1_OFFSETS(5); break;
+          case 6: NARROW_P1_OFFSETS(6); break;
+          case 7: NARROW_P1_OFFSETS(7); break;
+          default: NARROW_P1_OFFSETS(8); break;
+        }
+#undef NARROW_P1_OFFSETS
+        PDX_TRY(rcn);
+        {
+          PDX_PROFILE("run_starts", st);
+          // (row 0 of the pass-0 offsets = where every first digit's rows begin in the input of pass 1)
+          hipLaunchKernelGGL((k_level_starts<uint16_t>), dim3(1u << b0), dim3(256), 0, st, k16, n, gb->pass0_off, (int64_t)1 << b0, b0, b1, nhist, run_start);
+          PDX_HIP(hipMemsetAsync(dmax, 0, sizeof(unsigned int), st));
+          hipLaunchKernelGGL(k_run_max_len, dim3(grid_for(nruns, 256)), dim3(256), 0, st, run_start, nruns, dmax);
+          PDX_LAUNCH_CHECK();
+          PDX_HIP(hipMemcpyAsync(hmax_pinned(), dmax, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+          PDX_HIP(hipEventCreateWithFlags(&hmax_ready, hipEventDisableTiming));
+          PDX_HIP(hipEventRecord(hmax_ready, st));
+        }
 #define NARROW_P1(B)                                                                    \
-  rcn = radix_offsets<B, uint16_t>(k16, n, 0, nhist, nchunk, true, st);                  \
-  if (rcn == PDX_OK)                                                                    \
     rcn = vvalid ? radix_scatter_narrow<B, uint64_t, uint16_t, uint8_t, true>(k16, nv0, k8, nv1, n, nhist, st) \
                  : radix_scatter_narrow<B, uint64_t, uint16_t, uint8_t>(k16, nv0, k8, nv1, n, nhist, st)
         switch (b1) {
@@ -742,11 +837,9 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
           default: NARROW_P1(8); break;
         }
 #undef NARROW_P1
-        PDX_TRY(rcn);
-        {
-          PDX_PROFILE("run_starts", st);
-          // (row 0 of the pass-0 offsets = where every first digit's rows begin in the input of pass 1)
-          hipLaunchKernelGGL((k_level_starts<uint16_t>), dim3(1u << b0), dim3(256), 0, st, k16, n, gb->pass0_off, (int64_t)1 << b0, b0, b1, nhist, run_start);
+        if (rcn != PDX_OK) {
+          (void)hipEventDestroy(hmax_ready);
+          return rcn;
         }
         keys8 = k8;
         vs = nv1;
@@ -755,10 +848,15 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
                                     gb->slot_bits - low_bits));
       }
       unsigned int hmax = 0;
-      {
+      if (narrow) {
+        const hipError_t ew = hipEventSynchronize(hmax_ready);
+        (void)hipEventDestroy(hmax_ready);
+        if (ew != hipSuccess) return hip_fail(ew, "pdx_groupby_agg");
+        hmax = *hmax_pinned();
+      } else {
         PDX_PROFILE("run_starts", st);
         PDX_HIP(hipMemsetAsync(dmax, 0, sizeof(unsigned int), st));
-        if (!narrow) hipLaunchKernelGGL(k_run_starts, dim3(grid_for(nruns + 1, 256)), dim3(256), 0, st, keys_sorted, n, low_bits, nruns, run_start, dmax);
+        hipLaunchKernelGGL(k_run_starts, dim3(grid_for(nruns + 1, 256)), dim3(256), 0, st, keys_sorted, n, low_bits, nruns, run_start, dmax);
         hipLaunchKernelGGL(k_run_max_len, dim3(grid_for(nruns, 256)), dim3(256), 0, st, run_start, nruns, dmax);
         PDX_LAUNCH_CHECK();
         PDX_HIP(hipMemcpyAsync(&hmax, dmax, sizeof(hmax), hipMemcpyDeviceToHost, st));
@@ -1023,6 +1121,7 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
   owner->stream = st;
   pdx_groupby* gb = owner.get();
   gb->mode = 1;
+  gb->resample = true;
   gb->n = n;
   gb->key_dtype = PDX_TIMESTAMP_NS;
   *out = nullptr;
@@ -1118,7 +1217,7 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
 
 int pdx_resample_row_labels(pdx_groupby* gb, int64_t* out_labels, void* stream) {
   if (!gb || !out_labels) return fail(PDX_INVALID, "pdx_resample_row_labels: null argument");
-  if (gb->mode != 1) return fail(PDX_INVALID, "pdx_resample_row_labels: handle was not created by pdx_resample_create");
+  if (!gb->resample) return fail(PDX_INVALID, "pdx_resample_row_labels: handle was not created by pdx_resample_create");
   hipStream_t st = as_stream(stream);
   gb->stream = st;  // frees of the handle's blocks are ordered behind this stream
   if (gb->n) hipLaunchKernelGGL(k_row_labels, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->bin, gb->label_base, gb->n, out_labels);

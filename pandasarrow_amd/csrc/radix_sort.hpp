@@ -368,7 +368,17 @@ inline SortPlan make_sort_plan(int total_bits, int max_bits_per_pass = 8) {
   if (total_bits < 1) total_bits = 1;
   p.npasses = (total_bits + max_bits_per_pass - 1) / max_bits_per_pass;
   int left = total_bits;
-  for (int i = 0; i < p.npasses; ++i) {
+  int first = 0;
+  // PDX_SORT_BITS0 (diagnostic): width of the first digit; the other passes share the rest evenly
+  if (const char* e = getenv("PDX_SORT_BITS0")) {
+    const int b0 = atoi(e), rest = p.npasses - 1;
+    if (rest >= 1 && b0 >= 4 && b0 <= max_bits_per_pass && total_bits - b0 >= 4 * rest && total_bits - b0 <= max_bits_per_pass * rest) {
+      p.bits[0] = b0;
+      left -= b0;
+      first = 1;
+    }
+  }
+  for (int i = first; i < p.npasses; ++i) {
     int b = (left + (p.npasses - i) - 1) / (p.npasses - i);
     if (b < 4) b = 4;
     p.bits[i] = b;

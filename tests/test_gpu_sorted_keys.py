@@ -1,0 +1,176 @@
+"""GPU: keys that arrive grouped (non-decreasing) take the segments path of pdx_groupby_create -- same groups, same order, same bits
+as the dictionary path (checked against the oracle and against the library itself with PDX_GROUPBY_SORTED=0)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def px():
+    from pandasarrow_amd import _lib as L
+    from pandasarrow_amd import api, column
+
+    L.check(L.load().pdx_init(0))
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.L, ns.K, ns.api, ns.Column = L, column, api, column.Column
+    return ns
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint64) if a.dtype.itemsize == 8 else a
+
+
+KINDS = ["SUM", "MEAN", "MIN", "MAX", "COUNT", "VARIANCE", "STDDEV", "PRODUCT", "FIRST", "LAST"]
+
+
+def _check_against_oracle(px, keys, vals, valid=None, dtype=None):
+    K, L, C = px.K, px.L, px.Column
+    kc = C.from_numpy(keys, dtype=dtype) if dtype is not None else C.from_numpy(keys)
+    gb = K.GroupByHandle.create(kc)
+    ids, uniq, _, first = orc.group_ids(keys.view(np.int64) if keys.dtype == np.uint64 else keys)
+    G = len(uniq)
+    assert gb.num_groups == G
+    assert np.array_equal(_bits(gb.unique_keys().to_numpy()[0]), _bits(uniq))
+    assert np.array_equal(gb.group_ids().cpu().numpy().astype(np.uint32), ids)
+    assert np.array_equal(gb.first_rows().cpu().numpy(), first)
+    vc = C.from_numpy(vals, valid)
+    outs = gb.agg(vc, [getattr(L, "AGG_" + k) for k in KINDS])
+    for k, o in zip(KINDS, outs):
+        want, wok = orc.groupby_agg(getattr(orc, "AGG_" + k), ids, G, vals, valid)
+        got, gok = o.to_numpy()
+        if gok is None:
+            gok = np.ones(G, bool)
+        if k == "COUNT":
+            wok = np.ones(G, bool)
+        assert np.array_equal(gok, wok), k
+        assert np.array_equal(_bits(got)[wok], _bits(want)[wok]), k
+    return gb
+
+
+def _sorted_keys(rng, n, ngroups, lo=-(10**12), hi=10**12):
+    pool = np.sort(rng.choice(np.arange(lo, hi, max(1, (hi - lo) // (4 * ngroups + 1)), dtype=np.int64), size=ngroups, replace=False))
+    return np.sort(pool[rng.integers(0, ngroups, n)])
+
+
+@pytest.mark.parametrize("n,ngroups", [(2, 1), (2, 2), (65, 3), (4096, 4096), (4097, 17), (100_003, 1000), (1_000_003, 250_000), (3_000_001, 5)])
+@pytest.mark.parametrize("isf", [True, False])
+def test_sorted_int64_keys_vs_oracle(px, n, ngroups, isf):
+    rng = np.random.default_rng(n * 7 + ngroups)
+    keys = _sorted_keys(rng, n, min(ngroups, n))
+    vals = (orc.synth_vals(3, n) - 0.5) * 1e3 if isf else rng.integers(-(10**9), 10**9, n)
+    _check_against_oracle(px, keys, vals)
+    valid = rng.random(n) > 0.2
+    _check_against_oracle(px, keys, vals, valid)
+
+
+def test_sorted_uint64_keys_crossing_the_sign_bit(px):
+    rng = np.random.default_rng(5)
+    n = 50_000
+    pool = np.sort(np.concatenate([rng.integers(0, 2**62, 40, dtype=np.uint64), rng.integers(2**63, 2**64 - 1, 40, dtype=np.uint64)]))
+    keys = np.sort(pool[rng.integers(0, 80, n)])  # unsigned order: descends once when read as int64
+    assert (keys.view(np.int64)[1:] < keys.view(np.int64)[:-1]).sum() == 1
+    _check_against_oracle(px, keys, orc.synth_vals(1, n), dtype=px.L.UINT64)
+
+
+def test_sample_passes_but_not_sorted(px):
+    """one swapped pair between the sampled positions: the counting pass finds it and the dictionary build takes over"""
+    rng = np.random.default_rng(9)
+    n = 1_500_000  # 65536 sampled pairs of 1.5e6: most pairs are never sampled
+    keys = _sorted_keys(rng, n, 3000)
+    cuts = np.flatnonzero(keys[1:] != keys[:-1])
+    hit = 0
+    for c in cuts:  # swap across a run boundary at an unsampled pair
+        sampled = set(int(j * (n - 1) // 65536) for j in (int(c * 65536 // (n - 1)) + d for d in (-1, 0, 1, 2)) if 0 <= j < 65536)
+        if int(c) not in sampled:
+            keys[c], keys[c + 1] = keys[c + 1], keys[c]
+            hit += 1
+            if hit == 3:
+                break
+    assert hit == 3 and (keys[1:] < keys[:-1]).sum() == 3
+    gb = _check_against_oracle(px, keys, orc.synth_vals(2, n))
+    assert gb.num_groups == 3000
+
+
+def test_same_bits_with_the_path_disabled(px):
+    K, L, C = px.K, px.L, px.Column
+    rng = np.random.default_rng(11)
+    n = 700_001
+    keys = _sorted_keys(rng, n, 40_000)
+    vals = orc.synth_vals(4, n) * 1e6 - 5e5
+    valid = rng.random(n) > 0.05
+    kinds = [getattr(L, "AGG_" + k) for k in KINDS]
+
+    def run():
+        gb = K.GroupByHandle.create(C.from_numpy(keys))
+        return [gb.unique_keys().to_numpy()[0], gb.group_ids().cpu().numpy(), gb.first_rows().cpu().numpy()] + [
+            x for o in gb.agg(C.from_numpy(vals, valid), kinds) for x in o.to_numpy()]
+
+    a = run()
+    os.environ["PDX_GROUPBY_SORTED"] = "0"
+    try:
+        b = run()
+    finally:
+        os.environ.pop("PDX_GROUPBY_SORTED", None)
+    assert len(a) == len(b)
+    for j in range(0, len(a)):
+        x, y = a[j], b[j]
+        if x is None or y is None:
+            assert x is None and y is None
+            continue
+        if j >= 3 and (j - 3) % 2 == 0 and a[j + 1] is not None:  # values of a nullable output: compare where valid
+            ok = a[j + 1]
+            assert np.array_equal(_bits(x)[ok], _bits(y)[ok]), j
+        else:
+            assert np.array_equal(_bits(x), _bits(y)), j
+
+
+def test_sorted_keys_with_nulls_take_the_dictionary(px):
+    K, L, C = px.K, px.L, px.Column
+    keys = np.array([1, 1, 2, 2, 3, 3, 3], np.int64)
+    kvalid = np.array([1, 0, 1, 1, 0, 1, 1], bool)
+    gb = K.GroupByHandle.create(C.from_numpy(keys, kvalid))
+    assert gb.num_groups == 4  # 1, null, 2, 3
+    u, uok = gb.unique_keys().to_numpy()
+    assert list(uok) == [True, False, True, True] and list(u[uok]) == [1, 2, 3]
+    s = gb.agg(C.from_numpy(np.arange(7.0)), [L.AGG_SUM])[0].to_numpy()[0]
+    assert list(s) == [0.0, 1.0 + 4.0, 2.0 + 3.0, 5.0 + 6.0]
+
+
+def test_extra_aggs_and_downsample_on_a_sorted_index(px):
+    K, L, C, api = px.K, px.L, px.Column, px.api
+    rng = np.random.default_rng(21)
+    n = 300_000
+    ts = np.sort(rng.integers(1_600_000_000, 1_600_000_000 + 40 * 86400, n)) * 10**9
+    vals = orc.synth_vals(6, n) - 0.5
+    df = api.DataFrame({"v": vals, "w": rng.integers(0, 50, n)}, index=C.from_numpy(ts, dtype=L.TIMESTAMP_NS))
+
+    def run():
+        r = df.downsample("6H", True, False, False)
+        return [r.index().to_numpy()[0]] + [fn()[c].to_numpy()[0] for fn in (r.sum, r.mean, r.min, r.max, r.count) for c in ("v", "w")]
+
+    a = run()
+    os.environ["PDX_GROUPBY_SORTED"] = "0"
+    try:
+        b = run()
+    finally:
+        os.environ.pop("PDX_GROUPBY_SORTED", None)
+    assert len(a[0]) > 100
+    for x, y in zip(a, b):
+        assert np.array_equal(_bits(x), _bits(y))
+    # count_distinct / all / any run their own dictionaries on top of the handle's group ids
+    keys = _sorted_keys(rng, n, 500)
+    gb = K.GroupByHandle.create(C.from_numpy(keys))
+    ids, uniq, _, _ = orc.group_ids(keys)
+    w = rng.integers(0, 20, n)
+    got = gb.agg(C.from_numpy(w), [L.AGG_COUNT_DISTINCT])[0].to_numpy()[0]
+    assert np.array_equal(got, orc.groupby_count_distinct(ids, len(uniq), w))
