@@ -258,6 +258,18 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
 /* per-row labels (GroupInfo::downsample): device pointer to num_rows int64 */
 int pdx_resample_row_labels(pdx_groupby* gb, int64_t* out_labels, void* stream);
 
+/* DataFrame::downsample's grouping in one call (reference src/dataframe.cpp:1265-1290: arrow::compute::CeilTemporal /
+ * FloorTemporal(m_index, RoundTemporalOptions(multiple, unit, week_starts_monday, false, calendar_based_origin)), for the
+ * M / W / Y / Q and *E rules Subtract(one day), then Resampler(GroupBy) keyed on the rounded index).  The handle behaves like
+ * pdx_groupby_create(pdx_round_temporal(ts) + label_shift_ns): unique keys = the distinct rounded labels (+ shift) in
+ * first-occurrence order, null timestamps form one null group.  ceil_mode / unit / multiple / week_starts_monday /
+ * calendar_based_origin as in pdx_round_temporal; label_shift_ns is added to every label (e.g. -86400e9).
+ * When ts has no nulls and its rounded labels never descend (a sorted axis) the groups are found as runs of equal labels in
+ * ONE pass over ts -- the rounded column is never materialised or hashed; any other input takes pdx_round_temporal +
+ * pdx_groupby_create internally.  Same results either way.  The handle keeps no pointer into ts. */
+int pdx_downsample_create(const pdx_column* ts, int64_t multiple, int unit, int ceil_mode, int week_starts_monday,
+                          int calendar_based_origin, int64_t label_shift_ns, void* stream, pdx_groupby** out);
+
 /* ---------------------------------------------------------------- temporal rounding: DataFrame::downsample
  * Replaces arrow::compute::FloorTemporal / CeilTemporal(m_index, RoundTemporalOptions(freq_value, getCalendarUnit(freq_unit[0]),
  * weekStartsMonday, ceil_is_strictly_greater = false, calendar_based_origin = startEpoch)) at src/dataframe.cpp:1271-1276

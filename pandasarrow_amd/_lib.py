@@ -103,6 +103,7 @@ ABI_SYMBOLS = {
     "pdx_resample_create": (C.c_int, [_COL, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _P, C.POINTER(_P)]),
     "pdx_resample_row_labels": (C.c_int, [_P, _P, _P]),
     "pdx_round_temporal": (C.c_int, [C.c_int, _COL, C.c_int64, C.c_int, C.c_int, C.c_int, _MUT, _P]),
+    "pdx_downsample_create": (C.c_int, [_COL, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, C.POINTER(_P)]),
     "pdx_concat": (C.c_int, [_COL, C.c_int, _MUT, _P]),
     "pdx_ipc_open": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "pdx_ipc_destroy": (C.c_int, [_P]),

@@ -452,14 +452,43 @@ class DataFrame:
         mult, unit_s = _split_time_span(rule)
         if not unit_s or unit_s[0] not in _DOWNSAMPLE_UNITS:  # getCalendarUnit (src/core.cpp:135-172)
             raise L.PdxError(L.INVALID, "invalid unit got " + unit_s[:1])
-        binned = K.round_temporal(self.index, mult, _DOWNSAMPLE_UNITS[unit_s[0]], closed_label_right, weekStartsMonday, startEpoch)
-        if unit_s.endswith("E") or unit_s in ("M", "W", "Y", "Q"):
-            # Subtract(binned, date32 scalar 1) -> Cast(int64) -> Cast(timestamp[ns]): one day less on the int64 view
-            as_i64 = Column(L.INT64, binned.length, binned.values, binned.validity, binned.offset, binned.null_count)
-            shifted = K.binary(L.SUB, as_i64, 86400 * 10**9, True)
-            binned = Column(L.TIMESTAMP_NS, shifted.length, shifted.values, shifted.validity, 0, shifted.null_count)
-        framed = self._like(self.cols, index=binned)
-        return Resampler(framed, _handle=K.GroupByHandle.create(binned))
+        unit = _DOWNSAMPLE_UNITS[unit_s[0]]
+        one_day_less = unit_s.endswith("E") or unit_s in ("M", "W", "Y", "Q")
+        src = self.index
+
+        def binned_index():
+            # the frame the reference's Resampler carries is indexed by the rounded labels; nothing on the aggregation path reads
+            # that index (the result is indexed by the handle's unique labels), so it is only built when somebody looks at it
+            binned = K.round_temporal(src, mult, unit, closed_label_right, weekStartsMonday, startEpoch)
+            if one_day_less:
+                # Subtract(binned, date32 scalar 1) -> Cast(int64) -> Cast(timestamp[ns]): one day less on the int64 view
+                as_i64 = Column(L.INT64, binned.length, binned.values, binned.validity, binned.offset, binned.null_count)
+                shifted = K.binary(L.SUB, as_i64, 86400 * 10**9, True)
+                binned = Column(L.TIMESTAMP_NS, shifted.length, shifted.values, shifted.validity, 0, shifted.null_count)
+            return binned
+
+        framed = _LazyIndexFrame(self.names, self.cols, binned_index)
+        handle = K.GroupByHandle.downsample(src, mult, unit, closed_label_right, weekStartsMonday, startEpoch,
+                                            -86400 * 10**9 if one_day_less else 0)
+        return Resampler(framed, _handle=handle)
+
+
+class _LazyIndexFrame(DataFrame):
+    """A DataFrame whose index column is produced on first access (DataFrame.downsample's rounded index)."""
+
+    def __init__(self, names, cols, make_index):
+        self.names, self.cols = list(names), cols
+        self._make_index, self._index = make_index, None
+
+    @property
+    def index(self):
+        if self._index is None and self._make_index is not None:
+            self._index, self._make_index = self._make_index(), None
+        return self._index
+
+    @index.setter
+    def index(self, value):
+        self._index, self._make_index = value, None
 
 
 class GroupBy:

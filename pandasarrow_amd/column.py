@@ -346,6 +346,16 @@ class GroupByHandle:
                                         int(offset_ns), _stream(), C.byref(h)))
         return GroupByHandle(h, L.TIMESTAMP_NS, keep_alive=ts)
 
+    @staticmethod
+    def downsample(ts: Column, multiple, unit, ceil=False, week_starts_monday=True, calendar_based_origin=False, label_shift_ns=0):
+        """Groups of equal Ceil/FloorTemporal labels (+ label_shift_ns) of a timestamp index -- DataFrame::downsample's GroupBy."""
+        lib = L.load()
+        h = C.c_void_p()
+        ct = ts.c()
+        L.check(lib.pdx_downsample_create(C.byref(ct), int(multiple), int(unit), int(bool(ceil)), int(bool(week_starts_monday)),
+                                          int(bool(calendar_based_origin)), int(label_shift_ns), _stream(), C.byref(h)))
+        return GroupByHandle(h, L.TIMESTAMP_NS)
+
     def close(self):
         if self._h is not None and self._h.value:
             L.load().pdx_groupby_destroy(self._h)

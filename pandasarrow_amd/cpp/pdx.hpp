@@ -819,9 +819,11 @@ inline Resampler DataFrame::downsample(const std::string& rule, bool closed_labe
     binned = Series::run_binary(PDX_SUB, as_i64, Scalar((int64_t)86400000000000LL).to_array(), true);
     binned.dtype = PDX_TIMESTAMP_NS;
   }
-  auto ck = binned.c();
+  // the grouping itself comes from the un-rounded index in one call (runs of equal labels on a sorted axis: no dictionary of `binned`)
   pdx_groupby* h = nullptr;
-  ThrowOnFailure(pdx_groupby_create(&ck, nullptr, &h));
+  const bool day_less = unit.back() == 'E' || unit == "M" || unit == "W" || unit == "Y" || unit == "Q";
+  ThrowOnFailure(pdx_downsample_create(&ci, mult, calendar_unit(unit[0]), closed_label_right ? 1 : 0, weekStartsMonday, startEpoch,
+                                       day_less ? -86400000000000LL : 0, nullptr, &h));
   return Resampler(DataFrame(m_names, m_columns, binned), std::make_shared<GroupHandle>(h), PDX_TIMESTAMP_NS);
 }
 inline GroupBy DataFrame::group_by(const std::string& key) const { return GroupBy(key, *this); }

@@ -72,52 +72,6 @@ int compact_indices(int64_t n, Pred pred, Emit emit, int64_t* total_host, Scratc
   return PDX_OK;
 }
 
-// The two halves of compact_indices for callers that size their outputs from the total: count (block offsets stay in `offsets`,
-// which must hold ceil_div(n, kCompactTile) entries), then write.  Blocks without a selected row return at once in the write pass.
-template <typename Pred>
-int compact_count(int64_t n, Pred pred, int64_t* offsets, int64_t* total_dev, Scratch& s, hipStream_t st) {
-  const int64_t nblocks = ceil_div(n, kCompactTile);
-  hipLaunchKernelGGL((k_compact_count<Pred>), dim3((unsigned)nblocks), dim3(kCompactBlock), 0, st, n, pred, offsets);
-  PDX_TRY((device_exclusive_scan<int64_t, SumOp>(offsets, offsets, nblocks, total_dev, s, st)));
-  PDX_LAUNCH_CHECK();
-  return PDX_OK;
-}
-template <typename Pred, typename Emit>
-__global__ void __launch_bounds__(kCompactBlock) k_compact_write_sparse(int64_t n, Pred pred, Emit emit, const int64_t* __restrict__ block_offsets,
-                                                                        int64_t nblocks, const int64_t* __restrict__ total) {
-  __shared__ int wave_tot[4];
-  const int64_t pos0 = block_offsets[blockIdx.x];
-  const int64_t pos1 = (int64_t)blockIdx.x + 1 < nblocks ? block_offsets[blockIdx.x + 1] : *total;
-  if (pos0 == pos1) return;  // (uniform per workgroup)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int64_t base = (int64_t)blockIdx.x * kCompactTile + wave * (64 * kCompactItems);
-  int cnt = 0;
-  for (int s = 0; s < kCompactItems; ++s) {
-    int64_t i = base + s * 64 + lane;
-    bool p = i < n && pred(i);
-    cnt += __popcll(__ballot(p));
-  }
-  if (lane == 0) wave_tot[wave] = cnt;
-  __syncthreads();
-  int64_t pos = pos0;
-  for (int w = 0; w < wave; ++w) pos += wave_tot[w];
-  const uint64_t lt = (1ull << lane) - 1ull;
-  for (int s = 0; s < kCompactItems; ++s) {
-    int64_t i = base + s * 64 + lane;
-    bool p = i < n && pred(i);
-    uint64_t b = __ballot(p);
-    if (p) emit(pos + __popcll(b & lt), i);
-    pos += __popcll(b);
-  }
-}
-template <typename Pred, typename Emit>
-int compact_write(int64_t n, Pred pred, Emit emit, const int64_t* offsets, const int64_t* total_dev, hipStream_t st) {
-  const int64_t nblocks = ceil_div(n, kCompactTile);
-  hipLaunchKernelGGL((k_compact_write_sparse<Pred, Emit>), dim3((unsigned)nblocks), dim3(kCompactBlock), 0, st, n, pred, emit, offsets, nblocks, total_dev);
-  PDX_LAUNCH_CHECK();
-  return PDX_OK;
-}
-
 // count only
 template <typename Pred>
 int count_if(int64_t n, Pred pred, int64_t* total_host, Scratch& s, hipStream_t st) {

@@ -58,14 +58,19 @@ __global__ void k_mark_first_rows(const uint32_t* __restrict__ occ_first, int64_
   }
 }
 __global__ void k_rank_block_counts(const unsigned long long* __restrict__ bits, int64_t nwords, int64_t nblocks, int64_t* __restrict__ counts) {
-  int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += stride) {
-    int c = 0;
-    const int64_t w0 = b * kRankWords;
-#pragma unroll
-    for (int q = 0; q < kRankWords; ++q)
-      if (w0 + q < nwords) c += __popcll(bits[w0 + q]);
-    counts[b] = c;
+  // kRankWords lanes per block, one word each (coalesced), folded with shuffles
+  static_assert(kRankWords == 16, "four blocks per wave");
+  const int sub = threadIdx.x & (kRankWords - 1);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x / kRankWords;
+  const int64_t nb_round = (nblocks + 3) & ~(int64_t)3;  // whole waves stay in the loop (the shuffles need all lanes)
+  for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kRankWords; b < nb_round; b += stride) {
+    const int64_t w = b * kRankWords + sub;
+    int c = (b < nblocks && w < nwords) ? __popcll(bits[w]) : 0;
+    c += __shfl_xor(c, 8, 64);
+    c += __shfl_xor(c, 4, 64);
+    c += __shfl_xor(c, 2, 64);
+    c += __shfl_xor(c, 1, 64);
+    if (sub == 0 && b < nblocks) counts[b] = c;
   }
 }
 // k_assign_gids with the rank computed from the bit map (block_pre = exclusive prefix of k_rank_block_counts)

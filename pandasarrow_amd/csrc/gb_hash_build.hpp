@@ -83,8 +83,15 @@ __global__ void __launch_bounds__(256) k_hash_insert(const long long* __restrict
 constexpr int kPartBits = 8;
 // 32-bit hash of a key as the partitioned build sees it; the two keys with dedicated slots get fixed hashes whose low bits
 // equal the low bits of those slots' logical ids (cap -> 0, cap + 1 -> 1)
+// (three 32-bit multiplies: the high word folded in with one, then the two rounds of the "lowbias32" integer mixer -- the probe
+//  kernel is instruction-issue bound, and splitmix64's two 64-bit multiplies were a sixth of its vector instructions)
 __device__ __forceinline__ uint32_t key_hash32(long long k, bool is_null) {
-  uint32_t h = (uint32_t)(splitmix64((uint64_t)k) >> 32);
+  uint32_t h = (uint32_t)(unsigned long long)k ^ ((uint32_t)((unsigned long long)k >> 32) * 0x85EBCA6Bu);
+  h ^= h >> 16;
+  h *= 0x7FEB352Du;
+  h ^= h >> 15;
+  h *= 0x846CA68Bu;
+  h ^= h >> 16;
   if (k == kEmptyKey) h = 1;
   if (is_null) h = 0;
   return h;
@@ -253,7 +260,8 @@ constexpr int kProbeBlock = 1024;
 __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long* __restrict__ keys_part, const uint32_t* __restrict__ rows_part,
                                                                 const uint32_t* __restrict__ bucket_off,
                                                                 int64_t n, Slot* table, unsigned int cap, unsigned int region,
-                                                                uint32_t* __restrict__ slot_part, HashCtl* ctl, unsigned int pb, int64_t head_rows) {
+                                                                uint32_t* __restrict__ slot_part, HashCtl* ctl, unsigned int pb, int64_t head_rows,
+                                                                uint16_t* __restrict__ idx16 /* slot index inside the bucket's region, or null */) {
   __shared__ unsigned long long lkeys[kLdsRegionMax];
   __shared__ unsigned int lfirst[kLdsRegionMax];
   __shared__ unsigned int linserted;
@@ -342,6 +350,7 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
         logical = (idx << pb) | b;
       }
       slot_part[p0 + (int64_t)u * kProbeBlock] = logical;
+      if (idx16) idx16[p0 + (int64_t)u * kProbeBlock] = (uint16_t)((logical >> pb) & 0xFFFFu);
     }
     if (!sampled) {
       // cardinality sample: after the bucket's first U*kProbeBlock rows every thread has inserted its rows, so (rows, distinct)
@@ -379,7 +388,8 @@ struct TailChunk {
 constexpr int kTailChunkRows = 1 << 17;
 __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds_tail(const long long* __restrict__ keys_part, const uint32_t* __restrict__ rows_part,
                                                                      const TailChunk* __restrict__ chunks, Slot* table, unsigned int cap,
-                                                                     unsigned int region, uint32_t* __restrict__ slot_part, HashCtl* ctl, unsigned int pb) {
+                                                                     unsigned int region, uint32_t* __restrict__ slot_part, HashCtl* ctl, unsigned int pb,
+                                                                     uint16_t* __restrict__ idx16) {
   __shared__ unsigned long long lkeys[kLdsRegionMax];
   __shared__ unsigned int linserted;
   __shared__ unsigned int lspecial[2];
@@ -455,6 +465,7 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds_tail(const long 
         logical = (idx << pb) | b;
       }
       slot_part[p0 + (int64_t)u * kProbeBlock] = logical;
+      if (idx16) idx16[p0 + (int64_t)u * kProbeBlock] = (uint16_t)((logical >> pb) & 0xFFFFu);
     }
   }
   __syncthreads();

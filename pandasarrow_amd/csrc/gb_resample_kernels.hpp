@@ -139,35 +139,91 @@ __global__ void __launch_bounds__(1024) k_sample_descents(const long long* __res
   if ((unsigned long long)b < (unsigned long long)a) f |= 2u;
   if (f) atomicOr(flags, f);
 }
-// Run starts of the keys.  CHECK: the counting pass also proves the order (flags as above, plain stores of a constant).
-template <bool CHECK>
-struct KeyRunStartPred {
-  const long long* keys;
-  const uint8_t* valid;
-  int64_t off;
-  unsigned int* flags;  // [0] signed descents, [1] unsigned descents, [2] null rows
-  __device__ bool operator()(int64_t i) const {
-    if constexpr (CHECK) {
-      if (valid && !bit_get(valid, off + i)) flags[2] = 1u;
+// ---- runs of equal labels over the rows as they stand.  LabelFn: __device__ long long operator()(int64_t row) const.
+// Count pass: every lane evaluates its row's label ONCE (the neighbour's comes through a shuffle; lane 0 of a wave's first step
+// evaluates the row in front of the wave), the run-start flags of 64 rows go to marks[row >> 6] as one ballot word, descents are
+// flagged in both integer orders (flags[0] signed, flags[1] unsigned: either order clean proves that equal labels are neighbours).
+// Write pass: reads the n / 8 bytes of marks, never the rows; workgroups without a run start return at once.
+constexpr int kRunBlock = 256, kRunSteps = 16, kRunTile = kRunBlock * kRunSteps;  // 4096 rows per workgroup, 1024 per wave
+template <typename LabelFn>
+__global__ void __launch_bounds__(kRunBlock) k_label_run_count(int64_t n, LabelFn fn, unsigned long long* __restrict__ marks,
+                                                                int64_t* __restrict__ block_counts, unsigned int* __restrict__ flags) {
+  __shared__ int wave_tot[kRunBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t base = (int64_t)blockIdx.x * kRunTile + (int64_t)wave * (64 * kRunSteps);
+  int cnt = 0;
+  bool desc_s = false, desc_u = false;
+  long long last = 0;
+  if (lane == 0 && base > 0 && base < n) last = fn(base - 1);
+#pragma unroll 4
+  for (int s = 0; s < kRunSteps; ++s) {
+    const int64_t i = base + (int64_t)s * 64 + lane;
+    const bool act = i < n;
+    const long long label = act ? fn(i) : 0;
+    long long prev = __shfl_up(label, 1, 64);
+    if (lane == 0) prev = last;
+    const bool start = act && (i == 0 || label != prev);
+    if (act && i > 0) {
+      desc_s |= label < prev;
+      desc_u |= (unsigned long long)label < (unsigned long long)prev;
     }
-    if (i == 0) return true;
-    const long long a = keys[i - 1], b = keys[i];
-    if constexpr (CHECK) {
-      if (b < a) flags[0] = 1u;
-      if ((unsigned long long)b < (unsigned long long)a) flags[1] = 1u;
-    }
-    return a != b;
+    const unsigned long long b = __ballot(start);
+    if (lane == 0 && base + (int64_t)s * 64 < n) marks[(base >> 6) + s] = b;
+    cnt += __popcll(b);
+    last = __shfl(label, 63, 64);
   }
-};
-struct KeyRunStartEmit {
+  if (desc_s) flags[0] = 1u;
+  if (desc_u) flags[1] = 1u;
+  if (lane == 0) wave_tot[wave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < kRunBlock / 64; ++w) t += wave_tot[w];
+    block_counts[blockIdx.x] = t;
+  }
+}
+// Emit: __device__ void operator()(int64_t run, int64_t row) const
+template <typename Emit>
+__global__ void __launch_bounds__(kRunBlock) k_label_run_write(int64_t n, const unsigned long long* __restrict__ marks, Emit emit,
+                                                                const int64_t* __restrict__ block_offsets, int64_t nblocks,
+                                                                const int64_t* __restrict__ total) {
+  __shared__ int wave_tot[kRunBlock / 64];
+  const int64_t pos0 = block_offsets[blockIdx.x];
+  const int64_t pos1 = (int64_t)blockIdx.x + 1 < nblocks ? block_offsets[blockIdx.x + 1] : *total;
+  if (pos0 == pos1) return;  // (uniform per workgroup)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t base = (int64_t)blockIdx.x * kRunTile + (int64_t)wave * (64 * kRunSteps);
+  unsigned long long word = 0;
+  if (lane < kRunSteps && base + (int64_t)lane * 64 < n) word = marks[(base >> 6) + lane];
+  int c = __popcll(word);
+  for (int d = 8; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);  // lanes 0..15 hold the wave's words
+  if (lane == 0) wave_tot[wave] = c;
+  __syncthreads();
+  int64_t pos = pos0;
+  for (int w = 0; w < wave; ++w) pos += wave_tot[w];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int s = 0; s < kRunSteps; ++s) {
+    const unsigned long long b = __shfl(word, s, 64);
+    if ((b >> lane) & 1ull) emit(pos + __popcll(b & lt), base + (int64_t)s * 64 + lane);
+    pos += __popcll(b);
+  }
+}
+struct KeyLabel {
   const long long* keys;
+  __device__ long long operator()(int64_t i) const { return keys[i]; }
+};
+// the run's label is recomputed from its first row; `shift` is added on the way out (downsample's "one day less" for M / W / Q rules)
+template <typename LabelFn>
+struct RunEmit {
+  LabelFn fn;
+  long long shift;
   uint32_t* seg_start;
   int64_t* uniques;
   int64_t* first_rows;
   uint32_t* gid_of_occ;  // identity: the runs are the groups, in first-occurrence order
   __device__ void operator()(int64_t pos, int64_t i) const {
     seg_start[pos] = (uint32_t)i;
-    uniques[pos] = keys[i];
+    uniques[pos] = (long long)((unsigned long long)fn(i) + (unsigned long long)shift);
     first_rows[pos] = i;
     gid_of_occ[pos] = (uint32_t)pos;
   }

@@ -35,6 +35,7 @@
 #include "pairwise.hpp"
 #include "radix_sort.hpp"
 #include "scan.hpp"
+#include "temporal_round.hpp"
 
 namespace pdx {
 #include "gb_hash_build.hpp"
@@ -55,6 +56,63 @@ namespace pdx {
 #include "gb_more_aggs.hpp"
 
 }  // namespace pdx
+
+// Groups = runs of equal labels over the rows as they stand (segments mode).  *done = false when the labels descend somewhere in
+// both integer orders (the caller then builds a dictionary); otherwise the handle is complete.
+template <typename LabelFn>
+static int build_label_runs(pdx_groupby* gb, int64_t n, LabelFn fn, long long shift, Scratch& s, hipStream_t st, bool* done) {
+  *done = false;
+  const int64_t nblocks = ceil_div(n, (int64_t)kRunTile);
+  unsigned int* flags = s.get<unsigned int>(2);
+  unsigned long long* marks = s.get<unsigned long long>((size_t)((n + 63) >> 6));
+  int64_t* offsets = s.get<int64_t>((size_t)nblocks);
+  int64_t* total = s.get<int64_t>(1);
+  PDX_SCRATCH_CHECK(s);
+  unsigned int hflags[2] = {0, 0};
+  int64_t G = 0;
+  {
+    PDX_PROFILE("label_runs", st);
+    PDX_HIP(hipMemsetAsync(flags, 0, sizeof(hflags), st));
+    hipLaunchKernelGGL((k_label_run_count<LabelFn>), dim3((unsigned)nblocks), dim3(kRunBlock), 0, st, n, fn, marks, offsets, flags);
+    PDX_TRY((device_exclusive_scan<int64_t, SumOp>(offsets, offsets, nblocks, total, s, st)));
+    PDX_LAUNCH_CHECK();
+  }
+  PDX_HIP(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, st));
+  PDX_HIP(hipMemcpyAsync(&G, total, sizeof(G), hipMemcpyDeviceToHost, st));
+  PDX_HIP(hipStreamSynchronize(st));
+  if (hflags[0] && hflags[1]) return PDX_OK;
+  gb->mode = 1;
+  gb->G = G;
+  gb->seg_start = gb->own<uint32_t>((size_t)G + 1);
+  gb->uniques = gb->own<int64_t>((size_t)G);
+  gb->first_rows = gb->own<int64_t>((size_t)G);
+  gb->unique_ok = gb->own<uint8_t>((size_t)G);
+  gb->gid_of_occ = gb->own<uint32_t>((size_t)G);
+  if (!gb->seg_start || !gb->uniques || !gb->first_rows || !gb->unique_ok || !gb->gid_of_occ) return PDX_OOM;
+  {
+    PDX_PROFILE("label_runs", st);
+    hipLaunchKernelGGL((k_label_run_write<RunEmit<LabelFn>>), dim3((unsigned)nblocks), dim3(kRunBlock), 0, st, n, marks,
+                       RunEmit<LabelFn>{fn, shift, gb->seg_start, gb->uniques, gb->first_rows, gb->gid_of_occ}, offsets, nblocks, total);
+    hipLaunchKernelGGL(k_set_last, dim3(1), dim3(64), 0, st, gb->seg_start, G, (uint32_t)n);
+    PDX_HIP(hipMemsetAsync(gb->unique_ok, 1, (size_t)G, st));
+    PDX_LAUNCH_CHECK();
+  }
+  PDX_HIP(hipStreamSynchronize(st));
+  *done = true;
+  return PDX_OK;
+}
+
+template <int MODE, bool CEIL>
+struct RoundLabel {
+  const long long* ts;
+  RoundParams q;
+  __device__ long long operator()(int64_t i) const { return round_one<MODE, CEIL>(ts[i], q); }
+};
+__global__ void k_shift_labels(int64_t* __restrict__ labels, int64_t G, long long shift) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G; i += stride)
+    labels[i] = (long long)((unsigned long long)labels[i] + (unsigned long long)shift);
+}
 
 // one pinned word per host thread: the target of small device-to-host reads that must not block the launches queued behind them
 // (a copy into pageable memory is staged and waits; pinned memory makes hipMemcpyAsync + an event a real overlap)
@@ -125,41 +183,12 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     PDX_LAUNCH_CHECK();
     PDX_HIP(hipStreamSynchronize(st));
   }
-  if (want_sorted_sample) {
-    const int64_t nblocks = ceil_div(n, kCompactTile);
-    if (!(hflags[3] & 4u) && (hflags[3] & 3u) != 3u) {
-      int64_t* offsets = s.get<int64_t>((size_t)nblocks);
-      int64_t* total = s.get<int64_t>(1);
-      if (s.failed) return PDX_OOM;
-      int64_t G = 0;
-      {
-        PDX_PROFILE("sorted_key_runs", st);
-        PDX_TRY(compact_count(n, KeyRunStartPred<true>{keys, valid, key->offset, flags}, offsets, total, s, st));
-      }
-      PDX_HIP(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, st));
-      PDX_HIP(hipMemcpyAsync(&G, total, sizeof(G), hipMemcpyDeviceToHost, st));
-      PDX_HIP(hipStreamSynchronize(st));
-      if (!hflags[2] && !(hflags[0] && hflags[1])) {
-        gb->mode = 1;
-        gb->G = G;
-        gb->seg_start = gb->own<uint32_t>((size_t)G + 1);
-        gb->uniques = gb->own<int64_t>((size_t)G);
-        gb->first_rows = gb->own<int64_t>((size_t)G);
-        gb->unique_ok = gb->own<uint8_t>((size_t)G);
-        gb->gid_of_occ = gb->own<uint32_t>((size_t)G);
-        if (!gb->seg_start || !gb->uniques || !gb->first_rows || !gb->unique_ok || !gb->gid_of_occ) return PDX_OOM;
-        {
-          PDX_PROFILE("sorted_key_runs", st);
-          PDX_TRY(compact_write(n, KeyRunStartPred<false>{keys, nullptr, 0, nullptr},
-                                KeyRunStartEmit{keys, gb->seg_start, gb->uniques, gb->first_rows, gb->gid_of_occ}, offsets, total, st));
-        }
-        hipLaunchKernelGGL(k_set_last, dim3(1), dim3(64), 0, st, gb->seg_start, G, (uint32_t)n);
-        PDX_HIP(hipMemsetAsync(gb->unique_ok, 1, (size_t)G, st));
-        PDX_LAUNCH_CHECK();
-        PDX_HIP(hipStreamSynchronize(st));
-        *out = owner.release();
-        return PDX_OK;
-      }
+  if (want_sorted_sample && !(hflags[3] & 4u) && (hflags[3] & 3u) != 3u) {
+    bool done = false;
+    PDX_TRY(build_label_runs(gb, n, KeyLabel{keys}, 0, s, st, &done));
+    if (done) {
+      *out = owner.release();
+      return PDX_OK;
     }
   }
   // ---- dense-domain fast path: valid keys span a small integer range -> slot = key - min (or its residue form), no table
@@ -367,9 +396,11 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     gb->part_off = gb->own<uint32_t>((size_t)ntiles << kPartBits);
     gb->slot_part = gb->own<uint32_t>((size_t)n);
     gb->rows_part = gb->own<uint32_t>((size_t)n);
+    gb->idx16_part = gb->own<uint16_t>((size_t)n);
+    bool idx16_written = false;  // by the attempt that succeeded (the LDS build at the first partition level)
     uint32_t* chunk_sum = s.get<uint32_t>((size_t)(nchunks + 1) << kPartBits);  // + digit totals row
     long long* keys_part = s.get<long long>((size_t)n);
-    if (s.failed || !gb->bucket8 || !gb->part_off || !gb->slot_part || !gb->rows_part) return PDX_OOM;
+    if (s.failed || !gb->bucket8 || !gb->part_off || !gb->slot_part || !gb->rows_part || !gb->idx16_part) return PDX_OOM;
     {
       // one pass over the keys: bucket byte per row (kept: it is the digit of the value partition of every later aggregation)
       // + the partition histogram
@@ -415,8 +446,10 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
               chunks.push_back(TailChunk{(uint32_t)bi, (uint32_t)c0, (uint32_t)std::min<int64_t>(c0 + kTailChunkRows, be)});
           }
         }
+        uint16_t* idx16 = pb == (unsigned)kPartBits ? gb->idx16_part : nullptr;
+        idx16_written = idx16 != nullptr;
         hipLaunchKernelGGL(k_hash_probe_lds, dim3(1u << pb), dim3(kProbeBlock), 0, st, keys_part, gb->rows_part, boff, n,
-                           table, cap, region, gb->slot_part, ctl, pb, head_rows);
+                           table, cap, region, gb->slot_part, ctl, pb, head_rows, idx16);
         if (!chunks.empty()) {
           TailChunk* dchunks = s.get<TailChunk>(chunks.size());
           if (s.failed) {
@@ -425,10 +458,11 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
           }
           PDX_HIP(hipMemcpyAsync(dchunks, chunks.data(), chunks.size() * sizeof(TailChunk), hipMemcpyHostToDevice, st));
           hipLaunchKernelGGL(k_hash_probe_lds_tail, dim3((unsigned)chunks.size()), dim3(kProbeBlock), 0, st, keys_part, gb->rows_part, dchunks, table, cap,
-                             region, gb->slot_part, ctl, pb);
+                             region, gb->slot_part, ctl, pb, idx16);
           PDX_HIP(hipStreamSynchronize(st));  // `chunks` (pageable host memory) must outlive the copy
         }
       } else {
+        idx16_written = false;
         PDX_PROFILE("hash_probe_part", st);
         constexpr unsigned int kWindowBits = 16;  // 2^16 slots = 1 MB per bucket window; about two buckets are active at a time
         const unsigned int nsweeps = region > (1u << kWindowBits) ? region >> kWindowBits : 1u;
@@ -529,6 +563,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
       cap = (unsigned int)std::min<uint64_t>(std::max<uint64_t>(next, (uint64_t)cap * 2), std::max<uint64_t>(want * 4, 1u << 16));
     }
     gb->part_bits = (int)pb;
+    if (!idx16_written) gb->idx16_part = nullptr;  // (the block stays owned by the handle; nothing reads it)
     gb->owned.push_back(table);
     {
       Slot sp[2];
@@ -598,7 +633,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     PDX_HIP(hipMemsetAsync(bits, 0, (size_t)nwords * sizeof(unsigned long long), st));
     const int g = grid_for(G, 256);
     hipLaunchKernelGGL(k_mark_first_rows, dim3(g), dim3(256), 0, st, occ_first_tmp, G, bits);
-    hipLaunchKernelGGL(k_rank_block_counts, dim3(grid_for(nrb, 256)), dim3(256), 0, st, bits, nwords, nrb, block_pre);
+    hipLaunchKernelGGL(k_rank_block_counts, dim3(grid_for(nrb * kRankWords, 256)), dim3(256), 0, st, bits, nwords, nrb, block_pre);
     PDX_TRY((device_exclusive_scan<int64_t, SumOp>(block_pre, block_pre, nrb, (int64_t*)nullptr, s, st)));
     hipLaunchKernelGGL(k_assign_gids_ranked, dim3(g), dim3(256), 0, st, table, dense_min, dense_mask, gb->gid_of_slot, occ_first_tmp, occ_slot_tmp, G, bits,
                        block_pre, null_slot, gb->uniques, gb->unique_ok, gb->first_rows, region, gb->gid_of_occ);
@@ -767,6 +802,12 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
     const bool narrow = flr && narrow_env && !gb->slot_part && gb->pass0_off && low_plan.npasses == 2 &&
                         gb->slot_bits - low_plan.bits[0] <= (vvalid ? 15 : 16) && low_plan.bits[0] <= 8 && low_plan.bits[1] <= 8 &&
                         eff_bits == gb->slot_bits;
+    // The same for the hash-partitioned layout (LDS build, one level, values without nulls): the value partition by bucket plays
+    // pass 0, the build left every row's 13-bit index inside its bucket's region as a 2-byte key (idx16_part), so the one sort pass
+    // below the fused digit reads 2-byte keys and writes the top digit alone: 8 B/row less than carrying the 4-byte logical slot.
+    const int mid_bits = low_bits - part;
+    const bool narrow_part = flr && narrow_env && gb->slot_part && gb->idx16_part && !gb->digit2 && !vvalid && part == kPartBits && mid_bits >= 4 &&
+                             mid_bits <= 8 && eff_bits - part <= 16;
     const uint8_t* keys8 = nullptr;       // narrowing sort: the top digit of every partially sorted row
     bool sorted_done = false;             // narrowing sort, skewed keys: the classic path's inputs are already built
     uint32_t* ss_narrow = nullptr;
@@ -780,10 +821,11 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
       uint32_t *nhist = nullptr, *nchunk = nullptr;
       uint8_t* k8 = nullptr;
       hipEvent_t hmax_ready = nullptr;
-      if (narrow) {
-        const int b0 = low_plan.bits[0], b1 = low_plan.bits[1];
+      if (narrow || narrow_part) {
+        const int b0 = narrow ? low_plan.bits[0] : kPartBits, b1 = narrow ? low_plan.bits[1] : mid_bits;
         const int64_t ntiles = ceil_div(n, kSortTile), nchunks = ceil_div(ntiles, kColChunk);
-        uint16_t* k16 = s.get<uint16_t>((size_t)n);
+        uint16_t* k16 = narrow ? s.get<uint16_t>((size_t)n) : gb->idx16_part;
+        const uint32_t* prev_off = narrow ? gb->pass0_off : gb->part_off;  // (row 0 = where every first digit's rows begin in the input of pass 1)
         k8 = s.get<uint8_t>((size_t)n);
         nv0 = s.get<uint64_t>((size_t)n);
         nv1 = s.get<uint64_t>((size_t)n);
@@ -794,13 +836,15 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
 #define NARROW_P0(B)                                                                                                                         \
   rcn = vvalid ? radix_scatter_narrow<B, uint64_t, uint32_t, uint16_t, true>(gb->slot_of_row, vin, k16, nv0, n, gb->pass0_off, st, vvalid, values->offset) \
                : radix_scatter_narrow<B, uint64_t, uint32_t, uint16_t>(gb->slot_of_row, vin, k16, nv0, n, gb->pass0_off, st)
-        switch (b0) {
-          case 4: NARROW_P0(4); break;
-          case 5: NARROW_P0(5); break;
-          case 6: NARROW_P0(6); break;
-          case 7: NARROW_P0(7); break;
-          default: NARROW_P0(8); break;
-        }
+        if (narrow_part) rcn = radix_scatter_only<kPartBits, uint64_t, uint8_t>(gb->bucket8, vin, nullptr, nv0, n, 0, false, gb->part_off, st);
+        else
+          switch (b0) {
+            case 4: NARROW_P0(4); break;
+            case 5: NARROW_P0(5); break;
+            case 6: NARROW_P0(6); break;
+            case 7: NARROW_P0(7); break;
+            default: NARROW_P0(8); break;
+          }
 #undef NARROW_P0
         PDX_TRY(rcn);
         // pass 1 in two halves: its offsets first -- the run starts and the longest run (the host needs that number to choose the
@@ -818,7 +862,7 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
         {
           PDX_PROFILE("run_starts", st);
           // (row 0 of the pass-0 offsets = where every first digit's rows begin in the input of pass 1)
-          hipLaunchKernelGGL((k_level_starts<uint16_t>), dim3(1u << b0), dim3(256), 0, st, k16, n, gb->pass0_off, (int64_t)1 << b0, b0, b1, nhist, run_start);
+          hipLaunchKernelGGL((k_level_starts<uint16_t>), dim3(1u << b0), dim3(256), 0, st, k16, n, prev_off, (int64_t)1 << b0, b0, b1, nhist, run_start);
           PDX_HIP(hipMemsetAsync(dmax, 0, sizeof(unsigned int), st));
           hipLaunchKernelGGL(k_run_max_len, dim3(grid_for(nruns, 256)), dim3(256), 0, st, run_start, nruns, dmax);
           PDX_LAUNCH_CHECK();
@@ -848,7 +892,7 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
                                     gb->slot_bits - low_bits));
       }
       unsigned int hmax = 0;
-      if (narrow) {
+      if (narrow || narrow_part) {
         const hipError_t ew = hipEventSynchronize(hmax_ready);
         (void)hipEventDestroy(hmax_ready);
         if (ew != hipSuccess) return hip_fail(ew, "pdx_groupby_agg");
@@ -862,7 +906,7 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
         PDX_HIP(hipMemcpyAsync(&hmax, dmax, sizeof(hmax), hipMemcpyDeviceToHost, st));
         PDX_HIP(hipStreamSynchronize(st));
       }
-      if (narrow && hmax > (1u << 19)) {
+      if ((narrow || narrow_part) && hmax > (1u << 19)) {
         // skewed keys: the fused kernel is skipped.  Finish the sort with the one pass that is left (on the byte digits) and take the
         // group offsets from its scatter offsets: one more level of k_level_starts gives the start of every slot's rows
         ss_narrow = s.get<uint32_t>((size_t)G + 1);
@@ -1213,6 +1257,97 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
   if (e != hipSuccess) return hip_fail(e, "pdx_resample_create");
   *out = owner.release();
   return PDX_OK;
+}
+
+// DataFrame::downsample (reference src/dataframe.cpp:1265-1290): Ceil/FloorTemporal of the index, optionally one day less, then a
+// GroupBy keyed on the rounded index.  On a sorted axis the rounded labels are (almost always) non-decreasing, so the groups are
+// runs of equal labels: ONE pass over the timestamps rounds each row in registers, marks the run starts and proves the order --
+// the rounded column is never written or hashed (8 B/row instead of 16 + the dictionary build).  Anything else (nulls, an unsorted
+// axis, a calendar-origin ceil that steps back at an origin) goes through pdx_round_temporal + pdx_groupby_create as before.
+int pdx_downsample_create(const pdx_column* ts, int64_t multiple, int unit, int ceil_mode, int week_starts_monday, int calendar_based_origin,
+                          int64_t label_shift_ns, void* stream, pdx_groupby** out) {
+  PDX_TRY(check_column(ts, "pdx_downsample_create"));
+  if (!out) return fail(PDX_INVALID, "pdx_downsample_create: null output");
+  if (ts->dtype != PDX_TIMESTAMP_NS) return fail(PDX_INVALID, "pdx_downsample_create: index must be PDX_TIMESTAMP_NS");
+  RoundParams q{};
+  int mode = 0;
+  PDX_TRY(make_round_params(multiple, unit, week_starts_monday, calendar_based_origin, &q, &mode, "pdx_downsample_create"));
+  const int64_t n = ts->length;
+  if (n > 0x7FFFFFFFll) return fail(PDX_NOT_IMPLEMENTED, "pdx_downsample_create: more than 2^31-1 rows per call is not supported yet");
+  hipStream_t st = as_stream(stream);
+  *out = nullptr;
+  const bool runs_env = [] { const char* e = getenv("PDX_GROUPBY_SORTED"); return !(e && e[0] == '0'); }();
+  if (runs_env && n >= 1 && !validity_or_null(ts)) {
+    std::unique_ptr<pdx_groupby> owner(new pdx_groupby());
+    owner->stream = st;
+    pdx_groupby* gb = owner.get();
+    gb->n = n;
+    gb->key_dtype = PDX_TIMESTAMP_NS;
+    Scratch s;
+    const long long* t = static_cast<const long long*>(ts->values) + ts->offset;
+    bool done = false;
+    int rc = PDX_OK;
+#define DS_RUNS(M)                                                                                      \
+  rc = ceil_mode ? build_label_runs(gb, n, RoundLabel<M, true>{t, q}, label_shift_ns, s, st, &done)     \
+                 : build_label_runs(gb, n, RoundLabel<M, false>{t, q}, label_shift_ns, s, st, &done)
+    switch (mode) {
+      case 0: DS_RUNS(0); break;
+      case 1: DS_RUNS(1); break;
+      case 2: DS_RUNS(2); break;
+      case 3: DS_RUNS(3); break;
+      case 4: DS_RUNS(4); break;
+      case 5: DS_RUNS(5); break;
+      case 6: DS_RUNS(6); break;
+      case 7: DS_RUNS(7); break;
+      case 8: DS_RUNS(8); break;
+      default: DS_RUNS(9); break;
+    }
+#undef DS_RUNS
+    if (rc != PDX_OK) return rc;
+    if (done) {
+      *out = owner.release();
+      return PDX_OK;
+    }
+  }
+  // the general way: the rounded column, then a dictionary of it (first-occurrence order; nulls form their own group)
+  const bool has_nulls = validity_or_null(ts) != nullptr;
+  void* binned_vals = pool_alloc((size_t)(n ? n : 1) * sizeof(int64_t));
+  void* binned_valid = has_nulls ? pool_alloc((size_t)(n + 7) / 8 + 8) : nullptr;
+  if (!binned_vals || (has_nulls && !binned_valid)) {
+    if (binned_vals) pool_free(binned_vals);
+    if (binned_valid) pool_free(binned_valid);
+    return PDX_OOM;
+  }
+  pdx_mut_column mb{};
+  mb.dtype = PDX_TIMESTAMP_NS;
+  mb.length = n;
+  mb.values = binned_vals;
+  mb.validity = binned_valid;
+  int rc = pdx_round_temporal(ceil_mode, ts, multiple, unit, week_starts_monday, calendar_based_origin, &mb, stream);
+  if (rc == PDX_OK) {
+    pdx_column cb{};
+    cb.dtype = PDX_TIMESTAMP_NS;
+    cb.length = n;
+    cb.values = binned_vals;
+    cb.validity = binned_valid;
+    cb.offset = 0;
+    cb.null_count = has_nulls ? -1 : 0;
+    rc = pdx_groupby_create(&cb, stream, out);
+  }
+  if (rc == PDX_OK && *out && label_shift_ns != 0 && (*out)->G > 0) {
+    hipLaunchKernelGGL(k_shift_labels, dim3(grid_for((*out)->G, 256)), dim3(256), 0, st, (*out)->uniques, (*out)->G, (long long)label_shift_ns);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = fail(PDX_DEVICE, "pdx_downsample_create: label shift failed");
+  }
+  {
+    StreamNote note(st);
+    pool_free(binned_vals);
+    if (binned_valid) pool_free(binned_valid);
+  }
+  if (rc != PDX_OK && *out) {
+    pdx_groupby_destroy(*out);
+    *out = nullptr;
+  }
+  return rc;
 }
 
 int pdx_resample_row_labels(pdx_groupby* gb, int64_t* out_labels, void* stream) {

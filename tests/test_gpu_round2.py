@@ -141,6 +141,16 @@ def test_round_temporal_nulls_errors_large(px):
                 got = px.K.round_temporal(T, mult, unit, ceil, unit % 2 == 0, cbo).to_numpy()[0]
                 exp, _ = orc.round_temporal(ts, mult, unit, ceil, unit % 2 == 0, cbo)
                 assert np.array_equal(got, exp), (unit, mult, cbo, ceil)
+    # timestamps near the ends of int64 (the reciprocal-multiply division corrects its estimate with the exact remainder)
+    far = np.concatenate([rng.integers(-91 * 10**17, -89 * 10**17, 50_000), rng.integers(89 * 10**17, 91 * 10**17, 50_000),
+                          np.array([0, -1, 1, -10**9, 10**9 - 1, 59_999_999_999, 60_000_000_000, -60_000_000_001])])
+    F = px.Column.from_numpy(far, dtype=px.L.TIMESTAMP_NS)
+    for unit in range(0, 8):
+        for mult, cbo in ((1, False), (13, False), (13, True)):
+            for ceil in (False, True):
+                got = px.K.round_temporal(F, mult, unit, ceil, True, cbo).to_numpy()[0]
+                exp, _ = orc.round_temporal(far, mult, unit, ceil, True, cbo)
+                assert np.array_equal(got, exp), ("far", unit, mult, cbo, ceil)
 
 
 @pytest.mark.parametrize("name", G2.cases("downsample"))

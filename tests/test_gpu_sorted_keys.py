@@ -146,6 +146,84 @@ def test_sorted_keys_with_nulls_take_the_dictionary(px):
     assert list(s) == [0.0, 1.0 + 4.0, 2.0 + 3.0, 5.0 + 6.0]
 
 
+@pytest.mark.parametrize("rule,clr,epoch", [("1T", True, True), ("5T", False, True), ("7H", True, False), ("5H", True, True), ("D", True, True),
+                                            ("3D", False, False), ("3D", True, True), ("W", True, True), ("2W", False, False), ("2W", True, True),
+                                            ("M", True, True), ("2M", False, True), ("Q", True, True), ("90S", False, True)])
+def test_downsample_create_runs_vs_dictionary(px, rule, clr, epoch):
+    """pdx_downsample_create: one pass over a sorted axis (runs of equal rounded labels) against the same call with the run path
+    disabled (round_temporal + dictionary), and against the oracle's labels.  "5H" / "3D" / "2W" with a calendar origin and ceil
+    step back at an origin: the labels descend, the run path gives up and the dictionary takes over inside the same call."""
+    K, L, C, api = px.K, px.L, px.Column, px.api
+    rng = np.random.default_rng(len(rule) * 31 + clr * 7 + epoch)
+    n = 200_003
+    span = {"T": 3, "S": 1, "H": 60, "D": 400, "W": 2000, "M": 4000, "Q": 9000}[rule[-1]] * 86400
+    ts = np.sort(rng.integers(1_500_000_000, 1_500_000_000 + span, n)) * 10**9 + rng.integers(0, 10**9, n)
+    ts.sort()
+    vals = orc.synth_vals(8, n) - 0.5
+    valid = rng.random(n) > 0.1
+    df = api.DataFrame({"v": api.Series(vals, valid=valid), "w": rng.integers(-5, 50, n)}, index=C.from_numpy(ts, dtype=L.TIMESTAMP_NS))
+
+    wsm = len(rule) % 2 == 0
+
+    def run():
+        r = df.downsample(rule, clr, wsm, epoch)
+        out = [r.index().to_numpy()[0], None]
+        for fn in (r.sum, r.mean, r.min, r.max, r.count):
+            res = fn()
+            out += [res["v"].to_numpy()[0], res["v"].to_numpy()[1], res["w"].to_numpy()[0]]
+        return out, r.df.index.to_numpy()[0]
+
+    (a, abinned) = run()
+    os.environ["PDX_GROUPBY_SORTED"] = "0"
+    try:
+        (b, bbinned) = run()
+    finally:
+        os.environ.pop("PDX_GROUPBY_SORTED", None)
+    assert np.array_equal(abinned, bbinned)
+    assert len(a[0]) >= 2
+    for j, (x, y) in enumerate(zip(a, b)):
+        if x is None:
+            continue
+        if j >= 2 and (j - 2) % 3 == 0:  # float values of a nullable column: compare where valid
+            ok = a[j + 1]
+            assert np.array_equal(_bits(x)[ok], _bits(y)[ok]), (rule, j)
+        else:
+            assert np.array_equal(_bits(x), _bits(y)), (rule, j)
+    # the rounded labels of the groups are the distinct values of the rounded index, in first-occurrence order
+    _, first = np.unique(abinned, return_index=True)
+    assert np.array_equal(a[0], abinned[np.sort(first)])
+
+
+def test_downsample_create_nulls_unsorted_and_errors(px):
+    K, L, C = px.K, px.L, px.Column
+    rng = np.random.default_rng(3)
+    n = 50_000
+    ts = rng.integers(1_600_000_000, 1_600_000_000 + 30 * 86400, n) * 10**9  # unsorted
+    tvalid = rng.random(n) > 0.05
+    vals = orc.synth_vals(9, n)
+    for valid in (None, tvalid):
+        T = C.from_numpy(ts, valid, dtype=L.TIMESTAMP_NS)
+        h = K.GroupByHandle.downsample(T, 6, L.UNIT_HOUR, True, True, True, -86400 * 10**9)
+        binned = K.round_temporal(T, 6, L.UNIT_HOUR, True, True, True)
+        bv, bok = binned.to_numpy()
+        ref = K.GroupByHandle.create(binned)
+        u, uok = h.unique_keys().to_numpy()
+        ru, ruok = ref.unique_keys().to_numpy()
+        assert np.array_equal(uok, ruok) and np.array_equal(u[uok], ru[ruok] - 86400 * 10**9)
+        assert np.array_equal(h.group_ids().cpu().numpy(), ref.group_ids().cpu().numpy())
+        got = h.agg(C.from_numpy(vals), [L.AGG_SUM])[0].to_numpy()[0]
+        exp = ref.agg(C.from_numpy(vals), [L.AGG_SUM])[0].to_numpy()[0]
+        assert np.array_equal(_bits(got), _bits(exp))
+    with pytest.raises(RuntimeError):
+        K.GroupByHandle.downsample(C.from_numpy(ts, dtype=L.TIMESTAMP_NS), 0, L.UNIT_HOUR)
+    with pytest.raises(RuntimeError, match="PDX_TIMESTAMP_NS"):
+        K.GroupByHandle.downsample(C.from_numpy(ts), 1, L.UNIT_HOUR)
+    e = K.GroupByHandle.downsample(C.from_numpy(np.zeros(0, np.int64), dtype=L.TIMESTAMP_NS), 1, L.UNIT_DAY)
+    assert e.num_groups == 0
+    one = K.GroupByHandle.downsample(C.from_numpy(np.array([86400 * 10**9 + 5]), dtype=L.TIMESTAMP_NS), 1, L.UNIT_DAY, True)
+    assert list(one.unique_keys().to_numpy()[0]) == [2 * 86400 * 10**9]
+
+
 def test_extra_aggs_and_downsample_on_a_sorted_index(px):
     K, L, C, api = px.K, px.L, px.Column, px.api
     rng = np.random.default_rng(21)

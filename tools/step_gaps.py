@@ -1,5 +1,5 @@
 """Idle gaps between consecutive kernels of a rocprofv3 --kernel-trace CSV (one process, one stream): where the host round trips of a
-step sit.  usage: python tools/step_gaps.py <dir with *_kernel_trace.csv> [min_gap_us]"""
+step sit.  usage: python tools/step_gaps.py <dir with *_kernel_trace.csv> [min_gap_us] [all]   (all: also one line per kernel of the last step)"""
 import csv
 import glob
 import sys
@@ -19,9 +19,12 @@ last = rows[first:]
 t0 = last[0][0]
 total_gap = 0.0
 busy = 0.0
+show_all = len(sys.argv) > 3 and sys.argv[3] == "all"
 for (s0, e0, n0), (s1, e1, n1) in zip(last, last[1:]):
     gap = (s1 - e0) / 1e3
     busy += (e0 - s0) / 1e3
+    if show_all:
+        print(f"{(s0 - t0) / 1e3:10.1f} us  run {(e0 - s0) / 1e3:9.1f} us  {n0[:110]}")
     if gap > 0:
         total_gap += gap
     if gap >= min_gap:
