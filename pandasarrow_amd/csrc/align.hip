@@ -7,7 +7,7 @@
 //
 // Device form: both steps are the group-by dictionary (csrc/groupby.hip) applied to a concatenation.
 //   union   : uniques of concat(a, b) (first-occurrence dictionary), then a stable LSD radix sort of the 64-bit labels
-//             (three rounds of <= 22 key bits through the 32-bit pair sort, sign bit flipped for signed labels)
+//             (sort_packed64 below: eight 8-bit passes over (low key half, high key half | row) elements, constant digits skipped)
 //   reindex : group ids of concat(reverse(old), new); a new label is present iff its group's first row lies in the reversed old
 //             part, and that first row is the LAST position of the label in the old index.  Output = take indices with a
 //             validity bitmap (absent -> null); values then go through pdx_take, whose null indices yield null rows.
@@ -26,17 +26,6 @@ __global__ void k_concat2_i64(const long long* __restrict__ a, int64_t na, int r
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
     out[i] = i < na ? a[reverse_a ? na - 1 - i : i] : b[i - na];
 }
-__global__ void k_align_iota(uint32_t* __restrict__ out, int64_t n) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (uint32_t)i;
-}
-// sort key of one round: bits [shift, shift + nbits) of the order-preserving unsigned image of the label at perm[i]
-__global__ void k_label_chunk(const long long* __restrict__ labels, const uint32_t* __restrict__ perm, int64_t n, int shift, uint32_t mask,
-                              unsigned long long flip, uint32_t* __restrict__ out) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    out[i] = (uint32_t)((((unsigned long long)labels[perm[i]]) ^ flip) >> shift) & mask;
-}
 __global__ void k_gather_labels(const long long* __restrict__ labels, const uint32_t* __restrict__ perm, int64_t n, long long* __restrict__ out) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = labels[perm[i]];
@@ -52,56 +41,152 @@ __global__ void k_reindex_emit(const uint32_t* __restrict__ gids, const int64_t*
   }
 }
 
-// ---- sort keys: the order-preserving unsigned image of every value (ascending: as is, descending: complemented) and its class
-// (0 number, 1 NaN, 2 null): numbers first, then NaNs, then nulls in BOTH orders, as Arrow's array_sort_indices places them
-__global__ void k_sort_keys(const unsigned long long* __restrict__ v, const uint8_t* __restrict__ valid, int64_t off, int64_t n, int dtype, int descending,
-                            long long* __restrict__ key, long long* __restrict__ cls) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    unsigned long long u = v[i];
-    long long c = 0;
-    if (valid && !bit_get(valid, off + i)) {
-      c = 2;
-      u = 0;
-    } else if (dtype == PDX_FLOAT64) {
-      const double x = __longlong_as_double((long long)u);
-      if (x != x) {
-        c = 1;
-        u = 0;
-      } else {
-        if (x == 0.0) u = 0;  // -0.0 and 0.0 compare equal: one key, so the stable sort keeps their row order
-        u = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-      }
-    } else if (dtype != PDX_UINT64) {
-      u ^= 0x8000000000000000ull;  // int64 / timestamp
+// ---- 64-bit stable sort with row numbers.  An element is (lo: low 32 key bits, pay: high 32 key bits << 32 | row): four LSD passes on
+// `lo` carry the payload along, four more take their digit from the payload's own high half (k_radix_scatter PAYLOAD_DIGIT), so
+// the keys are never gathered through a permutation (the three-round form did: k_label_chunk read keys[perm[i]], ten 16 B/row
+// passes + four random gathers = 13.5 ms per 1e8 rows).  Digits that are equal in every key (OR == AND over the column) are skipped.
+
+// the order-preserving unsigned image of a value (ascending: as is, descending: complemented) and its class (0 number, 1 NaN,
+// 2 null): numbers first, then NaNs, then nulls in BOTH orders, as Arrow's array_sort_indices places them
+__device__ __forceinline__ unsigned long long sort_image(unsigned long long u, bool is_null, int dtype, int descending, int* cls) {
+  *cls = 0;
+  if (is_null) {
+    *cls = 2;
+    return 0;
+  }
+  if (dtype == PDX_FLOAT64) {
+    const double x = __longlong_as_double((long long)u);
+    if (x != x) {
+      *cls = 1;
+      return 0;
     }
-    if (descending && c == 0) u = ~u;
-    key[i] = (long long)u;
-    cls[i] = c;
+    if (x == 0.0) u = 0;  // -0.0 and 0.0 compare equal: one key, so the stable sort keeps their row order
+    u = (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+  } else if (dtype != PDX_UINT64) {
+    u ^= 0x8000000000000000ull;  // int64 / timestamp
+  }
+  return descending ? ~u : u;
+}
+struct SortStats {
+  unsigned long long bits_or, bits_and;  // over the keys of class 0
+  unsigned long long others;             // rows of class 1 / 2
+};
+__device__ __forceinline__ void sort_stats_flush(SortStats* st, unsigned long long o, unsigned long long a, unsigned long long others) {
+  for (int d = 32; d >= 1; d >>= 1) {
+    o |= __shfl_xor(o, d, 64);
+    a &= __shfl_xor(a, d, 64);
+    others += __shfl_xor(others, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicOr(&st->bits_or, o);
+    atomicAnd(&st->bits_and, a);
+    if (others) atomicAdd(&st->others, others);
   }
 }
-__global__ void k_perm_to_u64(const uint32_t* __restrict__ perm, int64_t n, unsigned long long* __restrict__ out) {
+// every row: class byte (cls8 != nullptr) and -- when lo / pay are given -- the packed element at the row's own position
+__global__ void k_sort_pack(const unsigned long long* __restrict__ v, const uint8_t* __restrict__ valid, int64_t off, int64_t n, int dtype, int descending,
+                            unsigned long long flip, uint8_t* __restrict__ cls8, uint32_t* __restrict__ lo, unsigned long long* __restrict__ pay,
+                            SortStats* __restrict__ stats) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = perm[i];
-}
-// Stable LSD sort of `perm` by the 64-bit keys keys64[perm[i]] ^ flip (unsigned order): three rounds of <= 22 bits through the
-// 32-bit pair sort.  perm is updated in place.
-static int argsort_rounds64(const long long* keys64, int64_t n, unsigned long long flip, uint32_t* perm, Scratch& s, hipStream_t st) {
-  uint32_t* chunk = s.get<uint32_t>((size_t)n);
-  uint32_t* k0 = s.get<uint32_t>((size_t)n);
-  uint32_t* k1 = s.get<uint32_t>((size_t)n);
-  uint32_t* v0 = s.get<uint32_t>((size_t)n);
-  uint32_t* v1 = s.get<uint32_t>((size_t)n);
-  PDX_SCRATCH_CHECK(s);
-  const int shifts[3] = {0, 22, 43}, widths[3] = {22, 21, 21};
-  for (int r = 0; r < 3; ++r) {
-    hipLaunchKernelGGL(k_label_chunk, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, keys64, perm, n, shifts[r], (1u << widths[r]) - 1, flip, chunk);
-    PDX_LAUNCH_CHECK();
-    const uint32_t* ks = nullptr;
-    const uint32_t* vs = nullptr;
-    PDX_TRY((radix_sort_pairs<uint32_t>(chunk, perm, k0, v0, k1, v1, n, widths[r], &ks, &vs, false, s, st)));
-    PDX_HIP(hipMemcpyAsync(perm, vs, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  unsigned long long o = 0, a = ~0ull, others = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int c;
+    const unsigned long long u = sort_image(v[i] ^ flip, valid && !bit_get(valid, off + i), dtype, descending, &c);
+    if (cls8) cls8[i] = (uint8_t)c;
+    if (c == 0) {
+      o |= u;
+      a &= u;
+      if (lo) {
+        lo[i] = (uint32_t)u;
+        pay[i] = (u & 0xFFFFFFFF00000000ull) | (unsigned long long)i;
+      }
+    } else {
+      ++others;
+    }
   }
+  sort_stats_flush(stats, o, a, others);
+}
+struct ClassPred {
+  const uint8_t* cls8;
+  int c;
+  __device__ bool operator()(int64_t i) const { return cls8[i] == c; }
+};
+struct PackEmit {  // the numbers, compacted in row order
+  const unsigned long long* v;
+  int dtype, descending;
+  uint32_t* lo;
+  unsigned long long* pay;
+  __device__ void operator()(int64_t pos, int64_t i) const {
+    int c;
+    const unsigned long long u = sort_image(v[i], false, dtype, descending, &c);
+    lo[pos] = (uint32_t)u;
+    pay[pos] = (u & 0xFFFFFFFF00000000ull) | (unsigned long long)i;
+  }
+};
+struct RowEmit {  // NaN / null rows behind the numbers, in row order
+  unsigned long long* out;
+  int64_t base;
+  __device__ void operator()(int64_t pos, int64_t i) const { out[base + pos] = (unsigned long long)i; }
+};
+__global__ void k_pay_rows_u64(const unsigned long long* __restrict__ pay, int64_t n, unsigned long long* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = pay[i] & 0xFFFFFFFFull;
+}
+__global__ void k_pay_rows_u32(const unsigned long long* __restrict__ pay, int64_t n, uint32_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (uint32_t)pay[i];
+}
+// Sorts the n packed elements (lo0, pay0) by their 64-bit key; `varying` = key bits that differ somewhere.  *sorted points at the
+// payloads in key order (one of the ping-pong buffers).
+static int sort_packed64(uint32_t* lo0, unsigned long long* pay0, int64_t n, unsigned long long varying, Scratch& s, hipStream_t st,
+                         const unsigned long long** sorted) {
+  *sorted = pay0;
+  if (n <= 1 || varying == 0) return PDX_OK;
+  const int64_t ntiles = ceil_div(n, kSortTile), nchunks = ceil_div(ntiles, kColChunk);
+  uint32_t* lo1 = s.get<uint32_t>((size_t)n);
+  unsigned long long* pay1 = s.get<unsigned long long>((size_t)n);
+  uint32_t* hist = s.get<uint32_t>((size_t)ntiles << 8);
+  uint32_t* chunk = s.get<uint32_t>((size_t)(nchunks + 1) << 8);
+  PDX_SCRATCH_CHECK(s);
+  const uint32_t* kin = lo0;
+  const unsigned long long* vin = pay0;
+  int last_lo = -1;
+  for (int d = 0; d < 4; ++d)
+    if ((varying >> (8 * d)) & 0xFFull) last_lo = d;
+  for (int d = 0; d < 8; ++d) {
+    if (!((varying >> (8 * d)) & 0xFFull)) continue;
+    unsigned long long* vout = vin == pay0 ? pay1 : pay0;
+    if (d < 4) {
+      uint32_t* kout = kin == lo0 ? lo1 : lo0;
+      PDX_TRY((radix_pass_dispatch<uint64_t>(8, kin, reinterpret_cast<const uint64_t*>(vin), kout, reinterpret_cast<uint64_t*>(vout), n, 8 * d, d != last_lo,
+                                             hist, chunk, st)));
+      if (d != last_lo) kin = kout;
+    } else {
+      PDX_TRY((radix_pass_payload_hi<8>(reinterpret_cast<const uint64_t*>(vin), reinterpret_cast<uint64_t*>(vout), n, 8 * (d - 4), hist, chunk, st)));
+    }
+    vin = vout;
+  }
+  *sorted = vin;
+  return PDX_OK;
+}
+// perm[i] = index of the i-th smallest label (labels ^ flip in unsigned order), stable
+static int argsort_labels64(const long long* labels, int64_t n, unsigned long long flip, uint32_t* perm, Scratch& s, hipStream_t st) {
+  uint32_t* lo = s.get<uint32_t>((size_t)n);
+  unsigned long long* pay = s.get<unsigned long long>((size_t)n);
+  SortStats* stats = s.get<SortStats>(1);
+  PDX_SCRATCH_CHECK(s);
+  const SortStats init{0ull, ~0ull, 0ull};
+  SortStats h{};
+  PDX_HIP(hipMemcpyAsync(stats, &init, sizeof(init), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_sort_pack, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, reinterpret_cast<const unsigned long long*>(labels), (const uint8_t*)nullptr,
+                     (int64_t)0, n, (int)PDX_UINT64, 0, flip, (uint8_t*)nullptr, lo, pay, stats);
+  PDX_LAUNCH_CHECK();
+  PDX_HIP(hipMemcpyAsync(&h, stats, sizeof(h), hipMemcpyDeviceToHost, st));
+  PDX_HIP(hipStreamSynchronize(st));
+  const unsigned long long* sorted = nullptr;
+  PDX_TRY(sort_packed64(lo, pay, n, h.bits_or ^ h.bits_and, s, st, &sorted));
+  hipLaunchKernelGGL(k_pay_rows_u32, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, sorted, n, perm);
+  PDX_LAUNCH_CHECK();
   return PDX_OK;
 }
 
@@ -192,9 +277,8 @@ int pdx_index_union(const pdx_column* a, const pdx_column* b, int sort, pdx_mut_
   // array_sort_indices ascending + Take: stable LSD sort of the 64-bit labels, three rounds through the 32-bit pair sort
   uint32_t* perm = s.get<uint32_t>((size_t)G);
   PDX_SCRATCH_CHECK(s);
-  hipLaunchKernelGGL(k_align_iota, dim3(grid_for(G, 256, 4)), dim3(256), 0, st, perm, G);
   const unsigned long long flip = a->dtype == PDX_UINT64 ? 0ull : 0x8000000000000000ull;
-  PDX_TRY(argsort_rounds64(uniq, G, flip, perm, s, st));
+  PDX_TRY(argsort_labels64(uniq, G, flip, perm, s, st));
   hipLaunchKernelGGL(k_gather_labels, dim3(grid_for(G, 256, 4)), dim3(256), 0, st, uniq, perm, G, static_cast<long long*>(out->values));
   PDX_LAUNCH_CHECK();
   if (out->validity) PDX_HIP(hipMemsetAsync(out->validity, 0xFF, (size_t)((G + 7) / 8), st));
@@ -217,32 +301,35 @@ int pdx_argsort(const pdx_column* col, int ascending, pdx_mut_column* out, void*
   if (n == 0) return PDX_OK;
   hipStream_t st = as_stream(stream);
   Scratch s;
-  long long* keys = s.get<long long>((size_t)n);
-  long long* cls = s.get<long long>((size_t)n);
-  uint32_t* perm = s.get<uint32_t>((size_t)n);
-  PDX_SCRATCH_CHECK(s);
   const uint8_t* valid = validity_or_null(col);
-  hipLaunchKernelGGL(k_sort_keys, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, static_cast<const unsigned long long*>(col->values) + col->offset, valid,
-                     col->offset, n, col->dtype, ascending ? 0 : 1, keys, cls);
-  hipLaunchKernelGGL(k_align_iota, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, perm, n);
+  const bool classes = valid || col->dtype == PDX_FLOAT64;  // NaNs / nulls go behind the numbers, in row order
+  const unsigned long long* v = static_cast<const unsigned long long*>(col->values) + col->offset;
+  unsigned long long* outp = static_cast<unsigned long long*>(out->values);
+  uint32_t* lo = s.get<uint32_t>((size_t)n);
+  unsigned long long* pay = s.get<unsigned long long>((size_t)n);
+  uint8_t* cls8 = classes ? s.get<uint8_t>((size_t)n) : nullptr;
+  SortStats* stats = s.get<SortStats>(1);
+  PDX_SCRATCH_CHECK(s);
+  const SortStats init{0ull, ~0ull, 0ull};
+  SortStats h{};
+  PDX_HIP(hipMemcpyAsync(stats, &init, sizeof(init), hipMemcpyHostToDevice, st));
+  // one pass: class bytes, the packed elements at their own positions (all that is needed when every row is a number), key statistics
+  hipLaunchKernelGGL(k_sort_pack, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, v, valid, col->offset, n, col->dtype, ascending ? 0 : 1, 0ull, cls8, lo, pay,
+                     stats);
   PDX_LAUNCH_CHECK();
-  PDX_TRY(argsort_rounds64(keys, n, 0ull, perm, s, st));
-  if (valid || col->dtype == PDX_FLOAT64) {
-    // most significant digit: the class (numbers, NaNs, nulls); one more stable round on 2 bits
-    uint32_t* chunk = s.get<uint32_t>((size_t)n);
-    uint32_t* k0 = s.get<uint32_t>((size_t)n);
-    uint32_t* k1 = s.get<uint32_t>((size_t)n);
-    uint32_t* v0 = s.get<uint32_t>((size_t)n);
-    uint32_t* v1 = s.get<uint32_t>((size_t)n);
-    PDX_SCRATCH_CHECK(s);
-    hipLaunchKernelGGL(k_label_chunk, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, cls, perm, n, 0, 3u, 0ull, chunk);
-    PDX_LAUNCH_CHECK();
-    const uint32_t* ks = nullptr;
-    const uint32_t* vs = nullptr;
-    PDX_TRY((radix_sort_pairs<uint32_t>(chunk, perm, k0, v0, k1, v1, n, 2, &ks, &vs, false, s, st)));
-    PDX_HIP(hipMemcpyAsync(perm, vs, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  PDX_HIP(hipMemcpyAsync(&h, stats, sizeof(h), hipMemcpyDeviceToHost, st));
+  PDX_HIP(hipStreamSynchronize(st));
+  int64_t n0 = n;
+  if (h.others) {  // numbers compacted to the front (row order), NaN rows, then null rows straight into the output
+    int64_t n1 = 0, n2 = 0;
+    PDX_TRY(compact_indices(n, ClassPred{cls8, 0}, PackEmit{v, col->dtype, ascending ? 0 : 1, lo, pay}, &n0, s, st));
+    PDX_TRY(compact_indices(n, ClassPred{cls8, 1}, RowEmit{outp, n0}, &n1, s, st));
+    PDX_TRY(compact_indices(n, ClassPred{cls8, 2}, RowEmit{outp, n0 + n1}, &n2, s, st));
+    if (n0 + n1 + n2 != n) return fail(PDX_DEVICE, "pdx_argsort: class counts do not add up");
   }
-  hipLaunchKernelGGL(k_perm_to_u64, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, perm, n, static_cast<unsigned long long*>(out->values));
+  const unsigned long long* sorted = nullptr;
+  PDX_TRY(sort_packed64(lo, pay, n0, h.bits_or ^ h.bits_and, s, st, &sorted));
+  if (n0) hipLaunchKernelGGL(k_pay_rows_u64, dim3(grid_for(n0, 256, 4)), dim3(256), 0, st, sorted, n0, outp);
   PDX_LAUNCH_CHECK();
   if (out->validity) PDX_HIP(hipMemsetAsync(out->validity, 0xFF, (size_t)((n + 7) / 8), st));
   PDX_HIP(hipStreamSynchronize(st));

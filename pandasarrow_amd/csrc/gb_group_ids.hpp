@@ -49,7 +49,7 @@ __global__ void k_assign_gids(const Slot* __restrict__ table, long long dense_mi
 // set bits in front of its own (the first rows are distinct).  n / 8 bytes of traffic and a handful of launches, where sorting the
 // (first row, slot) pairs took four LSD passes = twenty dependent small kernels (~0.45 ms of a 16 ms step at 1e6 groups, and a
 // full-size sort when almost every row is its own group).
-constexpr int kRankWords = 16;  // 64-bit words per counted block (1024 rows)
+constexpr int kRankWords = 4;  // 64-bit words per counted block (256 rows): a group reads <= 4 words + one prefix for its rank
 __global__ void k_mark_first_rows(const uint32_t* __restrict__ occ_first, int64_t G, unsigned long long* __restrict__ bits) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < G; j += stride) {
@@ -59,15 +59,13 @@ __global__ void k_mark_first_rows(const uint32_t* __restrict__ occ_first, int64_
 }
 __global__ void k_rank_block_counts(const unsigned long long* __restrict__ bits, int64_t nwords, int64_t nblocks, int64_t* __restrict__ counts) {
   // kRankWords lanes per block, one word each (coalesced), folded with shuffles
-  static_assert(kRankWords == 16, "four blocks per wave");
+  static_assert(kRankWords == 4, "sixteen blocks per wave");
   const int sub = threadIdx.x & (kRankWords - 1);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x / kRankWords;
-  const int64_t nb_round = (nblocks + 3) & ~(int64_t)3;  // whole waves stay in the loop (the shuffles need all lanes)
+  const int64_t nb_round = (nblocks + 15) & ~(int64_t)15;  // whole waves stay in the loop (the shuffles need all lanes)
   for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kRankWords; b < nb_round; b += stride) {
     const int64_t w = b * kRankWords + sub;
     int c = (b < nblocks && w < nwords) ? __popcll(bits[w]) : 0;
-    c += __shfl_xor(c, 8, 64);
-    c += __shfl_xor(c, 4, 64);
     c += __shfl_xor(c, 2, 64);
     c += __shfl_xor(c, 1, 64);
     if (sub == 0 && b < nblocks) counts[b] = c;

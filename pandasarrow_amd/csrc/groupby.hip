@@ -624,8 +624,25 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   gb->first_rows = gb->own<int64_t>((size_t)G);
   if (s.failed || !gb->occ_slot || !gb->gid_of_occ || !gb->uniques || !gb->unique_ok || !gb->first_rows) return PDX_OOM;
   hipMemcpyAsync(gb->occ_slot, occ_slot_tmp, (size_t)G * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
-  // order groups by first occurrence: gid = rank of the group's first row among all first rows (bit map + block prefix, no sort)
-  {
+  // order groups by first occurrence: gid = rank of the group's first row among all first rows (bit map + block prefix, no sort).
+  // Nearly every row its own group: the random bit sets / word reads of the map cost more than sorting the (first row, slot)
+  // pairs (measured at 1.5e8 groups of 2.5e8 rows: mark 5.6 + rank 10 ms against ~9 ms for the four sort passes)
+  const bool rank_by_sort = G > ((int64_t)1 << 22) && G * 8 > n;
+  if (rank_by_sort) {
+    uint32_t* k0 = s.get<uint32_t>((size_t)G);
+    uint32_t* v0 = s.get<uint32_t>((size_t)G);
+    uint32_t* k1 = s.get<uint32_t>((size_t)G);
+    uint32_t* v1 = s.get<uint32_t>((size_t)G);
+    PDX_SCRATCH_CHECK(s);
+    const uint32_t *ks = nullptr, *vs = nullptr;  // sort (first_row -> slot); first rows are distinct so any order of ties is moot
+    rc = radix_sort_pairs<uint32_t>(occ_first_tmp, occ_slot_tmp, k0, v0, k1, v1, G, ilog2((uint64_t)n + 1) < 31 ? ilog2((uint64_t)n + 1) : 31, &ks, &vs,
+                                    true, s, st);
+    if (rc != PDX_OK) return rc;
+    const int g = grid_for(G, 256);
+    hipLaunchKernelGGL(k_assign_gids, dim3(g), dim3(256), 0, st, table, dense_min, dense_mask, gb->gid_of_slot, ks, vs, G, null_slot, gb->uniques,
+                       gb->unique_ok, gb->first_rows, region);
+    hipLaunchKernelGGL(k_gid_of_occ, dim3(g), dim3(256), 0, st, gb->gid_of_slot, gb->occ_slot, G, gb->gid_of_occ);
+  } else {
     const int64_t nwords = (n + 63) >> 6, nrb = ceil_div(nwords, (int64_t)kRankWords);
     unsigned long long* bits = s.get<unsigned long long>((size_t)nwords);
     int64_t* block_pre = s.get<int64_t>((size_t)nrb);

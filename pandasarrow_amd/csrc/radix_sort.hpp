@@ -178,14 +178,17 @@ struct IotaSrc {
 // row's ORIGINAL index (| bit 31 when its validity bit in iota.valid is clear) is written to rows_out at the same position -- the
 // row-id partition that used to be a second scatter kernel with the same ranking and the same digit reads.  The local row (12 bits)
 // and the null flag ride in the unused upper bits of the staged digit word, so the kernel needs no extra LDS.
+// PAYLOAD_DIGIT (8-byte payloads): there is no key array; the digit is taken from the payload's HIGH 32 bits (at `shift`) -- the
+// upper half of a 64-bit sort key rides in the payload above a 32-bit row number (pdx_argsort, align.hip)
 template <int BITS, typename V, bool WRITE_KEYS, bool IOTA = false, typename K = uint32_t, typename KO = uint32_t, bool FLAGS = false,
-          bool EMIT_ROWS = false>
+          bool EMIT_ROWS = false, bool PAYLOAD_DIGIT = false>
 __global__ void __launch_bounds__(kScatBlock) k_radix_scatter(const K* __restrict__ keys_in, const V* __restrict__ vals_in,
                                                               KO* __restrict__ keys_out, V* __restrict__ vals_out, int64_t n,
                                                               int shift, const uint32_t* __restrict__ offsets /* [tiles][R] */,
                                                               int xcd_swizzle, IotaSrc iota = IotaSrc{nullptr, 0}, int drop = 0,
                                                               uint32_t* __restrict__ rows_out = nullptr) {
   static_assert(!EMIT_ROWS || (sizeof(K) == 1 && BITS <= 8 && !WRITE_KEYS && !IOTA && !FLAGS), "EMIT_ROWS: byte digits, payload + row ids only");
+  static_assert(!PAYLOAD_DIGIT || (sizeof(V) == 8 && sizeof(K) == 4 && !WRITE_KEYS && !IOTA && !FLAGS && !EMIT_ROWS), "PAYLOAD_DIGIT: 8-byte payload only");
   constexpr int R = 1 << BITS;
   constexpr int DPT = (R + kScatBlock - 1) / kScatBlock;
   __shared__ uint32_t cnt[kScatWaves][R];   // per-wave digit counters, later per-(wave,digit) local base
@@ -269,7 +272,8 @@ __global__ void __launch_bounds__(kScatBlock) k_radix_scatter(const K* __restric
 #pragma unroll
   for (int s = 0; s < kScatItems; ++s) {
     int r = wave * (64 * kScatItems) + s * 64 + lane;
-    if (bytes_staged) key[s] = reinterpret_cast<const K*>(skeys)[r];  // (key r of the tile: waves are laid out back to back)
+    if constexpr (PAYLOAD_DIGIT) key[s] = r < tile_rows ? (uint32_t)((unsigned long long)val[s] >> 32) : 0u;
+    else if (bytes_staged) key[s] = reinterpret_cast<const K*>(skeys)[r];  // (key r of the tile: waves are laid out back to back)
     else key[s] = r < tile_rows ? (uint32_t)keys_in[tile_base + r] : 0u;
   }
   if constexpr (FLAGS && !IOTA && sizeof(K) == 4) {
@@ -419,6 +423,42 @@ int radix_offsets(const K* kin, int64_t n, int shift, uint32_t* hist, uint32_t* 
     hipLaunchKernelGGL((k_radix_hist<BITS, K>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, kin, n, shift, hist);
   }
   return radix_scan_only<BITS>(hist, ntiles, chunk_sum, big, st);
+}
+// histogram of the digit at `shift` of the HIGH 32 bits of 8-byte payloads (see PAYLOAD_DIGIT)
+template <int BITS>
+__global__ void __launch_bounds__(kSortBlock) k_radix_hist_hi(const uint64_t* __restrict__ vals, int64_t n, int shift, uint32_t* __restrict__ hist) {
+  constexpr int R = 1 << BITS;
+  __shared__ uint32_t h[R];
+  for (int d = threadIdx.x; d < R; d += kSortBlock) h[d] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kSortTile;
+  uint64_t v[kSortItems];
+#pragma unroll
+  for (int k = 0; k < kSortItems; ++k) {
+    const int64_t i = base + k * kSortBlock + threadIdx.x;
+    v[k] = i < n ? vals[i] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < kSortItems; ++k)
+    if (base + k * kSortBlock + threadIdx.x < n) atomicAdd(&h[((uint32_t)(v[k] >> 32) >> shift) & (R - 1)], 1u);
+  __syncthreads();
+  for (int d = threadIdx.x; d < R; d += kSortBlock) hist[(int64_t)blockIdx.x * R + d] = h[d];
+}
+inline int sort_xcd_swizzle();
+// one stable pass of 8-byte payloads by the digit at `shift` of their high 32 bits
+template <int BITS>
+int radix_pass_payload_hi(const uint64_t* vin, uint64_t* vout, int64_t n, int shift, uint32_t* hist, uint32_t* chunk_sum, hipStream_t st) {
+  const int64_t ntiles = ceil_div(n, kSortTile);
+  {
+    PDX_PROFILE("radix_hist", st);
+    hipLaunchKernelGGL((k_radix_hist_hi<BITS>), dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, vin, n, shift, hist);
+  }
+  PDX_TRY((radix_scan_only<BITS>(hist, ntiles, chunk_sum, true, st)));
+  PDX_PROFILE("radix_scatter", st);
+  hipLaunchKernelGGL((k_radix_scatter<BITS, uint64_t, false, false, uint32_t, uint32_t, false, false, true>), dim3((unsigned)ntiles), dim3(kScatBlock), 0,
+                     st, (const uint32_t*)nullptr, vin, (uint32_t*)nullptr, vout, n, shift, hist, sort_xcd_swizzle(), IotaSrc{nullptr, 0});
+  PDX_LAUNCH_CHECK();
+  return PDX_OK;
 }
 inline int sort_xcd_swizzle() {
   static const int swz = [] { const char* e = getenv("PDX_SORT_XCD_SWIZZLE"); return (e && e[0] == '0') ? 0 : 1; }();

@@ -224,6 +224,46 @@ def test_downsample_create_nulls_unsorted_and_errors(px):
     assert list(one.unique_keys().to_numpy()[0]) == [2 * 86400 * 10**9]
 
 
+@pytest.mark.parametrize("case", ["small_range", "one_value", "uint64_top", "all_null", "all_nan", "nan_and_null", "high_bits_only", "n1", "ts_sorted"])
+def test_argsort_digit_skipping_and_classes(px, case):
+    """pdx_argsort's 64-bit sort skips digits that are equal in every key and places NaNs / nulls behind the numbers in row order"""
+    K, C = px.K, px.Column
+    rng = np.random.default_rng(len(case))
+    n = 300_007
+    valid = None
+    if case == "small_range":
+        v = rng.integers(-300, 300, n).astype(np.int64)  # two varying digits after the sign flip
+    elif case == "one_value":
+        v = np.full(n, -17, np.int64)
+    elif case == "uint64_top":
+        v = rng.integers(2**63 - 1000, 2**63 + 1000, n, dtype=np.uint64)
+    elif case == "all_null":
+        v, valid = rng.standard_normal(n), np.zeros(n, bool)
+    elif case == "all_nan":
+        v = np.full(n, np.nan)
+    elif case == "nan_and_null":
+        v = np.round(rng.standard_normal(n), 2)
+        v[rng.random(n) < 0.3] = np.nan
+        valid = rng.random(n) > 0.3
+    elif case == "high_bits_only":
+        v = (rng.integers(0, 50, n).astype(np.int64) << 40) - (1 << 44)
+    elif case == "n1":
+        v = np.array([3.5])
+    else:
+        v = np.sort(rng.integers(0, 10**15, n)).astype(np.int64)
+        valid = rng.random(n) > 0.01
+    col = C.from_numpy(v, valid) if v.dtype != np.uint64 else C.from_numpy(v, valid, dtype=px.L.UINT64)
+    vi = v.view(np.int64) if v.dtype == np.uint64 else v
+    for asc in (True, False):
+        got, _ = K.argsort(col, asc).to_numpy()
+        if v.dtype == np.uint64:  # the oracle restates Arrow on signed / float input: order the unsigned values directly
+            key = v if asc else ~v
+            exp = np.argsort(key, kind="stable").astype(np.uint64)
+        else:
+            exp = orc.argsort(vi, valid, asc)
+        assert np.array_equal(got.astype(np.uint64), exp), (case, asc)
+
+
 def test_extra_aggs_and_downsample_on_a_sorted_index(px):
     K, L, C, api = px.K, px.L, px.Column, px.api
     rng = np.random.default_rng(21)
