@@ -626,7 +626,8 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
   hipMemcpyAsync(gb->occ_slot, occ_slot_tmp, (size_t)G * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
   // order groups by first occurrence: gid = rank of the group's first row among all first rows (bit map + block prefix, no sort).
   // Nearly every row its own group: the random bit sets / word reads of the map cost more than sorting the (first row, slot)
-  // pairs (measured at 1.5e8 groups of 2.5e8 rows: mark 5.6 + rank 10 ms against ~9 ms for the four sort passes)
+  // pairs (measured at 1.5e8 groups of 2.5e8 rows, pdx_reindex_indices: 65 ms with the map -- 5.6 ms of bit sets, > 10 ms of rank
+  // reads -- against 54 ms with the sort)
   const bool rank_by_sort = G > ((int64_t)1 << 22) && G * 8 > n;
   if (rank_by_sort) {
     uint32_t* k0 = s.get<uint32_t>((size_t)G);
