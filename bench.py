@@ -211,6 +211,22 @@ def secondary_runs(torch, L, K, api, keys, vals, kinds, n_total, nkeys, steps):
     put("a12_downsample_1T_mean", n_total, 16.0 * n_total, timeit(lambda: df12.downsample("1T").mean(), reps=2),
         note="end to end: ceil_temporal + group-by of the rounded labels (sorted axis: runs of equal labels, no value sort) + mean")
     del ser, ts, df12
+    # (g) keys that arrive sorted (1000 consecutive rows per key): runs of equal keys, no dictionary, no value sort
+    rows = K.synth_ts(0, n_total, 0, 1)  # 0, 1, 2, ...
+    skeys = K.binary(L.DIV, K.Column(L.INT64, rows.length, rows.values, None, 0, 0), 1000, True)
+    del rows
+
+    def gb_sorted():
+        gb = K.GroupByHandle.create(skeys)
+        return gb.agg(vals, kinds)
+
+    put("groupby_sorted_keys", n_total, ALGO_BYTES_PER_ROW * n_total, timeit(gb_sorted, reps=2), workload=f"{n_total:.3g} rows, keys = row // 1000")
+    del skeys
+    # (h) SURVEY 8(f)-3: argsort of 1e8 random float64 values (8 B read + 8 B written per row)
+    m = min(100_000_000, n_total)
+    sv = K.synth_vals(5, m, 77)
+    put("8f3_argsort_f64", m, 16.0 * m, timeit(lambda: K.argsort(sv), reps=2))
+    del sv
     return out
 
 

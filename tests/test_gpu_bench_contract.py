@@ -40,7 +40,7 @@ def test_bench_single_gpu_contract():
     assert all(v for v in d["check"].values() if isinstance(v, bool))
     sec = d["secondary"]
     for k in ("groupby_general_keys_hash_path", "groupby_5pct_null_values", "C1_add_f64[1e+06]", "C2_filter_8cols+index", "C2_take_8cols+index",
-              "C5_resample_1min_mean", "a12_round_temporal_minute", "a12_downsample_1T_mean"):
+              "C5_resample_1min_mean", "a12_round_temporal_minute", "a12_downsample_1T_mean", "groupby_sorted_keys", "8f3_argsort_f64"):
         assert sec[k]["ms"] > 0 and 0 < sec[k]["frac"] < 1, k
 
 
