@@ -93,6 +93,8 @@ typedef struct pdx_scalar {
 } pdx_scalar;
 
 typedef enum pdx_binary_op { PDX_ADD = 0, PDX_SUB = 1, PDX_MUL = 2, PDX_DIV = 3 } pdx_binary_op;
+/* element-wise functions of one column (pdx_unary) */
+typedef enum pdx_unary_op { PDX_NEGATE = 0, PDX_ABS = 1, PDX_SIGN = 2, PDX_SQRT = 3, PDX_EXP = 4, PDX_BIT_NOT = 5 } pdx_unary_op;
 typedef enum pdx_compare_op { PDX_EQ = 0, PDX_NE = 1, PDX_LT = 2, PDX_LE = 3, PDX_GT = 4, PDX_GE = 5 } pdx_compare_op;
 typedef enum pdx_logical_op { PDX_AND = 0, PDX_OR = 1 } pdx_logical_op;
 /* which operand of pdx_binary / pdx_compare is a length-1 column that is broadcast (the `b_is_scalar` argument) */
@@ -166,6 +168,23 @@ int pdx_compare(int op, const pdx_column* a, const pdx_column* b, int b_is_scala
 /* Replaces CallFunction("and"|"or") (non-Kleene) at src/series.cpp:259-260 and "invert" at src/series.cpp:319. */
 int pdx_logical(int op, const pdx_column* a, const pdx_column* b, pdx_mut_column* out, void* stream);
 int pdx_invert(const pdx_column* a, pdx_mut_column* out, void* stream);
+/* Replaces CallFunction("negate" | "abs" | "sign" | "sqrt" | "exp" | "bit_wise_not", {array}): DataFrame::unary (operator-,
+ * operator~) and the UNARY_FUNCTION macros src/dataframe.cpp:251-275, 919-935, src/dataframe.h:494-502; Series::abs / exp /
+ * sign / sqrt src/series.h:89-109.  a: PDX_INT64, PDX_UINT64 or PDX_FLOAT64; out null where a is null.
+ *   NEGATE, ABS : the input type; integers wrap (negate(INT64_MIN) == abs(INT64_MIN) == INT64_MIN; uint64: negate wraps, abs is
+ *                 the identity)
+ *   SIGN        : float64 -> float64 (-1, 0, 1; NaN stays NaN); integers -> PDX_INT64 values -1 / 0 / 1 (Arrow returns int8:
+ *                 this backend's integer columns are 64 bits wide)
+ *   BIT_NOT     : integers only (PDX_NOT_IMPLEMENTED for float64, as Arrow has no such kernel)
+ *   SQRT, EXP   : -> PDX_FLOAT64.  Integer input is cast first the way Arrow's implicit cast does: a valid value outside
+ *                 +-2^53 fails the whole call with PDX_INVALID "Integer value ... not in range".  sqrt of a negative number
+ *                 is NaN.  SQRT is correctly rounded (bit-identical to the reference); EXP follows the device's libm and can
+ *                 differ from the reference's host libm in the last place (the reference's own result depends on its glibc
+ *                 build): the only element-wise result on this path that is not bit-reproducible. */
+int pdx_unary(int op, const pdx_column* a, pdx_mut_column* out, void* stream);
+/* Replaces CallFunction("power", {array, Datum(double)}): Series::pow / DataFrame::pow (src/dataframe.cpp:267-270).  Integer input
+ * is cast to float64 as in pdx_unary(SQRT); out: PDX_FLOAT64 = pow(a, exponent), last-place caveat as for EXP. */
+int pdx_power(const pdx_column* a, double exponent, pdx_mut_column* out, void* stream);
 
 /* ---------------------------------------------------------------- whole-array aggregates
  * Replaces CallFunction("sum"|"mean"|"min"|"max"|"count", {array}, ScalarAggregateOptions{skip_nulls=true,

@@ -209,6 +209,29 @@ def invert(a, offset=0):
     return unpack_bits(out, n)
 
 
+UNARY_NEGATE, UNARY_ABS, UNARY_SIGN, UNARY_SQRT, UNARY_EXP, UNARY_BIT_NOT, UNARY_POWER = 0, 1, 2, 3, 4, 5, 100
+
+
+def unary(op, a, valid=None, expo=0.0):
+    """negate / abs / sign / sqrt / exp / bit_wise_not / power(a, expo) of one array (src/dataframe.cpp:251-275, 919-935).
+    Returns the result array (float64 for sqrt / exp / power, int64 for the sign of integers, else the input type); validity
+    passes through.  Raises ValueError with Arrow's message when an integer cannot be cast to float64 exactly."""
+    a = np.ascontiguousarray(a)
+    dt = {"int64": 0, "uint64": 1, "float64": 2}[a.dtype.name]
+    out = np.zeros(max(len(a), 1), np.uint64)
+    bad = np.zeros(1, np.uint64)
+    rc = lib().orc_unary(C.c_int(op), C.c_int(dt), _p(a.view(np.uint64)), _p(pack_bits(valid, 0)), _i64(0), _i64(len(a)), C.c_double(expo), _p(out), _p(bad))
+    if rc == 1:
+        v = int(bad[0]) if dt == 1 else int(bad.view(np.int64)[0])
+        raise ValueError(f"Integer value {v} not in range: {'0' if dt == 1 else '-9007199254740992'} to 9007199254740992")
+    if rc != 0:
+        raise TypeError("no kernel matching input types")
+    out = out[: len(a)]
+    if op in (UNARY_SQRT, UNARY_EXP, UNARY_POWER) or dt == 2:
+        return out.view(np.float64)
+    return out.view(np.int64) if (dt == 0 or op == UNARY_SIGN) else out
+
+
 # ------------------------------------------------------------------ filter / take
 def _as_u64(v):
     v = np.ascontiguousarray(v)

@@ -860,3 +860,51 @@ int orc_groupby_count_distinct(const uint32_t* ids, int64_t n, int64_t G, const 
   free(p);
   return ORC_OK;
 }
+
+/* ---------------------------------------------------------------- functions of one column
+ * Arrow 25.0.0 scalar arithmetic kernels (unchecked variants, as CallFunction(name) without options selects them):
+ * negate / abs wrap for integers; sign = isnan(x) ? x : (x == 0 ? 0 : (signbit(x) ? -1 : 1)) for floats and (x > 0) - (x < 0)
+ * for integers; sqrt / exp / power run in float64 after the implicit SAFE cast of integer input (values outside +-2^53 fail);
+ * sqrt / exp / power call the host libm (std::sqrt / std::exp / std::pow), so exp and power are only as reproducible as it. */
+int orc_unary(int op, int dtype, const uint64_t* in_bits, const uint8_t* valid, int64_t off, int64_t n, double expo, uint64_t* out_bits,
+              uint64_t* bad) {
+  const int to_f64 = op == 3 || op == 4 || op == 100;
+  if (op == 5 && dtype == 2) return -1;
+  for (int64_t i = 0; i < n; ++i) {
+    const uint64_t u = in_bits[i];
+    uint64_t r = 0;
+    if (to_f64) {
+      double d;
+      if (dtype == 2) {
+        memcpy(&d, &u, 8);
+      } else {
+        int out_of_range = dtype == 1 ? u > (1ull << 53) : ((int64_t)u > (1ll << 53) || (int64_t)u < -(1ll << 53));
+        if (out_of_range && (!valid || ((valid[(off + i) >> 3] >> ((off + i) & 7)) & 1))) {
+          *bad = u;
+          return 1;
+        }
+        d = dtype == 1 ? (double)u : (double)(int64_t)u;
+      }
+      /* SquareRoot::Call: `if (arg < 0.0) return quiet_NaN()` -- the POSITIVE quiet NaN, not libm's -nan for a negative operand */
+      const double y = op == 3 ? (d < 0.0 ? (double)NAN : sqrt(d)) : op == 4 ? exp(d) : pow(d, expo);
+      memcpy(&r, &y, 8);
+    } else if (dtype == 2) {
+      double d, y;
+      memcpy(&d, &u, 8);
+      if (op == 0) y = -d;
+      else if (op == 1) y = fabs(d);
+      else y = d != d ? d : (d == 0.0 ? 0.0 : (signbit(d) ? -1.0 : 1.0));
+      memcpy(&r, &y, 8);
+    } else if (op == 0) {
+      r = 0ull - u;
+    } else if (op == 1) {
+      r = (dtype == 0 && (int64_t)u < 0) ? 0ull - u : u;
+    } else if (op == 2) {
+      r = dtype == 1 ? (uint64_t)(u != 0) : (uint64_t)(int64_t)(((int64_t)u > 0) - ((int64_t)u < 0));
+    } else {
+      r = ~u;
+    }
+    out_bits[i] = r;
+  }
+  return 0;
+}

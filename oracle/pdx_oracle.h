@@ -71,6 +71,13 @@ int orc_compare_i64(int op, const int64_t* a, const uint8_t* va, int64_t aoff, c
 int orc_logical(int op, const uint8_t* a, const uint8_t* va, int64_t aoff, const uint8_t* b, const uint8_t* vb, int64_t boff,
                 int64_t n, uint8_t* out_bits, uint8_t* out_valid);
 void orc_invert(const uint8_t* a, int64_t aoff, int64_t n, uint8_t* out_bits);
+/* CallFunction("negate" | "abs" | "sign" | "sqrt" | "exp" | "bit_wise_not" | "power") on one array (src/dataframe.cpp:251-275,
+ * 919-935): op 0..5 as pdx_unary_op, 100 = power(a, expo).  dtype: 0 int64, 1 uint64, 2 float64 (in_bits: the 8-byte patterns).
+ * out_bits: 8-byte patterns of the result (its type follows Arrow, integers' sign as int64).  Validity passes through (the
+ * caller copies it); `valid` is only consulted by the integer -> float64 cast check.  Returns 0, or 1 when a valid integer
+ * lies outside +-2^53 (*bad = that value), or -1 for a combination Arrow has no kernel for. */
+int orc_unary(int op, int dtype, const uint64_t* in_bits, const uint8_t* valid, int64_t off, int64_t n, double expo, uint64_t* out_bits,
+              uint64_t* bad);
 void orc_validity_and(const uint8_t* va, int64_t aoff, const uint8_t* vb, int64_t boff, int64_t n, uint8_t* out_valid);
 
 /* ---- filter / take on 8-byte columns (src/dataframe.cpp:461-492, src/series.cpp:130-159) ---- */

@@ -19,6 +19,7 @@ INT64, FLOAT64, BOOL, UINT64, TIMESTAMP_NS = range(5)
 ADD, SUB, MUL, DIV = range(4)
 EQ, NE, LT, LE, GT, GE = range(6)
 AND, OR = range(2)
+NEGATE, ABS, SIGN, SQRT, EXP, BIT_NOT = range(6)
 SCALAR_NONE, SCALAR_RHS, SCALAR_LHS = range(3)  # pdx_scalar_side: which operand of pdx_binary / pdx_compare is broadcast
 AGG_SUM, AGG_MEAN, AGG_MIN, AGG_MAX, AGG_COUNT = range(5)
 AGG_VARIANCE, AGG_STDDEV, AGG_PRODUCT, AGG_FIRST, AGG_LAST = range(5, 10)  # group-by only (include/pdx/abi.h)
@@ -80,6 +81,8 @@ ABI_SYMBOLS = {
     "pdx_compare": (C.c_int, [C.c_int, _COL, _COL, C.c_int, _MUT, _P]),
     "pdx_logical": (C.c_int, [C.c_int, _COL, _COL, _MUT, _P]),
     "pdx_invert": (C.c_int, [_COL, _MUT, _P]),
+    "pdx_unary": (C.c_int, [C.c_int, _COL, _MUT, _P]),
+    "pdx_power": (C.c_int, [_COL, C.c_double, _MUT, _P]),
     "pdx_aggregate": (C.c_int, [C.c_int, _COL, C.POINTER(PdxScalar), _P]),
     "pdx_filter_count": (C.c_int, [_COL, C.c_int, C.POINTER(C.c_int64), _P]),
     "pdx_filter": (C.c_int, [_COL, C.c_int, _COL, C.c_int, _MUT, _P]),

@@ -207,8 +207,13 @@ class Series:
     def __rsub__(self, o): return self._rbin(L.SUB, o)
     def __rmul__(self, o): return self._rbin(L.MUL, o)
     def __rtruediv__(self, o): return self._rbin(L.DIV, o)
-    def __neg__(self):  # "negate": x * -1 is bit-identical for int64 (wraps) and float64 (sign flip)
-        return self._wrap(K.binary(L.MUL, self.col, -1.0 if self.col.dtype == L.FLOAT64 else -1, True))
+    # ---- functions of one column: Series::abs / exp / pow / sign / sqrt (src/series.h:89-109), operator- = "negate"
+    def __neg__(self): return self._wrap(K.unary(L.NEGATE, self.col))
+    def abs(self): return self._wrap(K.unary(L.ABS, self.col))
+    def sign(self): return self._wrap(K.unary(L.SIGN, self.col))
+    def sqrt(self): return self._wrap(K.unary(L.SQRT, self.col))
+    def exp(self): return self._wrap(K.unary(L.EXP, self.col))
+    def pow(self, x): return self._wrap(K.power(self.col, x))
     # ---- comparisons (src/series.cpp:247-257)
     def __lt__(self, o): return self._cmp(L.LT, o)
     def __le__(self, o): return self._cmp(L.LE, o)
@@ -220,7 +225,8 @@ class Series:
     # ---- logical (src/series.cpp:259-261,319)
     def __and__(self, o): return self._wrap(K.logical(L.AND, self.col, self._rhs(o)[0]))
     def __or__(self, o): return self._wrap(K.logical(L.OR, self.col, self._rhs(o)[0]))
-    def __invert__(self): return self._wrap(K.invert(self.col))
+    def __invert__(self):  # bool: "invert" (src/series.cpp:319); integers: "bit_wise_not" (DataFrame::operator~, src/dataframe.h:500-502)
+        return self._wrap(K.invert(self.col) if self.col.dtype == L.BOOL else K.unary(L.BIT_NOT, self.col))
 
     # ---- NDFrame aggregations (src/ndframe.cpp:119-220)
     def _agg(self, kind):
@@ -336,6 +342,15 @@ class DataFrame:
     def __rsub__(self, o): return self._rbin(L.SUB, o)
     def __rmul__(self, o): return self._rbin(L.MUL, o)
     def __rtruediv__(self, o): return self._rbin(L.DIV, o)
+    # DataFrame::unary("negate" | "bit_wise_not") and UNARY_FUNCTION(abs | exp | sign | sqrt), pow (src/dataframe.cpp:251-275, 919-935)
+    def _unary(self, op): return self._like([K.unary(op, c) for c in self.cols])
+    def __neg__(self): return self._unary(L.NEGATE)
+    def __invert__(self): return self._unary(L.BIT_NOT)
+    def abs(self): return self._unary(L.ABS)
+    def sign(self): return self._unary(L.SIGN)
+    def sqrt(self): return self._unary(L.SQRT)
+    def exp(self): return self._unary(L.EXP)
+    def pow(self, x): return self._like([K.power(c, x) for c in self.cols])
 
     # ---- NDFrame::sum/mean/min/max/count on a DataFrame (src/ndframe.cpp:119-220): GetInternalArray() is ONE ChunkedArray whose
     # chunks are the columns (src/ndframe.h:329-335), so the aggregate runs over every value of the frame.  Arrow reduces a

@@ -194,6 +194,25 @@ def invert(a: Column) -> Column:
     return out._adopt(m)
 
 
+def unary(op, a: Column) -> Column:
+    """negate / abs / sign / sqrt / exp / bit_wise_not of one column (pdx_unary)."""
+    lib = L.load()
+    to_f64 = op in (L.SQRT, L.EXP)
+    out_dt = L.FLOAT64 if to_f64 else (L.INT64 if (op == L.SIGN and a.dtype != L.FLOAT64) else a.dtype)
+    out = Column.empty(out_dt, a.length, with_validity=a.has_nulls())
+    ca, m = a.c(), out.mut()
+    L.check(lib.pdx_unary(int(op), C.byref(ca), C.byref(m), _stream()))
+    return out._adopt(m)
+
+
+def power(a: Column, exponent: float) -> Column:
+    lib = L.load()
+    out = Column.empty(L.FLOAT64, a.length, with_validity=a.has_nulls())
+    ca, m = a.c(), out.mut()
+    L.check(lib.pdx_power(C.byref(ca), float(exponent), C.byref(m), _stream()))
+    return out._adopt(m)
+
+
 # ---------------------------------------------------------------- aggregates
 def aggregate(kind, a: Column):
     """-> (python value | None, count)."""

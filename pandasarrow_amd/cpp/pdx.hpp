@@ -275,7 +275,13 @@ class Series {
   Series operator-(const Scalar& o) const { return binary(PDX_SUB, o); }
   Series operator*(const Scalar& o) const { return binary(PDX_MUL, o); }
   Series operator/(const Scalar& o) const { return binary(PDX_DIV, o); }
-  Series operator-() const { return m_array.dtype == PDX_FLOAT64 ? binary(PDX_MUL, Scalar(-1.0)) : binary(PDX_MUL, Scalar((int64_t)-1)); }
+  // ---- functions of one column: Series::abs / exp / pow / sign / sqrt (src/series.h:89-109); operator- = CallFunction("negate")
+  Series operator-() const { return wrap(run_unary(PDX_NEGATE, m_array)); }
+  Series abs() const { return wrap(run_unary(PDX_ABS, m_array)); }
+  Series sign() const { return wrap(run_unary(PDX_SIGN, m_array)); }
+  Series sqrt() const { return wrap(run_unary(PDX_SQRT, m_array)); }
+  Series exp() const { return wrap(run_unary(PDX_EXP, m_array)); }
+  Series pow(double x) const { return wrap(run_power(m_array, x)); }
 
   // ---- comparisons (src/series.cpp:247-257) and logical (259-261, 319)
   Series compare(int op, const Series& o) const {
@@ -367,6 +373,23 @@ class Series {
     auto ca = a.c(), cb = b.c();
     auto m = out.mut();
     ThrowOnFailure(pdx_binary(op, &ca, &cb, scalar, &m, nullptr));
+    out.null_count = m.null_count;
+    return out;
+  }
+  static Array run_unary(int op, const Array& a) {
+    const int out_dt = (op == PDX_SQRT || op == PDX_EXP) ? PDX_FLOAT64 : (op == PDX_SIGN && a.dtype != PDX_FLOAT64) ? PDX_INT64 : a.dtype;
+    Array out = Array::Empty(out_dt, a.length, a.has_nulls());
+    auto ca = a.c();
+    auto m = out.mut();
+    ThrowOnFailure(pdx_unary(op, &ca, &m, nullptr));
+    out.null_count = m.null_count;
+    return out;
+  }
+  static Array run_power(const Array& a, double x) {
+    Array out = Array::Empty(PDX_FLOAT64, a.length, a.has_nulls());
+    auto ca = a.c();
+    auto m = out.mut();
+    ThrowOnFailure(pdx_power(&ca, x, &m, nullptr));
     out.null_count = m.null_count;
     return out;
   }
@@ -507,6 +530,23 @@ class DataFrame {
     std::vector<Array> out;
     Array s = o.to_array();
     for (auto& c : m_columns) out.push_back(Series::run_binary(op, c, s, true));
+    return DataFrame(m_names, out, m_index);
+  }
+  // DataFrame::unary("negate" | "bit_wise_not"), UNARY_FUNCTION(abs | exp | sign | sqrt), pow (src/dataframe.cpp:251-275, 919-935)
+  DataFrame unary(int op) const {
+    std::vector<Array> out;
+    for (auto& c : m_columns) out.push_back(Series::run_unary(op, c));
+    return DataFrame(m_names, out, m_index);
+  }
+  DataFrame operator-() const { return unary(PDX_NEGATE); }
+  DataFrame operator~() const { return unary(PDX_BIT_NOT); }
+  DataFrame abs() const { return unary(PDX_ABS); }
+  DataFrame sign() const { return unary(PDX_SIGN); }
+  DataFrame sqrt() const { return unary(PDX_SQRT); }
+  DataFrame exp() const { return unary(PDX_EXP); }
+  DataFrame pow(double x) const {
+    std::vector<Array> out;
+    for (auto& c : m_columns) out.push_back(Series::run_power(c, x));
     return DataFrame(m_names, out, m_index);
   }
   template <typename R> DataFrame operator+(const R& o) const { return binary(PDX_ADD, o); }

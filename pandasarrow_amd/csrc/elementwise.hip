@@ -308,7 +308,128 @@ static int check_numeric_pair(const pdx_column* a, const pdx_column* b, int scal
 
 using namespace pdx;
 
+// ---------------------------------------------------------------- functions of one column
+constexpr int kPowerOp = 100;  // internal op code of pdx_power
+template <int OP, typename TI, typename TO>
+__global__ void __launch_bounds__(256) k_unary(const TI* __restrict__ a, TO* __restrict__ out, int64_t n, double expo, const uint8_t* __restrict__ valid,
+                                               int64_t voff, unsigned long long* __restrict__ err /* [0] flag, [1] an offending value */) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const TI x = a[i];
+    TO r;
+    if constexpr (OP == PDX_NEGATE) {
+      if constexpr (__is_same(TI, double)) r = -x;
+      else r = (TO)(0ull - (unsigned long long)x);
+    } else if constexpr (OP == PDX_ABS) {
+      if constexpr (__is_same(TI, double)) r = __builtin_fabs(x);
+      else if constexpr (__is_same(TI, unsigned long long)) r = x;
+      else r = x < 0 ? (TO)(0ull - (unsigned long long)x) : x;
+    } else if constexpr (OP == PDX_SIGN) {
+      if constexpr (__is_same(TI, double)) r = x != x ? x : (x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0));
+      else if constexpr (__is_same(TI, unsigned long long)) r = x != 0;
+      else r = (x > 0) - (x < 0);
+    } else if constexpr (OP == PDX_BIT_NOT) {
+      r = (TO)~(unsigned long long)x;
+    } else {  // SQRT / EXP / power: float64 arithmetic; integers are cast first (Arrow: safe cast, only +-2^53 is exact)
+      double d;
+      if constexpr (__is_same(TI, double)) {
+        d = x;
+      } else {
+        bool bad;
+        if constexpr (__is_same(TI, unsigned long long)) bad = x > (1ull << 53);
+        else bad = x > (1ll << 53) || x < -(1ll << 53);
+        if (bad && (!valid || bit_get(valid, voff + i))) {
+          err[1] = (unsigned long long)x;
+          err[0] = 1ull;
+        }
+        d = (double)x;
+      }
+      if constexpr (OP == PDX_SQRT) {
+        // Arrow: a negative operand gives the positive quiet NaN; a NaN operand comes back quieted with its payload (x86 sqrtsd)
+        if (d < 0.0) r = __longlong_as_double(0x7FF8000000000000ll);
+        else if (d != d) r = __longlong_as_double(__double_as_longlong(d) | 0x0008000000000000ll);
+        else r = __builtin_sqrt(d);
+      }
+      else if constexpr (OP == PDX_EXP) r = exp(d);
+      else r = pow(d, expo);
+    }
+    out[i] = r;
+  }
+}
+template <int OP>
+static int launch_unary(const pdx_column* a, pdx_mut_column* out, double expo, unsigned long long* err, hipStream_t st) {
+  const int64_t n = a->length;
+  const dim3 grid(grid_for(n, 256, 4)), block(256);
+  const uint8_t* valid = validity_or_null(a);
+  constexpr bool to_f64 = OP == PDX_SQRT || OP == PDX_EXP || OP == kPowerOp;
+  if (a->dtype == PDX_FLOAT64) {
+    if constexpr (OP != PDX_BIT_NOT)
+      hipLaunchKernelGGL((k_unary<OP, double, double>), grid, block, 0, st, static_cast<const double*>(a->values) + a->offset,
+                         static_cast<double*>(out->values), n, expo, valid, a->offset, err);
+  } else if (a->dtype == PDX_UINT64) {
+    const unsigned long long* in = static_cast<const unsigned long long*>(a->values) + a->offset;
+    if constexpr (to_f64) hipLaunchKernelGGL((k_unary<OP, unsigned long long, double>), grid, block, 0, st, in, static_cast<double*>(out->values), n, expo, valid, a->offset, err);
+    else if constexpr (OP == PDX_SIGN) hipLaunchKernelGGL((k_unary<OP, unsigned long long, long long>), grid, block, 0, st, in, static_cast<long long*>(out->values), n, expo, valid, a->offset, err);
+    else hipLaunchKernelGGL((k_unary<OP, unsigned long long, unsigned long long>), grid, block, 0, st, in, static_cast<unsigned long long*>(out->values), n, expo, valid, a->offset, err);
+  } else {
+    const long long* in = static_cast<const long long*>(a->values) + a->offset;
+    if constexpr (to_f64) hipLaunchKernelGGL((k_unary<OP, long long, double>), grid, block, 0, st, in, static_cast<double*>(out->values), n, expo, valid, a->offset, err);
+    else hipLaunchKernelGGL((k_unary<OP, long long, long long>), grid, block, 0, st, in, static_cast<long long*>(out->values), n, expo, valid, a->offset, err);
+  }
+  PDX_LAUNCH_CHECK();
+  return PDX_OK;
+}
+static int unary_impl(int op, const pdx_column* a, double expo, pdx_mut_column* out, void* stream, const char* who) {
+  PDX_TRY(check_column(a, who));
+  if (a->dtype != PDX_INT64 && a->dtype != PDX_UINT64 && a->dtype != PDX_FLOAT64)
+    return fail(PDX_NOT_IMPLEMENTED, std::string(who) + ": input must be int64, uint64 or float64");
+  if (op != kPowerOp && (op < PDX_NEGATE || op > PDX_BIT_NOT)) return fail(PDX_INVALID, std::string(who) + ": unknown op");
+  if (op == PDX_BIT_NOT && a->dtype == PDX_FLOAT64) return fail(PDX_NOT_IMPLEMENTED, "Function 'bit_wise_not' has no kernel matching input types (double)");
+  const bool to_f64 = op == PDX_SQRT || op == PDX_EXP || op == kPowerOp;
+  const int out_dt = to_f64 ? PDX_FLOAT64 : (op == PDX_SIGN && a->dtype != PDX_FLOAT64) ? PDX_INT64 : a->dtype;
+  if (!out || out->length < a->length || out->dtype != out_dt) return fail(PDX_INVALID, std::string(who) + ": output dtype / length do not match the result");
+  const bool has_nulls = validity_or_null(a) != nullptr;
+  if (has_nulls && !out->validity) return fail(PDX_INVALID, std::string(who) + ": input carries nulls but output has no validity buffer");
+  hipStream_t st = as_stream(stream);
+  const int64_t n = a->length;
+  out->length = n;
+  out->null_count = has_nulls ? -1 : 0;
+  if (n == 0) return PDX_OK;
+  if (!out->values) return fail(PDX_INVALID, std::string(who) + ": null output buffer");
+  const bool need_err = to_f64 && a->dtype != PDX_FLOAT64;
+  Scratch scratch;
+  unsigned long long* err = nullptr;
+  if (need_err) {
+    err = scratch.get<unsigned long long>(2);
+    PDX_SCRATCH_CHECK(scratch);
+    PDX_HIP(hipMemsetAsync(err, 0, 2 * sizeof(unsigned long long), st));
+  }
+  switch (op) {
+    case PDX_NEGATE: PDX_TRY(launch_unary<PDX_NEGATE>(a, out, expo, err, st)); break;
+    case PDX_ABS: PDX_TRY(launch_unary<PDX_ABS>(a, out, expo, err, st)); break;
+    case PDX_SIGN: PDX_TRY(launch_unary<PDX_SIGN>(a, out, expo, err, st)); break;
+    case PDX_SQRT: PDX_TRY(launch_unary<PDX_SQRT>(a, out, expo, err, st)); break;
+    case PDX_EXP: PDX_TRY(launch_unary<PDX_EXP>(a, out, expo, err, st)); break;
+    case PDX_BIT_NOT: PDX_TRY(launch_unary<PDX_BIT_NOT>(a, out, expo, err, st)); break;
+    default: PDX_TRY(launch_unary<kPowerOp>(a, out, expo, err, st)); break;
+  }
+  if (out->validity) PDX_TRY(launch_validity_and(a, nullptr, 0, n, static_cast<uint8_t*>(out->validity), st));
+  if (need_err) {
+    unsigned long long h[2] = {0, 0};
+    PDX_HIP(hipMemcpyAsync(h, err, sizeof(h), hipMemcpyDeviceToHost, st));
+    PDX_HIP(hipStreamSynchronize(st));
+    if (h[0]) {
+      const std::string v = a->dtype == PDX_UINT64 ? std::to_string(h[1]) : std::to_string((long long)h[1]);
+      return fail(PDX_INVALID, "Integer value " + v + " not in range: " + (a->dtype == PDX_UINT64 ? "0" : "-9007199254740992") + " to 9007199254740992");
+    }
+  }
+  return PDX_OK;
+}
+
 extern "C" {
+
+int pdx_unary(int op, const pdx_column* a, pdx_mut_column* out, void* stream) { return unary_impl(op, a, 0.0, out, stream, "pdx_unary"); }
+int pdx_power(const pdx_column* a, double exponent, pdx_mut_column* out, void* stream) { return unary_impl(kPowerOp, a, exponent, out, stream, "pdx_power"); }
 
 int pdx_binary(int op, const pdx_column* a, const pdx_column* b, int b_is_scalar, pdx_mut_column* out, void* stream) {
   PDX_TRY(check_numeric_pair(a, b, b_is_scalar, "pdx_binary"));

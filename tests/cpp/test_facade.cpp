@@ -229,6 +229,15 @@ static void test_concat_and_frame_ops() {
   REQUIRE((c["y"].values<double>() == std::vector<double>{5.5, 6.5, 7.5}));
   REQUIRE(((a * Scalar(2))["x"].values<long>() == std::vector<long>{2, 4, 6}));
   REQUIRE(a.sum().as<long>() == 21);
+  // DataFrame::unary("negate" | "bit_wise_not"), UNARY_FUNCTION(abs | sign | sqrt), pow (src/dataframe.cpp:251-275, 919-935)
+  REQUIRE(((-a)["x"].values<long>() == std::vector<long>{-1, -2, -3}));
+  REQUIRE(((~a)["y"].values<long>() == std::vector<long>{-5, -6, -7}));
+  REQUIRE(((-a).abs()["x"].values<long>() == std::vector<long>{1, 2, 3}));
+  REQUIRE(((-a).sign()["y"].values<long>() == std::vector<long>{-1, -1, -1}));
+  REQUIRE((a.pow(2.0)["y"].values<double>() == std::vector<double>{16.0, 25.0, 36.0}));
+  REQUIRE((DataFrame({"q"}, {Array::Make(std::vector<double>{4.0, 6.25})}).sqrt()["q"].values<double>() == std::vector<double>{2.0, 2.5}));
+  REQUIRE(((-Series(Array::Make(std::vector<double>{1.5, -2.0}))).values<double>() == std::vector<double>{-1.5, 2.0}));
+  REQUIRE_THROWS(~b);  // bit_wise_not has no float64 kernel
   REQUIRE_THROWS(a + DataFrame(std::map<std::string, std::vector<int32_t>>{{"x", {1, 2}}, {"y", {4, 5}}}));
   auto f = a[a["x"] > Scalar(1)];  // DataFrame::where through operator[]
   REQUIRE((f["y"].values<long>() == std::vector<long>{5, 6}));

@@ -301,3 +301,96 @@ def test_frame_aggs_golden(px, name):
             assert np.float64(got).view(np.uint64) == np.float64(c[key]).view(np.uint64), (name, key, got, c[key])
         else:
             assert got == int(c[key]), (name, key)
+
+
+# ------------------------------------------------------------------ functions of one column: negate / abs / sign / sqrt / exp / bit_wise_not / power
+def _unary_golden():
+    import json
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "unary_golden.npz"))
+    return z, json.loads(str(z["manifest"]))
+
+
+def _ulp_distance(a_bits, b_bits):
+    """distance in units in the last place between float64 bit patterns (both finite or both the same special)"""
+    def key(u):
+        s = u.view(np.int64)
+        return np.where(s < 0, np.int64(-(2**63)) - s, s)  # monotone integer image of the floats
+    with np.errstate(over="ignore"):
+        return np.abs(key(np.ascontiguousarray(a_bits)) - key(np.ascontiguousarray(b_bits)))  # int64: exact for nearby values
+
+
+# exp / power go through the device's libm (ocml), the reference through its host's glibc: both claim < 1 ULP, so results may differ
+# in the last place or two.  Every other function is bit-exact.
+LIBM_TOL_ULP = 2
+
+
+@pytest.mark.parametrize("case", [c["case"] for c in _unary_golden()[1]["cases"]])
+def test_unary_golden(px, case):
+    z, m = _unary_golden()
+    L, K = px.L, px.K
+    ops = next(c["ops"] for c in m["cases"] if c["case"] == case)
+    dt = str(z[case + "/dtype"])
+    v, valid = z[case + "/in"].view(dt), z[case + "/valid"]
+    col = px.Column.from_numpy(v, None if valid.all() else valid, dtype=L.UINT64 if dt == "uint64" else None)
+    opcode = {"negate": L.NEGATE, "abs": L.ABS, "sign": L.SIGN, "sqrt": L.SQRT, "exp": L.EXP, "bit_wise_not": L.BIT_NOT}
+    for op in ops:
+        out = K.power(col, m["exponents"][int(op[6:])]) if op.startswith("power_") else K.unary(opcode[op], col)
+        got, gok = out.to_numpy()
+        assert (gok is None and valid.all()) or np.array_equal(gok, valid), (case, op)
+        g, e = np.ascontiguousarray(got).view(np.uint64)[valid], z[f"{case}/{op}"][valid]
+        if op == "exp" or op.startswith("power_"):
+            gf, ef = g.view(np.float64), e.view(np.float64)
+            assert np.array_equal(np.isnan(gf), np.isnan(ef)), (case, op)
+            fin = ~np.isnan(ef)
+            assert np.array_equal(np.isinf(gf[fin]), np.isinf(ef[fin])) and np.array_equal(np.sign(gf[fin]), np.sign(ef[fin])), (case, op)
+            both = fin & ~np.isinf(ef)
+            assert (_ulp_distance(g[both], e[both]) <= LIBM_TOL_ULP).all(), (case, op, _ulp_distance(g[both], e[both]).max())
+        else:
+            assert np.array_equal(g, e), (case, op)
+    for err in m["errors"]:
+        if err["case"] != case:
+            continue
+        with pytest.raises(RuntimeError) as ei:
+            K.power(col, 2.0) if err["op"] == "power" else K.unary(opcode[err["op"]], col)
+        if "not in range" in err["message"]:
+            assert "not in range: " + err["message"].split("not in range: ")[1] in str(ei.value)
+
+
+def test_unary_large_api_and_errors(px):
+    L, K, api = px.L, px.K, px.api
+    rng = np.random.default_rng(31)
+    n = 1_000_003
+    f = rng.standard_normal(n) * 10.0 ** rng.integers(-6, 7, n)
+    f[rng.random(n) < 0.01] = np.nan
+    fvalid = rng.random(n) > 0.1
+    i = rng.integers(-(2**53), 2**53, n)
+    for v, valid in ((f, None), (f, fvalid), (i, None), (i, fvalid)):
+        col = px.Column.from_numpy(v, valid)
+        for op, code in ((orc.UNARY_NEGATE, L.NEGATE), (orc.UNARY_ABS, L.ABS), (orc.UNARY_SIGN, L.SIGN), (orc.UNARY_SQRT, L.SQRT)):
+            got, gok = K.unary(code, col).to_numpy()
+            exp = orc.unary(op, v, valid)
+            ok = np.ones(n, bool) if valid is None else valid
+            assert np.array_equal(np.ascontiguousarray(got).view(np.uint64)[ok], np.ascontiguousarray(exp).view(np.uint64)[ok]), (v.dtype, op)
+        if v.dtype == np.int64:
+            got = K.unary(L.BIT_NOT, col).to_numpy()[0]
+            assert np.array_equal(got, ~v)
+    # Series / DataFrame mirrors
+    s = api.Series(np.array([1.0, -4.0, np.nan, 9.0]), valid=np.array([1, 1, 1, 0], bool))
+    assert np.array_equal((-s).to_numpy()[0][:2], [-1.0, 4.0]) and np.signbit((-s).to_numpy()[0][2])
+    assert np.array_equal(s.abs().to_numpy()[0][:2], [1.0, 4.0]) and np.array_equal(s.sqrt().to_numpy()[0][:1], [1.0])
+    assert np.isnan(s.sqrt().to_numpy()[0][1]) and not np.signbit(s.sqrt().to_numpy()[0][1])
+    assert list(s.sign().to_numpy()[1]) == [True, True, True, False]
+    assert np.allclose(s.pow(2.0).to_numpy()[0][:2], [1.0, 16.0]) and np.allclose(s.exp().to_numpy()[0][:1], [np.e])
+    df = api.DataFrame({"a": np.array([1, -2, 3]), "b": np.array([4, 5, -6])})
+    assert list((-df)["a"].to_numpy()[0]) == [-1, 2, -3] and list((~df)["b"].to_numpy()[0]) == [-5, -6, 5]
+    assert list(df.abs()["b"].to_numpy()[0]) == [4, 5, 6] and list(df.sign()["a"].to_numpy()[0]) == [1, -1, 1]
+    assert np.array_equal(df.sqrt()["a"].to_numpy()[0][[0, 2]], np.sqrt([1.0, 3.0])) and np.isnan(df.sqrt()["a"].to_numpy()[0][1])
+    assert np.array_equal(df.pow(2.0)["b"].to_numpy()[0], [16.0, 25.0, 36.0])
+    with pytest.raises(RuntimeError, match="bit_wise_not"):
+        K.unary(L.BIT_NOT, px.Column.from_numpy(f))
+    with pytest.raises(RuntimeError):
+        K.unary(17, px.Column.from_numpy(f))
+    with pytest.raises(RuntimeError):
+        K.unary(L.ABS, px.Column.from_numpy(np.array([True, False])))
+    assert K.unary(L.SQRT, px.Column.from_numpy(np.zeros(0))).length == 0

@@ -163,3 +163,35 @@ def test_frame_aggs(name):
             assert np.float64(got).view(np.uint64) == np.float64(c[key]).view(np.uint64), (name, key, got, c[key])
         else:
             assert got == int(c[key]), (name, key)
+
+
+# ------------------------------------------------------------------ functions of one column (src/dataframe.cpp:251-275, 919-935)
+def _unary_golden():
+    import json
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "unary_golden.npz"))
+    return z, json.loads(str(z["manifest"]))
+
+
+UNARY_OPS = {"negate": 0, "abs": 1, "sign": 2, "sqrt": 3, "exp": 4, "bit_wise_not": 5}
+
+
+@pytest.mark.parametrize("case", [c["case"] for c in _unary_golden()[1]["cases"]])
+def test_unary_oracle_vs_arrow(case):
+    """every op Arrow has a kernel for, bit for bit (exp / power included: the oracle calls the same host libm Arrow was built on)"""
+    z, m = _unary_golden()
+    ops = next(c["ops"] for c in m["cases"] if c["case"] == case)
+    v = z[case + "/in"].view(str(z[case + "/dtype"]))
+    valid = z[case + "/valid"]
+    for op in ops:
+        got = orc.unary(100, v, valid, m["exponents"][int(op[6:])]) if op.startswith("power_") else orc.unary(UNARY_OPS[op], v, valid)
+        exp = z[f"{case}/{op}"]
+        assert np.array_equal(np.ascontiguousarray(got).view(np.uint64)[valid], exp[valid]), (case, op)
+    for e in m["errors"]:
+        if e["case"] != case:
+            continue
+        op = 100 if e["op"] == "power" else UNARY_OPS[e["op"]]
+        with pytest.raises((ValueError, TypeError)) as ei:
+            orc.unary(op, v, valid, 2.0)
+        if "not in range" in e["message"]:
+            assert str(ei.value) == e["message"]
