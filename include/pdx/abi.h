@@ -92,7 +92,13 @@ typedef struct pdx_scalar {
   int64_t count;        /* number of valid inputs that produced it */
 } pdx_scalar;
 
-typedef enum pdx_binary_op { PDX_ADD = 0, PDX_SUB = 1, PDX_MUL = 2, PDX_DIV = 3 } pdx_binary_op;
+typedef enum pdx_binary_op {
+  PDX_ADD = 0, PDX_SUB = 1, PDX_MUL = 2, PDX_DIV = 3,
+  /* integer operands only: BINARY_OPERATOR(| & ^ << >>) src/series.cpp:237-245, BINARY_OPERATOR_DF src/dataframe.cpp:553-561.
+   * Shifts are Arrow's unchecked kernels: an amount that is negative or >= 63 (the precision of int64) returns the left operand
+   * unchanged; shift_right is arithmetic; shift_left wraps. */
+  PDX_BIT_OR = 4, PDX_BIT_AND = 5, PDX_BIT_XOR = 6, PDX_SHIFT_LEFT = 7, PDX_SHIFT_RIGHT = 8
+} pdx_binary_op;
 /* element-wise functions of one column (pdx_unary) */
 typedef enum pdx_unary_op { PDX_NEGATE = 0, PDX_ABS = 1, PDX_SIGN = 2, PDX_SQRT = 3, PDX_EXP = 4, PDX_BIT_NOT = 5 } pdx_unary_op;
 typedef enum pdx_compare_op { PDX_EQ = 0, PDX_NE = 1, PDX_LT = 2, PDX_LE = 3, PDX_GT = 4, PDX_GE = 5 } pdx_compare_op;
@@ -159,7 +165,8 @@ int pdx_synth_ts(int64_t start, int64_t n, int64_t t0_ns, int64_t step_ns, int64
  * src/series.cpp:25-28); PDX_SCALAR_LHS (2): a has length 1 and is broadcast (`2 - series`, `2 / series`:
  * Scalar::operator op(Series) -> BinaryImpl -> CallFunction(name, {scalar, s.array()}), src/scalar.cpp:24-36; the result has
  * b's length).  Integer arithmetic wraps; integer divide truncates toward zero, INT64_MIN / -1 == 0, a zero divisor at a valid
- * slot fails the whole call with PDX_INVALID "divide by zero".  out null where either input is null. */
+ * slot fails the whole call with PDX_INVALID "divide by zero".  out null where either input is null.
+ * PDX_BIT_OR .. PDX_SHIFT_RIGHT take int64 operands only (PDX_NOT_IMPLEMENTED otherwise: Arrow has no floating-point kernels). */
 int pdx_binary(int op, const pdx_column* a, const pdx_column* b, int b_is_scalar, pdx_mut_column* out, void* stream);
 /* Replaces CallFunction("equal"|"not_equal"|"less"|"less_equal"|"greater"|"greater_equal") at
  * src/series.cpp:247-257 and, with PDX_SCALAR_LHS, Scalar::operator{>,>=,<,<=,==,!=}(Series) at src/scalar.cpp:48-56.

@@ -21,6 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("PDX_ORACLE_SO") or os.path.join(_HERE, "_build", "libpdx_oracle.so")  # (override: tools/sanitize_cpu.sh)
 
 ADD, SUB, MUL, DIV = 0, 1, 2, 3
+BIT_OR, BIT_AND, BIT_XOR, SHIFT_LEFT, SHIFT_RIGHT = 4, 5, 6, 7, 8  # int64 operands only
 EQ, NE, LT, LE, GT, GE = 0, 1, 2, 3, 4, 5
 AND, OR = 0, 1
 AGG_SUM, AGG_MEAN, AGG_MIN, AGG_MAX, AGG_COUNT = 0, 1, 2, 3, 4

@@ -80,6 +80,20 @@ def main():
                 store[f"{case}/power_{k}"], _ = result_bits(r)
                 done.append(f"power_{k}")
             manifest["cases"].append({"case": case, "ops": done})
+    # ---- bit_wise_or / and / xor, shift_left / shift_right on int64 (src/series.cpp:237-245, src/dataframe.cpp:553-561)
+    n = 600
+    a = np.concatenate([np.array([1, -8, 5, 2**62, -1, 7, 0, -(2**63), 2**63 - 1], np.int64), rng.integers(-(2**63), 2**63 - 1, n)])
+    b = np.concatenate([np.array([1, 2, 64, 1, 63, -1, 62, 1, 62], np.int64), rng.integers(-3, 70, n)])
+    va, vb = rng.random(len(a)) > 0.2, rng.random(len(a)) > 0.2
+    store["bw/a"], store["bw/b"], store["bw/va"], store["bw/vb"] = a, b, va, vb
+    pa_a, pa_b = pa.array(a, mask=~va), pa.array(b, mask=~vb)
+    manifest["bitwise_scalars"] = [3, -1, 63, 0, 40]
+    for k, fn in enumerate(["bit_wise_or", "bit_wise_and", "bit_wise_xor", "shift_left", "shift_right"]):
+        r = pc.call_function(fn, [pa_a, pa_b])
+        store[f"bw/{fn}"], store[f"bw/{fn}_valid"] = result_bits(r)
+        for j, sc in enumerate(manifest["bitwise_scalars"]):
+            store[f"bw/{fn}_rhs{j}"], _ = result_bits(pc.call_function(fn, [pa_a, pa.scalar(sc, pa.int64())]))
+            store[f"bw/{fn}_lhs{j}"], _ = result_bits(pc.call_function(fn, [pa.scalar(sc, pa.int64()), pa_b]))
     manifest["exponents"] = EXPONENTS
     store["manifest"] = np.array(json.dumps(manifest))
     np.savez_compressed(OUT, **store)

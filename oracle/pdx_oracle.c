@@ -322,6 +322,13 @@ int orc_binary_i64(int op, const int64_t* a, const uint8_t* va, int64_t aoff, co
         if (x == INT64_MIN && y == -1) r = 0;
         else r = x / y;
         break;
+      /* bit_wise_or / and / xor, shift_left / shift_right (src/series.cpp:237-245): Arrow's unchecked shifts return the left
+       * operand when the amount is negative or >= std::numeric_limits<int64_t>::digits (63); shift_right is arithmetic */
+      case 4: r = (int64_t)((uint64_t)x | (uint64_t)y); break;
+      case 5: r = (int64_t)((uint64_t)x & (uint64_t)y); break;
+      case 6: r = (int64_t)((uint64_t)x ^ (uint64_t)y); break;
+      case 7: r = (y < 0 || y >= 63) ? x : (int64_t)((uint64_t)x << y); break;
+      case 8: r = (y < 0 || y >= 63) ? x : (x >> y); break;
       default: return ORC_INVALID;
     }
     out[i] = r;

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("PDX_LIB_PATH") or os.path.join(_HERE, "csrc", "libpdx
 OK, INVALID, INDEX_ERROR, OOM, DEVICE, NOT_IMPLEMENTED = range(6)
 INT64, FLOAT64, BOOL, UINT64, TIMESTAMP_NS = range(5)
 ADD, SUB, MUL, DIV = range(4)
+BIT_OR, BIT_AND, BIT_XOR, SHIFT_LEFT, SHIFT_RIGHT = range(4, 9)
 EQ, NE, LT, LE, GT, GE = range(6)
 AND, OR = range(2)
 NEGATE, ABS, SIGN, SQRT, EXP, BIT_NOT = range(6)

@@ -223,8 +223,13 @@ class Series:
     def __ne__(self, o): return self._cmp(L.NE, o)
     __hash__ = None
     # ---- logical (src/series.cpp:259-261,319)
-    def __and__(self, o): return self._wrap(K.logical(L.AND, self.col, self._rhs(o)[0]))
-    def __or__(self, o): return self._wrap(K.logical(L.OR, self.col, self._rhs(o)[0]))
+    # `&` / `|` on bool Series are the reference's && / || ("and" / "or", src/series.cpp:259-260); on integers they are its
+    # operator& / operator| / ^ / << / >> ("bit_wise_and" ... "shift_right", src/series.cpp:237-245)
+    def __and__(self, o): return self._wrap(K.logical(L.AND, self.col, self._rhs(o)[0])) if self.col.dtype == L.BOOL else self._bin(L.BIT_AND, o)
+    def __or__(self, o): return self._wrap(K.logical(L.OR, self.col, self._rhs(o)[0])) if self.col.dtype == L.BOOL else self._bin(L.BIT_OR, o)
+    def __xor__(self, o): return self._bin(L.BIT_XOR, o)
+    def __lshift__(self, o): return self._bin(L.SHIFT_LEFT, o)
+    def __rshift__(self, o): return self._bin(L.SHIFT_RIGHT, o)
     def __invert__(self):  # bool: "invert" (src/series.cpp:319); integers: "bit_wise_not" (DataFrame::operator~, src/dataframe.h:500-502)
         return self._wrap(K.invert(self.col) if self.col.dtype == L.BOOL else K.unary(L.BIT_NOT, self.col))
 
@@ -342,6 +347,12 @@ class DataFrame:
     def __rsub__(self, o): return self._rbin(L.SUB, o)
     def __rmul__(self, o): return self._rbin(L.MUL, o)
     def __rtruediv__(self, o): return self._rbin(L.DIV, o)
+    # BINARY_OPERATOR_DF(| & ^ << >>) (src/dataframe.cpp:553-561): integer frames
+    def __or__(self, o): return self._bin(L.BIT_OR, o)
+    def __and__(self, o): return self._bin(L.BIT_AND, o)
+    def __xor__(self, o): return self._bin(L.BIT_XOR, o)
+    def __lshift__(self, o): return self._bin(L.SHIFT_LEFT, o)
+    def __rshift__(self, o): return self._bin(L.SHIFT_RIGHT, o)
     # DataFrame::unary("negate" | "bit_wise_not") and UNARY_FUNCTION(abs | exp | sign | sqrt), pow (src/dataframe.cpp:251-275, 919-935)
     def _unary(self, op): return self._like([K.unary(op, c) for c in self.cols])
     def __neg__(self): return self._unary(L.NEGATE)

@@ -275,6 +275,17 @@ class Series {
   Series operator-(const Scalar& o) const { return binary(PDX_SUB, o); }
   Series operator*(const Scalar& o) const { return binary(PDX_MUL, o); }
   Series operator/(const Scalar& o) const { return binary(PDX_DIV, o); }
+  // BINARY_OPERATOR(| & ^ << >>) (src/series.cpp:237-245): bit_wise_or / and / xor, shift_left / shift_right on integers
+  Series operator|(const Series& o) const { return binary(PDX_BIT_OR, o); }
+  Series operator&(const Series& o) const { return binary(PDX_BIT_AND, o); }
+  Series operator^(const Series& o) const { return binary(PDX_BIT_XOR, o); }
+  Series operator<<(const Series& o) const { return binary(PDX_SHIFT_LEFT, o); }
+  Series operator>>(const Series& o) const { return binary(PDX_SHIFT_RIGHT, o); }
+  Series operator|(const Scalar& o) const { return binary(PDX_BIT_OR, o); }
+  Series operator&(const Scalar& o) const { return binary(PDX_BIT_AND, o); }
+  Series operator^(const Scalar& o) const { return binary(PDX_BIT_XOR, o); }
+  Series operator<<(const Scalar& o) const { return binary(PDX_SHIFT_LEFT, o); }
+  Series operator>>(const Scalar& o) const { return binary(PDX_SHIFT_RIGHT, o); }
   // ---- functions of one column: Series::abs / exp / pow / sign / sqrt (src/series.h:89-109); operator- = CallFunction("negate")
   Series operator-() const { return wrap(run_unary(PDX_NEGATE, m_array)); }
   Series abs() const { return wrap(run_unary(PDX_ABS, m_array)); }
@@ -549,6 +560,11 @@ class DataFrame {
     for (auto& c : m_columns) out.push_back(Series::run_power(c, x));
     return DataFrame(m_names, out, m_index);
   }
+  template <typename R> DataFrame operator|(const R& o) const { return binary(PDX_BIT_OR, o); }   // BINARY_OPERATOR_DF, src/dataframe.cpp:553-561
+  template <typename R> DataFrame operator&(const R& o) const { return binary(PDX_BIT_AND, o); }
+  template <typename R> DataFrame operator^(const R& o) const { return binary(PDX_BIT_XOR, o); }
+  template <typename R> DataFrame operator<<(const R& o) const { return binary(PDX_SHIFT_LEFT, o); }
+  template <typename R> DataFrame operator>>(const R& o) const { return binary(PDX_SHIFT_RIGHT, o); }
   template <typename R> DataFrame operator+(const R& o) const { return binary(PDX_ADD, o); }
   template <typename R> DataFrame operator-(const R& o) const { return binary(PDX_SUB, o); }
   template <typename R> DataFrame operator*(const R& o) const { return binary(PDX_MUL, o); }

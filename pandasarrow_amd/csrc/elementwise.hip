@@ -85,6 +85,18 @@ __device__ __forceinline__ TO apply_op(TO x, TO y, bool valid, unsigned long lon
   } else if constexpr (OP == PDX_MUL) {
     if constexpr (__is_same(TO, double)) return x86_nan(x * y, x, y);
     else return (int64_t)((uint64_t)x * (uint64_t)y);
+  } else if constexpr (OP >= PDX_BIT_OR) {  // integers only (the host never instantiates these for double)
+    const uint64_t ux = (uint64_t)(int64_t)x, uy = (uint64_t)(int64_t)y;
+    if constexpr (OP == PDX_BIT_OR) return (TO)(int64_t)(ux | uy);
+    else if constexpr (OP == PDX_BIT_AND) return (TO)(int64_t)(ux & uy);
+    else if constexpr (OP == PDX_BIT_XOR) return (TO)(int64_t)(ux ^ uy);
+    else {
+      // Arrow's unchecked shifts: an amount outside [0, digits) -- digits = 63 for int64 -- returns the left operand
+      const int64_t sh = (int64_t)y;
+      if (sh < 0 || sh >= 63) return x;
+      if constexpr (OP == PDX_SHIFT_LEFT) return (TO)(int64_t)(ux << sh);
+      else return (TO)((int64_t)x >> sh);
+    }
   } else {
     if constexpr (__is_same(TO, double)) {
       return x86_nan(x / y, x, y);
@@ -180,7 +192,18 @@ static void launch_binary_op(int op, const pdx_column* a, const pdx_column* b, i
     case PDX_ADD: launch_binary_sb<TA, TB, TO, PDX_ADD>(a, b, scalar, out, err, st); break;
     case PDX_SUB: launch_binary_sb<TA, TB, TO, PDX_SUB>(a, b, scalar, out, err, st); break;
     case PDX_MUL: launch_binary_sb<TA, TB, TO, PDX_MUL>(a, b, scalar, out, err, st); break;
-    default: launch_binary_sb<TA, TB, TO, PDX_DIV>(a, b, scalar, out, err, st); break;
+    case PDX_DIV: launch_binary_sb<TA, TB, TO, PDX_DIV>(a, b, scalar, out, err, st); break;
+    default:
+      if constexpr (__is_same(TA, int64_t) && __is_same(TB, int64_t) && __is_same(TO, int64_t)) {
+        switch (op) {
+          case PDX_BIT_OR: launch_binary_sb<TA, TB, TO, PDX_BIT_OR>(a, b, scalar, out, err, st); break;
+          case PDX_BIT_AND: launch_binary_sb<TA, TB, TO, PDX_BIT_AND>(a, b, scalar, out, err, st); break;
+          case PDX_BIT_XOR: launch_binary_sb<TA, TB, TO, PDX_BIT_XOR>(a, b, scalar, out, err, st); break;
+          case PDX_SHIFT_LEFT: launch_binary_sb<TA, TB, TO, PDX_SHIFT_LEFT>(a, b, scalar, out, err, st); break;
+          default: launch_binary_sb<TA, TB, TO, PDX_SHIFT_RIGHT>(a, b, scalar, out, err, st); break;
+        }
+      }
+      break;
   }
 }
 
@@ -433,7 +456,9 @@ int pdx_power(const pdx_column* a, double exponent, pdx_mut_column* out, void* s
 
 int pdx_binary(int op, const pdx_column* a, const pdx_column* b, int b_is_scalar, pdx_mut_column* out, void* stream) {
   PDX_TRY(check_numeric_pair(a, b, b_is_scalar, "pdx_binary"));
-  if (op < PDX_ADD || op > PDX_DIV) return fail(PDX_INVALID, "pdx_binary: unknown op");
+  if (op < PDX_ADD || op > PDX_SHIFT_RIGHT) return fail(PDX_INVALID, "pdx_binary: unknown op");
+  if (op >= PDX_BIT_OR && (a->dtype != PDX_INT64 || b->dtype != PDX_INT64))
+    return fail(PDX_NOT_IMPLEMENTED, "pdx_binary: bit-wise operators and shifts have no kernel matching floating-point input types");
   const pdx_column* arr = b_is_scalar == PDX_SCALAR_LHS ? b : a;  // the operand that gives the result its length
   if (!out || out->length < arr->length) return fail(PDX_INVALID, "pdx_binary: output too small");
   const bool is_f = a->dtype == PDX_FLOAT64 || b->dtype == PDX_FLOAT64;

@@ -238,6 +238,13 @@ static void test_concat_and_frame_ops() {
   REQUIRE((DataFrame({"q"}, {Array::Make(std::vector<double>{4.0, 6.25})}).sqrt()["q"].values<double>() == std::vector<double>{2.0, 2.5}));
   REQUIRE(((-Series(Array::Make(std::vector<double>{1.5, -2.0}))).values<double>() == std::vector<double>{-1.5, 2.0}));
   REQUIRE_THROWS(~b);  // bit_wise_not has no float64 kernel
+  REQUIRE(((a | Scalar(8))["x"].values<long>() == std::vector<long>{9, 10, 11}));
+  REQUIRE(((a & a)["y"].values<long>() == std::vector<long>{4, 5, 6}));
+  REQUIRE(((a ^ Scalar(1))["x"].values<long>() == std::vector<long>{0, 3, 2}));
+  REQUIRE(((a << Scalar(2))["y"].values<long>() == std::vector<long>{16, 20, 24}));
+  REQUIRE((((-a) >> Scalar(1))["x"].values<long>() == std::vector<long>{-1, -1, -2}));  // arithmetic shift
+  REQUIRE(((a << Scalar(64))["x"].values<long>() == std::vector<long>{1, 2, 3}));       // out-of-range amount: unchanged
+  REQUIRE_THROWS(b | Scalar(1));
   REQUIRE_THROWS(a + DataFrame(std::map<std::string, std::vector<int32_t>>{{"x", {1, 2}}, {"y", {4, 5}}}));
   auto f = a[a["x"] > Scalar(1)];  // DataFrame::where through operator[]
   REQUIRE((f["y"].values<long>() == std::vector<long>{5, 6}));

@@ -394,3 +394,34 @@ def test_unary_large_api_and_errors(px):
     with pytest.raises(RuntimeError):
         K.unary(L.ABS, px.Column.from_numpy(np.array([True, False])))
     assert K.unary(L.SQRT, px.Column.from_numpy(np.zeros(0))).length == 0
+
+
+@pytest.mark.parametrize("fn", ["bit_wise_or", "bit_wise_and", "bit_wise_xor", "shift_left", "shift_right"])
+def test_bitwise_and_shift_golden(px, fn):
+    """BINARY_OPERATOR(| & ^ << >>) (src/series.cpp:237-245): array-array, array-scalar and scalar-array against Arrow, bit for bit"""
+    z, m = _unary_golden()
+    L, K, C = px.L, px.K, px.Column
+    op = {"bit_wise_or": L.BIT_OR, "bit_wise_and": L.BIT_AND, "bit_wise_xor": L.BIT_XOR, "shift_left": L.SHIFT_LEFT, "shift_right": L.SHIFT_RIGHT}[fn]
+    a, b, va, vb = z["bw/a"], z["bw/b"], z["bw/va"], z["bw/vb"]
+    A, B = C.from_numpy(a, va, offset=3), C.from_numpy(b, vb, offset=5)
+    got, ok = K.binary(op, A, B).to_numpy()
+    assert np.array_equal(ok, z[f"bw/{fn}_valid"]) and np.array_equal(got.view(np.uint64)[ok], z[f"bw/{fn}"][ok])
+    for j, sc in enumerate(m["bitwise_scalars"]):
+        got, ok = K.binary(op, A, sc, True).to_numpy()
+        assert np.array_equal(ok, va) and np.array_equal(got.view(np.uint64)[va], z[f"bw/{fn}_rhs{j}"][va]), (fn, "rhs", sc)
+        got, ok = K.binary(op, sc, B).to_numpy()
+        assert np.array_equal(ok, vb) and np.array_equal(got.view(np.uint64)[vb], z[f"bw/{fn}_lhs{j}"][vb]), (fn, "lhs", sc)
+    # 1e6 rows against the oracle; Series operators; float operands have no kernel
+    rng = np.random.default_rng(17)
+    n = 1_000_001
+    x, y = rng.integers(-(2**63), 2**63 - 1, n), rng.integers(-2, 66, n)
+    exp, _ = orc.binary(getattr(orc, {"bit_wise_or": "BIT_OR", "bit_wise_and": "BIT_AND", "bit_wise_xor": "BIT_XOR", "shift_left": "SHIFT_LEFT",
+                                      "shift_right": "SHIFT_RIGHT"}[fn]), x, y)
+    assert np.array_equal(K.binary(op, C.from_numpy(x), C.from_numpy(y)).to_numpy()[0], exp)
+    S = px.api.Series
+    s, t = S(np.array([6, -8, 1])), S(np.array([3, 1, 62]))
+    pyop = {"bit_wise_or": lambda p, q: p | q, "bit_wise_and": lambda p, q: p & q, "bit_wise_xor": lambda p, q: p ^ q,
+            "shift_left": lambda p, q: p << q, "shift_right": lambda p, q: p >> q}[fn]
+    assert np.array_equal(pyop(s, t).to_numpy()[0], pyop(np.array([6, -8, 1]), np.array([3, 1, 62])))
+    with pytest.raises(RuntimeError, match="no kernel"):
+        K.binary(op, C.from_numpy(np.array([1.5])), C.from_numpy(np.array([2])))

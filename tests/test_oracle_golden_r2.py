@@ -195,3 +195,19 @@ def test_unary_oracle_vs_arrow(case):
             orc.unary(op, v, valid, 2.0)
         if "not in range" in e["message"]:
             assert str(ei.value) == e["message"]
+
+
+BITWISE = {"bit_wise_or": orc.BIT_OR, "bit_wise_and": orc.BIT_AND, "bit_wise_xor": orc.BIT_XOR, "shift_left": orc.SHIFT_LEFT, "shift_right": orc.SHIFT_RIGHT}
+
+
+@pytest.mark.parametrize("fn", list(BITWISE))
+def test_bitwise_oracle_vs_arrow(fn):
+    z, m = _unary_golden()
+    a, b, va, vb = z["bw/a"], z["bw/b"], z["bw/va"], z["bw/vb"]
+    got, ok = orc.binary(BITWISE[fn], a, b, va, vb)
+    assert np.array_equal(ok, z[f"bw/{fn}_valid"]) and np.array_equal(got.view(np.uint64)[ok], z[f"bw/{fn}"][ok])
+    for j, sc in enumerate(m["bitwise_scalars"]):
+        got, ok = orc.binary(BITWISE[fn], a, sc, va, None)
+        assert np.array_equal(got.view(np.uint64)[va], z[f"bw/{fn}_rhs{j}"][va]), (fn, "rhs", sc)
+        got, ok = orc.binary(BITWISE[fn], sc, b, None, vb)
+        assert np.array_equal(got.view(np.uint64)[vb], z[f"bw/{fn}_lhs{j}"][vb]), (fn, "lhs", sc)
