@@ -9,7 +9,8 @@ rocprofv3 -L > "$OUT/counters_list.txt" 2>&1
 i=0
 for set in "$@"; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/p$i" -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-check > "$OUT/p$i.log" 2>&1
+  # PMC_PROG (optional): another python program of this repo instead of the bench, e.g. PMC_PROG="tools/bench_nullsum.py"
+  timeout -k 10 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$OUT/p$i" -- python ${PMC_PROG:-bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-check} > "$OUT/p$i.log" 2>&1
   rc=$?
   echo "pass $i ($set): rc=$rc"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "timed out: stopping"; exit 1; fi
