@@ -199,7 +199,9 @@ def secondary_runs(torch, L, K, api, keys, vals, kinds, n_total, nkeys, steps):
     put("C2_filter_8cols+index", n, (0.125 + 8 * 9 * (1 + s)) * n, timeit(lambda: df.where(mask)), selectivity=round(s, 4))
     m = n // 2
     take_idx = api.Series(K.synth_keys(7, m, n))
-    put("C2_take_8cols+index", m, (8 + 16 * 9) * m, timeit(lambda: df.take(take_idx)), note="rows = output rows (random 8-B gathers)")
+    dt_take = timeit(lambda: df.take(take_idx))
+    put("C2_take_8cols+index", m, (8 + 16 * 9) * m, dt_take, note="rows = output rows (random 8-B gathers)",
+        random_gathers_per_s=round(9 * m / dt_take), sector_GBps_64B=round(9 * m * 64 / dt_take / 1e9, 1))
     del df, cols, mask, take_idx
     # (e) C5: resample('1min').mean() on a timestamp + fp64 Series (100 ms spacing -> 600 rows per bin)
     ts = K.synth_ts(0, n_total, 946_684_800 * 10**9, 100_000_000)
