@@ -175,6 +175,11 @@ int pdx_compare(int op, const pdx_column* a, const pdx_column* b, int b_is_scala
 /* Replaces CallFunction("and"|"or") (non-Kleene) at src/series.cpp:259-260 and "invert" at src/series.cpp:319. */
 int pdx_logical(int op, const pdx_column* a, const pdx_column* b, pdx_mut_column* out, void* stream);
 int pdx_invert(const pdx_column* a, pdx_mut_column* out, void* stream);
+/* Replaces arrow::compute::IfElse(cond, a, b): Series::if_else / Series::where(cond, other) with a Series or Scalar `other`
+ * (src/series.cpp:1203-1209, 1247-1253; pinned by tests/series_indexing_test.cpp:36-52).  cond: PDX_BOOL of the result's length;
+ * a, b: PDX_INT64 or PDX_FLOAT64 (mixed => float64); scalar_side (pdx_scalar_side): RHS = b has length 1, LHS = a has length 1.
+ * out[i] = cond[i] ? a[i] : b[i]; null where cond is null or the chosen operand is null (the other operand's nulls do not count). */
+int pdx_if_else(const pdx_column* cond, const pdx_column* a, const pdx_column* b, int scalar_side, pdx_mut_column* out, void* stream);
 /* Replaces CallFunction("negate" | "abs" | "sign" | "sqrt" | "exp" | "bit_wise_not", {array}): DataFrame::unary (operator-,
  * operator~) and the UNARY_FUNCTION macros src/dataframe.cpp:251-275, 919-935, src/dataframe.h:494-502; Series::abs / exp /
  * sign / sqrt src/series.h:89-109.  a: PDX_INT64, PDX_UINT64 or PDX_FLOAT64; out null where a is null.

@@ -210,6 +210,31 @@ def invert(a, offset=0):
     return unpack_bits(out, n)
 
 
+def if_else(cond, a, b, cond_valid=None, va=None, vb=None):
+    """arrow::compute::IfElse(cond, a, b) (src/series.cpp:1203-1209, 1247-1253): a or b may be a python scalar (None = null scalar).
+    int64 / float64 operands, mixed -> float64.  Returns (values, valid bool[n])."""
+    cond = np.asarray(cond, bool)
+    n = len(cond)
+
+    def prep(x, vx):
+        if x is None:
+            return np.zeros(1, np.int64), np.zeros(1, bool), True
+        if np.isscalar(x):
+            return np.array([x]), (None if vx is None else np.asarray(vx, bool)), True
+        return np.ascontiguousarray(x), (None if vx is None else np.asarray(vx, bool)), False
+
+    a, va, sa = prep(a, va)
+    b, vb, sb = prep(b, vb)
+    isf = a.dtype == np.float64 or b.dtype == np.float64
+    dt = np.float64 if isf else np.int64
+    a, b = a.astype(dt), b.astype(dt)
+    out = np.zeros(max(n, 1), np.uint64)
+    ov = np.zeros((n + 7) // 8 + 8, np.uint8)
+    lib().orc_if_else(_p(pack_bits(cond, 0)), _p(pack_bits(cond_valid, 0)), _p(a.view(np.uint64)), _p(pack_bits(va, 0)), C.c_int(sa), _p(b.view(np.uint64)),
+                      _p(pack_bits(vb, 0)), C.c_int(sb), _i64(n), _p(out), _p(ov))
+    return out[:n].view(dt), unpack_bits(ov, n)
+
+
 UNARY_NEGATE, UNARY_ABS, UNARY_SIGN, UNARY_SQRT, UNARY_EXP, UNARY_BIT_NOT, UNARY_POWER = 0, 1, 2, 3, 4, 5, 100
 
 

@@ -94,6 +94,20 @@ def main():
         for j, sc in enumerate(manifest["bitwise_scalars"]):
             store[f"bw/{fn}_rhs{j}"], _ = result_bits(pc.call_function(fn, [pa_a, pa.scalar(sc, pa.int64())]))
             store[f"bw/{fn}_lhs{j}"], _ = result_bits(pc.call_function(fn, [pa.scalar(sc, pa.int64()), pa_b]))
+    # ---- if_else(cond, a, b) (Series::if_else / where(cond, other), src/series.cpp:1203-1209, 1247-1253)
+    m = 500
+    cond, cv = rng.random(m) > 0.5, rng.random(m) > 0.15
+    ai, bi, af, bf = rng.integers(-99, 99, m), rng.integers(1000, 2000, m), rng.standard_normal(m), rng.standard_normal(m) + 100.0
+    va_, vb_ = rng.random(m) > 0.2, rng.random(m) > 0.2
+    store["ie/cond"], store["ie/cv"], store["ie/ai"], store["ie/bi"], store["ie/af"], store["ie/bf"], store["ie/va"], store["ie/vb"] = cond, cv, ai, bi, af, bf, va_, vb_
+    pc_cond = pa.array(cond, mask=~cv)
+    combos = {"ii": (pa.array(ai, mask=~va_), pa.array(bi, mask=~vb_)), "ff": (pa.array(af, mask=~va_), pa.array(bf, mask=~vb_)),
+              "if": (pa.array(ai, mask=~va_), pa.array(bf, mask=~vb_)), "fi": (pa.array(af, mask=~va_), pa.array(bi, mask=~vb_)),
+              "i_s7": (pa.array(ai, mask=~va_), pa.scalar(7, pa.int64())), "f_snull": (pa.array(af, mask=~va_), pa.scalar(None, pa.float64())),
+              "s2.5_i": (pa.scalar(2.5, pa.float64()), pa.array(bi, mask=~vb_)), "i_s1.5": (pa.array(ai, mask=~va_), pa.scalar(1.5, pa.float64()))}
+    manifest["if_else"] = list(combos)
+    for name, (x, y) in combos.items():
+        store[f"ie/{name}"], store[f"ie/{name}_valid"] = result_bits(pc.if_else(pc_cond, x, y))
     manifest["exponents"] = EXPONENTS
     store["manifest"] = np.array(json.dumps(manifest))
     np.savez_compressed(OUT, **store)

@@ -915,3 +915,16 @@ int orc_unary(int op, int dtype, const uint64_t* in_bits, const uint8_t* valid, 
   }
   return 0;
 }
+
+void orc_if_else(const uint8_t* cond_bits, const uint8_t* cond_valid, const uint64_t* a, const uint8_t* va, int a_scalar, const uint64_t* b,
+                 const uint8_t* vb, int b_scalar, int64_t n, uint64_t* out, uint8_t* out_valid) {
+  memset(out_valid, 0, (size_t)((n + 7) / 8));
+  for (int64_t i = 0; i < n; ++i) {
+    const int c = (cond_bits[i >> 3] >> (i & 7)) & 1;
+    const int cv = !cond_valid || ((cond_valid[i >> 3] >> (i & 7)) & 1);
+    const int64_t ia = a_scalar ? 0 : i, ib = b_scalar ? 0 : i;
+    const int av = !va || ((va[ia >> 3] >> (ia & 7)) & 1), bv = !vb || ((vb[ib >> 3] >> (ib & 7)) & 1);
+    out[i] = c ? a[ia] : b[ib];
+    if (cv && (c ? av : bv)) out_valid[i >> 3] |= (uint8_t)(1u << (i & 7));
+  }
+}

@@ -71,6 +71,10 @@ int orc_compare_i64(int op, const int64_t* a, const uint8_t* va, int64_t aoff, c
 int orc_logical(int op, const uint8_t* a, const uint8_t* va, int64_t aoff, const uint8_t* b, const uint8_t* vb, int64_t boff,
                 int64_t n, uint8_t* out_bits, uint8_t* out_valid);
 void orc_invert(const uint8_t* a, int64_t aoff, int64_t n, uint8_t* out_bits);
+/* arrow::compute::IfElse(cond, a, b) (src/series.cpp:1203-1209): 8-byte patterns; a_scalar / b_scalar: that operand has length 1.
+ * out_valid (bit-packed, n bits) = cond_valid & (cond ? a_valid : b_valid). */
+void orc_if_else(const uint8_t* cond_bits, const uint8_t* cond_valid, const uint64_t* a, const uint8_t* va, int a_scalar, const uint64_t* b,
+                 const uint8_t* vb, int b_scalar, int64_t n, uint64_t* out, uint8_t* out_valid);
 /* CallFunction("negate" | "abs" | "sign" | "sqrt" | "exp" | "bit_wise_not" | "power") on one array (src/dataframe.cpp:251-275,
  * 919-935): op 0..5 as pdx_unary_op, 100 = power(a, expo).  dtype: 0 int64, 1 uint64, 2 float64 (in_bits: the 8-byte patterns).
  * out_bits: 8-byte patterns of the result (its type follows Arrow, integers' sign as int64).  Validity passes through (the

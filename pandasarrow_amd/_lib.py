@@ -82,6 +82,7 @@ ABI_SYMBOLS = {
     "pdx_compare": (C.c_int, [C.c_int, _COL, _COL, C.c_int, _MUT, _P]),
     "pdx_logical": (C.c_int, [C.c_int, _COL, _COL, _MUT, _P]),
     "pdx_invert": (C.c_int, [_COL, _MUT, _P]),
+    "pdx_if_else": (C.c_int, [_COL, _COL, _COL, C.c_int, _MUT, _P]),
     "pdx_unary": (C.c_int, [C.c_int, _COL, _MUT, _P]),
     "pdx_power": (C.c_int, [_COL, C.c_double, _MUT, _P]),
     "pdx_aggregate": (C.c_int, [C.c_int, _COL, C.POINTER(PdxScalar), _P]),

@@ -248,7 +248,23 @@ class Series:
     def _index_col(self):
         return self.index
 
-    def where(self, mask: "Series"):
+    def if_else(self, cond: "Series", other):
+        """Series::if_else / where(cond, other) (src/series.cpp:1203-1209, 1247-1253): cond ? self : other (Series or Scalar)."""
+        if cond.col.dtype != L.BOOL:
+            raise L.PdxError(L.INVALID, "if_else condition must be boolean")
+        if isinstance(other, Series):
+            if other.size() != self.size():
+                raise L.PdxError(L.INVALID, f"Array arguments must all be the same length: {self.size()} vs {other.size()}")
+            other = other.col
+        elif isinstance(other, Scalar):
+            other = other.value
+        if cond.size() != self.size():
+            raise L.PdxError(L.INVALID, f"Array arguments must all be the same length: {self.size()} vs {cond.size()}")
+        return self._wrap(K.if_else(cond.col, self.col, other))
+
+    def where(self, mask: "Series", other=None):
+        if other is not None or isinstance(other, Scalar):
+            return self.if_else(mask, other)
         if self.is_index:
             raise L.PdxError(L.INVALID, "where() is not supported on an index Series")
         if mask.col.dtype != L.BOOL:

@@ -194,6 +194,21 @@ def invert(a: Column) -> Column:
     return out._adopt(m)
 
 
+def if_else(cond: Column, a, b) -> Column:
+    """cond ? a : b (pdx_if_else); a or b may be a python scalar / None (null scalar)."""
+    lib = L.load()
+    like_float = any(isinstance(x, Column) and x.dtype == L.FLOAT64 for x in (a, b)) or any(isinstance(x, float) for x in (a, b))
+    side = L.SCALAR_NONE
+    if not isinstance(b, Column):
+        b, side = _scalar_column(b, like_float), L.SCALAR_RHS
+    elif not isinstance(a, Column):
+        a, side = _scalar_column(a, like_float), L.SCALAR_LHS
+    out = Column.empty(_promoted(a, b), cond.length, with_validity=cond.has_nulls() or a.has_nulls() or b.has_nulls())
+    cc, ca, cb, m = cond.c(), a.c(), b.c(), out.mut()
+    L.check(lib.pdx_if_else(C.byref(cc), C.byref(ca), C.byref(cb), side, C.byref(m), _stream()))
+    return out._adopt(m)
+
+
 def unary(op, a: Column) -> Column:
     """negate / abs / sign / sqrt / exp / bit_wise_not of one column (pdx_unary)."""
     lib = L.load()

@@ -275,6 +275,17 @@ class Series {
   Series operator-(const Scalar& o) const { return binary(PDX_SUB, o); }
   Series operator*(const Scalar& o) const { return binary(PDX_MUL, o); }
   Series operator/(const Scalar& o) const { return binary(PDX_DIV, o); }
+  // Series::if_else / where(cond, other) (src/series.cpp:1203-1209, 1247-1253): cond ? *this : other
+  Series if_else(const Series& cond, const Series& other) const {
+    if (other.size() != size() || cond.size() != size()) throw std::runtime_error("Array arguments must all be the same length");
+    return wrap(run_if_else(cond.m_array, m_array, other.m_array, PDX_SCALAR_NONE));
+  }
+  Series if_else(const Series& cond, const Scalar& other) const {
+    if (cond.size() != size()) throw std::runtime_error("Array arguments must all be the same length");
+    return wrap(run_if_else(cond.m_array, m_array, other.to_array(), PDX_SCALAR_RHS));
+  }
+  Series where(const Series& cond, const Series& other) const { return if_else(cond, other); }
+  Series where(const Series& cond, const Scalar& other) const { return if_else(cond, other); }
   // BINARY_OPERATOR(| & ^ << >>) (src/series.cpp:237-245): bit_wise_or / and / xor, shift_left / shift_right on integers
   Series operator|(const Series& o) const { return binary(PDX_BIT_OR, o); }
   Series operator&(const Series& o) const { return binary(PDX_BIT_AND, o); }
@@ -384,6 +395,15 @@ class Series {
     auto ca = a.c(), cb = b.c();
     auto m = out.mut();
     ThrowOnFailure(pdx_binary(op, &ca, &cb, scalar, &m, nullptr));
+    out.null_count = m.null_count;
+    return out;
+  }
+  static Array run_if_else(const Array& cond, const Array& a, const Array& b, int side) {
+    const bool is_f = a.dtype == PDX_FLOAT64 || b.dtype == PDX_FLOAT64;
+    Array out = Array::Empty(is_f ? PDX_FLOAT64 : PDX_INT64, cond.length, cond.has_nulls() || a.has_nulls() || b.has_nulls());
+    auto cc = cond.c(), ca = a.c(), cb = b.c();
+    auto m = out.mut();
+    ThrowOnFailure(pdx_if_else(&cc, &ca, &cb, side, &m, nullptr));
     out.null_count = m.null_count;
     return out;
   }

@@ -449,7 +449,85 @@ static int unary_impl(int op, const pdx_column* a, double expo, pdx_mut_column* 
   return PDX_OK;
 }
 
+// ---------------------------------------------------------------- if_else(cond, a, b)
+// SCALAR as in k_binary.  Values: one grid-stride stream (cond bit -> a or b).  Validity: one thread per 64-row output word from the
+// words of cond, its validity and the operands' validity: valid = cond_valid & (cond ? a_valid : b_valid).
+template <typename TA, typename TB, typename TO, int SCALAR>
+__global__ void __launch_bounds__(256) k_if_else(const uint8_t* __restrict__ cond, int64_t coff, int64_t climit, const uint8_t* __restrict__ cvalid,
+                                                 const TA* __restrict__ a, const uint8_t* __restrict__ va, int64_t aoff, int64_t alimit,
+                                                 const TB* __restrict__ b, const uint8_t* __restrict__ vb, int64_t boff, int64_t blimit,
+                                                 TO* __restrict__ out, uint8_t* __restrict__ out_valid, int64_t n) {
+  constexpr bool SA = SCALAR == 2, SB = SCALAR == 1;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const TO as = SA ? Conv<TO>::from(a[0]) : TO(0), bs = SB ? Conv<TO>::from(b[0]) : TO(0);
+  const bool as_valid = !SA || !va || bit_get(va, aoff), bs_valid = !SB || !vb || bit_get(vb, boff);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const bool c = bit_get(cond, coff + i);
+    out[i] = c ? (SA ? as : Conv<TO>::from(a[i])) : (SB ? bs : Conv<TO>::from(b[i]));
+  }
+  if (!out_valid) return;
+  const int64_t nwords = (n + 63) >> 6;
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += stride) {
+    const int64_t base = w << 6;
+    const uint64_t c = load_bits64(cond, coff + base, climit);
+    const uint64_t cv = cvalid ? load_bits64(cvalid, coff + base, climit) : ~0ull;
+    const uint64_t av = SA ? (as_valid ? ~0ull : 0ull) : (va ? load_bits64(va, aoff + base, alimit) : ~0ull);
+    const uint64_t bv = SB ? (bs_valid ? ~0ull : 0ull) : (vb ? load_bits64(vb, boff + base, blimit) : ~0ull);
+    uint64_t r = cv & ((c & av) | (~c & bv));
+    const int64_t remain = n - base;
+    if (remain >= 64) {
+      reinterpret_cast<uint64_t*>(out_valid)[w] = r;
+    } else {
+      r &= (1ull << remain) - 1ull;
+      const int nbytes = (int)((remain + 7) >> 3);
+      for (int k = 0; k < nbytes; ++k) out_valid[(w << 3) + k] = (uint8_t)(r >> (8 * k));
+    }
+  }
+}
+template <typename TA, typename TB, typename TO>
+static void launch_if_else(const pdx_column* cond, const pdx_column* a, const pdx_column* b, int scalar, pdx_mut_column* out, int64_t n, hipStream_t st) {
+  const dim3 grid(grid_for(n, 256, 4)), block(256);
+  const uint8_t* cbits = static_cast<const uint8_t*>(cond->values);
+  const TA* pa = static_cast<const TA*>(a->values) + a->offset;
+  const TB* pb = static_cast<const TB*>(b->values) + b->offset;
+#define IE_ARGS cbits, cond->offset, cond->offset + cond->length, validity_or_null(cond), pa, validity_or_null(a), a->offset, a->offset + a->length, pb, \
+                validity_or_null(b), b->offset, b->offset + b->length, static_cast<TO*>(out->values), static_cast<uint8_t*>(out->validity), n
+  if (scalar == PDX_SCALAR_RHS) hipLaunchKernelGGL((k_if_else<TA, TB, TO, 1>), grid, block, 0, st, IE_ARGS);
+  else if (scalar == PDX_SCALAR_LHS) hipLaunchKernelGGL((k_if_else<TA, TB, TO, 2>), grid, block, 0, st, IE_ARGS);
+  else hipLaunchKernelGGL((k_if_else<TA, TB, TO, 0>), grid, block, 0, st, IE_ARGS);
+#undef IE_ARGS
+}
+
 extern "C" {
+
+int pdx_if_else(const pdx_column* cond, const pdx_column* a, const pdx_column* b, int scalar_side, pdx_mut_column* out, void* stream) {
+  PDX_TRY(check_column(cond, "pdx_if_else"));
+  if (cond->dtype != PDX_BOOL) return fail(PDX_INVALID, "pdx_if_else: the condition must be PDX_BOOL");
+  PDX_TRY(check_column(a, "pdx_if_else"));
+  PDX_TRY(check_column(b, "pdx_if_else"));
+  auto num = [](int dt) { return dt == PDX_INT64 || dt == PDX_FLOAT64; };
+  if (!num(a->dtype) || !num(b->dtype)) return fail(PDX_NOT_IMPLEMENTED, "pdx_if_else: only int64/float64 operands are supported");
+  if (scalar_side < 0 || scalar_side > PDX_SCALAR_LHS) return fail(PDX_INVALID, "pdx_if_else: scalar side must be 0 (none), 1 (rhs) or 2 (lhs)");
+  const int64_t n = cond->length;
+  if ((scalar_side == PDX_SCALAR_LHS ? a->length != 1 : a->length != n) || (scalar_side == PDX_SCALAR_RHS ? b->length != 1 : b->length != n))
+    return fail(PDX_INVALID, "pdx_if_else: Array arguments must all be the same length (a scalar operand has length 1)");
+  const bool is_f = a->dtype == PDX_FLOAT64 || b->dtype == PDX_FLOAT64;
+  if (!out || out->length < n || out->dtype != (is_f ? PDX_FLOAT64 : PDX_INT64)) return fail(PDX_INVALID, "pdx_if_else: output dtype / length do not match the result");
+  const bool has_nulls = validity_or_null(cond) || validity_or_null(a) || validity_or_null(b);
+  if (has_nulls && !out->validity) return fail(PDX_INVALID, "pdx_if_else: inputs carry nulls but output has no validity buffer");
+  hipStream_t st = as_stream(stream);
+  out->length = n;
+  out->null_count = has_nulls ? -1 : 0;
+  if (n == 0) return PDX_OK;
+  if (!out->values) return fail(PDX_INVALID, "pdx_if_else: null output buffer");
+  pdx_mut_column o = *out;
+  if (!is_f) launch_if_else<int64_t, int64_t, int64_t>(cond, a, b, scalar_side, &o, n, st);
+  else if (a->dtype == PDX_FLOAT64 && b->dtype == PDX_FLOAT64) launch_if_else<double, double, double>(cond, a, b, scalar_side, &o, n, st);
+  else if (a->dtype == PDX_FLOAT64) launch_if_else<double, int64_t, double>(cond, a, b, scalar_side, &o, n, st);
+  else launch_if_else<int64_t, double, double>(cond, a, b, scalar_side, &o, n, st);
+  PDX_LAUNCH_CHECK();
+  return PDX_OK;
+}
 
 int pdx_unary(int op, const pdx_column* a, pdx_mut_column* out, void* stream) { return unary_impl(op, a, 0.0, out, stream, "pdx_unary"); }
 int pdx_power(const pdx_column* a, double exponent, pdx_mut_column* out, void* stream) { return unary_impl(kPowerOp, a, exponent, out, stream, "pdx_power"); }

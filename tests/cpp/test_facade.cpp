@@ -83,6 +83,11 @@ static void test_series_where_take() {
   REQUIRE(result.size() == 3);
   REQUIRE((result.values<int>() == std::vector<int>{2, 4, 5}));
   REQUIRE_THROWS(s1.take(Series(std::vector<int>{0, 7})));  // ArrowIndexError
+  // where(mask, Scalar): the scalar where the mask is false (tests/series_indexing_test.cpp:36-52)
+  Series filled = s1.where(Series(std::vector<bool>{false, true, true, true, false}), Scalar(3));
+  REQUIRE((filled.values<int>() == std::vector<int>{3, 2, 3, 4, 3}));
+  REQUIRE((s1.if_else(Series(std::vector<bool>{true, false, true, false, true}), Series(std::vector<int>{9, 8, 7, 6, 5})).values<int>() ==
+           std::vector<int>{1, 8, 3, 6, 5}));
   auto picked = s1[s1 > Scalar(2)];                         // operator[](bool Series) == where
   REQUIRE((picked.values<int>() == std::vector<int>{3, 4, 5}));
 }

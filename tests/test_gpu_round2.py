@@ -425,3 +425,76 @@ def test_bitwise_and_shift_golden(px, fn):
     assert np.array_equal(pyop(s, t).to_numpy()[0], pyop(np.array([6, -8, 1]), np.array([3, 1, 62])))
     with pytest.raises(RuntimeError, match="no kernel"):
         K.binary(op, C.from_numpy(np.array([1.5])), C.from_numpy(np.array([2])))
+
+
+# ------------------------------------------------------------------ if_else + the reference's own frame tests on the device
+def test_if_else_golden_and_kat(px, kat):
+    z, m = _unary_golden()
+    K, C, L = px.K, px.Column, px.L
+    cond, cv, va, vb = z["ie/cond"], z["ie/cv"], z["ie/va"], z["ie/vb"]
+    Cc = C.from_numpy(cond, cv, offset=5)
+    col = lambda v, valid, off: C.from_numpy(v, valid, offset=off)
+    ops = {"ii": (col(z["ie/ai"], va, 1), col(z["ie/bi"], vb, 9)), "ff": (col(z["ie/af"], va, 0), col(z["ie/bf"], vb, 3)),
+           "if": (col(z["ie/ai"], va, 2), col(z["ie/bf"], vb, 0)), "fi": (col(z["ie/af"], va, 7), col(z["ie/bi"], vb, 1)),
+           "i_s7": (col(z["ie/ai"], va, 0), 7), "f_snull": (col(z["ie/af"], va, 0), None), "s2.5_i": (2.5, col(z["ie/bi"], vb, 4)),
+           "i_s1.5": (col(z["ie/ai"], va, 0), 1.5)}
+    for name, (a, b) in ops.items():
+        got, ok = K.if_else(Cc, a, b).to_numpy()
+        assert np.array_equal(ok, z[f"ie/{name}_valid"]), name
+        assert np.array_equal(np.ascontiguousarray(got).view(np.uint64)[ok], z[f"ie/{name}"][ok]), name
+    # no nulls anywhere, 1e6 rows
+    rng = np.random.default_rng(3)
+    n = 1_000_003
+    c, x, y = rng.random(n) > 0.3, rng.standard_normal(n), rng.integers(-9, 9, n)
+    got, ok = K.if_else(C.from_numpy(c), C.from_numpy(x), C.from_numpy(y)).to_numpy()
+    assert ok is None and np.array_equal(got, np.where(c, x, y.astype(np.float64)))
+    S, Scalar = px.api.Series, px.api.Scalar
+    for k in kat["if_else"]:
+        s, mk = S(np.array(k["v"])), S(np.array(k["mask"], bool))
+        assert list(s.where(mk, Scalar(k["other_scalar"])).to_numpy()[0]) == k["out"]
+        assert list(s.if_else(mk, S(np.full(len(k["v"]), k["other_scalar"]))).to_numpy()[0]) == k["out"]
+    with pytest.raises(RuntimeError, match="PDX_BOOL"):
+        K.if_else(C.from_numpy(np.array([1, 0])), C.from_numpy(np.array([1, 2])), 3)
+    with pytest.raises(RuntimeError, match="same length"):
+        K.if_else(C.from_numpy(np.array([True, False])), C.from_numpy(np.array([1, 2, 3])), 3)
+    assert K.if_else(C.from_numpy(np.zeros(0, bool)), C.from_numpy(np.zeros(0)), 1.0).length == 0
+
+
+def test_frame_kat_device(px, kat):
+    """tests/dataframe_arithmetric_test.cpp:22-310 and tests/dataframe_indexing_test.cpp:97-154 through the DataFrame mirror"""
+    api = px.api
+    for k in kat["frame_binary"]:
+        a = api.DataFrame({c: np.array(v, np.int64 if k["a_dtype"] == "int64" else np.float64) for c, v in k["a"].items()})
+        if "b" in k:
+            b = api.DataFrame({c: np.array(v, np.int64 if k["b_dtype"] == "int64" else np.float64) for c, v in k["b"].items()})
+            for key, res in (("add", a + b), ("sub", a - b), ("mul", a * b), ("div", a / b)):
+                for c in k["a"]:
+                    got = res[c].to_numpy()[0]
+                    if key in k:
+                        assert np.array_equal(got, np.array(k[key][c], got.dtype)), (k["src"], key, c)
+                    else:
+                        assert np.allclose(got, k["div_approx"][c], rtol=1e-12)
+            if "mismatch_rows" in k:
+                short = api.DataFrame({"colX": np.arange(k["mismatch_rows"]), "colY": np.arange(k["mismatch_rows"])})
+                with pytest.raises(RuntimeError):
+                    a + short
+        if "series" in k:
+            res = a + api.Series(np.array(k["series"]))
+            for c in k["a"]:
+                assert np.array_equal(res[c].to_numpy()[0], np.array(k["add"][c], np.float64))
+            with pytest.raises(RuntimeError):
+                a + api.Series(np.array(k["short_series"]))
+        if "scalar" in k:
+            res = a + api.Scalar(k["scalar"])
+            for c in k["a"]:
+                got = res[c].to_numpy()[0]
+                assert got.dtype == np.int64 and list(got) == k["add"][c]
+    for k in kat["frame_unary"]:
+        df = api.DataFrame({c: np.array(v) for c, v in k["cols"].items()})
+        for c in k["cols"]:
+            assert list(df.abs()[c].to_numpy()[0]) == k["abs"][c] and list(df.sign()[c].to_numpy()[0]) == k["sign"][c]
+            assert np.allclose(df.pow(2.0)[c].to_numpy()[0], k["pow2"][c])
+            for got, exp in zip(df.sqrt()[c].to_numpy()[0], k["sqrt"][c]):
+                assert np.isnan(got) if exp == "nan" else abs(got - exp) < 1e-3
+            exp_ref = k["exp_approx"].get(c) or k["exp_approx"][c + "_first2"]
+            assert np.allclose(df.exp()[c].to_numpy()[0][: len(exp_ref)], exp_ref, rtol=1e-4)

@@ -211,3 +211,53 @@ def test_bitwise_oracle_vs_arrow(fn):
         assert np.array_equal(got.view(np.uint64)[va], z[f"bw/{fn}_rhs{j}"][va]), (fn, "rhs", sc)
         got, ok = orc.binary(BITWISE[fn], sc, b, None, vb)
         assert np.array_equal(got.view(np.uint64)[vb], z[f"bw/{fn}_lhs{j}"][vb]), (fn, "lhs", sc)
+
+
+# ------------------------------------------------------------------ if_else + the reference's own frame tests
+def test_if_else_oracle_vs_arrow_and_kat(kat):
+    z, m = _unary_golden()
+    cond, cv, va, vb = z["ie/cond"], z["ie/cv"], z["ie/va"], z["ie/vb"]
+    ops = {"ii": (z["ie/ai"], z["ie/bi"], va, vb), "ff": (z["ie/af"], z["ie/bf"], va, vb), "if": (z["ie/ai"], z["ie/bf"], va, vb),
+           "fi": (z["ie/af"], z["ie/bi"], va, vb), "i_s7": (z["ie/ai"], 7, va, None), "f_snull": (z["ie/af"], None, va, None),
+           "s2.5_i": (2.5, z["ie/bi"], None, vb), "i_s1.5": (z["ie/ai"], 1.5, va, None)}
+    assert sorted(ops) == sorted(m["if_else"])
+    for name, (a, b, xa, xb) in ops.items():
+        got, ok = orc.if_else(cond, a, b, cv, xa, xb)
+        assert np.array_equal(ok, z[f"ie/{name}_valid"]), name
+        assert np.array_equal(np.ascontiguousarray(got).view(np.uint64)[ok], z[f"ie/{name}"][ok]), name
+    for k in kat["if_else"]:
+        got, ok = orc.if_else(np.array(k["mask"], bool), np.array(k["v"], np.int64), k["other_scalar"])
+        assert ok.all() and list(got) == k["out"]
+
+
+def test_frame_kat_oracle(kat):
+    """tests/dataframe_arithmetric_test.cpp + tests/dataframe_indexing_test.cpp through the oracle, column by column"""
+    for k in kat["frame_binary"]:
+        a = {c: np.array(v, np.int64 if k["a_dtype"] == "int64" else np.float64) for c, v in k["a"].items()}
+        if "b" in k:
+            b = {c: np.array(v, np.int64 if k["b_dtype"] == "int64" else np.float64) for c, v in k["b"].items()}
+            for op, key in ((orc.ADD, "add"), (orc.SUB, "sub"), (orc.MUL, "mul"), (orc.DIV, "div")):
+                for c in a:
+                    got, _ = orc.binary(op, a[c], b[c])
+                    if key in k:
+                        assert np.array_equal(got, np.array(k[key][c], got.dtype)), (k["src"], key, c)
+                    elif key == "div":
+                        assert np.allclose(got, k["div_approx"][c], rtol=1e-12), (k["src"], c)
+        if "series" in k:
+            for c in a:
+                assert np.array_equal(orc.binary(orc.ADD, a[c], np.array(k["series"]))[0], np.array(k["add"][c], np.float64))
+        if "scalar" in k:
+            for c in a:
+                got, _ = orc.binary(orc.ADD, a[c], k["scalar"])
+                assert got.dtype == np.int64 and list(got) == k["add"][c]
+    for k in kat["frame_unary"]:
+        for c, v in k["cols"].items():
+            v = np.array(v)
+            assert list(orc.unary(orc.UNARY_ABS, v)) == k["abs"][c] and list(orc.unary(orc.UNARY_SIGN, v)) == k["sign"][c]
+            assert np.allclose(orc.unary(orc.UNARY_POWER, v, None, 2.0), k["pow2"][c])
+            sq = orc.unary(orc.UNARY_SQRT, v)
+            for got, exp in zip(sq, k["sqrt"][c]):
+                assert np.isnan(got) if exp == "nan" else abs(got - exp) < 1e-3
+            ex = orc.unary(orc.UNARY_EXP, v)
+            exp_ref = k["exp_approx"].get(c) or k["exp_approx"][c + "_first2"]
+            assert np.allclose(ex[: len(exp_ref)], exp_ref, rtol=1e-4)
