@@ -618,19 +618,45 @@ class Resampler(GroupBy):
 def concat(frames, axis="index", join="outer", ignore_index=False, sort=False):
     """pd::concat(dfs, axis, join, ignore_index, sort) (src/concat.h:56-64, src/concat.cpp).
 
-    axis="index" (rows, src/concat.cpp:116-190) for same-schema frames: columns are appended, each frame's index is carried
-    along (``[0,1,0,1]``) unless ignore_index.
+    axis="index" (rows, src/concat.cpp:116-190): columns are appended by name (common numeric type for same-named columns, nulls
+    where a frame lacks a column; join="inner" keeps the columns without nulls), each frame's index is carried along
+    (``[0,1,0,1]``) unless ignore_index.
     axis="columns" (src/concat.cpp:192-244): the frames' indexes are merged pairwise -- Series::union_ (distinct labels in
     first-occurrence order) for join="outer", Series::intersection for "inner" -- optionally sorted, every frame whose index
     differs is reindexed onto the merged index (labels it lacks -> null rows), and the columns are laid side by side
     (duplicate names are kept; ignore_index renames them "0", "1", ...)."""
     if axis in ("columns", 1):
         return _concat_columns(frames, join, ignore_index, sort)
-    names = frames[0].names
+    if join not in ("outer", "inner"):
+        raise L.PdxError(L.INVALID, "join must be 'outer' or 'inner'")
+    # Concatenator::concatenateRows (src/concat.cpp:116-190): same-named columns are promoted to a common numeric type
+    # (resolveDuplicateFieldName + promoteTypes, src/concat.cpp:90-114, src/core.cpp:452-485), the schemas are unified in order of
+    # first appearance (ConcatenateTables, unify_schemas) with nulls where a frame lacks a column; join="inner" then drops every
+    # column that holds a null (the reference's test for "not present in all frames")
+    names = []
     for f in frames:
-        if f.names != names:
-            raise L.PdxError(L.NOT_IMPLEMENTED, "row concat of frames with different schemas (outer/inner join on the columns) is not implemented")
-    cols = [K.concat([f.cols[i] for f in frames]) for i in range(len(names))]
+        names += [nm for nm in f.names if nm not in names]
+    cols = []
+    for nm in names:
+        have = [f.cols[f.names.index(nm)] if nm in f.names else None for f in frames]
+        dts = {c.dtype for c in have if c is not None}
+        if dts <= {L.INT64, L.FLOAT64}:
+            dt = L.FLOAT64 if L.FLOAT64 in dts else L.INT64
+        elif len(dts) == 1:
+            dt = next(iter(dts))
+        else:
+            raise L.PdxError(L.NOT_IMPLEMENTED, f"concat: column '{nm}' has types without a common numeric type on this path")
+        parts = []
+        for f, c in zip(frames, have):
+            if c is None:
+                c = K.null_column(dt, f.num_rows())
+            elif c.dtype != dt:  # Cast(int64 -> double): value by value, as x * 1.0
+                c = K.binary(L.MUL, c, 1.0, True)
+            parts.append(c)
+        cols.append(K.concat(parts))
+    if join == "inner":
+        keep = [i for i, c in enumerate(cols) if c.validity is None or c.null_count == 0]  # (pdx_concat returns the exact null count)
+        names, cols = [names[i] for i in keep], [cols[i] for i in keep]
     index = None
     if not ignore_index:
         idx_parts = [f.index if f.index is not None else Column.from_numpy(np.arange(f.num_rows(), dtype=np.uint64)) for f in frames]

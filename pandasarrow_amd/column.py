@@ -194,6 +194,14 @@ def invert(a: Column) -> Column:
     return out._adopt(m)
 
 
+def null_column(dtype, n) -> Column:
+    """n nulls of `dtype` (device-side zeros: values and validity)."""
+    nbytes = _bitmap_bytes(n)
+    vdt = torch.uint8 if dtype == L.BOOL else (torch.float64 if dtype == L.FLOAT64 else torch.int64)
+    vals = torch.zeros(max(nbytes if dtype == L.BOOL else n, 1), dtype=vdt, device=_device())
+    return Column(dtype, n, vals, torch.zeros(nbytes, dtype=torch.uint8, device=_device()), 0, n)
+
+
 def if_else(cond: Column, a, b) -> Column:
     """cond ? a : b (pdx_if_else); a or b may be a python scalar / None (null scalar)."""
     lib = L.load()

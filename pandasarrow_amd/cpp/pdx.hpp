@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <array>
@@ -931,15 +932,52 @@ inline Array concat_arrays(const std::vector<Array>& parts) {
   out.null_count = m.null_count;
   return out;
 }
-inline DataFrame concat(const std::vector<DataFrame>& dfs, bool ignore_index = false) {
+// Concatenator::concatenateRows (src/concat.cpp:116-190): same-named columns are promoted to a common numeric type
+// (resolveDuplicateFieldName + promoteTypes, src/concat.cpp:90-114, src/core.cpp:452-485), schemas unified in order of first
+// appearance with nulls where a frame lacks a column; inner_join drops every column that holds a null
+inline DataFrame concat(const std::vector<DataFrame>& dfs, bool ignore_index = false, bool inner_join = false) {
   if (dfs.empty()) throw std::runtime_error("concat of zero frames");
+  std::vector<std::string> names;
   for (auto& d : dfs)
-    if (d.m_names != dfs[0].m_names) throw std::runtime_error("concat of frames with different schemas is not on the hot path");
+    for (auto& nm : d.m_names)
+      if (std::find(names.begin(), names.end(), nm) == names.end()) names.push_back(nm);
   std::vector<Array> cols;
-  for (size_t c = 0; c < dfs[0].m_columns.size(); ++c) {
+  std::vector<std::string> kept;
+  for (auto& nm : names) {
+    bool any_f = false, any_other = false;
+    int other_dt = -1;
+    for (auto& d : dfs) {
+      auto it = std::find(d.m_names.begin(), d.m_names.end(), nm);
+      if (it == d.m_names.end()) continue;
+      const int dt = d.m_columns[(size_t)(it - d.m_names.begin())].dtype;
+      if (dt == PDX_FLOAT64) any_f = true;
+      else if (dt != PDX_INT64) {
+        if (other_dt >= 0 && other_dt != dt) throw std::runtime_error("concat: no common numeric type for column " + nm);
+        other_dt = dt;
+        any_other = true;
+      }
+    }
+    if (any_other && any_f) throw std::runtime_error("concat: no common numeric type for column " + nm);
+    const int dt = any_other ? other_dt : any_f ? PDX_FLOAT64 : PDX_INT64;
     std::vector<Array> parts;
-    for (auto& d : dfs) parts.push_back(d.m_columns[c]);
-    cols.push_back(concat_arrays(parts));
+    for (auto& d : dfs) {
+      auto it = std::find(d.m_names.begin(), d.m_names.end(), nm);
+      if (it == d.m_names.end()) {
+        std::vector<int64_t> zeros((size_t)d.num_rows(), 0);
+        const std::vector<bool> none((size_t)d.num_rows(), false);
+        Array nul = Array::Make(zeros, &none);
+        nul.dtype = dt;
+        parts.push_back(nul);
+      } else {
+        Array c = d.m_columns[(size_t)(it - d.m_names.begin())];
+        if (c.dtype != dt) c = Series::run_binary(PDX_MUL, c, Scalar(1.0).to_array(), true);  // Cast(int64 -> double)
+        parts.push_back(c);
+      }
+    }
+    Array col = concat_arrays(parts);
+    if (inner_join && col.has_nulls() && col.null_count != 0) continue;
+    cols.push_back(col);
+    kept.push_back(nm);
   }
   std::optional<Array> index;
   if (!ignore_index) {  // each frame's index is carried along: [0,1,0,1] (tests/concat_test.cpp:40-50)
@@ -954,7 +992,7 @@ inline DataFrame concat(const std::vector<DataFrame>& dfs, bool ignore_index = f
     }
     index = concat_arrays(parts);
   }
-  return DataFrame(dfs[0].m_names, cols, index);
+  return DataFrame(kept, cols, index);
 }
 
 }  // namespace pd

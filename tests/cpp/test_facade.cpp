@@ -227,6 +227,20 @@ static void test_concat_and_frame_ops() {
   auto r = concat({df1, df3});
   REQUIRE((r["number"].values<long>() == std::vector<long>{1, 2, 3, 4}));
   REQUIRE((r.m_index->values_as<long>() == std::vector<long>{0, 1, 0, 1}));
+  // ConcatenateRows (tests/concat_test.cpp:591-749): schema union with null fill, int64 + double -> double, inner join
+  {
+    DataFrame d1({"a", "b"}, {Array::Make(std::vector<long>{1, 2, 3}), Array::Make(std::vector<long>{4, 5, 6})});
+    DataFrame d2({"a", "e"}, {Array::Make(std::vector<double>{7.0, 8.0, 9.0}), Array::Make(std::vector<long>{13, 14, 15})});
+    auto u = concat({d1, d2});
+    REQUIRE((u.m_names == std::vector<std::string>{"a", "b", "e"}));
+    REQUIRE(u["a"].dtype() == PDX_FLOAT64);
+    REQUIRE((u["a"].values<double>() == std::vector<double>{1, 2, 3, 7, 8, 9}));
+    REQUIRE(u["b"].m_array.null_count == 3);
+    REQUIRE(u["e"].m_array.null_count == 3);
+    auto in = concat({d1, d2}, /*ignore_index=*/false, /*inner_join=*/true);
+    REQUIRE((in.m_names == std::vector<std::string>{"a"}));
+    REQUIRE((in.m_index->values_as<long>() == std::vector<long>{0, 1, 2, 0, 1, 2}));
+  }
   DataFrame a(std::map<std::string, std::vector<int32_t>>{{"x", {1, 2, 3}}, {"y", {4, 5, 6}}});
   DataFrame b({"x", "y"}, {Array::Make(std::vector<double>{0.5, 0.5, 0.5}), Array::Make(std::vector<double>{1.5, 1.5, 1.5})});
   auto c = a + b;  // int32 frame (+) double frame -> double

@@ -196,6 +196,8 @@ def test_aggregate_kat(px, kat):
             assert s.min() == k["min"] and s.max() == k["max"]
         if "mean" in k:
             assert s.mean() == k["mean"]
+        if "count" in k:
+            assert s.count() == k["count"]
 
 
 # ------------------------------------------------------------------ filter / take / concat

@@ -498,3 +498,25 @@ def test_frame_kat_device(px, kat):
                 assert np.isnan(got) if exp == "nan" else abs(got - exp) < 1e-3
             exp_ref = k["exp_approx"].get(c) or k["exp_approx"][c + "_first2"]
             assert np.allclose(df.exp()[c].to_numpy()[0][: len(exp_ref)], exp_ref, rtol=1e-4)
+
+
+def test_concat_rows_kat(px, kat):
+    """Concatenator::concatenateRows (tests/concat_test.cpp:591-749): schema union, int64 / double promotion, null fill, inner join"""
+    api = px.api
+    for k in kat["concat_rows"]:
+        frames = []
+        for j, cols in enumerate(k["frames"]):
+            fl = set(k.get("float_cols", [[]] * len(k["frames"]))[j])
+            frames.append(api.DataFrame({c: np.array(v, np.float64 if c in fl else np.int64) for c, v in cols.items()}))
+        res = api.concat(frames, join=k["join"], ignore_index=bool(k.get("ignore_index")))
+        assert res.names == list(k["out"]), k["src"]
+        for c, exp in k["out"].items():
+            vals, valid = res[c].to_numpy()
+            ev = np.array([x is not None for x in exp])
+            assert (valid is None and ev.all()) or np.array_equal(valid, ev), (k["src"], c)
+            want = np.array([0 if x is None else x for x in exp], np.float64 if c in k.get("out_float", []) else np.int64)
+            assert vals.dtype == want.dtype and np.array_equal(vals[ev], want[ev]), (k["src"], c)
+        if k["index"] is None:
+            assert res.index is None
+        else:
+            assert list(res.index.to_numpy()[0]) == k["index"]

@@ -61,6 +61,8 @@ def test_agg_kat(kat):
             assert orc.agg(orc.AGG_MAX, v, valid)[0] == k["max"]
         if "mean" in k:
             assert orc.agg(orc.AGG_MEAN, v, valid)[0] == k["mean"]
+        if "count" in k:
+            assert orc.agg(orc.AGG_COUNT, v, valid)[0] == k["count"]
 
 
 # ------------------------------------------------------------------ element-wise
