@@ -347,7 +347,8 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
                 pmc = json.load(f)
-            if pmc.get("rows") == n_total and pmc.get("n_gpus") == world and pmc.get("source_hash") == source_hash():
+            # (the counters were collected on the single-GPU step: the sharded step -- also when forced at world size 1 -- runs other passes)
+            if pmc.get("rows") == n_total and pmc.get("n_gpus") == world and pmc.get("source_hash") == source_hash() and not sharded:
                 by_tag = pmc["by_bench_tag_hbm_bytes_per_launch"]
                 dk["traffic"] = by_tag.get(tag)
                 roof["traffic"] = pmc.get("step_hbm_bytes")
