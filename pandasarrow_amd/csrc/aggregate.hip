@@ -405,7 +405,10 @@ static int sum_nullable(const T* v, const uint8_t* valid, int64_t off, int64_t n
   PDX_HIP(hipStreamSynchronize(st));
   double* leaves = s.get<double>((size_t)(m ? m : 1));
   PDX_SCRATCH_CHECK(s);
-  const unsigned egrid = (unsigned)std::min<int64_t>(ceil_div(ceil_div(n, kSegRows), kEmitWaves), (int64_t)kCUs * 9);  // 9 workgroups fit a CU's LDS
+  // persistent waves: launch exactly what is resident at once (146 VGPRs -> 3 waves per SIMD = 6 two-wave workgroups per CU; a grid sized
+  // by the LDS alone -- 9 per CU -- left a third of the waves to run as a half-empty second round).  PDX_NULLSUM_WGS_PER_CU: diagnostic.
+  static const int wgs_per_cu = [] { const char* e = getenv("PDX_NULLSUM_WGS_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 6; }();
+  const unsigned egrid = (unsigned)std::min<int64_t>(ceil_div(ceil_div(n, kSegRows), kEmitWaves), (int64_t)kCUs * wgs_per_cu);
   hipLaunchKernelGGL((k_null_seg_emit<T>), dim3(egrid), dim3(kEmitWaves * 64), 0, st, v, valid, off, n, z, lc, leaves);
   PDX_LAUNCH_CHECK();
   return run_tree(leaves, m, nullptr, 0, nullptr, 0, result_dev, s, st);

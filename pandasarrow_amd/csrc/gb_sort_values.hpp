@@ -165,13 +165,16 @@ static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int
       PDX_LAUNCH_CHECK();
     }
   }
-  int grid = (int)std::min<int64_t>(ceil_div(nseg, kSegWaves), (int64_t)kCUs * 8);
+  // workgroups per CU: a multiple of what is resident at once (the 4-wave workgroups hold ~44 KB of LDS: 3 per CU), so that the waves'
+  // static shares of the groups run in full rounds (8 per CU meant 3 + 3 + 2).  PDX_SEG_WGS_PER_CU: diagnostic.
+  static const int seg_wgs_per_cu = [] { const char* e = getenv("PDX_SEG_WGS_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 9; }();
+  int grid = (int)std::min<int64_t>(ceil_div(nseg, kSegWaves), (int64_t)kCUs * seg_wgs_per_cu);
   dim3 g(grid), b(kSegWaves * 64);
   // mostly short groups: one kernel that batches the groups of <= kMidLen rows per wave and chunks through the longer ones
   const int64_t mid_max = [] { const char* e = getenv("PDX_SEG_MID_MAX"); return e ? atoll(e) : 1100ll; }();
   const int64_t min_len = -1;
   if (nrows / nseg < mid_max) {
-    const int64_t nwaves = (int64_t)kCUs * 8 * kSegWaves;
+    const int64_t nwaves = (int64_t)kCUs * seg_wgs_per_cu * kSegWaves;
     const int64_t gpw = std::max<int64_t>(64, ceil_div(nseg, nwaves));
     const int grid_mid = (int)ceil_div(ceil_div(nseg, gpw), kSegWaves);
 #define SEG_MID(PW, MM, IS) \
