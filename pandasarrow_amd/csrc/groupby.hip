@@ -952,7 +952,8 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
       if (hmax <= (1u << 19)) {  // a run is walked by ONE workgroup: keep the longest one short (skewed keys take the classic path)
         auto launch_flr = [&](const SegOut& oo, bool pw, bool mm, bool is, uint8_t* okbytes, const double* sqmean) {
           PDX_PROFILE("fused_last_digit_reduce", st);
-          const int grid = (int)std::min<int64_t>(nruns, (int64_t)kCUs * 24);
+          static const int flr_wgs_per_cu = [] { const char* e = getenv("PDX_FLR_WGS_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 24; }();
+          const int grid = (int)std::min<int64_t>(nruns, (int64_t)kCUs * flr_wgs_per_cu);
           const bool dense = pw && !mm && !is && !vvalid;
           // (values with nulls, sum / mean / count: the thread-per-leaf form is opt-in, PDX_FLR_NULL_PW=1 -- measured 11.3 ms against
           //  10.7 ms of the literal per-lane replay at 5 % nulls: its per-group walk over the leaf markers is as serial as the replay)
@@ -976,7 +977,8 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
           const char* fw_env = getenv("PDX_FLR_WAVE");
           const bool wave_form = !nullpw && (fw_env ? fw_env[0] != '0' : !dense);
           if (wave_form) {
-            const int wgrid = (int)std::min<int64_t>(nruns, (int64_t)kCUs * 12 * 4);
+            static const int fw_wgs_per_cu = [] { const char* e = getenv("PDX_FLR_WAVE_WGS_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 48; }();
+            const int wgrid = (int)std::min<int64_t>(nruns, (int64_t)kCUs * fw_wgs_per_cu);
             const bool pw_only = pw && !mm && !is;
             // counter levels: a group cannot outgrow its run, and a leaf holds 16 rows unless nulls cut it short
             const uint64_t max_leaves = vvalid ? (uint64_t)hmax + 1 : (uint64_t)hmax / 16 + 2;

@@ -306,8 +306,11 @@ static int run_gather(GatherCols& g, const IDX* idx, const uint8_t* idx_valid, i
   PDX_HIP(hipMemsetAsync(nulls, 0, sizeof(unsigned long long) * kMaxCols, st));
   if (m > 0) {
     int64_t nwords = (m + 63) >> 6;
-    hipLaunchKernelGGL((k_gather<IDX>), dim3(grid_for(ceil_div(nwords, kGatherU) * 64, 256)), dim3(256), 0, st, g, idx, idx_valid, idx_off, m, n_src, check, err,
-                       nulls);
+    // (109 VGPRs: 4 workgroups are resident per CU; 4 .. 32 per CU measured 11.0 .. 10.7 ms for the 4.5e8 gathers of the C2 take: the
+    //  memory system's random-access rate, not the launch shape, bounds this kernel)
+    static const int gather_wgs_per_cu = [] { const char* e = getenv("PDX_GATHER_WGS_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
+    hipLaunchKernelGGL((k_gather<IDX>), dim3(grid_for(ceil_div(nwords, kGatherU) * 64, 256, 1, kCUs * gather_wgs_per_cu)), dim3(256), 0, st, g, idx, idx_valid,
+                       idx_off, m, n_src, check, err, nulls);
     PDX_LAUNCH_CHECK();
   }
   ErrFlag h;
