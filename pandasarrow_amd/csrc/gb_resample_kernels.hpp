@@ -145,21 +145,24 @@ __global__ void __launch_bounds__(1024) k_sample_descents(const long long* __res
 // flagged in both integer orders (flags[0] signed, flags[1] unsigned: either order clean proves that equal labels are neighbours).
 // Write pass: reads the n / 8 bytes of marks, never the rows; workgroups without a run start return at once.
 constexpr int kRunBlock = 256, kRunSteps = 16, kRunTile = kRunBlock * kRunSteps;  // 4096 rows per workgroup, 1024 per wave
-template <typename LabelFn>
+constexpr int kRunWaveRows = 64 * kRunSteps;                                        // the unit of the counts / offsets: one wave's rows
+// BATCH: labels requested before the first of them is used -- 16 for plain keys (one dependent load per step left the kernel at
+// 4.4 TB/s), 4 where the label costs registers to compute (the calendar rounding: 16 at once was slower, 5.1 vs 4.7 ms end to end)
+template <typename LabelFn, int BATCH>
 __global__ void __launch_bounds__(kRunBlock) k_label_run_count(int64_t n, LabelFn fn, unsigned long long* __restrict__ marks,
-                                                                int64_t* __restrict__ block_counts, unsigned int* __restrict__ flags) {
-  __shared__ int wave_tot[kRunBlock / 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t base = (int64_t)blockIdx.x * kRunTile + (int64_t)wave * (64 * kRunSteps);
+                                                                int64_t* __restrict__ wave_counts, unsigned int* __restrict__ flags) {
+  static_assert(kRunSteps % BATCH == 0, "whole batches");
+  const int lane = threadIdx.x & 63;
+  const int64_t w = ((int64_t)blockIdx.x * kRunBlock + threadIdx.x) >> 6;  // wave = 1024-row slice
+  const int64_t base = w * kRunWaveRows;
+  if (base >= n) return;  // (whole waves leave: nothing below is a workgroup barrier)
+  long long last = 0;
+  if (lane == 0 && base > 0) last = fn(base - 1);
   int cnt = 0;
   bool desc_s = false, desc_u = false;
-  long long last = 0;
-  if (lane == 0 && base > 0 && base < n) last = fn(base - 1);
-#pragma unroll 4
-  for (int s = 0; s < kRunSteps; ++s) {
+  auto step = [&](int s, long long label) {
     const int64_t i = base + (int64_t)s * 64 + lane;
     const bool act = i < n;
-    const long long label = act ? fn(i) : 0;
     long long prev = __shfl_up(label, 1, 64);
     if (lane == 0) prev = last;
     const bool start = act && (i == 0 || label != prev);
@@ -171,36 +174,41 @@ __global__ void __launch_bounds__(kRunBlock) k_label_run_count(int64_t n, LabelF
     if (lane == 0 && base + (int64_t)s * 64 < n) marks[(base >> 6) + s] = b;
     cnt += __popcll(b);
     last = __shfl(label, 63, 64);
+  };
+  if constexpr (BATCH == kRunSteps) {
+    long long label[kRunSteps];
+#pragma unroll
+    for (int s = 0; s < kRunSteps; ++s) {
+      const int64_t i = base + (int64_t)s * 64 + lane;
+      label[s] = i < n ? fn(i) : 0;
+    }
+#pragma unroll
+    for (int s = 0; s < kRunSteps; ++s) step(s, label[s]);
+  } else {
+#pragma unroll BATCH
+    for (int s = 0; s < kRunSteps; ++s) {
+      const int64_t i = base + (int64_t)s * 64 + lane;
+      step(s, i < n ? fn(i) : 0);
+    }
   }
   if (desc_s) flags[0] = 1u;
   if (desc_u) flags[1] = 1u;
-  if (lane == 0) wave_tot[wave] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int t = 0;
-    for (int w = 0; w < kRunBlock / 64; ++w) t += wave_tot[w];
-    block_counts[blockIdx.x] = t;
-  }
+  if (lane == 0) wave_counts[w] = cnt;
 }
-// Emit: __device__ void operator()(int64_t run, int64_t row) const
+// Emit: __device__ void operator()(int64_t run, int64_t row) const.  One wave per 1024-row slice, no workgroup state.
 template <typename Emit>
 __global__ void __launch_bounds__(kRunBlock) k_label_run_write(int64_t n, const unsigned long long* __restrict__ marks, Emit emit,
-                                                                const int64_t* __restrict__ block_offsets, int64_t nblocks,
+                                                                const int64_t* __restrict__ wave_offsets, int64_t nwaves,
                                                                 const int64_t* __restrict__ total) {
-  __shared__ int wave_tot[kRunBlock / 64];
-  const int64_t pos0 = block_offsets[blockIdx.x];
-  const int64_t pos1 = (int64_t)blockIdx.x + 1 < nblocks ? block_offsets[blockIdx.x + 1] : *total;
-  if (pos0 == pos1) return;  // (uniform per workgroup)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t base = (int64_t)blockIdx.x * kRunTile + (int64_t)wave * (64 * kRunSteps);
+  const int lane = threadIdx.x & 63;
+  const int64_t w = ((int64_t)blockIdx.x * kRunBlock + threadIdx.x) >> 6;
+  if (w >= nwaves) return;
+  int64_t pos = wave_offsets[w];
+  const int64_t pos1 = w + 1 < nwaves ? wave_offsets[w + 1] : *total;
+  if (pos == pos1) return;  // (uniform per wave)
+  const int64_t base = w * kRunWaveRows;
   unsigned long long word = 0;
   if (lane < kRunSteps && base + (int64_t)lane * 64 < n) word = marks[(base >> 6) + lane];
-  int c = __popcll(word);
-  for (int d = 8; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);  // lanes 0..15 hold the wave's words
-  if (lane == 0) wave_tot[wave] = c;
-  __syncthreads();
-  int64_t pos = pos0;
-  for (int w = 0; w < wave; ++w) pos += wave_tot[w];
   const unsigned long long lt = (1ull << lane) - 1ull;
   for (int s = 0; s < kRunSteps; ++s) {
     const unsigned long long b = __shfl(word, s, 64);
@@ -209,6 +217,7 @@ __global__ void __launch_bounds__(kRunBlock) k_label_run_write(int64_t n, const 
   }
 }
 struct KeyLabel {
+  static constexpr int kBatch = 16;
   const long long* keys;
   __device__ long long operator()(int64_t i) const { return keys[i]; }
 };

@@ -62,10 +62,10 @@ namespace pdx {
 template <typename LabelFn>
 static int build_label_runs(pdx_groupby* gb, int64_t n, LabelFn fn, long long shift, Scratch& s, hipStream_t st, bool* done) {
   *done = false;
-  const int64_t nblocks = ceil_div(n, (int64_t)kRunTile);
+  const int64_t nblocks = ceil_div(n, (int64_t)kRunTile), nwaves = ceil_div(n, (int64_t)kRunWaveRows);
   unsigned int* flags = s.get<unsigned int>(2);
   unsigned long long* marks = s.get<unsigned long long>((size_t)((n + 63) >> 6));
-  int64_t* offsets = s.get<int64_t>((size_t)nblocks);
+  int64_t* offsets = s.get<int64_t>((size_t)nwaves);  // run starts in front of every 1024-row slice
   int64_t* total = s.get<int64_t>(1);
   PDX_SCRATCH_CHECK(s);
   unsigned int hflags[2] = {0, 0};
@@ -73,8 +73,8 @@ static int build_label_runs(pdx_groupby* gb, int64_t n, LabelFn fn, long long sh
   {
     PDX_PROFILE("label_runs", st);
     PDX_HIP(hipMemsetAsync(flags, 0, sizeof(hflags), st));
-    hipLaunchKernelGGL((k_label_run_count<LabelFn>), dim3((unsigned)nblocks), dim3(kRunBlock), 0, st, n, fn, marks, offsets, flags);
-    PDX_TRY((device_exclusive_scan<int64_t, SumOp>(offsets, offsets, nblocks, total, s, st)));
+    hipLaunchKernelGGL((k_label_run_count<LabelFn, LabelFn::kBatch>), dim3((unsigned)nblocks), dim3(kRunBlock), 0, st, n, fn, marks, offsets, flags);
+    PDX_TRY((device_exclusive_scan<int64_t, SumOp>(offsets, offsets, nwaves, total, s, st)));
     PDX_LAUNCH_CHECK();
   }
   PDX_HIP(hipMemcpyAsync(hflags, flags, sizeof(hflags), hipMemcpyDeviceToHost, st));
@@ -92,7 +92,7 @@ static int build_label_runs(pdx_groupby* gb, int64_t n, LabelFn fn, long long sh
   {
     PDX_PROFILE("label_runs", st);
     hipLaunchKernelGGL((k_label_run_write<RunEmit<LabelFn>>), dim3((unsigned)nblocks), dim3(kRunBlock), 0, st, n, marks,
-                       RunEmit<LabelFn>{fn, shift, gb->seg_start, gb->uniques, gb->first_rows, gb->gid_of_occ}, offsets, nblocks, total);
+                       RunEmit<LabelFn>{fn, shift, gb->seg_start, gb->uniques, gb->first_rows, gb->gid_of_occ}, offsets, nwaves, total);
     hipLaunchKernelGGL(k_set_last, dim3(1), dim3(64), 0, st, gb->seg_start, G, (uint32_t)n);
     PDX_HIP(hipMemsetAsync(gb->unique_ok, 1, (size_t)G, st));
     PDX_LAUNCH_CHECK();
@@ -104,6 +104,7 @@ static int build_label_runs(pdx_groupby* gb, int64_t n, LabelFn fn, long long sh
 
 template <int MODE, bool CEIL>
 struct RoundLabel {
+  static constexpr int kBatch = 4;
   const long long* ts;
   RoundParams q;
   __device__ long long operator()(int64_t i) const { return round_one<MODE, CEIL>(ts[i], q); }
