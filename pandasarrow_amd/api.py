@@ -244,6 +244,41 @@ class Series:
     def max(self): return self._agg(L.AGG_MAX)
     def count(self): return self._agg(L.AGG_COUNT)
 
+    def count_na(self):
+        """NDFrame::count_na (src/ndframe.cpp:119-126): CountOptions::ONLY_NULL."""
+        return self.size() - int(K.aggregate(L.AGG_COUNT, self.col)[0])
+
+    def _bool_counts(self, what):
+        if self.col.dtype != L.BOOL:  # Arrow has no "all" / "any" kernel for non-boolean input: the reference throws
+            raise L.PdxError(L.INVALID, f"Function '{what}' has no kernel matching input types")
+        true_valid = K.filter_count(self.col, emit_null=False)               # valid AND true
+        false_valid = K.filter_count(K.invert(self.col), emit_null=False)    # valid AND false
+        if true_valid + false_valid == 0:
+            raise L.PdxError(L.INVALID, f"{what}() of a Series without a valid value is null (min_count = 1)")
+        return true_valid, false_valid
+
+    def all(self):
+        """NDFrame::all (src/ndframe.cpp:110): every VALID value is true (nulls skipped)."""
+        return self._bool_counts("all")[1] == 0
+
+    def any(self):
+        """NDFrame::any (src/ndframe.cpp:112)."""
+        return self._bool_counts("any")[0] > 0
+
+    def unique(self):
+        """Series::unique: the distinct values in first-occurrence order (a null, if any, keeps its place) -- the group-by dictionary."""
+        key = self.col
+        h = K.GroupByHandle.create(key if key.dtype != L.FLOAT64 else Column(L.INT64, key.length, key.values, key.validity, key.offset, key.null_count))
+        u = h.unique_keys()
+        if key.dtype == L.FLOAT64:
+            u = Column(L.FLOAT64, u.length, u.values, u.validity, u.offset, u.null_count)
+        return Series(u if u.has_nulls() else Column(u.dtype, u.length, u.values, None, u.offset, 0), name=self.name)
+
+    def nunique(self):
+        """Series::nunique: distinct VALID values."""
+        u = self.unique().col
+        return u.length - (0 if u.validity is None else int(u.length - K.aggregate(L.AGG_COUNT, u)[0]))
+
     # ---- Series::where / take / operator[] (src/series.cpp:130-159, src/ndframe.cpp:347-350)
     def _index_col(self):
         return self.index

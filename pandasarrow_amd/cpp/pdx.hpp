@@ -347,7 +347,41 @@ class Series {
   Scalar min() const { return agg(PDX_AGG_MIN); }
   Scalar max() const { return agg(PDX_AGG_MAX); }
   Scalar count() const { return agg(PDX_AGG_COUNT); }
+  // NDFrame::count_na / all / any / nunique (src/ndframe.cpp:110-127), Series::unique (src/series.h:380)
+  int64_t count_na() const { return size() - count().as<int64_t>(); }
+  bool all() const { return bool_counts("all").second == 0; }
+  bool any() const { return bool_counts("any").first > 0; }
+  Series unique() const {
+    if (m_array.dtype == PDX_FLOAT64 || m_array.dtype == PDX_BOOL) throw std::runtime_error("unique: integer-like columns only through this facade");
+    auto ck = m_array.c();
+    pdx_groupby* h = nullptr;
+    ThrowOnFailure(pdx_groupby_create(&ck, nullptr, &h));
+    const int64_t G = pdx_groupby_num_groups(h);
+    Array u = Array::Empty(m_array.dtype, G, true);
+    auto mu = u.mut();
+    const int rc = pdx_groupby_unique_keys(h, &mu, nullptr);
+    pdx_groupby_destroy(h);
+    ThrowOnFailure(rc);
+    u.null_count = mu.null_count;
+    return Series(u, std::nullopt, m_name);
+  }
+  int64_t nunique() const { return unique().count().as<int64_t>(); }
 
+ private:
+  // (valid AND true, valid AND false) of a boolean Series; Arrow has no all / any kernel for other types, and min_count = 1
+  std::pair<int64_t, int64_t> bool_counts(const char* what) const {
+    if (m_array.dtype != PDX_BOOL) throw std::runtime_error(std::string("Function '") + what + "' has no kernel matching input types");
+    int64_t t = 0, f = 0;
+    auto cm = m_array.c();
+    ThrowOnFailure(pdx_filter_count(&cm, /*emit_null=*/0, &t, nullptr));
+    Series inv = !(*this);
+    auto ci = inv.m_array.c();
+    ThrowOnFailure(pdx_filter_count(&ci, /*emit_null=*/0, &f, nullptr));
+    if (t + f == 0) throw std::runtime_error(std::string(what) + "() of a Series without a valid value is null");
+    return {t, f};
+  }
+
+ public:
   // ---- where / take / operator[] (src/series.cpp:130-159, src/ndframe.cpp:347-350)
   Series where(const Series& mask) const {
     if (m_is_index) throw std::runtime_error("where() is not supported on an index Series");

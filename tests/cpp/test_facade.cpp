@@ -94,6 +94,21 @@ static void test_series_where_take() {
 
 // tests/series_aggregation_test.cpp:122-196 ; NaN -> null on construction tests/series_test.cpp:127-186
 static void test_series_aggregations() {
+  // all / any / count_na / unique / nunique (tests/series_aggregation_test.cpp:12-120)
+  REQUIRE(Series(std::vector<bool>{false, true, true, false, true}).all() == false);
+  REQUIRE(Series(std::vector<bool>{true, true, true, true, true}).all() == true);
+  REQUIRE_THROWS(Series(std::vector<int>{1, 2, 3, 4, 5}).any());
+  REQUIRE(Series(std::vector<bool>{true, false, true, true, false}).any() == true);
+  REQUIRE(Series(std::vector<bool>{false, false, false, false, false}).any() == false);
+  REQUIRE(Series(std::vector<int>{1, 2, 3, 4, 5}).count_na() == 0);
+  {
+    const std::vector<bool> v7{true, true, true, true, true, true, false};
+    REQUIRE(Series(Array::Make(std::vector<int>{1, 2, 3, 4, 5, 6, 7}, &v7)).count_na() == 1);
+    const std::vector<bool> v13{true, true, true, true, true, true, true, true, true, true, true, true, false};
+    REQUIRE(Series(Array::Make(std::vector<int>{1, 2, 3, 4, 5, 0, 7, 1, 2, 3, 4, 5, -1}, &v13)).nunique() == 7);
+  }
+  REQUIRE(Series(std::vector<int>{1, 2, 3, 4, 5, 0, 7, 1, 2, 3, 4, 5}).nunique() == 7);
+  REQUIRE((Series(std::vector<int>{1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 6}).unique().values<int>() == std::vector<int>{1, 2, 3, 4, 5, 6}));
   Series s(std::vector<int>{1, 2, 3, 4, 5});
   REQUIRE(s.min().as<int>() == 1 && s.max().as<int>() == 5);
   Series sn(std::vector<int>{1, 2, 3, 4, 5}, std::vector<bool>{true, true, true, true, false});

@@ -520,3 +520,34 @@ def test_concat_rows_kat(px, kat):
             assert res.index is None
         else:
             assert list(res.index.to_numpy()[0]) == k["index"]
+
+
+def test_series_misc_kat(px, kat):
+    """all / any / count / count_na / nunique / unique as the reference's tests pin them (tests/series_aggregation_test.cpp:12-120)"""
+    S = px.api.Series
+    for k in kat["series_misc"]:
+        if "bool" in k:
+            s = S(np.array(k["bool"], bool))
+            if "all" in k:
+                assert s.all() == k["all"], k["src"]
+            if "any" in k:
+                assert s.any() == k["any"], k["src"]
+            if "non_bool_throws" in k:
+                with pytest.raises(RuntimeError):
+                    S(np.array(k["non_bool_throws"])).any()
+            continue
+        valid = np.array(k["valid"], bool)
+        s = S(np.array(k["v"], np.int64), valid=None if valid.all() else valid)
+        if "count" in k:
+            assert s.count() == k["count"] and s.count_na() == k["count_na"], k["src"]
+        if "nunique" in k:
+            assert s.nunique() == k["nunique"], k["src"]
+        if "unique" in k:
+            assert list(s.unique().to_numpy()[0]) == k["unique"], k["src"]
+    # nulls are skipped by all / any; a Series without a valid value is null (min_count = 1): the mirror raises
+    assert S(np.array([True, False, True]), valid=np.array([1, 0, 1], bool)).all() is True
+    assert S(np.array([False, True, False]), valid=np.array([1, 0, 1], bool)).any() is False
+    with pytest.raises(RuntimeError):
+        S(np.array([True, True]), valid=np.zeros(2, bool)).all()
+    big = np.random.default_rng(1).integers(0, 1000, 300_000)
+    assert S(big).nunique() == len(np.unique(big)) and np.array_equal(S(big).unique().to_numpy()[0], big[np.sort(np.unique(big, return_index=True)[1])])
