@@ -249,6 +249,28 @@ int pdx_groupby_first_rows(const pdx_groupby* gb, int64_t* out_rows, void* strea
  * dtype of values, COUNT -> INT64.  outs[k].length must be >= G.  A group with no valid value yields a null
  * (validity required in that case) except COUNT. */
 int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds, int nk, pdx_mut_column* outs, void* stream);
+/* The grouped layout of one column, built once and reused: what GroupBy's constructor does for every column of the frame
+ * (processEach, src/dataframe.cpp:1539-1554: MakeGroupings + ApplyGroupings), so that gb.sum(c); gb.mean(c); gb.count(c)
+ * (src/group_by.h:85-139 -- the reference has no multi-kind call) cost ONE value sort and ONE reduce instead of three of each.
+ * pdx_groupby_bind sorts `values` by group now and keeps the result (plus, after the first aggregation, the per-group sum /
+ * count / min / max) in the handle; every later pdx_groupby_agg whose `values` has the same values pointer, offset, dtype and
+ * validity pointer is served from it.  Contract: the column's buffers stay alive and UNCHANGED until pdx_groupby_unbind /
+ * pdx_groupby_destroy (Arrow buffers are immutable; the facades' GroupBy holds the frame).  Nothing is cached for columns that
+ * were not bound.  values == NULL in unbind: every bound column.  The bound layouts of one handle are limited to
+ * pdx_groupby_bind_limit bytes (default: a quarter of the device's memory, or PDX_BIND_MAX_BYTES): the least recently used
+ * one is dropped first -- its next aggregation simply sorts again.  pdx_groupby_bound_bytes: device bytes held right now. */
+int pdx_groupby_bind(pdx_groupby* gb, const pdx_column* values, void* stream);
+int pdx_groupby_unbind(pdx_groupby* gb, const pdx_column* values);
+int pdx_groupby_bind_limit(pdx_groupby* gb, size_t max_bytes);
+int64_t pdx_groupby_bound_bytes(const pdx_groupby* gb);
+/* The path the last pdx_groupby_agg on this handle took, as "key=value" words (diagnostic; tests assert it so that a moved
+ * threshold fails a test instead of silently changing which kernels run):
+ *   slots=dense|hash_lds|hash_part|hash_part2|hash_global|runs|bins   how keys became slots (pdx_groupby_create)
+ *   sort=narrow:7+7|narrow_part:8+6|lsd:skip6|lsd|none[+finish]       the value sort (narrowing 4->2->1 byte keys, ...)
+ *   layout=fused|full [skew=1]                                        fused last digit vs fully sorted (skew: a run > 2^19 rows)
+ *   reducer=flr_reduce_dense|flr_reduce|flr_wave|seg_reduce|seg_reduce_nullable|none
+ *   bound=0|1 [cache=fill|hit] */
+int pdx_groupby_last_plan(const pdx_groupby* gb, char* buf, size_t buf_len);
 
 /* ---------------------------------------------------------------- exact multi-GPU fp64 sum (partial-tree exchange)
  * The reference's per-group sum is Arrow's pairwise tree over the group's rows in GLOBAL row order; with row-range shards a

@@ -99,6 +99,11 @@ ABI_SYMBOLS = {
     "pdx_groupby_map_ids": (C.c_int, [_P, _P, _P, _P]),
     "pdx_groupby_first_rows": (C.c_int, [_P, _P, _P]),
     "pdx_groupby_agg": (C.c_int, [_P, _COL, C.POINTER(C.c_int), C.c_int, _MUT, _P]),
+    "pdx_groupby_bind": (C.c_int, [_P, _COL, _P]),
+    "pdx_groupby_unbind": (C.c_int, [_P, _COL]),
+    "pdx_groupby_bind_limit": (C.c_int, [_P, C.c_size_t]),
+    "pdx_groupby_bound_bytes": (C.c_int64, [_P]),
+    "pdx_groupby_last_plan": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
     "pdx_groupby_group_values": (C.c_int, [_P, _COL, _P, C.POINTER(_P)]),
     "pdx_grouped_destroy": (C.c_int, [_P]),
     "pdx_grouped_counts": (C.c_int, [_P, _P, _P]),

@@ -54,6 +54,30 @@ def _split_time_span(rule):
     return (int(rule[:k]) if k else 1), rule[k:]
 
 
+def _take_filled(cols, idx, fill_value):
+    """pdx_take by reindex indices; rows whose INDEX is null (label absent from the old index) get `fill_value` through one
+    pdx_if_else per column on the indices' validity bitmap (cond = label present): present-but-null values stay null."""
+    outs = K.take(cols, idx)
+    if fill_value is None or idx.validity is None:
+        return outs
+    fv = fill_value.value if isinstance(fill_value, Scalar) else fill_value
+    if fv is None:
+        return outs
+    present = Column(L.BOOL, idx.length, idx.validity, None, idx.offset)
+    filled = []
+    for c in outs:
+        is_float = isinstance(fv, (float, np.floating))
+        if c.dtype == L.BOOL or (c.dtype == L.FLOAT64) != is_float:
+            have = "double" if is_float else "int64"
+            want = {L.FLOAT64: "double", L.BOOL: "bool", L.UINT64: "uint64", L.TIMESTAMP_NS: "timestamp[ns]"}.get(c.dtype, "int64")
+            raise L.PdxError(L.INVALID, f"Cannot append scalar of type {have} to builder for type {want}")
+        view = Column(L.INT64, c.length, c.values, c.validity, c.offset, c.null_count) if c.dtype in (L.UINT64, L.TIMESTAMP_NS) else c
+        r = K.if_else(present, view, fv)
+        r.dtype = c.dtype
+        filled.append(r)
+    return filled
+
+
 class Scalar:
     """pd::Scalar (src/scalar.h:62-241): a value or null."""
 
@@ -162,16 +186,16 @@ class Series:
         return K.filter_count(K.compare(L.EQ, ai, bi)) == a.length
 
     def reindex(self, new_index, fill_value=None):
-        """values at the LAST position of every new label, null where the label is absent"""
-        if fill_value is not None:
-            raise L.PdxError(L.NOT_IMPLEMENTED, "reindex(fill_value=...) is not implemented on the device path")
+        """values at the LAST position of every new label; a label the old index lacks gives null, or `fill_value`
+        (Series::reindex, src/series.cpp:1255-1309: `fillValue ? AppendScalar(*fillValue) : AppendNull()`, 1295-1302).  A present
+        label whose value is null stays null.  The fill value's type must be the column's (Arrow's AppendScalar check)."""
         if not isinstance(new_index, Column):
             new_index = Column.from_numpy(np.asarray(new_index))
         old = self._explicit_index()
         if old.dtype != new_index.dtype:
             raise L.PdxError(L.INVALID, "type(NewIndex) != type(CurrentIndex).")
         idx = K.reindex_indices(old, new_index)
-        return Series(K.take([self.col], idx)[0], index=new_index, name=self.name)
+        return Series(_take_filled([self.col], idx, fill_value)[0], index=new_index, name=self.name)
 
     def broadcast(self, other):
         if self._same_index(other):
@@ -398,16 +422,62 @@ class DataFrame:
     def __rsub__(self, o): return self._rbin(L.SUB, o)
     def __rmul__(self, o): return self._rbin(L.MUL, o)
     def __rtruediv__(self, o): return self._rbin(L.DIV, o)
+    # BINARY_OPERATOR_DF(> >= < <= == !=) (src/dataframe.cpp:563-573, declared src/dataframe.h:476-520 with DataFrame / Series /
+    # Scalar right-hand sides): the compare kernel over every column -> a frame of bit-packed boolean columns
+    def _cmp(self, op, other):
+        if isinstance(other, DataFrame):
+            if other.num_rows() != self.num_rows() or other.num_columns() != self.num_columns():
+                raise L.PdxError(L.INVALID, "DataFrame shapes differ")
+            return self._like([K.compare(op, a, b) for a, b in zip(self.cols, other.cols)])
+        if isinstance(other, Series):
+            if other.size() != self.num_rows():
+                raise L.PdxError(L.INVALID, f"Array arguments must all be the same length: {self.num_rows()} vs {other.size()}")
+            return self._like([K.compare(op, a, other.col) for a in self.cols])
+        if isinstance(other, Scalar):
+            other = other.value
+        return self._like([K.compare(op, a, other, True) for a in self.cols])
+
+    def __lt__(self, o): return self._cmp(L.LT, o)
+    def __le__(self, o): return self._cmp(L.LE, o)
+    def __gt__(self, o): return self._cmp(L.GT, o)
+    def __ge__(self, o): return self._cmp(L.GE, o)
+    def __eq__(self, o): return self._cmp(L.EQ, o)  # noqa: E711
+    def __ne__(self, o): return self._cmp(L.NE, o)
+    __hash__ = None
+
+    # BINARY_OPERATOR_DF(&&, and) / (||, or) (src/dataframe.cpp:575-577): non-Kleene "and" / "or" over boolean frames.  Python has
+    # no overloadable && / ||: like Series, `&` / `|` mean these on boolean frames and bit_wise_and / bit_wise_or on integer ones.
+    def _logical(self, op, other):
+        n = self.num_rows()
+        if isinstance(other, DataFrame):
+            if other.num_rows() != n or other.num_columns() != self.num_columns():
+                raise L.PdxError(L.INVALID, "DataFrame shapes differ")
+            rhs = other.cols
+        elif isinstance(other, Series):
+            if other.size() != n:
+                raise L.PdxError(L.INVALID, f"Array arguments must all be the same length: {n} vs {other.size()}")
+            rhs = [other.col] * self.num_columns()
+        else:  # Scalar / bool / None: Arrow broadcasts the scalar; a null scalar makes every row null
+            v = other.value if isinstance(other, Scalar) else other
+            rhs = [K.null_column(L.BOOL, n) if v is None else Column.from_numpy(np.full(n, bool(v)))] * self.num_columns()
+        if any(c.dtype != L.BOOL for c in list(self.cols) + list(rhs)):
+            raise L.PdxError(L.NOT_IMPLEMENTED, 'Function \'and\' / \'or\' has no kernel matching input types (boolean columns expected)')
+        return self._like([K.logical(op, a, b) for a, b in zip(self.cols, rhs)])
+
+    def _is_bool(self): return bool(self.cols) and all(c.dtype == L.BOOL for c in self.cols)
+    def logical_and(self, o): return self._logical(L.AND, o)
+    def logical_or(self, o): return self._logical(L.OR, o)
     # BINARY_OPERATOR_DF(| & ^ << >>) (src/dataframe.cpp:553-561): integer frames
-    def __or__(self, o): return self._bin(L.BIT_OR, o)
-    def __and__(self, o): return self._bin(L.BIT_AND, o)
+    def __or__(self, o): return self._logical(L.OR, o) if self._is_bool() else self._bin(L.BIT_OR, o)
+    def __and__(self, o): return self._logical(L.AND, o) if self._is_bool() else self._bin(L.BIT_AND, o)
     def __xor__(self, o): return self._bin(L.BIT_XOR, o)
     def __lshift__(self, o): return self._bin(L.SHIFT_LEFT, o)
     def __rshift__(self, o): return self._bin(L.SHIFT_RIGHT, o)
     # DataFrame::unary("negate" | "bit_wise_not") and UNARY_FUNCTION(abs | exp | sign | sqrt), pow (src/dataframe.cpp:251-275, 919-935)
     def _unary(self, op): return self._like([K.unary(op, c) for c in self.cols])
     def __neg__(self): return self._unary(L.NEGATE)
-    def __invert__(self): return self._unary(L.BIT_NOT)
+    def __invert__(self):  # integer frames: "bit_wise_not" (DataFrame::operator~); boolean frames: "invert" as Series::operator!
+        return self._like([K.invert(c) for c in self.cols]) if self._is_bool() else self._unary(L.BIT_NOT)
     def abs(self): return self._unary(L.ABS)
     def sign(self): return self._unary(L.SIGN)
     def sqrt(self): return self._unary(L.SQRT)
@@ -479,6 +549,19 @@ class DataFrame:
         cols = self.cols + ([self.index] if self.index is not None else [])
         outs = K.take(cols, idx.col)
         return self._like(outs[: len(self.cols)], index=outs[-1] if self.index is not None else None)
+
+    def reindex(self, new_index, fill_value=None):
+        """DataFrame::reindex / reindexAsync (src/dataframe.cpp:1139-1186, src/dataframe.h:403-406): every column at the LAST position
+        of each new label; absent labels -> null or `fill_value`.  One take plan (pdx_reindex_indices) serves all columns."""
+        if not isinstance(new_index, Column):
+            new_index = Column.from_numpy(np.asarray(new_index))
+        old = _frame_index(self)
+        if old.dtype != new_index.dtype:
+            raise L.PdxError(L.INVALID, "type(NewIndex) != type(CurrentIndex).")
+        idx = K.reindex_indices(old, new_index)
+        return self._like(_take_filled(self.cols, idx, fill_value), index=new_index)
+
+    reindexAsync = reindex
 
     # ---- Arrow IPC (src/dataframe.cpp:726-791)
     def toBinary(self, columns=None, index=None, metadata=None) -> bytes:

@@ -444,6 +444,37 @@ class GroupByHandle:
         L.check(L.load().pdx_resample_row_labels(self._h, out.data_ptr(), _stream()))
         return out[: self.num_rows]
 
+    def bind(self, values: Column):
+        """Group `values` once and keep the layout (+ later the per-group sum / count / min / max) in the handle: the reference's
+        GroupBy constructor does this for every column (processEach, src/dataframe.cpp:1539-1554).  The handle keeps the column alive."""
+        cv = values.c()
+        L.check(L.load().pdx_groupby_bind(self._h, C.byref(cv), _stream()))
+        if not hasattr(self, "_bound"):
+            self._bound = []
+        self._bound.append(values)
+        return self
+
+    def unbind(self, values: Column | None = None):
+        if values is None:
+            L.check(L.load().pdx_groupby_unbind(self._h, None))
+            self._bound = []
+        else:
+            cv = values.c()
+            L.check(L.load().pdx_groupby_unbind(self._h, C.byref(cv)))
+            self._bound = [b for b in getattr(self, "_bound", []) if b is not values]
+
+    def bound_bytes(self) -> int:
+        return int(L.load().pdx_groupby_bound_bytes(self._h))
+
+    def bind_limit(self, max_bytes: int):
+        L.check(L.load().pdx_groupby_bind_limit(self._h, int(max_bytes)))
+
+    def last_plan(self) -> dict:
+        """The path the last agg() took: {'slots': 'dense', 'sort': 'narrow:7+7', 'layout': 'fused', 'reducer': 'flr_reduce_dense', ...}."""
+        buf = C.create_string_buffer(512)
+        L.check(L.load().pdx_groupby_last_plan(self._h, buf, 512))
+        return dict(w.split("=", 1) for w in buf.value.decode().split() if "=" in w)
+
     def agg(self, values: Column, kinds):
         """All `kinds` from one grouped pass.  -> list of Columns (G rows, group-id order)."""
         kinds = list(kinds)

@@ -170,6 +170,7 @@ struct Scalar {
   Scalar(int64_t v) { s.dtype = PDX_INT64; s.is_valid = 1; s.v.i64 = v; }
   Scalar(int v) : Scalar((int64_t)v) {}
   Scalar(double v) { s.dtype = PDX_FLOAT64; s.is_valid = 1; s.v.f64 = v; }
+  Scalar(bool v) { s.dtype = PDX_BOOL; s.is_valid = 1; s.v.i64 = v ? 1 : 0; }
   bool isValid() const { return s.is_valid != 0; }
   template <typename T>
   T as() const {
@@ -182,6 +183,7 @@ struct Scalar {
   bool operator==(double x) const { return s.is_valid && (s.dtype == PDX_FLOAT64 ? s.v.f64 == x : (double)s.v.i64 == x); }
   Array to_array() const {
     std::vector<bool> valid{isValid()};
+    if (s.dtype == PDX_BOOL) return Array::Make(std::vector<bool>{s.v.i64 != 0}, &valid);
     return s.dtype == PDX_FLOAT64 ? Array::Make(std::vector<double>{s.v.f64}, &valid) : Array::Make(std::vector<int64_t>{s.v.i64}, &valid);
   }
 };
@@ -237,15 +239,38 @@ class Series {
     ThrowOnFailure(pdx_filter_count(&cm, /*emit_null=*/0, &m, nullptr));
     return m == m_index->length;
   }
-  Series reindex(const Array& newIndex) const {
-    if (!m_index) throw std::runtime_error("reindex needs an explicit index");
-    if (newIndex.dtype != m_index->dtype) throw std::runtime_error("type(NewIndex) != type(CurrentIndex).");
+  // fillValue (src/series.cpp:1295-1302: `fillValue ? AppendScalar(*fillValue->scalar) : AppendNull()`): labels the old index lacks
+  // get the scalar instead of null -- one pdx_if_else on the take indices' validity bitmap (cond = label present), so a present
+  // label whose value is null stays null.  The scalar's type must be the column's (Arrow's AppendScalar check).
+  static Array fill_absent(const Array& taken, const Array& idx, const std::optional<Scalar>& fillValue) {
+    if (!fillValue || !fillValue->isValid() || !idx.validity) return taken;
+    static const char* names[] = {"int64", "double", "bool", "uint64", "timestamp[ns]"};
+    if (taken.dtype == PDX_BOOL || fillValue->s.dtype == PDX_BOOL || (taken.dtype == PDX_FLOAT64) != (fillValue->s.dtype == PDX_FLOAT64))
+      throw std::runtime_error(std::string("Cannot append scalar of type ") + names[fillValue->s.dtype] + " to builder for type " + names[taken.dtype]);
+    Array present;
+    present.dtype = PDX_BOOL;
+    present.length = idx.length;
+    present.offset = idx.offset;
+    present.values = idx.validity;
+    Array view = taken;
+    if (view.dtype != PDX_FLOAT64) view.dtype = PDX_INT64;  // uint64 / timestamp labels move as 64-bit patterns
+    Array out = run_if_else(present, view, fillValue->to_array(), PDX_SCALAR_RHS);
+    out.dtype = taken.dtype;
+    return out;
+  }
+  static Array reindex_plan(const Array& oldIndex, const Array& newIndex) {
+    if (newIndex.dtype != oldIndex.dtype) throw std::runtime_error("type(NewIndex) != type(CurrentIndex).");
     Array idx = Array::Empty(PDX_INT64, newIndex.length, true);
-    auto co = m_index->c(), cn = newIndex.c();
+    auto co = oldIndex.c(), cn = newIndex.c();
     auto mi = idx.mut();
     ThrowOnFailure(pdx_reindex_indices(&co, &cn, &mi, nullptr));
     idx.null_count = mi.null_count;
-    return Series(run_take({m_array}, idx)[0], newIndex, m_name);
+    return idx;
+  }
+  Series reindex(const Array& newIndex, const std::optional<Scalar>& fillValue = std::nullopt) const {
+    if (!m_index) throw std::runtime_error("reindex needs an explicit index");
+    Array idx = reindex_plan(*m_index, newIndex);
+    return Series(fill_absent(run_take({m_array}, idx)[0], idx, fillValue), newIndex, m_name);
   }
   std::array<Series, 2> broadcast(const Series& o) const {
     if (same_index(o)) return {*this, o};
@@ -615,6 +640,66 @@ class DataFrame {
     for (auto& c : m_columns) out.push_back(Series::run_power(c, x));
     return DataFrame(m_names, out, m_index);
   }
+  // BINARY_OPERATOR_DF(> >= < <= == !=) (src/dataframe.cpp:563-573; DataFrame / Series / Scalar right-hand sides declared at
+  // src/dataframe.h:476-520): the compare kernel over every column -> a frame of bit-packed boolean columns
+  DataFrame compare(int op, const DataFrame& o) const {
+    if (o.num_rows() != num_rows() || o.num_columns() != num_columns()) throw std::runtime_error("DataFrame shapes differ");
+    std::vector<Array> out;
+    for (size_t i = 0; i < m_columns.size(); ++i) out.push_back(Series::run_compare(op, m_columns[i], o.m_columns[i], false));
+    return DataFrame(m_names, out, m_index);
+  }
+  DataFrame compare(int op, const Series& o) const {
+    if (o.size() != num_rows()) throw std::runtime_error("Array arguments must all be the same length");
+    std::vector<Array> out;
+    for (auto& c : m_columns) out.push_back(Series::run_compare(op, c, o.m_array, false));
+    return DataFrame(m_names, out, m_index);
+  }
+  DataFrame compare(int op, const Scalar& o) const {
+    std::vector<Array> out;
+    Array s = o.to_array();
+    for (auto& c : m_columns) out.push_back(Series::run_compare(op, c, s, true));
+    return DataFrame(m_names, out, m_index);
+  }
+  template <typename R> DataFrame operator>(const R& o) const { return compare(PDX_GT, o); }
+  template <typename R> DataFrame operator>=(const R& o) const { return compare(PDX_GE, o); }
+  template <typename R> DataFrame operator<(const R& o) const { return compare(PDX_LT, o); }
+  template <typename R> DataFrame operator<=(const R& o) const { return compare(PDX_LE, o); }
+  template <typename R> DataFrame operator==(const R& o) const { return compare(PDX_EQ, o); }
+  template <typename R> DataFrame operator!=(const R& o) const { return compare(PDX_NE, o); }
+  // BINARY_OPERATOR_DF(&&, and) / (||, or) (src/dataframe.cpp:575-577): Arrow's non-Kleene "and" / "or" over boolean frames; a
+  // Scalar is broadcast (a null scalar makes every row null)
+  DataFrame logical(int op, const DataFrame& o) const {
+    if (o.num_rows() != num_rows() || o.num_columns() != num_columns()) throw std::runtime_error("DataFrame shapes differ");
+    std::vector<Array> out;
+    for (size_t i = 0; i < m_columns.size(); ++i) out.push_back(Series::run_logical(op, m_columns[i], o.m_columns[i]));
+    return DataFrame(m_names, out, m_index);
+  }
+  DataFrame logical(int op, const Series& o) const {
+    if (o.size() != num_rows()) throw std::runtime_error("Array arguments must all be the same length");
+    std::vector<Array> out;
+    for (auto& c : m_columns) out.push_back(Series::run_logical(op, c, o.m_array));
+    return DataFrame(m_names, out, m_index);
+  }
+  DataFrame logical(int op, const Scalar& o) const {
+    if (o.s.dtype != PDX_BOOL) throw std::runtime_error("Function 'and' / 'or' has no kernel matching input types (boolean expected)");
+    const std::vector<bool> ok((size_t)num_rows(), o.isValid());
+    Array b = Array::Make(std::vector<bool>((size_t)num_rows(), o.s.v.i64 != 0), o.isValid() ? nullptr : &ok);
+    std::vector<Array> out;
+    for (auto& c : m_columns) out.push_back(Series::run_logical(op, c, b));
+    return DataFrame(m_names, out, m_index);
+  }
+  template <typename R> DataFrame operator&&(const R& o) const { return logical(PDX_AND, o); }
+  template <typename R> DataFrame operator||(const R& o) const { return logical(PDX_OR, o); }
+  // DataFrame::reindex / reindexAsync (src/dataframe.cpp:1139-1186, src/dataframe.h:403-406): ONE take plan for every column
+  DataFrame reindex(const Array& newIndex, const std::optional<Scalar>& fillValue = std::nullopt) const {
+    if (!m_index) throw std::runtime_error("reindex needs an explicit index");
+    Array idx = Series::reindex_plan(*m_index, newIndex);
+    auto taken = Series::run_take(m_columns, idx);
+    std::vector<Array> out;
+    for (auto& t : taken) out.push_back(Series::fill_absent(t, idx, fillValue));
+    return DataFrame(m_names, out, newIndex);
+  }
+  DataFrame reindexAsync(const Array& newIndex, const std::optional<Scalar>& fillValue = std::nullopt) const { return reindex(newIndex, fillValue); }
   template <typename R> DataFrame operator|(const R& o) const { return binary(PDX_BIT_OR, o); }   // BINARY_OPERATOR_DF, src/dataframe.cpp:553-561
   template <typename R> DataFrame operator&(const R& o) const { return binary(PDX_BIT_AND, o); }
   template <typename R> DataFrame operator^(const R& o) const { return binary(PDX_BIT_XOR, o); }

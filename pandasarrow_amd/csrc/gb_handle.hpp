@@ -1,5 +1,80 @@
 // gb_handle.hpp -- part of groupby.hip: the opaque handle behind pdx_groupby (hash group-by or resample segments).
 #pragma once
+#include <string>
+
+// One column's values in grouped order: what the reference's GroupBy constructor materialises per column (processEach,
+// src/dataframe.cpp:1539-1554: MakeGroupings + ApplyGroupings) and every later sum() / mean() / count() reuses
+// (src/group_by.h:85-139).  Built by build_layout (gb_layout.hpp) either for ONE pdx_groupby_agg call (a local object) or once
+// per bound column (pdx_groupby_bind: kept in the handle, found again by the column's identity).
+struct GroupedLayout {
+  // identity of the column (bound layouts): Arrow buffers are immutable, the binder promises they outlive the binding
+  const void* values = nullptr;
+  const void* validity = nullptr;
+  int64_t offset = 0;
+  int dtype = 0;
+  bool bound = false;
+  uint64_t last_use = 0;
+  size_t bytes = 0;  // device bytes the layout owns
+  // (A) fused form: rows stably sorted by the LOW low_bits slot bits only; the top digit of every row in keys8 (narrowing sort) or in
+  // keys_sorted (4-byte slots, bit 31 = null flag); run_start[r] = first row of the run with low bits r.  The fused last-digit
+  // kernels rank by the top digit and reduce in one pass.
+  bool fused = false;
+  int low_bits = 0;
+  int64_t nruns = 0;
+  unsigned int hmax = 0;  // rows of the longest run
+  const uint8_t* keys8 = nullptr;
+  const uint32_t* fkeys = nullptr;
+  const uint64_t* fvals = nullptr;
+  const uint32_t* run_start = nullptr;
+  // (B) full form: every group's values contiguous in row order (classic reducers, product / first / last, skewed keys)
+  bool full = false;
+  const void* vals_sorted = nullptr;
+  const uint32_t* flag_keys = nullptr;  // nullable values: bit 31 of the key of every grouped row = null
+  const uint32_t* seg_start = nullptr;  // G + 1
+  const uint32_t* out_index = nullptr;  // segment -> group id (nullptr: segment order is group order)
+  const uint8_t* row_valid = nullptr;   // segments mode: validity is read in place
+  // cached per-group results of a bound column (the five standard kinds come from one reduce; later calls copy)
+  double* c_sum = nullptr;
+  long long* c_isum = nullptr;
+  long long* c_count = nullptr;
+  void* c_min = nullptr;
+  void* c_max = nullptr;
+  uint8_t* c_ok = nullptr;
+  bool have_pw = false, have_is = false, have_mm = false, have_count = false;
+  std::string plan;  // how the layout was built (pdx_groupby_last_plan)
+  hipStream_t stream = nullptr;
+  std::vector<void*> owned;
+  std::vector<size_t> owned_bytes;
+  template <typename T>
+  T* own(size_t count) {
+    const size_t b = (count ? count : 1) * sizeof(T);
+    T* p = static_cast<T*>(pool_alloc(b));
+    if (p) {
+      owned.push_back(p);
+      owned_bytes.push_back(b);
+      bytes += b;
+    }
+    return p;
+  }
+  void disown(const void* p) {  // give one block back early (a sort's ping-pong buffer that does not hold the result)
+    for (size_t i = 0; i < owned.size(); ++i)
+      if (owned[i] == p) {
+        StreamNote note(stream);
+        pool_free(owned[i]);
+        bytes -= owned_bytes[i];
+        owned.erase(owned.begin() + (long)i);
+        owned_bytes.erase(owned_bytes.begin() + (long)i);
+        return;
+      }
+  }
+  GroupedLayout() = default;
+  GroupedLayout(const GroupedLayout&) = delete;
+  GroupedLayout& operator=(const GroupedLayout&) = delete;
+  ~GroupedLayout() {
+    StreamNote note(stream);
+    pool_free_many(owned.data(), (int)owned.size());
+  }
+};
 
 struct pdx_groupby {
   int mode = 0;  // 0 = hash group-by, 1 = contiguous segments (resample bins; runs of equal keys when the keys arrive sorted)
@@ -35,6 +110,11 @@ struct pdx_groupby {
   BinParams bin{};
   long long label_base = 0;
   mutable hipStream_t stream = nullptr;  // the stream of the last call that used the handle (pool frees are ordered behind it)
+  // bound columns (pdx_groupby_bind): grouped layouts + cached results, least recently used first out when over the byte limit
+  std::vector<std::unique_ptr<GroupedLayout>> bound;
+  size_t bind_limit = 0;   // 0 = default (a quarter of the device's memory)
+  uint64_t use_clock = 0;
+  std::string last_plan;   // the path the last pdx_groupby_agg took (pdx_groupby_last_plan)
   std::vector<void*> owned;
   template <typename T>
   T* own(size_t count) {
@@ -43,6 +123,8 @@ struct pdx_groupby {
     return p;
   }
   ~pdx_groupby() {
+    for (auto& b : bound) b->stream = stream;
+    bound.clear();
     StreamNote note(stream);
     pool_free_many(owned.data(), (int)owned.size());
   }

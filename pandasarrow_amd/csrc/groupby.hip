@@ -27,6 +27,8 @@
 //      k_seg_reduce_sub + k_seg_combine_big (many waves per long group), k_seg_reduce_nullable.
 // All fp64 sums reproduce Arrow's pairwise summation bit for bit.  Algorithmic bytes: 16 B/row (8 key + 8 value).
 #include <stdlib.h>
+#include <string.h>
+#include <string>
 #include <algorithm>
 #include <memory>
 #include <vector>
@@ -129,6 +131,10 @@ static unsigned int* hmax_pinned() {
   }
   return p;
 }
+
+namespace pdx {
+#include "gb_layout.hpp"
+}  // namespace pdx
 
 extern "C" {
 
@@ -731,6 +737,214 @@ int pdx_groupby_map_ids(pdx_groupby* gb, const int64_t* map, int64_t* out, void*
   return PDX_OK;
 }
 
+// ---------------------------------------------------------------- stage 2 of pdx_groupby_agg: reducers over a GroupedLayout
+}  // extern "C"
+
+namespace pdx {
+struct AggRequest {
+  SegOut o{};
+  bool want_pw = false, want_mm = false, want_is = false, want_std5 = false;
+  // the "next" kinds (variance, stddev, product, first, last) run after the five standard ones on the same grouped values
+  double *var_out = nullptr, *std_out = nullptr;
+  void *prod_out = nullptr, *first_out = nullptr, *last_out = nullptr;
+  bool is_f = true;
+  bool std_only() const { return (want_std5 || var_out || std_out) && !prod_out && !first_out && !last_out; }  // (variance: two more fused passes)
+};
+
+// The fused last digit: rank by the top 6 slot bits + Arrow's leaf / counter recurrence in one pass over a fused layout.
+// ok_bytes (nullable values): 1 = the group has a valid value; sqmean: second pass of variance.
+static int reduce_fused(const pdx_groupby* gb, const GroupedLayout& L, const AggTuning& t, const SegOut& oo, bool pw, bool mm, bool is, uint8_t* okbytes,
+                        const double* sqmean, hipStream_t st, std::string* reducer) {
+  PDX_PROFILE("fused_last_digit_reduce", st);
+  const bool nullable = L.validity != nullptr, is_f = L.dtype == PDX_FLOAT64;
+  const int64_t nruns = L.nruns, n = gb->n;
+  const int low_bits = L.low_bits;
+  const uint8_t* keys8 = L.keys8;
+  const uint32_t* keys_sorted = L.fkeys;
+  const uint64_t* vs = L.fvals;
+  const uint32_t* run_start = L.run_start;
+  const int grid = (int)std::min<int64_t>(nruns, (int64_t)kCUs * t.flr_wgs_per_cu);
+  const bool dense = pw && !mm && !is && !nullable;
+  // (values with nulls, sum / mean / count: the thread-per-leaf form is opt-in, PDX_FLR_NULL_PW=1 -- measured 11.3 ms against
+  //  10.7 ms of the literal per-lane replay at 5 % nulls: its per-group walk over the leaf markers is as serial as the replay)
+  const bool nullpw = pw && !mm && !is && nullable && t.null_pw;
+#define FLR_LAUNCH(TT, DD)                                                                                                                       \
+  if (keys8 && nullpw)                                                                                                                           \
+    hipLaunchKernelGGL((k_flr_reduce<TT, false, uint8_t, true>), dim3(grid), dim3(kSortBlock), 0, st, keys8, reinterpret_cast<const TT*>(vs), run_start, \
+                       nruns, low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, 1, sqmean);                                       \
+  else if (nullpw)                                                                                                                               \
+    hipLaunchKernelGGL((k_flr_reduce<TT, false, uint32_t, true>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const TT*>(vs),   \
+                       run_start, nruns, low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, 1, sqmean);                            \
+  else if (keys8)                                                                                                                                \
+    hipLaunchKernelGGL((k_flr_reduce<TT, DD, uint8_t>), dim3(grid), dim3(kSortBlock), 0, st, keys8, reinterpret_cast<const TT*>(vs), run_start, nruns, \
+                       low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, nullable ? 1 : 0, sqmean);                               \
+  else                                                                                                                                           \
+    hipLaunchKernelGGL((k_flr_reduce<TT, DD>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const TT*>(vs), run_start, nruns, \
+                       low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, nullable ? 1 : 0, sqmean)
+  // one WAVE per run (flr_wave.hpp) for everything but the dense sum / mean / count: nullable values, min / max and int64 sums
+  // were a per-lane replay by wave 0 alone in the workgroup-per-run kernel (5 % nulls: 10.7 -> 4.9 ms per 1e9 rows); the dense
+  // fast path of k_flr_reduce (thread per leaf) is still ahead of the wave form (3.0 vs 3.3 ms).  PDX_FLR_WAVE=1 / 0 force either.
+  const bool wave_form = !nullpw && (t.wave_force >= 0 ? t.wave_force != 0 : !dense);
+  if (reducer) *reducer = wave_form ? "flr_wave" : (nullpw ? "flr_reduce_nullpw" : (dense ? "flr_reduce_dense" : "flr_reduce"));
+  if (wave_form) {
+    const int wgrid = (int)std::min<int64_t>(nruns, (int64_t)kCUs * t.fw_wgs_per_cu);
+    const bool pw_only = pw && !mm && !is;
+    // counter levels: a group cannot outgrow its run, and a leaf holds 16 rows unless nulls cut it short
+    const uint64_t max_leaves = nullable ? (uint64_t)L.hmax + 1 : (uint64_t)L.hmax / 16 + 2;
+    const int fw_levels = std::max(2, ilog2(max_leaves + 1));  // 2^levels > leaves: level index <= levels - 1
+    const size_t fw_lds = (size_t)fw_lds_bytes(nullable, fw_levels);
+#define FW_LAUNCH(TT, KK, KPTR, NN, PP)                                                                                                  \
+  hipLaunchKernelGGL((k_flr_wave<TT, KK, NN, PP>), dim3(wgrid), dim3(64), fw_lds, st, KPTR, reinterpret_cast<const TT*>(vs), n, run_start, nruns, low_bits, \
+                     gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, sqmean, fw_levels)
+#define FW_DISPATCH(TT)                                                                        \
+  if (keys8) {                                                                                 \
+    if (nullable) { if (pw_only) FW_LAUNCH(TT, uint8_t, keys8, true, true); else FW_LAUNCH(TT, uint8_t, keys8, true, false); }          \
+    else { if (pw_only) FW_LAUNCH(TT, uint8_t, keys8, false, true); else FW_LAUNCH(TT, uint8_t, keys8, false, false); }              \
+  } else {                                                                                     \
+    if (nullable) { if (pw_only) FW_LAUNCH(TT, uint32_t, keys_sorted, true, true); else FW_LAUNCH(TT, uint32_t, keys_sorted, true, false); } \
+    else { if (pw_only) FW_LAUNCH(TT, uint32_t, keys_sorted, false, true); else FW_LAUNCH(TT, uint32_t, keys_sorted, false, false); } \
+  }
+    if (is_f) { FW_DISPATCH(double) } else { FW_DISPATCH(long long) }
+#undef FW_DISPATCH
+#undef FW_LAUNCH
+  } else if (is_f) {
+    if (dense) { FLR_LAUNCH(double, true); }
+    else { FLR_LAUNCH(double, false); }
+  } else {
+    if (dense) { FLR_LAUNCH(long long, true); }
+    else { FLR_LAUNCH(long long, false); }
+  }
+#undef FLR_LAUNCH
+  PDX_LAUNCH_CHECK();
+  return PDX_OK;
+}
+
+// one segmented reduce of `vals` (float64 or int64 per f64) over a full layout into `oo`; ok_bytes (nullable values only): 1 = the
+// group has a valid value.  vals == nullptr: the layout's own values.
+static int reduce_full(const pdx_groupby* gb, const GroupedLayout& L, const void* vals, bool f64, const SegOut& oo, bool pw, bool mm, bool is,
+                       const uint32_t* oidx, uint8_t* ok_bytes, Scratch& s, hipStream_t st) {
+  PDX_PROFILE("seg_reduce", st);
+  const int64_t n = gb->n, G = gb->G;
+  if (!L.validity) {
+    if (f64) return launch_seg_reduce_dense<double>(static_cast<const double*>(vals), L.seg_start, G, oidx, oo, pw, mm, is, n, s, st);
+    return launch_seg_reduce_dense<long long>(static_cast<const long long*>(vals), L.seg_start, G, oidx, oo, pw, mm, is, n, s, st);
+  }
+  const int grid = (int)std::min<int64_t>(ceil_div(G, kSegWaves), (int64_t)kCUs * 8);
+  if (f64)
+    hipLaunchKernelGGL((k_seg_reduce_nullable<double>), dim3(grid), dim3(kSegWaves * 64), 0, st, static_cast<const double*>(vals), L.flag_keys, L.row_valid,
+                       L.offset, L.seg_start, G, oidx, oo, ok_bytes);
+  else
+    hipLaunchKernelGGL((k_seg_reduce_nullable<long long>), dim3(grid), dim3(kSegWaves * 64), 0, st, static_cast<const long long*>(vals), L.flag_keys,
+                       L.row_valid, L.offset, L.seg_start, G, oidx, oo, ok_bytes);
+  PDX_LAUNCH_CHECK();
+  return reduce_huge_nullable_groups(vals, f64 ? PDX_FLOAT64 : PDX_INT64, L.flag_keys, L.row_valid, L.offset, L.seg_start, G, oidx, n, oo, ok_bytes, s, st);
+}
+
+__global__ void k_mean_from_cache(const double* __restrict__ sum, const long long* __restrict__ cnt, int64_t G, double* __restrict__ out) {
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G; i += stride) out[i] = cnt[i] ? sum[i] / (double)cnt[i] : 0.0;
+}
+
+static GroupedLayout* find_bound(pdx_groupby* gb, const pdx_column* values) {
+  const void* vv = validity_or_null(values);
+  for (auto& b : gb->bound)
+    if (b->values == values->values && b->offset == values->offset && b->dtype == values->dtype && b->validity == vv) {
+      b->last_use = ++gb->use_clock;
+      return b.get();
+    }
+  return nullptr;
+}
+static size_t bind_limit_bytes(const pdx_groupby* gb) {
+  if (gb->bind_limit) return gb->bind_limit;
+  if (const char* e = getenv("PDX_BIND_MAX_BYTES")) return (size_t)atoll(e);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return (size_t)64 << 30;
+  }
+  return total_b / 4;
+}
+// least recently used layouts go first until the bound set fits the limit (the newest one always stays)
+static void enforce_bind_limit(pdx_groupby* gb, const GroupedLayout* keep) {
+  const size_t limit = bind_limit_bytes(gb);
+  for (;;) {
+    size_t total = 0;
+    for (auto& b : gb->bound) total += b->bytes;
+    if (total <= limit || gb->bound.size() <= 1) return;
+    size_t victim = gb->bound.size();
+    for (size_t i = 0; i < gb->bound.size(); ++i)
+      if (gb->bound[i].get() != keep && (victim == gb->bound.size() || gb->bound[i]->last_use < gb->bound[victim]->last_use)) victim = i;
+    if (victim == gb->bound.size()) return;
+    gb->bound[victim]->stream = gb->stream;
+    gb->bound.erase(gb->bound.begin() + (long)victim);
+  }
+}
+}  // namespace pdx
+
+extern "C" {
+
+int pdx_groupby_bind(pdx_groupby* gb, const pdx_column* values, void* stream) {
+  if (!gb) return fail(PDX_INVALID, "pdx_groupby_bind: null handle");
+  PDX_TRY(check_column(values, "pdx_groupby_bind"));
+  if (values->length != gb->n) return fail(PDX_INVALID, "pdx_groupby_bind: values length differs from the grouped key length");
+  if (values->dtype != PDX_FLOAT64 && values->dtype != PDX_INT64)
+    return fail(PDX_NOT_IMPLEMENTED, "pdx_groupby_bind: values must be int64 or float64 (boolean columns are order-free: nothing to keep)");
+  hipStream_t st = as_stream(stream);
+  gb->stream = st;
+  if (find_bound(gb, values)) return PDX_OK;
+  std::unique_ptr<GroupedLayout> L(new GroupedLayout());
+  L->bound = true;
+  L->last_use = ++gb->use_clock;
+  if (gb->G > 0) {
+    const AggTuning t = AggTuning::read();
+    PDX_TRY(build_layout(gb, values, true, t, *L, st));
+    PDX_HIP(hipStreamSynchronize(st));
+  } else {
+    L->values = values->values;
+    L->validity = validity_or_null(values);
+    L->offset = values->offset;
+    L->dtype = values->dtype;
+    L->stream = st;
+  }
+  gb->bound.push_back(std::move(L));
+  enforce_bind_limit(gb, gb->bound.back().get());
+  return PDX_OK;
+}
+int pdx_groupby_unbind(pdx_groupby* gb, const pdx_column* values) {
+  if (!gb) return fail(PDX_INVALID, "pdx_groupby_unbind: null handle");
+  for (auto& b : gb->bound) b->stream = gb->stream;
+  if (!values) {
+    gb->bound.clear();
+    return PDX_OK;
+  }
+  const void* vv = validity_or_null(values);
+  for (size_t i = 0; i < gb->bound.size(); ++i)
+    if (gb->bound[i]->values == values->values && gb->bound[i]->offset == values->offset && gb->bound[i]->dtype == values->dtype &&
+        gb->bound[i]->validity == vv) {
+      gb->bound.erase(gb->bound.begin() + (long)i);
+      break;
+    }
+  return PDX_OK;
+}
+int pdx_groupby_bind_limit(pdx_groupby* gb, size_t max_bytes) {
+  if (!gb) return fail(PDX_INVALID, "pdx_groupby_bind_limit: null handle");
+  gb->bind_limit = max_bytes;
+  enforce_bind_limit(gb, nullptr);
+  return PDX_OK;
+}
+int64_t pdx_groupby_bound_bytes(const pdx_groupby* gb) {
+  if (!gb) return -1;
+  size_t total = 0;
+  for (auto& b : gb->bound) total += b->bytes;
+  return (int64_t)total;
+}
+int pdx_groupby_last_plan(const pdx_groupby* gb, char* buf, size_t buf_len) {
+  if (!gb || !buf || buf_len == 0) return fail(PDX_INVALID, "pdx_groupby_last_plan: null argument");
+  if (gb->last_plan.size() + 1 > buf_len) return fail(PDX_INVALID, "pdx_groupby_last_plan: buffer too small");
+  memcpy(buf, gb->last_plan.c_str(), gb->last_plan.size() + 1);
+  return PDX_OK;
+}
+
 int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds, int nk, pdx_mut_column* outs, void* stream) {
   if (!gb || !kinds || !outs || nk <= 0) return fail(PDX_INVALID, "pdx_groupby_agg: null argument");
   PDX_TRY(check_column(values, "pdx_groupby_agg"));
@@ -746,11 +960,9 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   gb->stream = st;  // frees of the handle's blocks are ordered behind this stream
   const int64_t n = gb->n, G = gb->G;
   const uint8_t* vvalid = validity_or_null(values);
-  SegOut o{};
-  bool want_pw = false, want_mm = false, want_is = false, want_std5 = false;
-  // the "next" kinds (variance, stddev, product, first, last) run after the five standard ones on the same grouped values
-  double *var_out = nullptr, *std_out = nullptr;
-  void *prod_out = nullptr, *first_out = nullptr, *last_out = nullptr;
+  AggRequest rq;
+  rq.is_f = is_f;
+  SegOut& o = rq.o;
   for (int k = 0; k < nk; ++k) {
     pdx_mut_column* oc = &outs[k];
     if (oc->length < G) return fail(PDX_INVALID, "pdx_groupby_agg: output too small");
@@ -760,19 +972,19 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
     switch (kinds[k]) {
       case PDX_AGG_SUM:
         want_dt = is_f ? PDX_FLOAT64 : PDX_INT64;
-        if (is_f) { o.sum_f = static_cast<double*>(oc->values); want_pw = true; }
-        else { o.sum_i = static_cast<long long*>(oc->values); want_is = true; }
-        want_std5 = true;
+        if (is_f) { o.sum_f = static_cast<double*>(oc->values); rq.want_pw = true; }
+        else { o.sum_i = static_cast<long long*>(oc->values); rq.want_is = true; }
+        rq.want_std5 = true;
         break;
-      case PDX_AGG_MEAN: want_dt = PDX_FLOAT64; o.mean = static_cast<double*>(oc->values); want_pw = true; want_std5 = true; break;
-      case PDX_AGG_MIN: want_dt = values->dtype; o.vmin = oc->values; want_mm = true; want_std5 = true; break;
-      case PDX_AGG_MAX: want_dt = values->dtype; o.vmax = oc->values; want_mm = true; want_std5 = true; break;
-      case PDX_AGG_COUNT: want_dt = PDX_INT64; o.count = static_cast<long long*>(oc->values); needs_validity = false; want_std5 = true; break;
-      case PDX_AGG_VARIANCE: want_dt = PDX_FLOAT64; var_out = static_cast<double*>(oc->values); break;
-      case PDX_AGG_STDDEV: want_dt = PDX_FLOAT64; std_out = static_cast<double*>(oc->values); break;
-      case PDX_AGG_PRODUCT: want_dt = values->dtype; prod_out = oc->values; break;
-      case PDX_AGG_FIRST: want_dt = values->dtype; first_out = oc->values; break;
-      case PDX_AGG_LAST: want_dt = values->dtype; last_out = oc->values; break;
+      case PDX_AGG_MEAN: want_dt = PDX_FLOAT64; o.mean = static_cast<double*>(oc->values); rq.want_pw = true; rq.want_std5 = true; break;
+      case PDX_AGG_MIN: want_dt = values->dtype; o.vmin = oc->values; rq.want_mm = true; rq.want_std5 = true; break;
+      case PDX_AGG_MAX: want_dt = values->dtype; o.vmax = oc->values; rq.want_mm = true; rq.want_std5 = true; break;
+      case PDX_AGG_COUNT: want_dt = PDX_INT64; o.count = static_cast<long long*>(oc->values); needs_validity = false; rq.want_std5 = true; break;
+      case PDX_AGG_VARIANCE: want_dt = PDX_FLOAT64; rq.var_out = static_cast<double*>(oc->values); break;
+      case PDX_AGG_STDDEV: want_dt = PDX_FLOAT64; rq.std_out = static_cast<double*>(oc->values); break;
+      case PDX_AGG_PRODUCT: want_dt = values->dtype; rq.prod_out = oc->values; break;
+      case PDX_AGG_FIRST: want_dt = values->dtype; rq.first_out = oc->values; break;
+      case PDX_AGG_LAST: want_dt = values->dtype; rq.last_out = oc->values; break;
       default: return fail(PDX_INVALID, "pdx_groupby_agg: unknown aggregate kind");
     }
     if (oc->dtype != want_dt) return fail(PDX_INVALID, "pdx_groupby_agg: output dtype does not match the aggregate's result type");
@@ -782,384 +994,133 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
     oc->null_count = needs_validity ? -1 : 0;
   }
   if (G == 0) return PDX_OK;
+  const AggTuning t = AggTuning::read();
+  // ---- stage 1: the grouped layout (a bound column brings its own)
+  GroupedLayout local;
+  GroupedLayout* Lp = find_bound(gb, values);
+  const bool bound = Lp != nullptr;
+  if (!Lp) Lp = &local;
+  GroupedLayout& L = *Lp;
+  const bool std_only = rq.std_only();
+  const size_t bytes_before = L.bytes;
+  if ((!L.fused && !L.full) || (!std_only && !L.full)) PDX_TRY(build_layout(gb, values, std_only, t, L, st));
+  const bool use_fused = std_only && L.fused;
   Scratch s;
-  const void* vals_sorted = nullptr;
-  const uint32_t* keys_sorted = nullptr;
-  const uint32_t* seg_start = nullptr;
-  const uint32_t* out_index = nullptr;
-  const uint8_t* row_valid = nullptr;  // segments mode reads validity in place
-  if (gb->mode == 0) {
-    const uint64_t* vin = static_cast<const uint64_t*>(values->values) + values->offset;
-    const uint64_t* vs = nullptr;
-    // ---- fused last digit (the five standard kinds): sort by all but the top 6 slot bits, then rank + reduce in one kernel
-    // (diagnostic switches are read on every call: tests flip them inside one process)
-    const bool flr_env = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT"); return !(e && e[0] == '0'); }();
-    const int part = gb->slot_part ? gb->part_bits : 0;
-    // partitioned hash slots: the table itself is a power of two; only the two special slots (null key, INT64_MIN key) need one
-    // more bit, so without them the top digit is drawn from the table's own bits (all 64 values used)
-    const int eff_bits = (gb->slot_part && !gb->special_slots) ? gb->slot_bits - 1 : gb->slot_bits;
-    const int low_bits = eff_bits - kFlrBits;
-    const bool std_only = (want_std5 || var_out || std_out) && !prod_out && !first_out && !last_out;  // (variance: two more fused passes)
-    const int64_t flr_min_rows = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_MIN_ROWS"); return e ? atoll(e) : (1ll << 22); }();
-    // a run is one workgroup's sequential work: it has to span a few tiles to amortise its prologue (1e8 groups: 119-row runs)
-    const int64_t flr_min_run = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_MIN_RUN"); return e ? atoll(e) : 8192ll; }();
-    const int flr_min_low = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS"); return e ? atoi(e) : 10; }();
-    // (hash-partitioned slots: only without the special slots -- with them the top digit is half empty and the runs half as long,
-    //  measured slower than the classic path)
-    const bool flr_hash = [] { const char* e = getenv("PDX_FUSED_LAST_DIGIT_HASH"); return !(e && e[0] == '0'); }();
-    bool flr = flr_env && std_only && n >= flr_min_rows && low_bits - part >= 4 && low_bits >= flr_min_low && low_bits <= 26 &&
-               (!gb->slot_part || (flr_hash && !gb->special_slots)) && (n >> low_bits) >= flr_min_run;
-    if (flr && !gb->slot_part && gb->pass0_off)  // the stored pass-0 offsets belong to the first digit of the FULL plan
-      flr = make_sort_plan(gb->slot_bits, sort_max_bits()).bits[0] == make_sort_plan(low_bits, sort_max_bits()).bits[0];
-    // Narrowing sort (dense slots, values without nulls, two passes below the fused digit): a digit that has been sorted on is
-    // dropped from the key, so pass 0 writes 2-byte keys, pass 1 reads them and writes the top digit alone in a byte, which is all
-    // the fused kernel reads: 12 B/row less traffic than carrying the 4-byte slot through.  Run starts then come from the scatter
-    // offsets (k_level_starts) instead of a search in the sorted slots.
-    const SortPlan low_plan = make_sort_plan(low_bits, sort_max_bits());
-    const bool narrow_env = [] { const char* e = getenv("PDX_SORT_NARROW"); return !(e && e[0] == '0'); }();
-    // (values with nulls: the null flag rides in the narrow key's top bit, read from the validity bitmap by pass 0 itself)
-    const bool narrow = flr && narrow_env && !gb->slot_part && gb->pass0_off && low_plan.npasses == 2 &&
-                        gb->slot_bits - low_plan.bits[0] <= (vvalid ? 15 : 16) && low_plan.bits[0] <= 8 && low_plan.bits[1] <= 8 &&
-                        eff_bits == gb->slot_bits;
-    // The same for the hash-partitioned layout (LDS build, one level, values without nulls): the value partition by bucket plays
-    // pass 0, the build left every row's 13-bit index inside its bucket's region as a 2-byte key (idx16_part), so the one sort pass
-    // below the fused digit reads 2-byte keys and writes the top digit alone: 8 B/row less than carrying the 4-byte logical slot.
-    const int mid_bits = low_bits - part;
-    const bool narrow_part = flr && narrow_env && gb->slot_part && gb->idx16_part && !gb->digit2 && !vvalid && part == kPartBits && mid_bits >= 4 &&
-                             mid_bits <= 8 && eff_bits - part <= 16;
-    const uint8_t* keys8 = nullptr;       // narrowing sort: the top digit of every partially sorted row
-    bool sorted_done = false;             // narrowing sort, skewed keys: the classic path's inputs are already built
-    uint32_t* ss_narrow = nullptr;
-    if (flr) {
-      const int64_t nruns = (int64_t)1 << low_bits;
-      uint32_t* run_start = s.get<uint32_t>((size_t)nruns + 1);
-      unsigned int* dmax = s.get<unsigned int>(1);
-      uint8_t* okb = vvalid ? s.get<uint8_t>((size_t)G) : nullptr;
-      PDX_SCRATCH_CHECK(s);
-      uint64_t *nv0 = nullptr, *nv1 = nullptr;
-      uint32_t *nhist = nullptr, *nchunk = nullptr;
-      uint8_t* k8 = nullptr;
-      hipEvent_t hmax_ready = nullptr;
-      if (narrow || narrow_part) {
-        const int b0 = narrow ? low_plan.bits[0] : kPartBits, b1 = narrow ? low_plan.bits[1] : mid_bits;
-        const int64_t ntiles = ceil_div(n, kSortTile), nchunks = ceil_div(ntiles, kColChunk);
-        uint16_t* k16 = narrow ? s.get<uint16_t>((size_t)n) : gb->idx16_part;
-        const uint32_t* prev_off = narrow ? gb->pass0_off : gb->part_off;  // (row 0 = where every first digit's rows begin in the input of pass 1)
-        k8 = s.get<uint8_t>((size_t)n);
-        nv0 = s.get<uint64_t>((size_t)n);
-        nv1 = s.get<uint64_t>((size_t)n);
-        nhist = s.get<uint32_t>((size_t)ntiles << 8);
-        nchunk = s.get<uint32_t>((size_t)(nchunks + 1) << 8);
-        PDX_SCRATCH_CHECK(s);
-        int rcn = PDX_OK;
-#define NARROW_P0(B)                                                                                                                         \
-  rcn = vvalid ? radix_scatter_narrow<B, uint64_t, uint32_t, uint16_t, true>(gb->slot_of_row, vin, k16, nv0, n, gb->pass0_off, st, vvalid, values->offset) \
-               : radix_scatter_narrow<B, uint64_t, uint32_t, uint16_t>(gb->slot_of_row, vin, k16, nv0, n, gb->pass0_off, st)
-        if (narrow_part) rcn = radix_scatter_only<kPartBits, uint64_t, uint8_t>(gb->bucket8, vin, nullptr, nv0, n, 0, false, gb->part_off, st);
-        else
-          switch (b0) {
-            case 4: NARROW_P0(4); break;
-            case 5: NARROW_P0(5); break;
-            case 6: NARROW_P0(6); break;
-            case 7: NARROW_P0(7); break;
-            default: NARROW_P0(8); break;
-          }
-#undef NARROW_P0
-        PDX_TRY(rcn);
-        // pass 1 in two halves: its offsets first -- the run starts and the longest run (the host needs that number to choose the
-        // reducer) follow from them alone -- then the scatter, which runs while the host reads the number back
-#define NARROW_P1_OFFSETS(B) rcn = radix_offsets<B, uint16_t>(k16, n, 0, nhist, nchunk, true, st)
-        switch (b1) {
-          case 4: NARROW_P1_OFFSETS(4); break;
-          case 5: NARROW_P1_OFFSETS(5); break;
-          case 6: NARROW_P1_OFFSETS(6); break;
-          case 7: NARROW_P1_OFFSETS(7); break;
-          default: NARROW_P1_OFFSETS(8); break;
-        }
-#undef NARROW_P1_OFFSETS
-        PDX_TRY(rcn);
-        {
-          PDX_PROFILE("run_starts", st);
-          // (row 0 of the pass-0 offsets = where every first digit's rows begin in the input of pass 1)
-          hipLaunchKernelGGL((k_level_starts<uint16_t>), dim3(1u << b0), dim3(256), 0, st, k16, n, prev_off, (int64_t)1 << b0, b0, b1, nhist, run_start);
-          PDX_HIP(hipMemsetAsync(dmax, 0, sizeof(unsigned int), st));
-          hipLaunchKernelGGL(k_run_max_len, dim3(grid_for(nruns, 256)), dim3(256), 0, st, run_start, nruns, dmax);
-          PDX_LAUNCH_CHECK();
-          PDX_HIP(hipMemcpyAsync(hmax_pinned(), dmax, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-          PDX_HIP(hipEventCreateWithFlags(&hmax_ready, hipEventDisableTiming));
-          PDX_HIP(hipEventRecord(hmax_ready, st));
-        }
-#define NARROW_P1(B)                                                                    \
-    rcn = vvalid ? radix_scatter_narrow<B, uint64_t, uint16_t, uint8_t, true>(k16, nv0, k8, nv1, n, nhist, st) \
-                 : radix_scatter_narrow<B, uint64_t, uint16_t, uint8_t>(k16, nv0, k8, nv1, n, nhist, st)
-        switch (b1) {
-          case 4: NARROW_P1(4); break;
-          case 5: NARROW_P1(5); break;
-          case 6: NARROW_P1(6); break;
-          case 7: NARROW_P1(7); break;
-          default: NARROW_P1(8); break;
-        }
-#undef NARROW_P1
-        if (rcn != PDX_OK) {
-          (void)hipEventDestroy(hmax_ready);
-          return rcn;
-        }
-        keys8 = k8;
-        vs = nv1;
-      } else {
-        PDX_TRY(sort_values_by_slot(gb, vin, vvalid, values->offset, [&](size_t bytes) { return (void*)s.get<uint8_t>(bytes); }, s, st, &keys_sorted, &vs,
-                                    gb->slot_bits - low_bits));
-      }
-      unsigned int hmax = 0;
-      if (narrow || narrow_part) {
-        const hipError_t ew = hipEventSynchronize(hmax_ready);
-        (void)hipEventDestroy(hmax_ready);
-        if (ew != hipSuccess) return hip_fail(ew, "pdx_groupby_agg");
-        hmax = *hmax_pinned();
-      } else {
-        PDX_PROFILE("run_starts", st);
-        PDX_HIP(hipMemsetAsync(dmax, 0, sizeof(unsigned int), st));
-        hipLaunchKernelGGL(k_run_starts, dim3(grid_for(nruns + 1, 256)), dim3(256), 0, st, keys_sorted, n, low_bits, nruns, run_start, dmax);
-        hipLaunchKernelGGL(k_run_max_len, dim3(grid_for(nruns, 256)), dim3(256), 0, st, run_start, nruns, dmax);
-        PDX_LAUNCH_CHECK();
-        PDX_HIP(hipMemcpyAsync(&hmax, dmax, sizeof(hmax), hipMemcpyDeviceToHost, st));
-        PDX_HIP(hipStreamSynchronize(st));
-      }
-      if ((narrow || narrow_part) && hmax > (1u << 19)) {
-        // skewed keys: the fused kernel is skipped.  Finish the sort with the one pass that is left (on the byte digits) and take the
-        // group offsets from its scatter offsets: one more level of k_level_starts gives the start of every slot's rows
-        ss_narrow = s.get<uint32_t>((size_t)G + 1);
-        uint32_t* slot_start = s.get<uint32_t>(((size_t)nruns << kFlrBits) + 1);
-        PDX_SCRATCH_CHECK(s);
-        PDX_TRY((radix_offsets<kFlrBits, uint8_t>(k8, n, 0, nhist, nchunk, true, st)));
-        if (vvalid) {  // the classic nullable reducers read the null flag from bit 31 of a 4-byte key per grouped row: write flags only
-          uint32_t* fkeys = s.get<uint32_t>((size_t)n);
-          PDX_SCRATCH_CHECK(s);
-          PDX_TRY((radix_scatter_narrow<kFlrBits, uint64_t, uint8_t, uint32_t, true>(k8, nv1, fkeys, nv0, n, nhist, st)));
-          keys_sorted = fkeys;
-        } else {
-          PDX_TRY((radix_scatter_narrow<kFlrBits, uint64_t, uint8_t, uint8_t>(k8, nv1, (uint8_t*)nullptr, nv0, n, nhist, st)));
-        }
-        {
-          PDX_PROFILE("seg_starts", st);
-          hipLaunchKernelGGL((k_level_starts<uint8_t>), dim3((unsigned)std::min<int64_t>(nruns, 65536)), dim3(256), 0, st, k8, n, run_start, nruns, low_bits,
-                             kFlrBits, nhist, slot_start);
-          hipLaunchKernelGGL(k_seg_starts_from_slots, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, slot_start, n, gb->occ_slot, G, ss_narrow);
-        }
-        PDX_LAUNCH_CHECK();
-        vs = nv0;
-        sorted_done = true;
-      }
-      if (hmax <= (1u << 19)) {  // a run is walked by ONE workgroup: keep the longest one short (skewed keys take the classic path)
-        auto launch_flr = [&](const SegOut& oo, bool pw, bool mm, bool is, uint8_t* okbytes, const double* sqmean) {
-          PDX_PROFILE("fused_last_digit_reduce", st);
-          static const int flr_wgs_per_cu = [] { const char* e = getenv("PDX_FLR_WGS_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 24; }();
-          const int grid = (int)std::min<int64_t>(nruns, (int64_t)kCUs * flr_wgs_per_cu);
-          const bool dense = pw && !mm && !is && !vvalid;
-          // (values with nulls, sum / mean / count: the thread-per-leaf form is opt-in, PDX_FLR_NULL_PW=1 -- measured 11.3 ms against
-          //  10.7 ms of the literal per-lane replay at 5 % nulls: its per-group walk over the leaf markers is as serial as the replay)
-          const bool nullpw = pw && !mm && !is && vvalid && [] { const char* e = getenv("PDX_FLR_NULL_PW"); return e && e[0] == '1'; }();
-#define FLR_LAUNCH(TT, DD)                                                                                                                       \
-  if (keys8 && nullpw)                                                                                                                           \
-    hipLaunchKernelGGL((k_flr_reduce<TT, false, uint8_t, true>), dim3(grid), dim3(kSortBlock), 0, st, keys8, reinterpret_cast<const TT*>(vs), run_start, \
-                       nruns, low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, 1, sqmean);                                       \
-  else if (nullpw)                                                                                                                               \
-    hipLaunchKernelGGL((k_flr_reduce<TT, false, uint32_t, true>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const TT*>(vs),   \
-                       run_start, nruns, low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, 1, sqmean);                            \
-  else if (keys8)                                                                                                                                \
-    hipLaunchKernelGGL((k_flr_reduce<TT, DD, uint8_t>), dim3(grid), dim3(kSortBlock), 0, st, keys8, reinterpret_cast<const TT*>(vs), run_start, nruns, \
-                       low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, vvalid ? 1 : 0, sqmean);                                 \
-  else                                                                                                                                           \
-    hipLaunchKernelGGL((k_flr_reduce<TT, DD>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const TT*>(vs), run_start, nruns, \
-                       low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, vvalid ? 1 : 0, sqmean)
-          // one WAVE per run (flr_wave.hpp) for everything but the dense sum / mean / count: nullable values, min / max and int64 sums
-          // were a per-lane replay by wave 0 alone in the workgroup-per-run kernel (5 % nulls: 10.7 -> 4.9 ms per 1e9 rows); the dense
-          // fast path of k_flr_reduce (thread per leaf) is still ahead of the wave form (3.0 vs 3.3 ms).  PDX_FLR_WAVE=1 / 0 force either.
-          const char* fw_env = getenv("PDX_FLR_WAVE");
-          const bool wave_form = !nullpw && (fw_env ? fw_env[0] != '0' : !dense);
-          if (wave_form) {
-            static const int fw_wgs_per_cu = [] { const char* e = getenv("PDX_FLR_WAVE_WGS_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 48; }();
-            const int wgrid = (int)std::min<int64_t>(nruns, (int64_t)kCUs * fw_wgs_per_cu);
-            const bool pw_only = pw && !mm && !is;
-            // counter levels: a group cannot outgrow its run, and a leaf holds 16 rows unless nulls cut it short
-            const uint64_t max_leaves = vvalid ? (uint64_t)hmax + 1 : (uint64_t)hmax / 16 + 2;
-            const int fw_levels = std::max(2, ilog2(max_leaves + 1));  // 2^levels > leaves: level index <= levels - 1
-            const size_t fw_lds = (size_t)fw_lds_bytes(vvalid != nullptr, fw_levels);
-#define FW_LAUNCH(TT, KK, KPTR, NN, PP)                                                                                                  \
-  hipLaunchKernelGGL((k_flr_wave<TT, KK, NN, PP>), dim3(wgrid), dim3(64), fw_lds, st, KPTR, reinterpret_cast<const TT*>(vs), n, run_start, nruns, low_bits, \
-                     gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, sqmean, fw_levels)
-#define FW_DISPATCH(TT)                                                                        \
-  if (keys8) {                                                                                 \
-    if (vvalid) { if (pw_only) FW_LAUNCH(TT, uint8_t, keys8, true, true); else FW_LAUNCH(TT, uint8_t, keys8, true, false); }          \
-    else { if (pw_only) FW_LAUNCH(TT, uint8_t, keys8, false, true); else FW_LAUNCH(TT, uint8_t, keys8, false, false); }              \
-  } else {                                                                                     \
-    if (vvalid) { if (pw_only) FW_LAUNCH(TT, uint32_t, keys_sorted, true, true); else FW_LAUNCH(TT, uint32_t, keys_sorted, true, false); } \
-    else { if (pw_only) FW_LAUNCH(TT, uint32_t, keys_sorted, false, true); else FW_LAUNCH(TT, uint32_t, keys_sorted, false, false); } \
-  }
-            if (is_f) { FW_DISPATCH(double) } else { FW_DISPATCH(long long) }
-#undef FW_DISPATCH
-#undef FW_LAUNCH
-          } else if (is_f) {
-            if (dense) { FLR_LAUNCH(double, true); }
-            else { FLR_LAUNCH(double, false); }
-          } else {
-            if (dense) { FLR_LAUNCH(long long, true); }
-            else { FLR_LAUNCH(long long, false); }
-          }
-#undef FLR_LAUNCH
-        };
-        if (want_std5) launch_flr(o, want_pw, want_mm, want_is, okb, nullptr);
-        PDX_LAUNCH_CHECK();
-        uint8_t* ok2 = nullptr;
-        if (var_out || std_out) {
-          // Arrow's two passes on the same partially sorted rows: per-group mean, then the pairwise sum of (x - mean)^2
-          double* mean_g = s.get<double>((size_t)G);
-          double* m2 = s.get<double>((size_t)G);
-          long long* cnt_g = s.get<long long>((size_t)G);
-          uint8_t* ok1 = vvalid ? s.get<uint8_t>((size_t)G) : nullptr;
-          ok2 = vvalid ? s.get<uint8_t>((size_t)G) : nullptr;
-          PDX_SCRATCH_CHECK(s);
-          SegOut o1{};
-          o1.mean = mean_g;
-          launch_flr(o1, true, false, false, ok1, nullptr);
-          SegOut o2{};
-          o2.sum_f = m2;
-          o2.count = cnt_g;
-          launch_flr(o2, true, false, false, ok2, mean_g);
-          hipLaunchKernelGGL(k_var_finish, dim3(grid_for(G, 256)), dim3(256), 0, st, m2, cnt_g, G, var_out, std_out);
-          PDX_LAUNCH_CHECK();
-        }
-        for (int k = 0; k < nk; ++k) {
-          uint8_t* bits = static_cast<uint8_t*>(outs[k].validity);
-          if (!bits) continue;
-          const uint8_t* src = (kinds[k] == PDX_AGG_VARIANCE || kinds[k] == PDX_AGG_STDDEV) ? ok2 : okb;
-          if (!src || kinds[k] == PDX_AGG_COUNT) PDX_HIP(hipMemsetAsync(bits, 0xFF, (size_t)((G + 7) / 8), st));
-          else hipLaunchKernelGGL(k_pack_bytes, dim3(grid_for((G + 7) / 8, 256)), dim3(256), 0, st, src, G, bits);
-        }
-        PDX_LAUNCH_CHECK();
-        PDX_HIP(hipStreamSynchronize(st));
-        return PDX_OK;
-      }
-    }
-    // stable sort of (slot, value) by slot: each group's values become contiguous in row order
-    uint32_t* ss = sorted_done ? ss_narrow : s.get<uint32_t>((size_t)G + 1);
-    PDX_SCRATCH_CHECK(s);
-    if (sorted_done) {
-      // (narrowing sort, skewed keys: values and group offsets were built above)
-    } else if (flr) {
-      // the fused kernel was skipped (a run longer than 2^19 rows: skewed keys): finish the sort with the one pass that is left
-      uint32_t* k2 = s.get<uint32_t>((size_t)n);
-      uint64_t* v2 = s.get<uint64_t>((size_t)n);
-      PDX_SCRATCH_CHECK(s);
-      const uint32_t* ks2 = nullptr;
-      const uint64_t* vs2 = nullptr;
-      PDX_TRY((radix_sort_pairs<uint64_t>(keys_sorted, vs, k2, v2, k2, v2, n, kFlrBits, &ks2, &vs2, true, s, st, low_bits)));
-      keys_sorted = ks2;
-      vs = vs2;
-    } else if (G == 1 && gb->slot_of_row) {
-      // one group: the rows are grouped as they stand (no sort); null flags, if any, still go into a key per row
-      keys_sorted = gb->slot_of_row;
-      if (vvalid) {
-        uint32_t* fk1 = s.get<uint32_t>((size_t)n);
-        PDX_SCRATCH_CHECK(s);
-        hipLaunchKernelGGL(k_flag_keys, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, gb->slot_of_row, vvalid, values->offset, n, fk1);
-        keys_sorted = fk1;
-      }
-      vs = vin;
-    } else {
-      PDX_TRY(sort_values_by_slot(gb, vin, vvalid, values->offset, [&](size_t bytes) { return (void*)s.get<uint8_t>(bytes); }, s, st, &keys_sorted, &vs));
-    }
-    vals_sorted = vs;
-    if (!sorted_done) {
-      PDX_PROFILE("seg_starts", st);
-      hipLaunchKernelGGL(k_seg_starts, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, keys_sorted, n, gb->occ_slot, G, ss);
-    }
-    PDX_LAUNCH_CHECK();
-    seg_start = ss;
-    out_index = gb->gid_of_occ;
-  } else {
-    vals_sorted = static_cast<const uint64_t*>(values->values) + values->offset;
-    seg_start = gb->seg_start;
-    row_valid = vvalid;
-  }
-  const uint32_t* fk = (gb->mode == 0 && vvalid) ? keys_sorted : nullptr;  // null flags of the grouped layout
-  // one segmented reduce of `vals` (float64 or int64 per f64) into `oo`; ok_bytes (nullable values only): 1 = the group has a valid value
-  auto reduce = [&](const void* vals, bool f64, const SegOut& oo, bool pw, bool mm, bool is, const uint32_t* oidx, uint8_t* ok_bytes) -> int {
-    PDX_PROFILE("seg_reduce", st);
-    if (!vvalid) {
-      if (f64) return launch_seg_reduce_dense<double>(static_cast<const double*>(vals), seg_start, G, oidx, oo, pw, mm, is, n, s, st);
-      return launch_seg_reduce_dense<long long>(static_cast<const long long*>(vals), seg_start, G, oidx, oo, pw, mm, is, n, s, st);
-    }
-    int grid = (int)std::min<int64_t>(ceil_div(G, kSegWaves), (int64_t)kCUs * 8);
-    if (f64)
-      hipLaunchKernelGGL((k_seg_reduce_nullable<double>), dim3(grid), dim3(kSegWaves * 64), 0, st, static_cast<const double*>(vals), fk, row_valid,
-                         values->offset, seg_start, G, oidx, oo, ok_bytes);
-    else
-      hipLaunchKernelGGL((k_seg_reduce_nullable<long long>), dim3(grid), dim3(kSegWaves * 64), 0, st, static_cast<const long long*>(vals), fk,
-                         row_valid, values->offset, seg_start, G, oidx, oo, ok_bytes);
-    PDX_LAUNCH_CHECK();
-    return reduce_huge_nullable_groups(vals, f64 ? PDX_FLOAT64 : PDX_INT64, fk, row_valid, values->offset, seg_start, G, oidx, n, oo, ok_bytes, s, st);
-  };
+  std::string reducer;
   auto pack_validity = [&](uint8_t* bits, const uint8_t* ok_bytes) {
     if (!bits) return;
     if (!ok_bytes) hipMemsetAsync(bits, 0xFF, (size_t)((G + 7) / 8), st);
     else hipLaunchKernelGGL(k_pack_bytes, dim3(grid_for((G + 7) / 8, 256)), dim3(256), 0, st, ok_bytes, G, bits);
   };
-  uint8_t* ok = nullptr;
-  if (vvalid) {
-    ok = s.get<uint8_t>((size_t)G);
-    PDX_SCRATCH_CHECK(s);
-  }
-  if (want_std5) {
-    PDX_TRY(reduce(vals_sorted, is_f, o, want_pw, want_mm, want_is, out_index, ok));
+  // the five standard kinds from one reduce into `oo`
+  auto reduce_std = [&](const SegOut& oo, bool pw, bool mm, bool is, uint8_t* okb) -> int {
+    if (use_fused) return reduce_fused(gb, L, t, oo, pw, mm, is, okb, nullptr, st, &reducer);
+    reducer = vvalid ? "seg_reduce_nullable" : "seg_reduce";
+    return reduce_full(gb, L, L.vals_sorted, is_f, oo, pw, mm, is, L.out_index, okb, s, st);
+  };
+  std::string cache_note;
+  if (rq.want_std5 && bound) {
+    // a bound column keeps its per-group sum / count (/ min / max): sum(); mean(); count() as three calls cost one reduce
+    const bool want_sumfam = rq.want_pw || rq.want_is || o.count;
+    const bool need_sumfam = want_sumfam && !L.have_pw, need_mm = rq.want_mm && !L.have_mm;
+    if (need_sumfam || need_mm) {
+      if (!L.c_count) L.c_count = L.own<long long>((size_t)G);
+      if (vvalid && !L.c_ok) L.c_ok = L.own<uint8_t>((size_t)G);
+      if (need_sumfam && !L.c_sum) L.c_sum = L.own<double>((size_t)G);
+      if (need_sumfam && !is_f && !L.c_isum) L.c_isum = L.own<long long>((size_t)G);
+      if (need_mm && !L.c_min) {
+        L.c_min = L.own<uint64_t>((size_t)G);
+        L.c_max = L.own<uint64_t>((size_t)G);
+      }
+      if (!L.c_count || (vvalid && !L.c_ok) || (need_sumfam && (!L.c_sum || (!is_f && !L.c_isum))) || (need_mm && (!L.c_min || !L.c_max))) return PDX_OOM;
+      SegOut c{};
+      c.count = L.c_count;
+      if (need_sumfam) {
+        c.sum_f = L.c_sum;
+        if (!is_f) c.sum_i = L.c_isum;
+      }
+      if (need_mm) {
+        c.vmin = L.c_min;
+        c.vmax = L.c_max;
+      }
+      PDX_TRY(reduce_std(c, need_sumfam, need_mm, need_sumfam && !is_f, L.c_ok));
+      L.have_pw = L.have_pw || need_sumfam;
+      L.have_mm = L.have_mm || need_mm;
+      cache_note = " cache=fill";
+    } else {
+      cache_note = " cache=hit";
+      reducer = "none";
+    }
+    const size_t gb8 = (size_t)G * 8;
+    if (o.sum_f) PDX_HIP(hipMemcpyAsync(o.sum_f, L.c_sum, gb8, hipMemcpyDeviceToDevice, st));
+    if (o.sum_i) PDX_HIP(hipMemcpyAsync(o.sum_i, L.c_isum, gb8, hipMemcpyDeviceToDevice, st));
+    if (o.count) PDX_HIP(hipMemcpyAsync(o.count, L.c_count, gb8, hipMemcpyDeviceToDevice, st));
+    if (o.vmin) PDX_HIP(hipMemcpyAsync(o.vmin, L.c_min, gb8, hipMemcpyDeviceToDevice, st));
+    if (o.vmax) PDX_HIP(hipMemcpyAsync(o.vmax, L.c_max, gb8, hipMemcpyDeviceToDevice, st));
+    if (o.mean) hipLaunchKernelGGL(k_mean_from_cache, dim3(grid_for(G, 256)), dim3(256), 0, st, L.c_sum, L.c_count, G, o.mean);
     for (int k = 0; k < nk; ++k)
-      if (kinds[k] <= PDX_AGG_COUNT) pack_validity(static_cast<uint8_t*>(outs[k].validity), kinds[k] == PDX_AGG_COUNT ? nullptr : ok);
+      if (kinds[k] <= PDX_AGG_COUNT) pack_validity(static_cast<uint8_t*>(outs[k].validity), kinds[k] == PDX_AGG_COUNT ? nullptr : L.c_ok);
+    PDX_LAUNCH_CHECK();
+  } else if (rq.want_std5) {
+    uint8_t* okb = vvalid ? s.get<uint8_t>((size_t)G) : nullptr;
+    PDX_SCRATCH_CHECK(s);
+    PDX_TRY(reduce_std(o, rq.want_pw, rq.want_mm, rq.want_is, okb));
+    for (int k = 0; k < nk; ++k)
+      if (kinds[k] <= PDX_AGG_COUNT) pack_validity(static_cast<uint8_t*>(outs[k].validity), kinds[k] == PDX_AGG_COUNT ? nullptr : okb);
     PDX_LAUNCH_CHECK();
   }
-  if (var_out || std_out) {
+  if (rq.var_out || rq.std_out) {
     // Arrow's two passes: mean = pairwise sum / count, then the pairwise sum of (x - mean)^2 over the same valid runs
-    double* mean_seg = s.get<double>((size_t)G);
-    double* d = s.get<double>((size_t)n);
     double* m2 = s.get<double>((size_t)G);
     long long* cnt_g = s.get<long long>((size_t)G);
     uint8_t* ok2 = vvalid ? s.get<uint8_t>((size_t)G) : nullptr;
-    uint8_t* ok_seg = vvalid ? s.get<uint8_t>((size_t)G) : nullptr;
+    uint8_t* ok1 = vvalid ? s.get<uint8_t>((size_t)G) : nullptr;
+    double* mean_g = s.get<double>((size_t)G);
     PDX_SCRATCH_CHECK(s);
     SegOut o1{};
-    o1.mean = mean_seg;
-    PDX_TRY(reduce(vals_sorted, is_f, o1, true, false, false, nullptr, ok_seg));  // segment order
-    {
-      PDX_PROFILE("seg_sqdev", st);
-      const int grid = (int)std::min<int64_t>(ceil_div(G, 4), (int64_t)kCUs * 16);
-      if (is_f) hipLaunchKernelGGL((k_seg_sqdev<double>), dim3(grid), dim3(256), 0, st, static_cast<const double*>(vals_sorted), seg_start, G, mean_seg, d);
-      else hipLaunchKernelGGL((k_seg_sqdev<long long>), dim3(grid), dim3(256), 0, st, static_cast<const long long*>(vals_sorted), seg_start, G, mean_seg, d);
-      PDX_LAUNCH_CHECK();
-    }
+    o1.mean = mean_g;
     SegOut o2{};
     o2.sum_f = m2;
     o2.count = cnt_g;
-    PDX_TRY(reduce(d, true, o2, true, false, false, out_index, ok2));
-    hipLaunchKernelGGL(k_var_finish, dim3(grid_for(G, 256)), dim3(256), 0, st, m2, cnt_g, G, var_out, std_out);
+    if (use_fused) {
+      // on the same partially sorted rows: per-group mean (group-id order), then the squared deviations formed inside the kernel
+      PDX_TRY(reduce_fused(gb, L, t, o1, true, false, false, ok1, nullptr, st, &reducer));
+      PDX_TRY(reduce_fused(gb, L, t, o2, true, false, false, ok2, mean_g, st, nullptr));
+    } else {
+      if (reducer.empty()) reducer = vvalid ? "seg_reduce_nullable" : "seg_reduce";
+      double* d = s.get<double>((size_t)n);
+      PDX_SCRATCH_CHECK(s);
+      PDX_TRY(reduce_full(gb, L, L.vals_sorted, is_f, o1, true, false, false, nullptr, ok1, s, st));  // segment order
+      {
+        PDX_PROFILE("seg_sqdev", st);
+        const int grid = (int)std::min<int64_t>(ceil_div(G, 4), (int64_t)kCUs * 16);
+        if (is_f) hipLaunchKernelGGL((k_seg_sqdev<double>), dim3(grid), dim3(256), 0, st, static_cast<const double*>(L.vals_sorted), L.seg_start, G, mean_g, d);
+        else hipLaunchKernelGGL((k_seg_sqdev<long long>), dim3(grid), dim3(256), 0, st, static_cast<const long long*>(L.vals_sorted), L.seg_start, G, mean_g, d);
+        PDX_LAUNCH_CHECK();
+      }
+      PDX_TRY(reduce_full(gb, L, d, true, o2, true, false, false, L.out_index, ok2, s, st));
+    }
+    hipLaunchKernelGGL(k_var_finish, dim3(grid_for(G, 256)), dim3(256), 0, st, m2, cnt_g, G, rq.var_out, rq.std_out);
     for (int k = 0; k < nk; ++k)
       if (kinds[k] == PDX_AGG_VARIANCE || kinds[k] == PDX_AGG_STDDEV) pack_validity(static_cast<uint8_t*>(outs[k].validity), ok2);
     PDX_LAUNCH_CHECK();
   }
-  if (prod_out || first_out || last_out) {
-    uint8_t* pok = (vvalid && prod_out) ? s.get<uint8_t>((size_t)G) : nullptr;
-    uint8_t* fok = (vvalid && first_out) ? s.get<uint8_t>((size_t)G) : nullptr;
-    uint8_t* lok = (vvalid && last_out) ? s.get<uint8_t>((size_t)G) : nullptr;
+  if (rq.prod_out || rq.first_out || rq.last_out) {
+    uint8_t* pok = (vvalid && rq.prod_out) ? s.get<uint8_t>((size_t)G) : nullptr;
+    uint8_t* fok = (vvalid && rq.first_out) ? s.get<uint8_t>((size_t)G) : nullptr;
+    uint8_t* lok = (vvalid && rq.last_out) ? s.get<uint8_t>((size_t)G) : nullptr;
     PDX_SCRATCH_CHECK(s);
     {
       PDX_PROFILE("seg_product_first_last", st);
       const int pf_grid = (int)std::min<int64_t>(ceil_div(G, 4), (int64_t)kCUs * 16);
       if (is_f)
-        hipLaunchKernelGGL((k_seg_product_first_last<double>), dim3(pf_grid), dim3(256), 0, st, static_cast<const double*>(vals_sorted), fk,
-                           row_valid, values->offset, seg_start, G, out_index, static_cast<double*>(prod_out), pok, static_cast<double*>(first_out), fok,
-                           static_cast<double*>(last_out), lok);
+        hipLaunchKernelGGL((k_seg_product_first_last<double>), dim3(pf_grid), dim3(256), 0, st, static_cast<const double*>(L.vals_sorted), L.flag_keys,
+                           L.row_valid, values->offset, L.seg_start, G, L.out_index, static_cast<double*>(rq.prod_out), pok, static_cast<double*>(rq.first_out),
+                           fok, static_cast<double*>(rq.last_out), lok);
       else
-        hipLaunchKernelGGL((k_seg_product_first_last<long long>), dim3(pf_grid), dim3(256), 0, st, static_cast<const long long*>(vals_sorted),
-                           fk, row_valid, values->offset, seg_start, G, out_index, static_cast<long long*>(prod_out), pok,
-                           static_cast<long long*>(first_out), fok, static_cast<long long*>(last_out), lok);
+        hipLaunchKernelGGL((k_seg_product_first_last<long long>), dim3(pf_grid), dim3(256), 0, st, static_cast<const long long*>(L.vals_sorted),
+                           L.flag_keys, L.row_valid, values->offset, L.seg_start, G, L.out_index, static_cast<long long*>(rq.prod_out), pok,
+                           static_cast<long long*>(rq.first_out), fok, static_cast<long long*>(rq.last_out), lok);
     }
     for (int k = 0; k < nk; ++k) {
       if (kinds[k] == PDX_AGG_PRODUCT) pack_validity(static_cast<uint8_t*>(outs[k].validity), pok);
@@ -1167,10 +1128,14 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
       if (kinds[k] == PDX_AGG_LAST) pack_validity(static_cast<uint8_t*>(outs[k].validity), lok);
     }
     PDX_LAUNCH_CHECK();
+    if (reducer.empty() || reducer == "none") reducer = "seg_product_first_last";
   }
-  PDX_HIP(hipStreamSynchronize(st));  // scratch is returned to the pool on exit
+  gb->last_plan = L.plan + " reducer=" + reducer + (bound ? " bound=1" : " bound=0") + cache_note;
+  if (bound && L.bytes != bytes_before) enforce_bind_limit(gb, &L);
+  PDX_HIP(hipStreamSynchronize(st));  // outputs are valid on return; scratch and a local layout go back to the pool on exit
   return PDX_OK;
 }
+
 
 int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right, int label_right, int origin_type,
                         int64_t origin_custom_ns, int64_t offset_ns, void* stream, pdx_groupby** out) {
