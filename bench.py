@@ -15,7 +15,7 @@ results left in HBM.  Rank 0 prints ONE JSON line:
                        device time (HIP events recorded by the library on the launch stream) two ways: `achieved` with the whole
                        operator's 16 B/row per launch (the contract's definition; it flatters a multi-pass step) and `own_bytes`
                        with the bytes that kernel itself has to move.  `traffic` = HBM bytes per launch of that kernel from
-                       rocprofv3 PMC counters (profiles/r02_pmc_traffic.json), dropped when the library sources changed since.
+                       rocprofv3 PMC counters (profiles/r03_pmc_traffic.json), dropped when the library sources changed since.
   cpu_baseline         the reference's Arrow call sequence on this box's host cores: Arrow C++ itself when the pyarrow wheel's
                        libarrow is present (oracle/_build/arrow_seq, kind "port": same kernels the reference calls, without its
                        unordered_map<ScalarPtr> bookkeeping), else the oracle's C restatement.
@@ -54,8 +54,12 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=float, default=1e9, help="total rows (strong scaling: split by row range over the ranks)")
     ap.add_argument("--keys", type=float, default=1e6)
-    ap.add_argument("--cpu-sample-rows", type=float, default=3e7,
-                    help="rows of the same workload timed on the host cores (rank 0, N=1): ~25 s of Arrow C++ (its ApplyGroupings is single threaded)")
+    ap.add_argument("--cpu-sample-rows", type=float, default=1e8,
+                    help="rows of the same workload timed on the host cores (rank 0, N=1): SURVEY 8d's 1e8 rows / 1e6 keys = 100 rows per group, "
+                         "~10-15 s of Arrow C++ (3e6 per-group CallFunction dispatches + the single-threaded ApplyGroupings)")
+    ap.add_argument("--chain-check-rows", type=float, default=1.35e8,
+                    help="rows of the same workload pushed through the HIP path and the oracle after the timed region: enough for the default "
+                         "thresholds to pick the SAME kernel chain as the timed step (narrowing sort + fused last digit need >= 8192 rows per run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other configs / the general-keys run after the timed region")
     ap.add_argument("--no-check", action="store_true", help="skip the size-independent result checks after the timed region")
@@ -96,7 +100,8 @@ def cpu_baseline(sample_rows, nkeys, gpu_check=None):
     except AttributeError:
         usable = ncpu
     threads = max(1, min(usable, 64))
-    out = {"unit": "Grows/s", "cores": ncpu, "threads": threads, "usable_cores": usable, "kind": "port"}
+    out = {"unit": "Grows/s", "cores": ncpu, "threads": threads, "usable_cores": usable, "kind": "port",
+           "rows_per_group": round(sample_rows / max(1, min(nkeys, sample_rows)), 1)}
     arrow = None
     try:
         arrow = orc.arrow_seq_run(sample_rows, nkeys, threads)  # Arrow C++ itself (pyarrow wheel's libarrow), if it could be built
@@ -168,12 +173,32 @@ def secondary_runs(torch, L, K, api, keys, vals, kinds, n_total, nkeys, steps):
         return gb, gb.agg(vals, kinds)
 
     # (a) the same step when the keys may NOT use the dense-integer shortcut: hash partition + LDS-resident open addressing
+    prev_dense = os.environ.get("PDX_GROUPBY_DENSE")
     os.environ["PDX_GROUPBY_DENSE"] = "0"
     try:
-        put("groupby_general_keys_hash_path", n_total, ALGO_BYTES_PER_ROW * n_total, timeit(gb_step, reps=max(2, min(steps, 3))),
+        dt_hash = timeit(gb_step, reps=max(2, min(steps, 3)))
+        gbh, _ = gb_step()
+        put("groupby_general_keys_hash_path", n_total, ALGO_BYTES_PER_ROW * n_total, dt_hash, plan=gbh.last_plan(),
             workload=f"same {n_total:.3g} rows / {nkeys:.3g} keys with PDX_GROUPBY_DENSE=0 (every key through the hash table)")
-    finally:
-        del os.environ["PDX_GROUPBY_DENSE"]
+        del gbh
+    finally:  # (the caller's own setting comes back: a general-keys collection run must stay general for the rows below)
+        if prev_dense is None:
+            del os.environ["PDX_GROUPBY_DENSE"]
+        else:
+            os.environ["PDX_GROUPBY_DENSE"] = prev_dense
+
+    # (a2) the reference's API has no multi-kind call: user code is gb.sum(c); gb.mean(c); gb.count(c) (src/group_by.h:85-139) on the
+    # per-group arrays its constructor built once (processEach, src/dataframe.cpp:1539-1554).  Same here with a bound column: the
+    # first call sorts by group and reduces, the other two are served from the handle.
+    def gb_three_calls():
+        gb = K.GroupByHandle.create(keys)
+        gb.bind(vals)
+        return gb, [gb.agg(vals, [k])[0] for k in kinds]
+
+    dt3 = timeit(gb_three_calls, reps=max(2, min(steps, 3)))
+    dt1 = timeit(gb_step, reps=max(2, min(steps, 3)))
+    put("groupby_reference_api_three_calls", n_total, ALGO_BYTES_PER_ROW * n_total, dt3, fused_call_ms=round(dt1 * 1e3, 3),
+        ratio_to_fused_call=round(dt3 / dt1, 3), workload="create + bind + sum(); mean(); count() as three pdx_groupby_agg calls")
     # (b) 5 % null values (SURVEY 8d secondary run)
     vmask = K.compare(L.NE, K.synth_keys(3, n_total, 20), 0)
     vn = K.Column(L.FLOAT64, n_total, vals.values, vmask.values, 0, -1)
@@ -345,16 +370,16 @@ def main():
         # HBM traffic per launch from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes, tools/collect_profiles.sh):
         # only valid for the configuration AND the sources it was measured on
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             # (the counters were collected on the single-GPU step: the sharded step -- also when forced at world size 1 -- runs other passes)
             if pmc.get("rows") == n_total and pmc.get("n_gpus") == world and pmc.get("source_hash") == source_hash() and not sharded:
                 by_tag = pmc["by_bench_tag_hbm_bytes_per_launch"]
                 dk["traffic"] = by_tag.get(tag)
                 roof["traffic"] = pmc.get("step_hbm_bytes")
-                roof["traffic_source"] = "profiles/r02_pmc_traffic.json (source_hash %s)" % pmc["source_hash"]
+                roof["traffic_source"] = "profiles/r03_pmc_traffic.json (source_hash %s)" % pmc["source_hash"]
             else:
-                roof["traffic_note"] = "profiles/r02_pmc_traffic.json was measured on another configuration or build: dropped"
+                roof["traffic_note"] = "profiles/r03_pmc_traffic.json was measured on another configuration or build: dropped"
         except (OSError, ValueError, KeyError):
             pass
 
@@ -393,6 +418,28 @@ def main():
         if cpu.get("gpu_matches_oracle_bit_exact") is False:
             raise SystemExit("HIP result differs from the oracle on the cpu_baseline sample")
 
+    # the timed kernel chain against the oracle: a prefix of the same workload long enough for the default thresholds to choose the
+    # same path as the full-size step (asserted through the plan), compared per key bit for bit
+    chain = None
+    if rank == 0 and not sharded and not args.no_check and not args.no_cpu_baseline:
+        import numpy as np
+        import oracle as orc
+
+        m = int(min(args.chain_check_rows, n_total))
+        gbf = K.GroupByHandle.create(keys)
+        gbf.agg(vals, kinds)
+        full_plan = gbf.last_plan()
+        del gbf
+        gbc = K.GroupByHandle.create(keys.slice(0, m))
+        oc = gbc.agg(vals.slice(0, m), kinds)
+        ek, es, em, ec = orc.groupby_sum_mean_count(orc.synth_keys(0, m, nkeys), orc.synth_vals(0, m), nthreads=min(64, os.cpu_count() or 1))
+        same = bool(np.array_equal(gbc.unique_keys().to_numpy()[0], ek) and np.array_equal(oc[0].to_numpy()[0].view(np.uint64), es.view(np.uint64))
+                    and np.array_equal(oc[1].to_numpy()[0].view(np.uint64), em.view(np.uint64)) and np.array_equal(oc[2].to_numpy()[0], ec))
+        chain = {"rows": m, "plan": gbc.last_plan(), "timed_step_plan": full_plan, "same_path_as_timed_step": gbc.last_plan() == full_plan,
+                 "gpu_matches_oracle_bit_exact": same}
+        if not same:
+            raise SystemExit(f"HIP result differs from the oracle on the production-chain sample: {chain}")
+
     if rank == 0:
         line = {
             "metric": "Grows/sec hash group-by-sum, 1e9 int64 rows x 1e6 keys", "value": value, "unit": "Grows/s", "n_gpus": world,
@@ -402,7 +449,10 @@ def main():
                                    + (", 1 GPU" if world == 1 else f", row-range sharded over {world} GPUs (RCCL exchange)"),
                        "rows": n_total, "keys": nkeys, "rows_per_gpu": n_local, "parity": "bit-exact vs Arrow-order pairwise sum",
                        "path": "sharded" if sharded else "single"},
-            "roofline": roof, "cpu_baseline": cpu, "check": check, "secondary": secondary,
+            "roofline": roof, "cpu_baseline": cpu, "check": check, "chain_check": chain,
+            # the metric's literal reading ("hash group-by"): the same step with every key through the LDS-bucketed hash table
+            "general_keys_hash_path": (secondary or {}).get("groupby_general_keys_hash_path"),
+            "secondary": secondary,
         }
         print(json.dumps(line), flush=True)
     if sharded:

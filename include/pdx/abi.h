@@ -252,9 +252,9 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
 /* The grouped layout of one column, built once and reused: what GroupBy's constructor does for every column of the frame
  * (processEach, src/dataframe.cpp:1539-1554: MakeGroupings + ApplyGroupings), so that gb.sum(c); gb.mean(c); gb.count(c)
  * (src/group_by.h:85-139 -- the reference has no multi-kind call) cost ONE value sort and ONE reduce instead of three of each.
- * pdx_groupby_bind sorts `values` by group now and keeps the result (plus, after the first aggregation, the per-group sum /
- * count / min / max) in the handle; every later pdx_groupby_agg whose `values` has the same values pointer, offset, dtype and
- * validity pointer is served from it.  Contract: the column's buffers stay alive and UNCHANGED until pdx_groupby_unbind /
+ * pdx_groupby_bind registers `values` with the handle: the first pdx_groupby_agg of the column sorts it by group and keeps the
+ * result (plus the per-group sum / count / min / max it computes) in the handle; every later pdx_groupby_agg whose `values` has
+ * the same values pointer, offset, dtype and validity pointer is served from it.  Contract: the column's buffers stay alive and UNCHANGED until pdx_groupby_unbind /
  * pdx_groupby_destroy (Arrow buffers are immutable; the facades' GroupBy holds the frame).  Nothing is cached for columns that
  * were not bound.  values == NULL in unbind: every bound column.  The bound layouts of one handle are limited to
  * pdx_groupby_bind_limit bytes (default: a quarter of the device's memory, or PDX_BIND_MAX_BYTES): the least recently used

@@ -464,6 +464,23 @@ def reindex_indices(old_index, new_index):
     return np.where(present, order[np.maximum(j, 0)], 0).astype(np.int64), present
 
 
+def reindex(values, valid, old_index, new_index, fill=None):
+    """Series::reindex(newIndex, fillValue) (src/series.cpp:1255-1309): the value at the LAST position of every new label (a null value
+    stays null); a label the old index lacks gives `fill` (AppendScalar(*fillValue)) or null.  Returns (values, valid)."""
+    values = np.asarray(values)
+    valid = np.ones(len(values), bool) if valid is None else np.asarray(valid, bool)
+    pos, present = reindex_indices(old_index, new_index)
+    if len(values) == 0:
+        out, ok = np.zeros(len(pos), values.dtype), np.zeros(len(pos), bool)
+    else:
+        out, ok = values[pos].copy(), valid[pos] & present
+    out[~ok] = 0
+    if fill is not None:
+        out[~present] = fill
+        ok = ok | ~present
+    return out, ok
+
+
 # ------------------------------------------------------------------ temporal rounding / DataFrame::downsample (SURVEY 8a a12)
 UNIT_NANOSECOND, UNIT_MICROSECOND, UNIT_MILLISECOND, UNIT_SECOND, UNIT_MINUTE, UNIT_HOUR, UNIT_DAY, UNIT_WEEK, UNIT_MONTH, UNIT_QUARTER = range(10)
 UNIT_NAMES = ["nanosecond", "microsecond", "millisecond", "second", "minute", "hour", "day", "week", "month", "quarter"]

@@ -658,12 +658,24 @@ class GroupBy:
         self.df = df
         self.key = key
         self._h = _handle if _handle is not None else K.GroupByHandle.create(df[key].col)
+        self._bound_names = set()
 
     def groupSize(self):
         return self._h.num_groups
 
     def unique(self) -> Column:
         return self._h.unique_keys()
+
+    def _col(self, name) -> Column:
+        """The frame's column, bound to the handle on first use: the reference's constructor groups every column once (processEach,
+        src/dataframe.cpp:1539-1554) and sum() / mean() / count() reuse that (src/group_by.h:85-139); here the first aggregation of a
+        column sorts it by group, later ones reuse the layout and the cached per-group results.  The GroupBy holds the frame, so
+        the bound buffers stay alive and unchanged."""
+        c = self.df.cols[self.df.names.index(name)]
+        if c.dtype in (L.INT64, L.FLOAT64) and name not in self._bound_names:
+            self._h.bind(c)
+            self._bound_names.add(name)
+        return c
 
     def group_ids(self):
         return self._h.group_ids()
@@ -672,7 +684,7 @@ class GroupBy:
         single = isinstance(args, str)
         names = [args] if single else list(args)
         uniq = self.unique()
-        outs = [self._h.agg(self.df.cols[self.df.names.index(nm)], [kind])[0] for nm in names]
+        outs = [self._h.agg(self._col(nm), [kind])[0] for nm in names]
         if single:
             return Series(outs[0], index=uniq, name=names[0])
         return DataFrame(dict(zip(names, outs)), index=uniq)
@@ -699,14 +711,14 @@ class GroupBy:
         single = isinstance(args, str)
         cols = {}
         for nm in ([args] if single else list(args)):
-            mn, mx = self._h.agg(self.df.cols[self.df.names.index(nm)], [L.AGG_MIN, L.AGG_MAX])
+            mn, mx = self._h.agg(self._col(nm), [L.AGG_MIN, L.AGG_MAX])
             cols["min" if single else nm + "_min"], cols["max" if single else nm + "_max"] = mn, mx
         return DataFrame(cols, index=None)
 
     def agg(self, name, kinds):
         """sum/mean/count of one column from a single grouped pass (the headline query)."""
         uniq = self.unique()
-        outs = self._h.agg(self.df.cols[self.df.names.index(name)], kinds)
+        outs = self._h.agg(self._col(name), kinds)
         return uniq, outs
 
 

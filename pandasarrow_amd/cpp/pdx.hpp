@@ -900,6 +900,10 @@ struct GroupBy {
     Array out = Array::Empty(out_dt, (int64_t)groupSize(), boolean || (v.has_nulls() && !counting));
     auto c = v.c();
     auto m = out.mut();
+    // the reference's constructor groups every column once (processEach, src/dataframe.cpp:1539-1554) and sum() / mean() / count()
+    // reuse it: the first aggregation of a column binds it (one sort by group, kept in the handle together with the per-group
+    // results); `df` keeps the buffers alive and unchanged for as long as the handle can look them up
+    if (v.dtype == PDX_INT64 || v.dtype == PDX_FLOAT64) ThrowOnFailure(pdx_groupby_bind(handle->h, &c, nullptr));
     ThrowOnFailure(pdx_groupby_agg(handle->h, &c, &kind, 1, &m, nullptr));
     out.null_count = m.null_count;
     return out;

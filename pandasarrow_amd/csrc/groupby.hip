@@ -895,17 +895,13 @@ int pdx_groupby_bind(pdx_groupby* gb, const pdx_column* values, void* stream) {
   std::unique_ptr<GroupedLayout> L(new GroupedLayout());
   L->bound = true;
   L->last_use = ++gb->use_clock;
-  if (gb->G > 0) {
-    const AggTuning t = AggTuning::read();
-    PDX_TRY(build_layout(gb, values, true, t, *L, st));
-    PDX_HIP(hipStreamSynchronize(st));
-  } else {
-    L->values = values->values;
-    L->validity = validity_or_null(values);
-    L->offset = values->offset;
-    L->dtype = values->dtype;
-    L->stream = st;
-  }
+  // registration only: the first pdx_groupby_agg of the column builds the layout ITS kinds need (the fused form for the standard
+  // kinds, the fully sorted form for product / first / last), later calls reuse it
+  L->values = values->values;
+  L->validity = validity_or_null(values);
+  L->offset = values->offset;
+  L->dtype = values->dtype;
+  L->stream = st;
   gb->bound.push_back(std::move(L));
   enforce_bind_limit(gb, gb->bound.back().get());
   return PDX_OK;

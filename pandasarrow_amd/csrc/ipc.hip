@@ -251,9 +251,14 @@ int parse_record_batch(Fb& fb, const Message& m, pdx_ipc_frame* fr) {
     f.validity_len = fb.rd<int64_t>(bufs + 4 + 16 * (size_t)(2 * i) + 8);
     f.values_off = fb.rd<int64_t>(bufs + 4 + 16 * (size_t)(2 * i + 1));
     f.values_len = fb.rd<int64_t>(bufs + 4 + 16 * (size_t)(2 * i + 1) + 8);
-    const int64_t need = f.bit_width == 1 ? (f.length + 7) / 8 : f.length * (f.bit_width / 8);
-    if (f.length != fr->num_rows || f.length < 0 || f.null_count < 0 || f.values_off < 0 || f.validity_off < 0 || f.values_len < need ||
-        f.values_off + f.values_len > m.body_length || f.validity_off + f.validity_len > m.body_length ||
+    // every number below comes from an untrusted stream: no sum or product may wrap.  A buffer lies inside the body iff
+    // 0 <= off <= body and 0 <= len <= body - off; the row count is bounded by the body's bits before `need` is formed.
+    const int64_t body = m.body_length;
+    auto inside = [body](int64_t off, int64_t len) { return off >= 0 && len >= 0 && off <= body && len <= body - off; };
+    const bool counts_ok = f.length == fr->num_rows && f.length >= 0 && f.null_count >= 0 && f.null_count <= f.length && body >= 0 &&
+                           (f.length == 0 || f.length / 8 <= body);  // (>= 1 bit per row in the body: length * 8 cannot wrap below)
+    const int64_t need = !counts_ok ? 0 : f.bit_width == 1 ? (f.length + 7) / 8 : f.length * (int64_t)(f.bit_width / 8);
+    if (!counts_ok || !inside(f.values_off, f.values_len) || !inside(f.validity_off, f.validity_len) || f.values_len < need ||
         (f.null_count > 0 && f.validity_len < (f.length + 7) / 8) || (f.values_off & 7) || (f.validity_off & 7))
       return fail(PDX_INVALID, "pdx_ipc_open: field '" + f.name + "': buffer layout is inconsistent with the batch");
   }
@@ -514,11 +519,24 @@ int pdx_ipc_load(pdx_ipc_frame* fr, void* stream) {
   if (fr->loaded) return PDX_OK;
   hipStream_t st = as_stream(stream);
   fr->stream = st;
+  // a failed load leaves NOTHING behind (a second call starts clean instead of orphaning the first call's blocks in the pool)
+  auto undo = [fr](int rc) {
+    for (void*& w : fr->widened) {
+      pool_free(w);
+      w = nullptr;
+    }
+    pool_free(fr->dev_body);
+    fr->dev_body = nullptr;
+    return rc;
+  };
   fr->widened.assign(fr->fields.size(), nullptr);
   fr->dev_body = pool_alloc((size_t)fr->body_length + 64);  // slack: kernels may read whole 64-bit bitmap words
   if (!fr->dev_body) return PDX_OOM;
   // ONE host->device copy: the body is already the Arrow layout the kernels read
-  if (fr->body_length) PDX_HIP(hipMemcpyAsync(fr->dev_body, fr->body, (size_t)fr->body_length, hipMemcpyHostToDevice, st));
+  if (fr->body_length) {
+    const hipError_t ec = hipMemcpyAsync(fr->dev_body, fr->body, (size_t)fr->body_length, hipMemcpyHostToDevice, st);
+    if (ec != hipSuccess) return undo(hip_fail(ec, "pdx_ipc_load: copy of the record batch body"));
+  }
   static const int64_t unit_to_ns[4] = {1000000000LL, 1000000LL, 1000LL, 1LL};
   for (size_t i = 0; i < fr->fields.size(); ++i) {
     const FieldInfo& f = fr->fields[i];
@@ -526,15 +544,19 @@ int pdx_ipc_load(pdx_ipc_frame* fr, void* stream) {
     const int64_t mul = f.pdx_dtype == PDX_TIMESTAMP_NS ? unit_to_ns[f.ts_unit & 3] : 1;
     if (!narrow && mul == 1) continue;
     void* w = pool_alloc((size_t)(f.length > 0 ? f.length : 1) * 8);
-    if (!w) return PDX_OOM;
+    if (!w) return undo(PDX_OOM);
     fr->widened[i] = w;
     if (f.length)
       hipLaunchKernelGGL(k_widen, dim3(grid_for(f.length, 256, 4)), dim3(256), 0, st, static_cast<const uint8_t*>(fr->dev_body) + f.values_off,
                          f.bit_width, f.is_signed ? 1 : 0, f.type_id == kTyFloat ? 1 : 0, mul, f.length, w);
-    PDX_LAUNCH_CHECK();
+    const hipError_t el = hipGetLastError();
+    if (el != hipSuccess) return undo(hip_fail(el, "pdx_ipc_load: k_widen"));
   }
-  PDX_HIP(hipStreamSynchronize(st));  // the caller may free the blob once this returns
-  fr->body = nullptr;
+  {
+    const hipError_t es = hipStreamSynchronize(st);
+    if (es != hipSuccess) return undo(hip_fail(es, "pdx_ipc_load"));
+  }
+  fr->body = nullptr;  // the caller may free the blob once this returns
   fr->loaded = true;
   return PDX_OK;
 }

@@ -57,6 +57,17 @@ def golden2():
     return _golden2
 
 
+_golden3 = None
+
+
+def golden3():
+    """Round-3 additions (oracle/gen_golden_r3.py): DataFrame comparisons / and / or, reindex with a fill value."""
+    global _golden3
+    if _golden3 is None:
+        _golden3 = Golden("arrow_golden_r3.npz")
+    return _golden3
+
+
 @pytest.fixture(scope="session")
 def gold():
     return golden()

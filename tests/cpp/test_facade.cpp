@@ -298,6 +298,83 @@ static void test_sort() {
   REQUIRE((withnull.argsort(false).values<long>() == std::vector<long>{0, 2, 1}));
 }
 
+// BINARY_OPERATOR_DF(> >= < <= == != && ||) (src/dataframe.cpp:563-577, src/dataframe.h:476-520) and DataFrame / Series::reindex with
+// a fill value (src/dataframe.cpp:1139-1186, src/series.cpp:1295-1302; vectors: tests/dataframe_indexing_test.cpp:203-229)
+static void test_frame_compare_logical_reindex() {
+  DataFrame a({"x", "y"}, {Array::Make(std::vector<double>{1.0, 5.0, 3.0}), Array::Make(std::vector<double>{4.0, 0.5, 3.0})});
+  DataFrame b({"x", "y"}, {Array::Make(std::vector<double>{2.0, 5.0, 1.0}), Array::Make(std::vector<double>{4.0, 1.5, std::nan("")})});
+  REQUIRE(((a > b)["x"].values<int>() == std::vector<int>{0, 0, 1}));
+  REQUIRE(((a >= b)["x"].values<int>() == std::vector<int>{0, 1, 1}));
+  auto lt = (a < b)["y"].values<int>(), eq = (a == b)["y"].values<int>();  // (row 2 of b.y is null: only the valid rows are pinned)
+  REQUIRE(lt[0] == 0 && lt[1] == 1 && eq[0] == 1 && eq[1] == 0);
+  REQUIRE(((a != b)["y"].m_array.valid_flags() == std::vector<bool>{true, true, false}));  // NaN -> null on construction -> null out
+  REQUIRE((a > b)["x"].dtype() == PDX_BOOL);
+  Series s(std::vector<double>{1.0, 1.0, 3.0});
+  REQUIRE(((a <= s)["x"].values<int>() == std::vector<int>{1, 0, 1}));
+  REQUIRE(((a > Scalar(2.0))["y"].values<int>() == std::vector<int>{1, 0, 1}));
+  DataFrame m = (a > Scalar(2.0)) && (a <= Scalar(4.0));
+  REQUIRE((m["x"].values<int>() == std::vector<int>{0, 0, 1}));
+  REQUIRE((m["y"].values<int>() == std::vector<int>{1, 0, 1}));
+  REQUIRE((((a > Scalar(4.0)) || (a < Scalar(1.0)))["y"].values<int>() == std::vector<int>{0, 1, 0}));
+  REQUIRE(((m || Scalar(true))["x"].values<int>() == std::vector<int>{1, 1, 1}));
+  REQUIRE(((m && Scalar(false))["y"].values<int>() == std::vector<int>{0, 0, 0}));
+  REQUIRE(((m && (a["x"] > Scalar(0.0)))["y"].values<int>() == std::vector<int>{1, 0, 1}));
+  REQUIRE_THROWS(a > DataFrame({"x"}, {Array::Make(std::vector<double>{1.0, 2.0, 3.0})}));
+  REQUIRE_THROWS(a == Series(std::vector<double>{1.0}));
+  REQUIRE_THROWS(a && a);  // "and" has no float64 kernel
+  REQUIRE((a[m["y"]]["x"].values<double>() == std::vector<double>{1.0, 3.0}));
+  // tests/dataframe_indexing_test.cpp:203-229
+  DataFrame in({"col1", "col2"}, {Array::Make(std::vector<long>{1, 2, 3, 4, 5}), Array::Make(std::vector<long>{5, 4, 3, 2, 1})},
+               Array::Make(std::vector<long>{1, 2, 3, 4, 5}));
+  Array newIndex = Array::Make(std::vector<long>{1, 2, 4, 5, 6});
+  DataFrame out = in.reindex(newIndex);
+  REQUIRE((out.m_index->values_as<long>() == std::vector<long>{1, 2, 4, 5, 6}));
+  REQUIRE((out["col1"].m_array.valid_flags() == std::vector<bool>{true, true, true, true, false}));
+  REQUIRE((out["col2"].m_array.valid_flags() == std::vector<bool>{true, true, true, true, false}));
+  auto c1 = out["col1"].values<long>(), c2 = out["col2"].values<long>();
+  REQUIRE((std::vector<long>(c1.begin(), c1.begin() + 4) == std::vector<long>{1, 2, 4, 5}));
+  REQUIRE((std::vector<long>(c2.begin(), c2.begin() + 4) == std::vector<long>{5, 4, 2, 1}));
+  // the same with a fill value (src/series.cpp:1295-1302): the absent label 6 takes it, nothing is null
+  DataFrame filled = in.reindexAsync(newIndex, Scalar(-1));
+  REQUIRE((filled["col1"].values<long>() == std::vector<long>{1, 2, 4, 5, -1}));
+  REQUIRE((filled["col2"].values<long>() == std::vector<long>{5, 4, 2, 1, -1}));
+  REQUIRE((filled["col1"].m_array.valid_flags() == std::vector<bool>(5, true)));
+  Series sv(Array::Make(std::vector<double>{10.0, std::nan(""), 30.0}), Array::Make(std::vector<long>{7, 8, 7}), "v");
+  Series r = sv.reindex(Array::Make(std::vector<long>{8, 7, 9}), Scalar(0.5));  // 8: present but null stays null; 7: LAST position; 9: filled
+  REQUIRE((r.m_array.valid_flags() == std::vector<bool>{false, true, true}));
+  REQUIRE(r.values<double>()[1] == 30.0 && r.values<double>()[2] == 0.5);
+  REQUIRE_THROWS(sv.reindex(Array::Make(std::vector<long>{9}), Scalar(1)));  // int64 scalar into a double builder
+}
+
+// GroupBy binds a column on its first aggregation (reference: the constructor's processEach, src/dataframe.cpp:1539-1554):
+// sum(); mean(); count() as three calls = one sort, one reduce -- the second and third are served from the handle's cache
+static void test_groupby_bound_columns() {
+  const int n = 50000;
+  std::vector<long> key(n);
+  std::vector<double> val(n);
+  for (int i = 0; i < n; ++i) { key[i] = (i * 7919) % 97; val[i] = 0.25 * (i % 13) - 1.0; }
+  DataFrame df({"k", "v"}, {Array::Make(key), Array::Make(val)});
+  GroupBy g("k", df);
+  auto s1 = g.sum("v").values<double>();
+  char plan[256];
+  ThrowOnFailure(pdx_groupby_last_plan(g.handle->h, plan, sizeof plan));
+  REQUIRE(std::string(plan).find("bound=1 cache=fill") != std::string::npos);
+  auto m1 = g.mean("v").values<double>();
+  ThrowOnFailure(pdx_groupby_last_plan(g.handle->h, plan, sizeof plan));
+  REQUIRE(std::string(plan).find("bound=1 cache=hit") != std::string::npos);
+  auto c1 = g.count("v").values<long>();
+  REQUIRE(pdx_groupby_bound_bytes(g.handle->h) >= (int64_t)n * 8);
+  GroupBy g2("k", df);  // an independent handle gives the same bits
+  REQUIRE((g2.sum("v").values<double>() == s1));
+  REQUIRE((g2.mean("v").values<double>() == m1));
+  long total = 0;
+  for (long c : c1) total += c;
+  REQUIRE(total == n);
+  for (size_t i = 0; i < s1.size(); ++i) REQUIRE(m1[i] == s1[i] / (double)c1[i]);
+  ThrowOnFailure(pdx_groupby_unbind(g.handle->h, nullptr));
+  REQUIRE(pdx_groupby_bound_bytes(g.handle->h) == 0);
+}
+
 int main() {
   ThrowOnFailure(pdx_init(0));
   test_series_math();
@@ -308,6 +385,8 @@ int main() {
   test_resample();
   test_concat_and_frame_ops();
   test_sort();
+  test_frame_compare_logical_reindex();
+  test_groupby_bound_columns();
   std::printf("%d checks, %d failed\n", g_checks, g_failed);
   return g_failed ? 1 : 0;
 }

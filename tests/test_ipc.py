@@ -67,6 +67,74 @@ def test_rejects_garbage_and_truncation(lib):
         assert rc != 0 and lib.load().pdx_last_error()
 
 
+def _record_batch_structs(blob):
+    """-> (position of FieldNode[0], position of Buffer[0], body length, position of RecordBatch.length) of the first RecordBatch message.
+    A 20-line flatbuffer walk (continuation marker, metadata length, Message table -> header union -> RecordBatch.nodes / .buffers)."""
+    import struct
+
+    def field(table, slot):
+        vt = table - struct.unpack_from("<i", blob, table)[0]
+        vsize = struct.unpack_from("<H", blob, vt)[0]
+        if 4 + 2 * slot + 2 > vsize:
+            return None
+        o = struct.unpack_from("<H", blob, vt + 4 + 2 * slot)[0]
+        return table + o if o else None
+
+    def indirect(pos):
+        return pos + struct.unpack_from("<I", blob, pos)[0]
+
+    pos = 0
+    while pos + 8 <= len(blob):
+        assert struct.unpack_from("<I", blob, pos)[0] == 0xFFFFFFFF
+        mlen = struct.unpack_from("<i", blob, pos + 4)[0]
+        meta = pos + 8
+        msg = indirect(meta)
+        header_type = blob[field(msg, 1)]
+        body_len = struct.unpack_from("<q", blob, field(msg, 3))[0] if field(msg, 3) else 0
+        if header_type == 3:  # MessageHeader.RecordBatch
+            rb = indirect(field(msg, 2))
+            return indirect(field(rb, 1)) + 4, indirect(field(rb, 2)) + 4, body_len, field(rb, 0)
+        pos = meta + mlen + body_len
+    raise AssertionError("no record batch in the stream")
+
+
+def test_rejects_crafted_offsets_and_lengths(lib):
+    """FieldNode / Buffer entries of a VALID stream patched to values whose sums or products wrap int64.  The open must
+    refuse each of them (the reference's reader, Arrow's, does): accepted, they would send a kernel reading far outside the upload."""
+    import struct
+
+    good = bytearray(bytes(Z["mixed_9/blob"]))
+    nodes, bufs, body, rb_len = _record_batch_structs(good)
+    ncols = len(MAN["cases"]["mixed_9"]["columns"])
+    rc, h, _keep = _open(lib, np.frombuffer(bytes(good), np.uint8))
+    assert rc == 0
+    lib.load().pdx_ipc_destroy(h)
+    rows = struct.unpack_from("<q", good, nodes)[0]
+    assert rows == MAN["cases"]["mixed_9"]["rows"]
+    big = 0x7FFFFFFFFFFFFFF8
+    patches = [
+        ("values offset + length wraps", bufs + 16 * 1, (big, 16)),                 # Buffer[1] = column 0's values
+        ("negative values length", bufs + 16 * 1 + 8, (-8,)),
+        ("validity offset + length wraps", bufs + 16 * 0, (big, 64)),
+        ("negative validity length", bufs + 16 * 0 + 8, (-1,)),
+        ("values offset past the body", bufs + 16 * 1, (body + 8, 0)),
+        ("row count whose byte size wraps", "rows", (1 << 61,)),                  # (batch length and every FieldNode agree on it)
+        ("row count beyond the body", "rows", (body * 8 + 64,)),
+        ("null count above the row count", nodes + 8, (rows + 1,)),
+        ("negative null count", nodes + 8, (-1,)),
+    ]
+    for what, at, vals in patches:
+        bad = bytearray(good)
+        if at == "rows":
+            for pos in [rb_len] + [nodes + 16 * i for i in range(ncols)]:
+                struct.pack_into("<q", bad, pos, vals[0])
+        else:
+            struct.pack_into("<" + "q" * len(vals), bad, at, *vals)
+        rc, h, _keep = _open(lib, np.frombuffer(bytes(bad), np.uint8))
+        assert rc == lib.INVALID, what
+        assert "inconsistent" in lib.load().pdx_last_error().decode() or "does not match" in lib.load().pdx_last_error().decode(), what
+
+
 def _bits(x):
     return np.concatenate([np.packbits(np.asarray(x, bool), bitorder="little"), np.zeros(16, np.uint8)])
 

@@ -3,7 +3,7 @@
 # tools/summarize_profiles.py then condenses them into profiles/ (tracked).  Counters are collected in their own passes
 # (--pmc with --kernel-trace only), FETCH_SIZE and WRITE_SIZE separately (TCC slots), as MI355X_MICROARCH.md prescribes.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT" && mkdir -p "$OUT"
