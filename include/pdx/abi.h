@@ -226,6 +226,11 @@ int pdx_scatter(const pdx_column* cols, int ncols, const pdx_column* indices, pd
  * pdx_groupby_create replaces GroupBy::makeGroups (src/dataframe.cpp:1571-1600): Grouper::Make + Consume
  * (dense group ids in FIRST-OCCURRENCE order, a null key is its own group) + GetUniques.  The reference's eager
  * MakeGroupings/ApplyGroupings of every column (src/dataframe.cpp:1539-1569) is deferred to pdx_groupby_agg.
+ * GROUP ORDER: exactly first occurrence (group g's first row precedes group g+1's).  Arrow's Grouper is first-occurrence on the
+ * reference's own tests and on any input with few new keys per 1024-row mini-batch of its swiss table, but only approximately so
+ * when many new keys meet in one mini-batch (Arrow 25.0.0: 13 286 of 43 183 result rows sit elsewhere at 1e5 rows / 5e4 uniform
+ * keys); per key every aggregate is bit-identical.  The deviation is frozen in tests/golden/group_order_arrow25.npz and asserted by
+ * tests/test_oracle_golden_r3.py / tests/test_gpu_round3.py.
  * key: PDX_INT64 / PDX_TIMESTAMP_NS / PDX_UINT64.  Limits: length < 2^31 rows per call; keys that do not span a dense integer
  * range go through a hash table of at most 2^30 slots (about 7e8 distinct keys; the LDS-resident build covers 2.7e8). */
 typedef struct pdx_groupby pdx_groupby;
@@ -398,6 +403,36 @@ int pdx_ipc_column(const pdx_ipc_frame* frame, int i, pdx_column* out);
 int pdx_ipc_write(const pdx_column* cols, const char* const* names, int ncols, const char* const* metadata_kv, int nmeta, int columns_on_host,
                   void* stream, void** out_blob, size_t* out_size);
 int pdx_ipc_free_blob(void* blob);
+
+/* ---------------------------------------------------------------- Parquet files -> device columns
+ * Replaces, for the column types of this path, DataFrame::readParquet (src/dataframe.cpp:646-683: parquet::arrow::OpenFile ->
+ * FileReader::ReadTable -> TableBatchReader::ToRecordBatches, exactly ONE record batch).  The host parses the metadata only (the
+ * Thrift-compact footer in pdx_parquet_open, the page headers in pdx_parquet_load); the column chunks go to the device in ONE copy
+ * and every page payload is decoded there: Snappy blocks, RLE / bit-packed definition levels -> validity bitmap, PLAIN and
+ * dictionary-encoded (PLAIN_DICTIONARY / RLE_DICTIONARY) values -> 8-byte values, data pages v1 and v2.
+ *   pdx_parquet_open    parse a file held in HOST memory (no GPU needed); the bytes must stay alive until pdx_parquet_load returns.
+ *                       Columns: flat BOOLEAN / INT32 / INT64 / FLOAT / DOUBLE leaves, REQUIRED or OPTIONAL; INT annotations widen to
+ *                       int64 / uint64, FLOAT to float64, TIMESTAMP(ms | us | ns) becomes timestamp[ns].  One row group, as the
+ *                       reference: more give PDX_INVALID "DataFrame Only supports Parquet Table with single record batch", an empty
+ *                       table "Cannot Initialize DataFrame with empty parquet table".  PDX_NOT_IMPLEMENTED, naming the column and the
+ *                       feature, for strings / BYTE_ARRAY, nested or repeated columns, INT96, DATE / TIME / DECIMAL annotations,
+ *                       codecs other than UNCOMPRESSED / SNAPPY, DELTA_* / BYTE_STREAM_SPLIT encodings, encryption.
+ *   pdx_parquet_load    upload + decode; synchronises `stream`.  Malformed pages (bad Snappy blocks, short value sections,
+ *                       dictionary indices out of range) are detected on the device and fail the call with PDX_INVALID.
+ *   pdx_parquet_column  the i-th column (device pointers owned by the file object until pdx_parquet_destroy; before the load only
+ *                       dtype, length and the chunk statistics' null_count, -1 when the writer left it out).
+ * The file's key_value_metadata (pandas / ARROW:schema entries) is available as strings. */
+typedef struct pdx_parquet_file pdx_parquet_file;
+int pdx_parquet_open(const void* blob, size_t size, pdx_parquet_file** out);
+int pdx_parquet_destroy(pdx_parquet_file* file);
+int pdx_parquet_num_columns(const pdx_parquet_file* file);
+int64_t pdx_parquet_num_rows(const pdx_parquet_file* file);
+const char* pdx_parquet_column_name(const pdx_parquet_file* file, int i);
+int pdx_parquet_num_metadata(const pdx_parquet_file* file);
+const char* pdx_parquet_metadata_key(const pdx_parquet_file* file, int i);
+const char* pdx_parquet_metadata_value(const pdx_parquet_file* file, int i);
+int pdx_parquet_load(pdx_parquet_file* file, void* stream);
+int pdx_parquet_column(const pdx_parquet_file* file, int i, pdx_column* out);
 
 #ifdef __cplusplus
 }

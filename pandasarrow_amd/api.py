@@ -593,6 +593,26 @@ class DataFrame:
         df.metadata = frame.metadata
         return df
 
+    @staticmethod
+    def readParquet(path_or_bytes):
+        """DataFrame::readParquet (src/dataframe.cpp:646-683): a Parquet file with ONE row group -> a frame on the device.  The
+        footer and the page headers are walked on the host; the column chunks travel in one copy and are decoded by kernels
+        (Snappy, definition levels, PLAIN / dictionary values).  The reference builds `DataFrame{recordBatch}`: default range index."""
+        if isinstance(path_or_bytes, (bytes, bytearray, memoryview)):
+            blob = bytes(path_or_bytes)
+        else:
+            try:
+                with open(path_or_bytes, "rb") as fh:
+                    blob = fh.read()
+            except OSError as e:  # arrow::io::ReadableFile::Open fails -> std::runtime_error(status)
+                raise L.PdxError(L.INVALID, f"IOError: Failed to open local file '{path_or_bytes}': {e.strerror}") from None
+        pf = K.ParquetFile(blob)
+        pairs = pf.load()
+        df = DataFrame.__new__(DataFrame)
+        df.names, df.cols, df.index = [nm for nm, _ in pairs], [c for _, c in pairs], None
+        df.metadata = pf.metadata
+        return df
+
     # ---- group_by / resample (src/dataframe.cpp:1227-1262)
     def group_by(self, key):
         return GroupBy(key, self)

@@ -622,6 +622,58 @@ class IpcFrame:
         return cols
 
 
+class ParquetFile:
+    """Owner of a pdx_parquet_file*: the parsed footer of ONE Parquet file and, after load(), its decoded device columns
+    (DataFrame::readParquet, reference src/dataframe.cpp:646-683)."""
+
+    def __init__(self, blob):
+        lib = L.load()
+        self._blob = blob if isinstance(blob, bytes) else bytes(blob)  # must outlive load()
+        self._h = C.c_void_p()
+        L.check(lib.pdx_parquet_open(self._blob, len(self._blob), C.byref(self._h)))
+        self.names = [lib.pdx_parquet_column_name(self._h, i).decode() for i in range(lib.pdx_parquet_num_columns(self._h))]
+        self.num_rows = int(lib.pdx_parquet_num_rows(self._h))
+        self.metadata = {lib.pdx_parquet_metadata_key(self._h, i).decode("utf-8", "replace"): lib.pdx_parquet_metadata_value(self._h, i)
+                         for i in range(lib.pdx_parquet_num_metadata(self._h))}
+
+    def __del__(self):
+        try:
+            if self._h is not None and self._h.value:
+                L.load().pdx_parquet_destroy(self._h)
+            self._h = None
+        except Exception:
+            pass
+
+    def schema(self):
+        """[(name, pdx dtype, null_count from the chunk statistics or -1)] without touching the GPU."""
+        out = []
+        for i, nm in enumerate(self.names):
+            c = L.PdxColumn()
+            L.check(L.load().pdx_parquet_column(self._h, i, C.byref(c)))
+            out.append((nm, int(c.dtype), int(c.null_count)))
+        return out
+
+    def load(self):
+        """One host->device copy of the column chunks + the decode kernels -> [(name, Column)] aliasing the file object's memory."""
+        _device()
+        L.check(L.load().pdx_parquet_load(self._h, _stream()))
+        self._blob = None
+        cols = []
+        n = self.num_rows
+        for i, nm in enumerate(self.names):
+            c = L.PdxColumn()
+            L.check(L.load().pdx_parquet_column(self._h, i, C.byref(c)))
+            if c.dtype == L.BOOL:
+                vals = torch.as_tensor(_FrameMemory(self, c.values, (n + 7) // 8 + 8, "|u1"), device=_device())
+            else:
+                vals = torch.as_tensor(_FrameMemory(self, c.values, max(n, 1), "<f8" if c.dtype == L.FLOAT64 else "<i8"), device=_device())
+            vb = None
+            if c.validity:
+                vb = torch.as_tensor(_FrameMemory(self, c.validity, (n + 7) // 8 + 8, "|u1"), device=_device())
+            cols.append((nm, Column(int(c.dtype), n, vals, vb, 0, int(c.null_count))))
+        return cols
+
+
 def ipc_write(cols, names, metadata=None) -> bytes:
     """One schema + one record batch (+ custom metadata) + end-of-stream, the layout DataFrame::toBinary produces."""
     lib = L.load()

@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstring>
 #include <algorithm>
+#include <cstdio>
 #include <map>
 #include <memory>
 #include <array>
@@ -831,6 +832,39 @@ class DataFrame {
       }
     }
     return DataFrame(names, cols, idx);
+  }
+
+  // readParquet (src/dataframe.cpp:646-683): ONE row group -> a frame on the device with the default range index.  The file is read
+  // into host memory, the library walks the footer / page headers there, the column chunks travel in one copy and are decoded by kernels
+  static DataFrame readParquet(const uint8_t* blob, size_t size) {
+    pdx_parquet_file* raw = nullptr;
+    ThrowOnFailure(pdx_parquet_open(blob, size, &raw));
+    std::shared_ptr<void> file(raw, [](void* p) { pdx_parquet_destroy(static_cast<pdx_parquet_file*>(p)); });
+    ThrowOnFailure(pdx_parquet_load(raw, nullptr));
+    std::vector<std::string> names;
+    std::vector<Array> cols;
+    for (int i = 0; i < pdx_parquet_num_columns(raw); ++i) {
+      pdx_column c{};
+      ThrowOnFailure(pdx_parquet_column(raw, i, &c));
+      Array a;
+      a.dtype = c.dtype;
+      a.length = c.length;
+      a.null_count = c.null_count;
+      a.values = std::make_shared<DeviceBuffer>(c.values, c.dtype == PDX_BOOL ? bitmap_bytes(c.length) : (size_t)c.length * 8, file);
+      if (c.validity) a.validity = std::make_shared<DeviceBuffer>(c.validity, bitmap_bytes(c.length), file);
+      names.push_back(pdx_parquet_column_name(raw, i));
+      cols.push_back(a);
+    }
+    return DataFrame(names, cols, std::nullopt);
+  }
+  static DataFrame readParquet(const std::string& path) {
+    std::FILE* fh = std::fopen(path.c_str(), "rb");
+    if (!fh) throw std::runtime_error("IOError: Failed to open local file '" + path + "'");
+    std::vector<uint8_t> bytes;
+    uint8_t buf[1 << 16];
+    for (size_t got; (got = std::fread(buf, 1, sizeof buf, fh)) > 0;) bytes.insert(bytes.end(), buf, buf + got);
+    std::fclose(fh);
+    return readParquet(bytes.data(), bytes.size());
   }
 
   inline GroupBy group_by(const std::string& key) const;

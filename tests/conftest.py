@@ -86,14 +86,17 @@ def bits_equal(a, b):
     return a.shape == b.shape and bool(np.all(a == b))
 
 
-def assert_f64_bits(a, b, valid=None, what=""):
+def assert_f64_bits(a, b, valid=None, what="", nan_bits=False):
+    """bit-exact float64 comparison.  nan_bits=False: any NaN equals any NaN (results of the sum trees, where only NaN-ness is
+    guaranteed: a group holding +inf and -inf sums to -qNaN on x86 and +qNaN on CDNA); nan_bits=True: sign and payload of a NaN
+    must match too (element-wise kernels, which spell out the x86 operand rule the golden vectors were produced under)."""
     a = np.ascontiguousarray(a, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
     assert a.shape == b.shape, f"{what}: shape {a.shape} != {b.shape}"
     ua, ub = a.view(np.uint64), b.view(np.uint64)
     neq = ua != ub
-    # all NaNs count as equal (Arrow does not pin NaN payloads)
-    neq &= ~(np.isnan(a) & np.isnan(b))
+    if not nan_bits:
+        neq &= ~(np.isnan(a) & np.isnan(b))
     if valid is not None:
         neq &= np.asarray(valid, bool)
     if neq.any():

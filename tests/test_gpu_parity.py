@@ -64,7 +64,7 @@ def test_elementwise_golden(px, name, offset):
         else:
             assert ev.all()
         if vals.dtype == np.float64:
-            assert_f64_bits(vals, c[k], valid=ev, what=f"{name} {k}")
+            assert_f64_bits(vals, c[k], valid=ev, what=f"{name} {k}", nan_bits=True)  # x86 NaN operand rule: sign and payload too
         else:
             assert np.array_equal(vals[ev], c[k][ev]), f"{name} {k}"
     for k, op in CMPS.items():
@@ -118,7 +118,7 @@ def test_elementwise_large_vs_oracle(px):
     a, b = orc.synth_vals(0, n, 1), orc.synth_vals(0, n, 2) - 0.5
     A, B = px.K.synth_vals(0, n, 1), px.Column.from_numpy(b)
     for op in OPS.values():
-        assert_f64_bits(px.K.binary(op, A, B).to_numpy()[0], orc.binary(op, a, b)[0], what=f"op{op}")
+        assert_f64_bits(px.K.binary(op, A, B).to_numpy()[0], orc.binary(op, a, b)[0], what=f"op{op}", nan_bits=True)
     for op in CMPS.values():
         assert np.array_equal(px.K.compare(op, A, B).to_numpy()[0], orc.compare(op, a, b)[0])
     m1, m2 = px.K.compare(4, A, 0.5), px.K.compare(2, B, 0.0)

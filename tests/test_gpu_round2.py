@@ -60,7 +60,7 @@ def test_scalar_lhs_golden(px, name, offset):
         if vals.dtype == np.float64:
             if nan_exact:  # which operand's NaN payload survives is part of the pinned behaviour
                 assert np.array_equal(vals.view(np.uint64), c[k].view(np.uint64)), f"{name} {k}: NaN bits"
-            assert_f64_bits(vals, c[k], valid=ev, what=f"{name} {k}")
+            assert_f64_bits(vals, c[k], valid=ev, what=f"{name} {k}", nan_bits=True)
         else:
             assert c[k].dtype == np.int64 and np.array_equal(vals[ev], c[k][ev]), f"{name} {k}"
     if "eq" not in c:

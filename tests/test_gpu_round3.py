@@ -388,3 +388,23 @@ def test_frame_reindex_kat(px, kat):
             ok = np.ones(len(got), bool) if ok is None else ok
             assert list(ok.astype(int)) == k["out_valid"][c], k["src"]
             assert [x for x, o in zip(got, ok) if o] == [x for x, o in zip(k["out"][c], k["out_valid"][c]) if o], k["src"]
+
+
+# ------------------------------------------------------------------ group ORDER: first occurrence, also where Arrow 25's differs
+@pytest.mark.parametrize("name", ["rows1e5_keys5e4", "rows2e6_keys1e4"])
+@pytest.mark.parametrize("dense", ["1", "0"])
+def test_group_order_is_first_occurrence_where_arrow_differs(px, monkeypatch, name, dense):
+    """tests/golden/group_order_arrow25.npz (oracle/gen_golden_order.py): inputs on which Arrow 25's Grouper order is NOT first
+    occurrence.  The HIP path gives first-occurrence order on both key->slot paths; the set of groups is Arrow's."""
+    from test_oracle_golden_r3 import _order_cases, order_case_keys
+
+    monkeypatch.setenv("PDX_GROUPBY_DENSE", dense)
+    z, cases = _order_cases()
+    info = cases[name]
+    keys = order_case_keys(info)
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys))
+    uk = gb.unique_keys().to_numpy()[0]
+    ids, uniq, _, first = orc.group_ids(keys)
+    assert np.array_equal(uk, uniq) and np.array_equal(gb.first_rows().cpu().numpy(), first)
+    arrow_order = z[f"{name}/arrow_order"]
+    assert np.array_equal(np.sort(arrow_order), np.sort(uk)) and int((arrow_order != uk).sum()) == info["positions_that_differ"]

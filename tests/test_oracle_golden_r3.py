@@ -84,3 +84,35 @@ def test_frame_reindex_kat_oracle(kat):
             got, ok = orc.reindex(vals, valid, np.array(k["index"], np.int64), np.array(k["new_index"], np.int64), None)
             assert list(ok.astype(int)) == k["out_valid"][c], k["src"]
             assert [x for x, o in zip(got, ok) if o] == [x for x, o in zip(k["out"][c], k["out_valid"][c]) if o], k["src"]
+
+
+# ------------------------------------------------------------------ the documented deviation: result ROW ORDER on large inputs
+def _order_cases():
+    import json
+    import os
+
+    from conftest import GOLDEN_DIR
+
+    z = np.load(os.path.join(GOLDEN_DIR, "group_order_arrow25.npz"))
+    return z, json.loads(str(z["manifest"]))["cases"]
+
+
+def order_case_keys(info):
+    return np.random.default_rng(info["seed"]).integers(0, info["keys"], info["rows"]).astype(np.int64)
+
+
+@pytest.mark.parametrize("name", ["rows1e5_keys5e4", "rows2e6_keys1e4"])
+def test_group_order_deviation_is_exactly_as_documented(name):
+    """Arrow 25's Grouper (reference: src/dataframe.cpp:1580-1591) orders groups only approximately by first occurrence when many new
+    keys meet in one mini-batch of its swiss table; this backend defines FIRST-OCCURRENCE order (include/pdx/abi.h at
+    pdx_groupby_create).  Frozen from Arrow 25.0.0 (oracle/gen_golden_order.py): the key SETS are equal, the number of positions that
+    differ is the recorded one -- if Arrow's order ever became reproducible here, this test is the place that would notice."""
+    z, cases = _order_cases()
+    info = cases[name]
+    keys = order_case_keys(info)
+    ids, uniq, isnull, first = orc.group_ids(keys)
+    assert len(uniq) == info["groups"] and not isnull.any()
+    assert np.array_equal(first, np.sort(first)) and np.array_equal(uniq, keys[first])      # ours: first occurrence, exactly
+    arrow_order = z[f"{name}/arrow_order"]
+    assert np.array_equal(np.sort(arrow_order), np.sort(uniq))                               # same groups
+    assert int((arrow_order != uniq).sum()) == info["positions_that_differ"] > 0             # different row order, as documented
