@@ -310,11 +310,28 @@ def main():
     else:
         from pandasarrow_amd import dist as pdist
 
-        engine = pdist.HipEngine()
+        # The sharded step runs inside the library (csrc/dist.hip behind pdx_dist_*): orchestration, glue kernels and the RCCL calls
+        # (ncclAllGather, grouped ncclSend / ncclRecv) -- python only creates the communicator.  PDX_BENCH_DIST=torch keeps the older
+        # orchestration in pandasarrow_amd/dist.py over torch.distributed; it is also the fallback when the communicator cannot be
+        # created (reported in config.path).  With a non-RCCL process group (rehearsals on one GPU) the library's custom transport
+        # rides on that group.
+        dist_path = "c-abi"
+        cd = None
+        if os.environ.get("PDX_BENCH_DIST", "c") != "torch":
+            try:
+                cd = pdist.CDist("rccl" if backend == "nccl" else "torch")
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] pdx_dist communicator failed ({type(e).__name__}: {e}); using the torch.distributed orchestration", file=sys.stderr)
+        if cd is not None:
+            def step():
+                # sum/mean/count with the exact partial-tree exchange (fragments + aligned subtree nodes, no rows shipped)
+                return cd.groupby_sum_mean_count(keys, vals, row_offset=lo)
+        else:
+            dist_path = "torch"
+            engine = pdist.HipEngine()
 
-        def step():
-            # sum/mean/count with the exact partial-tree exchange (fragments + aligned subtree nodes, no rows shipped)
-            return pdist.groupby_sum_mean_count_sharded(engine, keys, vals, row_offset=lo)
+            def step():
+                return pdist.groupby_sum_mean_count_sharded(engine, keys, vals, row_offset=lo)
 
     def barrier():
         torch.cuda.synchronize()
@@ -448,7 +465,7 @@ def main():
             "config": {"workload": f"group_by(int64 key).agg(sum,mean,count), {n_total:.3g} rows / {nkeys:.3g} keys"
                                    + (", 1 GPU" if world == 1 else f", row-range sharded over {world} GPUs (RCCL exchange)"),
                        "rows": n_total, "keys": nkeys, "rows_per_gpu": n_local, "parity": "bit-exact vs Arrow-order pairwise sum",
-                       "path": "sharded" if sharded else "single"},
+                       "path": ("sharded-" + dist_path) if sharded else "single"},
             "roofline": roof, "cpu_baseline": cpu, "check": check, "chain_check": chain,
             # the metric's literal reading ("hash group-by"): the same step with every key through the LDS-bucketed hash table
             "general_keys_hash_path": (secondary or {}).get("groupby_general_keys_hash_path"),

@@ -404,6 +404,49 @@ int pdx_ipc_write(const pdx_column* cols, const char* const* names, int ncols, c
                   void* stream, void** out_blob, size_t* out_size);
 int pdx_ipc_free_blob(void* blob);
 
+/* ---------------------------------------------------------------- row-range shards across the GPUs of one node
+ * One process per GPU; every rank holds a row range of the frame, ranks in row order.  The reference has no distributed code: the
+ * contract is the SINGLE-process result of df.group_by(key).sum / mean / count (src/group_by.h:85-139, src/pd_core_macros.h:5-147)
+ * and of pd::concat (src/concat.cpp:116-190), bit for bit.  librccl is opened at run time and called directly (ncclAllGather,
+ * grouped ncclSend / ncclRecv over xGMI): no python, no torch in the loop -- a C++ host shards through this same header.
+ *   pdx_dist_unique_id   rank 0: 128 bytes (an ncclUniqueId) to hand to the other ranks by whatever channel the host has.
+ *   pdx_dist_init        ncclCommInitRank on the calling thread's current device (after pdx_init(device)).
+ *   pdx_dist_init_custom the same orchestration over the caller's own transport: two primitives on DEVICE buffers, ordered on the
+ *                        given stream -- all_gather (every rank contributes `bytes` bytes, received in rank order) and
+ *                        all_to_all_v (byte ranges send_off/send_bytes[peer] of `send` go to peer, recv_off/recv_bytes[peer] of `recv`
+ *                        come from peer).  Return 0 for success.  (tests: three processes sharing one GPU, where RCCL refuses
+ *                        duplicate devices.)
+ *   pdx_dist_groupby_sum_mean_count   keys / values: this rank's shard (values: float64 without nulls); row_offset: index of the
+ *                        shard's first row in the whole frame.  Partial-tree exchange: the global first-occurrence dictionary from
+ *                        an all-gather(v) of the local uniques, the per-group row counts all-gathered, then per group and rank only the
+ *                        boundary-leaf fragments + aligned subtree nodes travel (ONE all-to-all(v)) and the owners replay them through
+ *                        Arrow's binary counter.  Every rank ends with the FULL result (G groups in first-occurrence order).
+ *   pdx_dist_groupby_fetch   copies of the result columns (any pointer may be NULL; capacity >= num_groups rows).
+ *   pdx_dist_concat      all-gather(v) of one column's shards in rank order (values + validity).
+ * PDX_DIST_FORCE_COLLECTIVES=1 keeps every collective on the wire at world size 1 (tests on a one-GPU box). */
+typedef struct pdx_dist_transport {
+  void* ctx;
+  int (*all_gather)(void* ctx, const void* send, void* recv, size_t bytes, void* stream);
+  int (*all_to_all_v)(void* ctx, const void* send, const size_t* send_off, const size_t* send_bytes, void* recv, const size_t* recv_off,
+                      const size_t* recv_bytes, void* stream);
+} pdx_dist_transport;
+typedef struct pdx_dist pdx_dist;
+typedef struct pdx_dist_groupby pdx_dist_groupby;
+int pdx_dist_unique_id(void* out_id128);
+int pdx_dist_init(const void* id128, int world, int rank, pdx_dist** out);
+int pdx_dist_init_custom(const pdx_dist_transport* transport, int world, int rank, pdx_dist** out);
+int pdx_dist_destroy(pdx_dist* d);
+int pdx_dist_world(const pdx_dist* d);
+int pdx_dist_rank(const pdx_dist* d);
+int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const pdx_column* values, int64_t row_offset, void* stream,
+                                    pdx_dist_groupby** out);
+int64_t pdx_dist_groupby_num_groups(const pdx_dist_groupby* g);
+int64_t pdx_dist_groupby_num_records(const pdx_dist_groupby* g);
+int pdx_dist_groupby_fetch(const pdx_dist_groupby* g, pdx_mut_column* keys, int64_t* first_rows, double* sums, double* means, int64_t* counts,
+                           void* stream);
+int pdx_dist_groupby_destroy(pdx_dist_groupby* g);
+int pdx_dist_concat(pdx_dist* d, const pdx_column* part, pdx_mut_column* out, void* stream);
+
 /* ---------------------------------------------------------------- Parquet files -> device columns
  * Replaces, for the column types of this path, DataFrame::readParquet (src/dataframe.cpp:646-683: parquet::arrow::OpenFile ->
  * FileReader::ReadTable -> TableBatchReader::ToRecordBatches, exactly ONE record batch).  The host parses the metadata only (the

@@ -127,6 +127,18 @@ ABI_SYMBOLS = {
     "pdx_ipc_column": (C.c_int, [_P, C.c_int, _COL]),
     "pdx_ipc_write": (C.c_int, [_COL, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_int, _P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "pdx_ipc_free_blob": (C.c_int, [_P]),
+    "pdx_dist_unique_id": (C.c_int, [_P]),
+    "pdx_dist_init": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "pdx_dist_init_custom": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "pdx_dist_destroy": (C.c_int, [_P]),
+    "pdx_dist_world": (C.c_int, [_P]),
+    "pdx_dist_rank": (C.c_int, [_P]),
+    "pdx_dist_groupby_sum_mean_count": (C.c_int, [_P, _COL, _COL, C.c_int64, _P, C.POINTER(_P)]),
+    "pdx_dist_groupby_num_groups": (C.c_int64, [_P]),
+    "pdx_dist_groupby_num_records": (C.c_int64, [_P]),
+    "pdx_dist_groupby_fetch": (C.c_int, [_P, _MUT, _P, _P, _P, _P, _P]),
+    "pdx_dist_groupby_destroy": (C.c_int, [_P]),
+    "pdx_dist_concat": (C.c_int, [_P, _COL, _MUT, _P]),
     "pdx_parquet_open": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "pdx_parquet_destroy": (C.c_int, [_P]),
     "pdx_parquet_num_columns": (C.c_int, [_P]),

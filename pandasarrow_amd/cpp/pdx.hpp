@@ -1152,4 +1152,53 @@ inline DataFrame concat(const std::vector<DataFrame>& dfs, bool ignore_index = f
   return DataFrame(kept, cols, index);
 }
 
+// ---------------------------------------------------------------- row-range shards over the GPUs of one node (pdx_dist_*)
+// The reference has no distributed code: this is what its host code would call to shard df.group_by(key).sum / mean / count over one
+// process per GPU.  Every process holds a row range of the frame (ranks in row order) and ends with the FULL result, bit-identical
+// to the single-process one.  The unique id travels by whatever channel the host has (MPI, a file, a socket): 128 bytes.
+namespace dist {
+struct Communicator {
+  pdx_dist* h = nullptr;
+  static std::array<char, 128> unique_id() {  // rank 0
+    std::array<char, 128> id{};
+    ThrowOnFailure(pdx_dist_unique_id(id.data()));
+    return id;
+  }
+  Communicator(const std::array<char, 128>& id, int world, int rank) { ThrowOnFailure(pdx_dist_init(id.data(), world, rank, &h)); }
+  ~Communicator() { pdx_dist_destroy(h); }
+  Communicator(const Communicator&) = delete;
+  Communicator& operator=(const Communicator&) = delete;
+  int world() const { return pdx_dist_world(h); }
+  int rank() const { return pdx_dist_rank(h); }
+};
+// shard.group_by(key).{sum, mean, count}(col) over all shards: a frame indexed by the global unique keys (first-occurrence order over
+// the WHOLE column) with columns "sum", "mean", "count"; row_offset = index of the shard's first row in the whole frame
+inline DataFrame group_by_sum_mean_count(Communicator& comm, const DataFrame& shard, const std::string& key, const std::string& col, int64_t row_offset) {
+  const Array& k = shard.m_columns[(size_t)shard.column_index(key)];
+  const Array& v = shard.m_columns[(size_t)shard.column_index(col)];
+  auto ck = k.c(), cv = v.c();
+  pdx_dist_groupby* raw = nullptr;
+  ThrowOnFailure(pdx_dist_groupby_sum_mean_count(comm.h, &ck, &cv, row_offset, nullptr, &raw));
+  std::shared_ptr<pdx_dist_groupby> g(raw, [](pdx_dist_groupby* p) { pdx_dist_groupby_destroy(p); });
+  const int64_t G = pdx_dist_groupby_num_groups(raw);
+  Array keys = Array::Empty(k.dtype, G, true), sums = Array::Empty(PDX_FLOAT64, G, false), means = Array::Empty(PDX_FLOAT64, G, false),
+        counts = Array::Empty(PDX_INT64, G, false);
+  auto mk = keys.mut();
+  ThrowOnFailure(pdx_dist_groupby_fetch(raw, &mk, nullptr, static_cast<double*>(sums.values->ptr), static_cast<double*>(means.values->ptr),
+                                        static_cast<int64_t*>(counts.values->ptr), nullptr));
+  return DataFrame({"sum", "mean", "count"}, {sums, means, counts}, keys);
+}
+// pd::concat of the shards' columns in rank order (the all-gather(v) merge)
+inline Array concat(Communicator& comm, const Array& part, int64_t total_rows) {
+  Array out = Array::Empty(part.dtype, total_rows, true);
+  auto c = part.c();
+  auto m = out.mut();
+  ThrowOnFailure(pdx_dist_concat(comm.h, &c, &m, nullptr));
+  out.length = m.length;
+  out.null_count = m.null_count;
+  if (m.null_count == 0) out.validity.reset();
+  return out;
+}
+}  // namespace dist
+
 }  // namespace pd

@@ -29,8 +29,11 @@ namespace {
 
 // ---------------------------------------------------------------- RCCL, resolved at run time
 struct Rccl {
+  struct Id128 {  // ncclUniqueId: 128 opaque bytes, passed BY VALUE to ncclCommInitRank
+    char b[128];
+  };
   typedef int (*GetUniqueId_t)(void*);
-  typedef int (*CommInitRank_t)(void**, int, /* ncclUniqueId by value: */ struct Id128 { char b[128]; }, int);
+  typedef int (*CommInitRank_t)(void**, int, Id128, int);
   typedef int (*CommDestroy_t)(void*);
   typedef int (*AllGather_t)(const void*, void*, size_t, int, void*, hipStream_t);
   typedef int (*SendRecv_t)(void*, size_t, int, int, void*, hipStream_t);
@@ -120,9 +123,14 @@ int rccl_all_to_all_v(void* vctx, const void* send, const size_t* send_off, cons
 }
 
 // ---------------------------------------------------------------- glue kernels (everything that was torch in pandasarrow_amd/dist.py)
-__global__ void k_bits_to_i64(const uint8_t* __restrict__ bits, int64_t n, int64_t* __restrict__ out) {
+// bit `off + i` of a validity bitmap (nullptr: all valid) as one 0 / 1 word per row: the form validity travels in
+__global__ void k_bits_to_i64(const uint8_t* __restrict__ bits, int64_t off, int64_t n, int64_t* __restrict__ out) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = bits ? (int64_t)bit_get(bits, i) : 1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = bits ? (int64_t)bit_get(bits, off + i) : 1;
+}
+__global__ void k_iota_i64(int64_t n, int64_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = i;
 }
 __global__ void k_i64_to_bits(const int64_t* __restrict__ v, int64_t n, uint8_t* __restrict__ bits) {
   const int64_t nb = (n + 7) / 8, stride = (int64_t)gridDim.x * blockDim.x;
@@ -369,7 +377,7 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
     PDX_TRY(pdx_groupby_unique_keys(h.gb, &m, st));
     PDX_TRY(pdx_groupby_first_rows(h.gb, fr, st));
     if (Gl) {
-      hipLaunchKernelGGL(k_bits_to_i64, dim3(grid_for(Gl, 256)), dim3(256), 0, st, uk_bits, Gl, uok);
+      hipLaunchKernelGGL(k_bits_to_i64, dim3(grid_for(Gl, 256)), dim3(256), 0, st, uk_bits, (int64_t)0, Gl, uok);
       hipLaunchKernelGGL(k_add_const, dim3(grid_for(Gl, 256)), dim3(256), 0, st, fr, Gl, row_offset);
     }
     PDX_LAUNCH_CHECK();
@@ -394,10 +402,9 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
       PDX_HIP(hipMemcpyAsync(res->keys, uk, (size_t)G * 8, hipMemcpyDeviceToDevice, st));
       PDX_HIP(hipMemcpyAsync(res->keys_ok, uok, (size_t)G * 8, hipMemcpyDeviceToDevice, st));
       PDX_HIP(hipMemcpyAsync(res->first_rows, fr, (size_t)G * 8, hipMemcpyDeviceToDevice, st));
-      hipLaunchKernelGGL(k_scatter_iota, dim3(grid_for(G, 256)), dim3(256), 0, st, fr /* any array */, 0, my_map);  // (no-op launch shape)
-      // identity map
-      hipLaunchKernelGGL(k_map_from_ids, dim3(1), dim3(1), 0, st, (const uint32_t*)nullptr, 0, 0, my_map);
+      hipLaunchKernelGGL(k_iota_i64, dim3(grid_for(G, 256)), dim3(256), 0, st, G, my_map);  // one rank: local ids ARE the global ids
     }
+    PDX_LAUNCH_CHECK();
   }
   int64_t* cat_keys = nullptr;
   if (!solo) {
@@ -436,7 +443,7 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
     PDX_TRY(pdx_groupby_first_rows(h.gb_cat, cat_first_rows, st));
     if (total_u) PDX_TRY(pdx_groupby_group_ids(h.gb_cat, gid_cat, st));
     if (G) {
-      hipLaunchKernelGGL(k_bits_to_i64, dim3(grid_for(G, 256)), dim3(256), 0, st, gk_bits, G, res->keys_ok);
+      hipLaunchKernelGGL(k_bits_to_i64, dim3(grid_for(G, 256)), dim3(256), 0, st, gk_bits, (int64_t)0, G, res->keys_ok);
       hipLaunchKernelGGL(k_gather_i64, dim3(grid_for(G, 256)), dim3(256), 0, st, cat_first, cat_first_rows, G, res->first_rows);
     }
     if (Gl) hipLaunchKernelGGL(k_map_from_ids, dim3(grid_for(Gl, 256)), dim3(256), 0, st, gid_cat, off, Gl, my_map);
@@ -458,8 +465,6 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
     if (G) {
       PDX_HIP(hipMemcpyAsync(res->counts, cnt_local, (size_t)G * 8, hipMemcpyDeviceToDevice, st));
       PDX_HIP(hipMemsetAsync(prefix_local, 0, (size_t)G * 8, st));
-      // identity map for the records' global ids
-      hipLaunchKernelGGL(k_scatter_iota, dim3(grid_for(G, 256)), dim3(256), 0, st, (const int64_t*)nullptr, 0, my_map);
     }
   } else {
     // ---- 4. rows per (global group, rank): dense count vectors, all-gathered; prefix over the lower ranks
@@ -607,30 +612,8 @@ int pdx_dist_concat(pdx_dist* d, const pdx_column* part, pdx_mut_column* out, vo
     const int64_t n = part->length;
     int64_t* okw = s.get<int64_t>((size_t)n);
     int64_t* all_ok = s.get<int64_t>((size_t)total);
-    uint8_t* shifted = nullptr;
     PDX_SCRATCH_CHECK(s);
-    const uint8_t* vb = validity_or_null(part);
-    if (vb && part->offset) {  // bit_get reads from bit 0: shift the window down first
-      shifted = s.get<uint8_t>((size_t)(n + 7) / 8 + 16);
-      PDX_SCRATCH_CHECK(s);
-      pdx_column src = *part;
-      pdx_mut_column tmp{};
-      (void)src;
-      (void)tmp;
-    }
-    if (n) {
-      if (vb && part->offset) {
-        // (element offset into the bitmap: materialise through a per-row read with the offset applied)
-        struct OffBits {
-          const uint8_t* b;
-          int64_t off;
-        };
-        (void)shifted;
-        hipLaunchKernelGGL(k_bits_to_i64, dim3(grid_for(n, 256)), dim3(256), 0, st, (const uint8_t*)nullptr, n, okw);  // placeholder: all valid
-        return fail(PDX_NOT_IMPLEMENTED, "pdx_dist_concat: a sliced (offset != 0) nullable shard: pass an unsliced copy");
-      }
-      hipLaunchKernelGGL(k_bits_to_i64, dim3(grid_for(n, 256)), dim3(256), 0, st, vb, n, okw);
-    }
+    if (n) hipLaunchKernelGGL(k_bits_to_i64, dim3(grid_for(n, 256)), dim3(256), 0, st, validity_or_null(part), part->offset, n, okw);
     PDX_LAUNCH_CHECK();
     PDX_TRY(all_gather_v(d, okw, sizes, 8, all_ok, st));
     if (total) hipLaunchKernelGGL(k_i64_to_bits, dim3(grid_for((total + 7) / 8, 256)), dim3(256), 0, st, all_ok, total, static_cast<uint8_t*>(out->validity));

@@ -276,6 +276,156 @@ class HipEngine:
         return [self.values(c) for c in self.select_eq(cols, by_col, value)]
 
 
+# ---------------------------------------------------------------- the sharded path behind the C ABI (pdx_dist_*, csrc/dist.hip)
+class _RawDeviceBytes:
+    """`nbytes` of device memory at `ptr` as a CUDA-array-interface object (the custom transport wraps the library's buffers)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+class CDist:
+    """Binding over the C ABI's sharded path: the orchestration, the glue kernels and the collectives all live in libpdx_hip.so
+    (csrc/dist.hip); python only creates the communicator.
+
+    transport="rccl":  the library's built-in transport -- ncclCommInitRank with an id that rank 0 creates and the process group
+                       broadcasts; every collective is an RCCL call made by the library itself (the production path, what a C++
+                       host gets from pdx_dist_init).
+    transport="torch": pdx_dist_init_custom with callbacks over torch.distributed (host staging; any backend, e.g. gloo).  For
+                       rehearsals with several ranks on ONE GPU, where RCCL refuses duplicate devices -- never a measurement."""
+
+    def __init__(self, transport="rccl"):
+        import ctypes as C
+
+        self.W, self.r = _world()
+        self.lib = L.load()
+        self._h = C.c_void_p()
+        self.transport = transport
+        if transport == "rccl":
+            ident = (C.c_char * 128)()
+            if self.r == 0:
+                L.check(self.lib.pdx_dist_unique_id(ident))
+            if dist.is_initialized() and self.W > 1:
+                dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+                t = torch.tensor(list(bytes(ident)), dtype=torch.uint8, device=dev)
+                dist.broadcast(t, 0)
+                ident = (C.c_char * 128)(*bytes(t.cpu().tolist()))
+            L.check(self.lib.pdx_dist_init(ident, self.W, self.r, C.byref(self._h)))
+        elif transport == "torch":
+            AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+            A2A = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t),
+                              C.POINTER(C.c_size_t), C.c_void_p)
+
+            class Transport(C.Structure):
+                _fields_ = [("ctx", C.c_void_p), ("all_gather", AG), ("all_to_all_v", A2A)]
+
+            dev = torch.device("cuda", torch.cuda.current_device())
+            W, r = self.W, self.r
+
+            def view(ptr, nbytes):
+                return torch.as_tensor(_RawDeviceBytes(ptr, nbytes), device=dev)
+
+            def all_gather(ctx, send, recv, nbytes, stream):
+                try:
+                    torch.cuda.synchronize()
+                    mine = view(send, nbytes).cpu()
+                    outs = [torch.empty_like(mine) for _ in range(W)]
+                    dist.all_gather(outs, mine)
+                    view(recv, nbytes * W).copy_(torch.cat(outs))
+                    torch.cuda.synchronize()
+                    return 0
+                except Exception:  # noqa: BLE001  (an exception must not unwind through the C frames)
+                    import traceback
+
+                    traceback.print_exc()
+                    return 4
+
+            def all_to_all_v(ctx, send, soff, sbytes, recv, roff, rbytes, stream):
+                try:
+                    torch.cuda.synchronize()
+                    table = torch.tensor([[soff[p], sbytes[p]] for p in range(W)], dtype=torch.int64)
+                    tables = [torch.empty_like(table) for _ in range(W)]
+                    dist.all_gather(tables, table)
+                    for src in range(W):  # (gloo has no all-to-all: every source broadcasts the extent it sends, receivers slice)
+                        ext = int((tables[src][:, 0] + tables[src][:, 1]).max().item())
+                        buf = view(send, ext).cpu() if src == r else torch.empty(ext, dtype=torch.uint8)
+                        if ext:
+                            dist.broadcast(buf, src)
+                        o, b = int(tables[src][r, 0]), int(tables[src][r, 1])
+                        assert b == rbytes[src], "send and receive counts disagree"
+                        if b:
+                            view(recv + roff[src], b).copy_(buf[o:o + b])
+                    torch.cuda.synchronize()
+                    return 0
+                except Exception:  # noqa: BLE001
+                    import traceback
+
+                    traceback.print_exc()
+                    return 4
+
+            self._cb = (AG(all_gather), A2A(all_to_all_v))  # keep the thunks alive
+            self._tr = Transport(None, self._cb[0], self._cb[1])
+            L.check(self.lib.pdx_dist_init_custom(C.byref(self._tr), self.W, self.r, C.byref(self._h)))
+        else:
+            raise ValueError(transport)
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            self.lib.pdx_dist_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def groupby_sum_mean_count(self, keys, vals, row_offset=0):
+        """The headline query over row-range shards, entirely inside the library.  Same result dict as
+        groupby_sum_mean_count_sharded (the FULL result on every rank)."""
+        import ctypes as C
+
+        from . import column as K
+
+        h = C.c_void_p()
+        ck, cv = keys.c(), vals.c()
+        L.check(self.lib.pdx_dist_groupby_sum_mean_count(self._h, C.byref(ck), C.byref(cv), int(row_offset), K._stream(), C.byref(h)))
+        try:
+            G = int(self.lib.pdx_dist_groupby_num_groups(h))
+            kcol = K.Column.empty(keys.dtype, G, with_validity=True)
+            m = kcol.mut()
+            dev = K._device()
+            first = torch.empty(max(G, 1), dtype=torch.int64, device=dev)
+            sums = torch.empty(max(G, 1), dtype=torch.float64, device=dev)
+            means = torch.empty(max(G, 1), dtype=torch.float64, device=dev)
+            counts = torch.empty(max(G, 1), dtype=torch.int64, device=dev)
+            L.check(self.lib.pdx_dist_groupby_fetch(h, C.byref(m), first.data_ptr(), sums.data_ptr(), means.data_ptr(), counts.data_ptr(), K._stream()))
+            kcol._adopt(m)
+            kv, kok = kcol.to_numpy()
+            records = int(self.lib.pdx_dist_groupby_num_records(h))
+        finally:
+            self.lib.pdx_dist_groupby_destroy(h)
+        keys_t = kcol.values[:G]
+        ok_t = torch.ones(G, dtype=torch.bool, device=dev) if kok is None else torch.from_numpy(kok).to(dev)
+        return {"G": G, "keys": keys_t, "keys_ok": ok_t, "first_rows": first[:G], "kinds": [L.AGG_SUM, L.AGG_MEAN, L.AGG_COUNT],
+                "outs": [(sums[:G], None), (means[:G], None), (counts[:G], None)], "records": records}
+
+    def concat(self, col):
+        """all-gather(v) of one column's shards in rank order (pdx_dist_concat)."""
+        import ctypes as C
+
+        from . import column as K
+
+        sizes = all_gather_sizes(col.length, K._device()) if self.transport == "torch" or dist.is_initialized() else [col.length]
+        out = K.Column.empty(col.dtype, sum(sizes), with_validity=True)
+        m, c = out.mut(), col.c()
+        L.check(self.lib.pdx_dist_concat(self._h, C.byref(c), C.byref(m), K._stream()))
+        out._adopt(m)
+        if out.null_count == 0:
+            out.validity = None
+        return out
+
+
 # ---------------------------------------------------------------- sharded group-by
 def groupby_agg_sharded(engine, keys, vals, kinds, row_offset=0):
     """Every rank passes its row-range shard (engine columns).  Returns a dict with the FULL result on every rank:

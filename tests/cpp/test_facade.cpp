@@ -375,6 +375,36 @@ static void test_groupby_bound_columns() {
   REQUIRE(pdx_groupby_bound_bytes(g.handle->h) == 0);
 }
 
+// The sharded path through the C ABI from C++ (pdx_dist_*: RCCL opened by the library, no python): one rank, every collective kept on
+// the wire (PDX_DIST_FORCE_COLLECTIVES=1), against the single-GPU GroupBy of the same frame -- bit for bit
+static void test_sharded_groupby_from_cpp() {
+  setenv("PDX_DIST_FORCE_COLLECTIVES", "1", 1);
+  const int n = 300007;
+  std::vector<long> key(n);
+  std::vector<double> val(n);
+  uint64_t x = 88172645463325252ull;
+  for (int i = 0; i < n; ++i) {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    key[i] = (long)(x % 4099) * 7919 - 12345;
+    val[i] = (double)(x >> 11) * 0x1.0p-53 - 0.5;
+  }
+  DataFrame df({"k", "v"}, {Array::Make(key), Array::Make(val)});
+  dist::Communicator comm(dist::Communicator::unique_id(), 1, 0);
+  REQUIRE(comm.world() == 1 && comm.rank() == 0);
+  DataFrame res = dist::group_by_sum_mean_count(comm, df, "k", "v", 0);
+  GroupBy g("k", df);
+  REQUIRE((res.m_index->values_as<long>() == g.unique().values_as<long>()));
+  REQUIRE((res["sum"].values<double>() == g.sum("v").values<double>()));
+  REQUIRE((res["mean"].values<double>() == g.mean("v").values<double>()));
+  REQUIRE((res["count"].values<long>() == g.count("v").values<long>()));
+  Array cat = dist::concat(comm, df.m_columns[1], n);
+  REQUIRE(cat.length == n && (cat.values_as<double>() == val));
+  Series withnull(std::vector<double>{1.0, std::nan(""), 3.0});
+  Array cn = dist::concat(comm, withnull.m_array, 3);
+  REQUIRE((cn.valid_flags() == std::vector<bool>{true, false, true}));
+  unsetenv("PDX_DIST_FORCE_COLLECTIVES");
+}
+
 int main() {
   ThrowOnFailure(pdx_init(0));
   test_series_math();
@@ -387,6 +417,7 @@ int main() {
   test_sort();
   test_frame_compare_logical_reindex();
   test_groupby_bound_columns();
+  test_sharded_groupby_from_cpp();
   std::printf("%d checks, %d failed\n", g_checks, g_failed);
   return g_failed ? 1 : 0;
 }

@@ -1,0 +1,153 @@
+"""GPU: the sharded path behind the C ABI (pdx_dist_*, csrc/dist.hip) -- orchestration, glue kernels and collectives inside
+libpdx_hip.so.
+
+* one rank, RCCL transport, PDX_DIST_FORCE_COLLECTIVES=1: ncclCommInitRank, ncclAllGather and grouped ncclSend / ncclRecv made by the
+  library itself, in a fresh child process (RCCL state is per process);
+* three ranks sharing the box's one GPU over the custom transport (callbacks on torch.distributed / gloo: RCCL refuses duplicate
+  devices): the same C orchestration with real cross-rank data -- global dictionary, count exchange, partial records to owners,
+  replay, result gather -- bit-identical to the single-process oracle; concat with nulls and unequal shard sizes."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _data(n, nk, null_keys=False):
+    keys = orc.synth_keys(0, n, nk) * 7919 - 12345
+    vals = orc.synth_vals(0, n) - 0.5
+    kvalid = None
+    if null_keys:
+        kvalid = np.random.default_rng(4).random(n) > 0.02
+    return keys, vals, kvalid
+
+
+def _check(res, keys, vals, kvalid):
+    ids, uniq, isnull, first = orc.group_ids(keys, kvalid)
+    assert res["G"] == len(uniq)
+    assert np.array_equal(res["keys_ok"], ~isnull) and np.array_equal(res["keys"][~isnull], uniq[~isnull])
+    assert np.array_equal(res["first_rows"], first)
+    for j, kind in enumerate((0, 1, 4)):
+        exp = orc.groupby_agg(kind, ids, len(uniq), vals, nthreads=4)[0]
+        got = res["outs"][j]
+        assert np.array_equal(got.view(np.uint64), exp.view(np.uint64)), kind
+
+
+def _to_host(res):
+    return {"G": res["G"], "keys": res["keys"].cpu().numpy(), "keys_ok": res["keys_ok"].cpu().numpy(), "first_rows": res["first_rows"].cpu().numpy(),
+            "outs": [v.cpu().numpy() for v, _ in res["outs"]], "records": res["records"]}
+
+
+def _rccl_worker(q):
+    os.environ["PDX_DIST_FORCE_COLLECTIVES"] = "1"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+
+    from pandasarrow_amd import _lib as L
+    from pandasarrow_amd import dist as pdist
+    from pandasarrow_amd.column import Column
+
+    torch.cuda.set_device(0)
+    L.check(L.load().pdx_init(0))
+    out = {}
+    cd = pdist.CDist("rccl")   # no process group: world size 1, the library creates its own RCCL communicator
+    for name, (n, nk, nullk) in {"small": (200_003, 3000, False), "null_keys": (150_001, 500, True), "large_dense": (4_700_021, 300_000, False)}.items():
+        keys, vals, kvalid = _data(n, nk, nullk)
+        if name == "large_dense":
+            keys = orc.synth_keys(0, n, nk) + 1_000_000
+        out[name] = _to_host(cd.groupby_sum_mean_count(Column.from_numpy(keys, kvalid), Column.from_numpy(vals)))
+    v = np.arange(1000, dtype=np.float64) / 7
+    ok = np.arange(1000) % 5 != 0
+    c = cd.concat(Column.from_numpy(v, ok, offset=3))
+    out["concat"] = c.to_numpy()
+    cd.close()
+    q.put(out)
+
+
+def test_c_abi_sharded_one_rank_rccl_on_the_wire():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(q,))
+    p.start()
+    got = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    for name, (n, nk, nullk) in {"small": (200_003, 3000, False), "null_keys": (150_001, 500, True), "large_dense": (4_700_021, 300_000, False)}.items():
+        keys, vals, kvalid = _data(n, nk, nullk)
+        if name == "large_dense":
+            keys = orc.synth_keys(0, n, nk) + 1_000_000
+        _check(got[name], keys, vals, kvalid)
+    cv, cok = got["concat"]
+    assert np.array_equal(cv, np.arange(1000, dtype=np.float64) / 7) and np.array_equal(cok, np.arange(1000) % 5 != 0)
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pandasarrow_amd import _lib as L
+        from pandasarrow_amd import dist as pdist
+        from pandasarrow_amd.column import Column
+
+        torch.cuda.set_device(0)
+        L.check(L.load().pdx_init(0))
+        cd = pdist.CDist("torch")
+        out = {}
+        # unequal shards (the last rank holds 40 % of the rows); keys whose first occurrence lies on different ranks; a null key
+        for name, (n, nk, nullk) in {"uniform": (300_007, 3000, False), "null_keys": (200_003, 700, True), "few_groups": (100_003, 5, False)}.items():
+            keys, vals, kvalid = _data(n, nk, nullk)
+            cuts = [0, n * 25 // 100, n * 60 // 100, n]
+            lo, hi = cuts[rank], cuts[rank + 1]
+            res = cd.groupby_sum_mean_count(Column.from_numpy(keys[lo:hi], None if kvalid is None else kvalid[lo:hi]), Column.from_numpy(vals[lo:hi]),
+                                            row_offset=lo)
+            out[name] = _to_host(res)
+        rng = np.random.default_rng(11)
+        v, ok = rng.standard_normal(10_000), rng.random(10_000) > 0.1
+        cuts = [0, 1, 7003, 10_000]
+        lo, hi = cuts[rank], cuts[rank + 1]
+        out["concat"] = cd.concat(Column.from_numpy(v[lo:hi], ok[lo:hi] if rank != 1 else None)).to_numpy()   # rank 1's shard has no bitmap
+        cd.close()
+        if rank == 0:
+            q.put(out)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c_abi_sharded_three_ranks_one_gpu():
+    import torch.multiprocessing as mp
+
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for name, (n, nk, nullk) in {"uniform": (300_007, 3000, False), "null_keys": (200_003, 700, True), "few_groups": (100_003, 5, False)}.items():
+        keys, vals, kvalid = _data(n, nk, nullk)
+        _check(got[name], keys, vals, kvalid)
+        assert got[name]["records"] > 0
+    rng = np.random.default_rng(11)
+    v, ok = rng.standard_normal(10_000), rng.random(10_000) > 0.1
+    ok[1:7003] = True
+    cv, cok = got["concat"]
+    assert np.array_equal(cok, ok) and np.array_equal(cv[ok].view(np.uint64), v[ok].view(np.uint64))

@@ -137,15 +137,16 @@ def test_rccl_branches_world_size_one():
 def test_bench_under_torchrun_nccl():
     """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` with the N > 1 code path forced: init_process_group
     ("nccl", device_id=...), the sharded step with its RCCL collectives, the MAX all-reduce of the time, one JSON line."""
-    env = dict(os.environ, PDX_BENCH_FORCE_DIST="1", PDX_DIST_FORCE_COLLECTIVES="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--rows", "2e7", "--keys", "1e5", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 1 and line["config"]["path"] == "sharded" and line["value"] > 0
-    assert all(v for v in line["check"].values() if isinstance(v, bool))
+    for which, path in (("c", "sharded-c-abi"), ("torch", "sharded-torch")):  # the library's own RCCL calls; the older torch.distributed orchestration
+        env = dict(os.environ, PDX_BENCH_FORCE_DIST="1", PDX_DIST_FORCE_COLLECTIVES="1", PDX_BENCH_DIST=which)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+               "--rows", "2e7", "--keys", "1e5", "--no-cpu-baseline"]
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == 1 and line["config"]["path"] == path and line["value"] > 0, (which, line["config"])
+        assert all(v for v in line["check"].values() if isinstance(v, bool))
 
 
 def test_bench_refuses_gpus_mismatch():
