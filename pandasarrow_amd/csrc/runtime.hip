@@ -1,5 +1,6 @@
 // runtime.hip -- status/error plumbing, scratch pool, host<->device helpers, synthetic input generators.
 #include <string.h>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -39,15 +40,16 @@ int check_column(const pdx_column* c, const char* what) {
 // from several host threads on their own streams (the reference drives this boundary from tbb::parallel_for workers,
 // src/pd_core_macros.h:21,56,94,122) and from one thread that switches devices.
 namespace {
-struct EventCache {
+struct EventCache {  // per device: an event belongs to the device that was current when it was created and can only be recorded there
   std::mutex mu;
-  std::vector<hipEvent_t> free_events;
-  hipEvent_t get() {
+  std::map<int, std::vector<hipEvent_t>> free_events;
+  hipEvent_t get(int dev) {
     {
       std::lock_guard<std::mutex> lk(mu);
-      if (!free_events.empty()) {
-        hipEvent_t e = free_events.back();
-        free_events.pop_back();
+      auto& v = free_events[dev];
+      if (!v.empty()) {
+        hipEvent_t e = v.back();
+        v.pop_back();
         return e;
       }
     }
@@ -58,9 +60,9 @@ struct EventCache {
     }
     return e;
   }
-  void put(hipEvent_t e) {
+  void put(int dev, hipEvent_t e) {
     std::lock_guard<std::mutex> lk(mu);
-    free_events.push_back(e);
+    free_events[dev].push_back(e);
   }
 };
 EventCache& event_cache() {
@@ -70,8 +72,9 @@ EventCache& event_cache() {
 // one event shared by every block released together (a Scratch scope, a handle): refcounted, returned to the cache by the last block
 struct FreeMark {
   hipEvent_t ev = nullptr;
+  int device = 0;
   ~FreeMark() {
-    if (ev) event_cache().put(ev);
+    if (ev) event_cache().put(device, ev);
   }
 };
 struct FreeBlock {
@@ -100,6 +103,7 @@ size_t bucket(size_t bytes) {
   size_t step = p2 >> 3;
   return (bytes + step - 1) / step * step;
 }
+std::atomic<long> g_sync_fallbacks{0};  // pool frees that had to drain the stream because no event could be recorded (should stay 0)
 thread_local hipStream_t t_stream = nullptr;  // the stream of the ABI call this thread is serving (note_stream)
 bool block_ready(const FreeBlock& b, hipStream_t want) {
   if (!b.mark || !b.mark->ev || b.stream == want) return true;
@@ -155,14 +159,18 @@ void pool_free_many(void* const* ptrs, int n) {
   if (n <= 0) return;
   // one event for the whole batch, recorded behind everything this thread has queued on its stream so far
   std::shared_ptr<FreeMark> mark;
-  hipEvent_t ev = event_cache().get();
+  int cur_dev = 0;
+  if (hipGetDevice(&cur_dev) != hipSuccess) (void)hipGetLastError();
+  hipEvent_t ev = event_cache().get(cur_dev);
   if (ev && hipEventRecord(ev, t_stream) == hipSuccess) {
     mark = std::make_shared<FreeMark>();
     mark->ev = ev;
+    mark->device = cur_dev;
   } else {
     // no event: fall back to draining the stream so the blocks are safe for everybody
     (void)hipGetLastError();
-    if (ev) event_cache().put(ev);
+    if (ev) event_cache().put(cur_dev, ev);
+    g_sync_fallbacks.fetch_add(1, std::memory_order_relaxed);
     (void)hipStreamSynchronize(t_stream);
     (void)hipGetLastError();
   }
@@ -344,6 +352,8 @@ int pdx_profile_report(char* buf, size_t buf_len) {
   }
   std::string out;
   for (auto& kv : agg) out += kv.first + " " + std::to_string(kv.second.first) + " " + std::to_string(kv.second.second) + "\n";
+  // (diagnostic: frees that could not record an event and drained their stream instead -- a lost-asynchrony signal, expected 0)
+  if (const long fb = g_sync_fallbacks.load(std::memory_order_relaxed)) out += "pool_sync_fallback " + std::to_string(fb) + " 0.0\n";
   if (out.size() + 1 > buf_len) return fail(PDX_INVALID, "pdx_profile_report: buffer too small");
   memcpy(buf, out.c_str(), out.size() + 1);
   return PDX_OK;

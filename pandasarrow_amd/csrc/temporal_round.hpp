@@ -24,20 +24,25 @@ __device__ __forceinline__ long long fdiv(long long a, long long b) {
   return (a % b < 0) ? q - 1 : q;
 }
 // The same for a divisor known on the host (inv = 1.0 / b): estimate the quotient in double precision, then correct it with the
-// exact int64 remainder.  |estimate - a / b| <= |a / b| * 2^-51 + 1, i.e. at most a few units for any int64 a and b >= 1000 (every
-// unit from the microsecond up), so the loops below run zero or one time for real timestamps and never more than a handful.
+// exact int64 remainder.  |estimate - a / b| <= |a / b| * 2^-51 + 1: at most one unit off for real timestamps and b >= 1 us (the
+// common rules), so ONE conditional step settles it; a small divisor (rules like "7n": b < 1000 against |a| ~ 1e18) can leave the
+// estimate hundreds of units off -- that case takes one exact 64-bit division of the (small) remainder instead of a loop of unit steps.
 // The 64-bit division this replaces made the rounding kernels ALU bound (3.6 ms per 1e9 rows at 16 B/row).
 __device__ __forceinline__ long long fdiv_c(long long a, long long b, double inv) {
   if (b == 1) return a;
   long long q = (long long)__builtin_floor((double)a * inv);
   long long r = (long long)((unsigned long long)a - (unsigned long long)q * (unsigned long long)b);
-  while (r < 0) {
+  if (r < 0) {
     --q;
     r += b;
-  }
-  while (r >= b) {
+  } else if (r >= b) {
     ++q;
     r -= b;
+  }
+  if (r < 0 || r >= b) {  // rare: still outside [0, b) -- floor-divide the remainder exactly
+    long long adj = r / b;
+    if (r % b < 0) --adj;
+    q += adj;
   }
   return q;
 }
