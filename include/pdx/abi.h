@@ -231,7 +231,8 @@ int pdx_scatter(const pdx_column* cols, int ncols, const pdx_column* indices, pd
  * when many new keys meet in one mini-batch (Arrow 25.0.0: 13 286 of 43 183 result rows sit elsewhere at 1e5 rows / 5e4 uniform
  * keys); per key every aggregate is bit-identical.  The deviation is frozen in tests/golden/group_order_arrow25.npz and asserted by
  * tests/test_oracle_golden_r3.py / tests/test_gpu_round3.py.
- * key: PDX_INT64 / PDX_TIMESTAMP_NS / PDX_UINT64.  Limits: length < 2^31 rows per call; keys that do not span a dense integer
+ * key: PDX_INT64 / PDX_TIMESTAMP_NS / PDX_UINT64.  Limits: length < 2^31 rows per call (row ids are 32 bits wide inside the handle;
+ * pdx_groupby_sum_mean_count_chunked serves longer inputs for the headline query by an exact merge of chunks); keys that do not span a dense integer
  * range go through a hash table of at most 2^30 slots (about 7e8 distinct keys; the LDS-resident build covers 2.7e8). */
 typedef struct pdx_groupby pdx_groupby;
 int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out);
@@ -446,6 +447,11 @@ int pdx_dist_groupby_fetch(const pdx_dist_groupby* g, pdx_mut_column* keys, int6
                            void* stream);
 int pdx_dist_groupby_destroy(pdx_dist_groupby* g);
 int pdx_dist_concat(pdx_dist* d, const pdx_column* part, pdx_mut_column* out, void* stream);
+/* The headline query on ONE GPU for inputs beyond the per-call limit of pdx_groupby_create (2^31 - 1 rows: the reference's own
+ * Grouper::MakeGroupings breaks there): the rows are cut into chunks of chunk_rows (0 = the largest the limit allows; tests
+ * pass small values), every chunk plays one rank of the exchange above on a host thread of its own, and the partial-tree records merge
+ * the chunks' sums bit-identically to ONE pairwise tree over the whole column.  Result handle as pdx_dist_groupby_sum_mean_count. */
+int pdx_groupby_sum_mean_count_chunked(const pdx_column* keys, const pdx_column* values, int64_t chunk_rows, void* stream, pdx_dist_groupby** out);
 
 /* ---------------------------------------------------------------- Parquet files -> device columns
  * Replaces, for the column types of this path, DataFrame::readParquet (src/dataframe.cpp:646-683: parquet::arrow::OpenFile ->

@@ -139,6 +139,7 @@ ABI_SYMBOLS = {
     "pdx_dist_groupby_fetch": (C.c_int, [_P, _MUT, _P, _P, _P, _P, _P]),
     "pdx_dist_groupby_destroy": (C.c_int, [_P]),
     "pdx_dist_concat": (C.c_int, [_P, _COL, _MUT, _P]),
+    "pdx_groupby_sum_mean_count_chunked": (C.c_int, [_COL, _COL, C.c_int64, _P, C.POINTER(_P)]),
     "pdx_parquet_open": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "pdx_parquet_destroy": (C.c_int, [_P]),
     "pdx_parquet_num_columns": (C.c_int, [_P]),

@@ -18,7 +18,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 #include "compact.hpp"
@@ -203,6 +205,78 @@ struct InvEmit {
   int64_t* order;
   __device__ void operator()(int64_t pos, int64_t g) const { order[pos] = inv[g]; }
 };
+
+// ---------------------------------------------------------------- in-process transport: W virtual ranks = W host threads on ONE device
+// (pdx_groupby_sum_mean_count_chunked: inputs beyond 2^31 rows are cut into chunks that play the ranks of the exchange above)
+struct LocalShared {
+  int W = 1;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t generation = 0;
+  bool aborted = false;
+  std::vector<const uint8_t*> send;
+  std::vector<const size_t*> soff, sbytes;
+  // returns false when a rank has failed: everybody unwinds instead of waiting for it
+  bool barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    if (aborted) return false;
+    const uint64_t g = generation;
+    if (++arrived == W) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != g || aborted; });
+    }
+    return !aborted;
+  }
+  void abort() {
+    std::lock_guard<std::mutex> lk(mu);
+    aborted = true;
+    cv.notify_all();
+  }
+};
+struct LocalCtx {
+  LocalShared* sh;
+  int rank;
+};
+int local_fail() { return fail(PDX_DEVICE, "chunked group-by: another chunk failed"); }
+int local_all_gather(void* vctx, const void* send, void* recv, size_t bytes, void* stream) {
+  LocalCtx* c = static_cast<LocalCtx*>(vctx);
+  LocalShared* sh = c->sh;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PDX_HIP(hipStreamSynchronize(st));  // my contribution is complete before a peer reads it
+  sh->send[(size_t)c->rank] = static_cast<const uint8_t*>(send);
+  if (!sh->barrier()) return local_fail();
+  for (int p = 0; p < sh->W && bytes; ++p)
+    PDX_HIP(hipMemcpyAsync(static_cast<uint8_t*>(recv) + (size_t)p * bytes, sh->send[(size_t)p], bytes, hipMemcpyDeviceToDevice, st));
+  PDX_HIP(hipStreamSynchronize(st));
+  if (!sh->barrier()) return local_fail();  // nobody reuses its send buffer before every peer has copied it
+  return PDX_OK;
+}
+int local_all_to_all_v(void* vctx, const void* send, const size_t* send_off, const size_t* send_bytes, void* recv, const size_t* recv_off,
+                       const size_t* recv_bytes, void* stream) {
+  LocalCtx* c = static_cast<LocalCtx*>(vctx);
+  LocalShared* sh = c->sh;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PDX_HIP(hipStreamSynchronize(st));
+  sh->send[(size_t)c->rank] = static_cast<const uint8_t*>(send);
+  sh->soff[(size_t)c->rank] = send_off;
+  sh->sbytes[(size_t)c->rank] = send_bytes;
+  if (!sh->barrier()) return local_fail();
+  for (int p = 0; p < sh->W; ++p) {
+    const size_t b = sh->sbytes[(size_t)p][c->rank];
+    if (b != recv_bytes[p]) {
+      sh->abort();
+      return fail(PDX_DEVICE, "chunked group-by: internal: send and receive counts disagree");
+    }
+    if (b) PDX_HIP(hipMemcpyAsync(static_cast<uint8_t*>(recv) + recv_off[p], sh->send[(size_t)p] + sh->soff[(size_t)p][c->rank], b, hipMemcpyDeviceToDevice, st));
+  }
+  PDX_HIP(hipStreamSynchronize(st));
+  if (!sh->barrier()) return local_fail();
+  return PDX_OK;
+}
 
 }  // namespace
 }  // namespace pdx
@@ -620,6 +694,88 @@ int pdx_dist_concat(pdx_dist* d, const pdx_column* part, pdx_mut_column* out, vo
     PDX_LAUNCH_CHECK();
   }
   PDX_HIP(hipStreamSynchronize(st));
+  return PDX_OK;
+}
+
+
+// Inputs of more than 2^31 - 1 rows (the per-call limit of the 32-bit row ids inside pdx_groupby_create): the rows are cut into chunks,
+// every chunk plays one rank of the exchange above -- a host thread with its own stream on the SAME device, the collectives are
+// device-to-device copies between the threads' buffers -- and the partial-tree records make the merged sums bit-identical to one
+// pairwise tree over the whole column.  chunk_rows = 0: the largest chunk the limit allows.
+int pdx_groupby_sum_mean_count_chunked(const pdx_column* keys, const pdx_column* values, int64_t chunk_rows, void* stream, pdx_dist_groupby** out) {
+  if (!out) return fail(PDX_INVALID, "pdx_groupby_sum_mean_count_chunked: null output");
+  *out = nullptr;
+  PDX_TRY(check_column(keys, "pdx_groupby_sum_mean_count_chunked"));
+  PDX_TRY(check_column(values, "pdx_groupby_sum_mean_count_chunked"));
+  if (values->length != keys->length) return fail(PDX_INVALID, "pdx_groupby_sum_mean_count_chunked: keys and values differ in length");
+  if (values->dtype != PDX_FLOAT64 || validity_or_null(values))
+    return fail(PDX_NOT_IMPLEMENTED, "pdx_groupby_sum_mean_count_chunked: float64 values without nulls");
+  const int64_t n = keys->length, kMaxChunk = 0x7FFFF000ll;
+  if (chunk_rows <= 0 || chunk_rows > kMaxChunk) chunk_rows = kMaxChunk;
+  const int W = (int)std::max<int64_t>(1, ceil_div(n, chunk_rows));
+  if (W > 64) return fail(PDX_INVALID, "pdx_groupby_sum_mean_count_chunked: more than 64 chunks");
+  int device = 0;
+  PDX_HIP(hipGetDevice(&device));
+  (void)stream;  // (every chunk runs on a stream of its own; the call returns when all of them have finished)
+  LocalShared sh;
+  sh.W = W;
+  sh.send.assign((size_t)W, nullptr);
+  sh.soff.assign((size_t)W, nullptr);
+  sh.sbytes.assign((size_t)W, nullptr);
+  std::vector<int> rcs((size_t)W, PDX_OK);
+  std::vector<std::string> errs((size_t)W);
+  std::vector<pdx_dist_groupby*> results((size_t)W, nullptr);
+  auto work = [&](int r) {
+    int rc = PDX_OK;
+    hipStream_t st = nullptr;
+    pdx_dist* d = nullptr;
+    LocalCtx ctx{&sh, r};
+    do {
+      if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+        rc = fail(PDX_DEVICE, "chunked group-by: no stream for a chunk");
+        break;
+      }
+      pdx_dist_transport tr{&ctx, local_all_gather, local_all_to_all_v};
+      if ((rc = pdx_dist_init_custom(&tr, W, r, &d)) != PDX_OK) break;
+      const int64_t lo = (int64_t)r * chunk_rows, len = std::min<int64_t>(chunk_rows, n - lo);
+      pdx_column k = *keys, v = *values;
+      k.offset += lo;
+      k.length = len;
+      v.offset += lo;
+      v.length = len;
+      rc = pdx_dist_groupby_sum_mean_count(d, &k, &v, lo, st, &results[(size_t)r]);
+    } while (false);
+    if (rc != PDX_OK) {
+      errs[(size_t)r] = pdx_last_error();
+      sh.abort();
+    }
+    rcs[(size_t)r] = rc;
+    if (d) pdx_dist_destroy(d);
+    if (st) {
+      (void)hipStreamSynchronize(st);
+      if (results[(size_t)r]) results[(size_t)r]->stream = nullptr;  // the chunk's stream dies with this thread: later frees go to the default stream
+      (void)hipStreamDestroy(st);
+    }
+  };
+  if (W == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> threads;
+    for (int r = 0; r < W; ++r) threads.emplace_back(work, r);
+    for (auto& t : threads) t.join();
+  }
+  int rc = PDX_OK;
+  for (int r = 0; r < W; ++r)
+    if (rcs[(size_t)r] != PDX_OK && (rc == PDX_OK || errs[(size_t)r].find("another chunk failed") == std::string::npos)) {
+      rc = rcs[(size_t)r];
+      set_error(errs[(size_t)r]);
+    }
+  for (int r = 1; r < W; ++r) delete results[(size_t)r];  // every chunk holds the full result: keep the first
+  if (rc != PDX_OK) {
+    delete results[0];
+    return rc;
+  }
+  *out = results[0];
   return PDX_OK;
 }
 

@@ -284,6 +284,46 @@ class _RawDeviceBytes:
         self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
 
 
+def _fetch_dist_result(lib, h, key_dtype):
+    """pdx_dist_groupby* -> the result dict of the sharded entry points (device tensors); destroys the handle."""
+    import ctypes as C
+
+    from . import column as K
+
+    try:
+        G = int(lib.pdx_dist_groupby_num_groups(h))
+        kcol = K.Column.empty(key_dtype, G, with_validity=True)
+        m = kcol.mut()
+        dev = K._device()
+        first = torch.empty(max(G, 1), dtype=torch.int64, device=dev)
+        sums = torch.empty(max(G, 1), dtype=torch.float64, device=dev)
+        means = torch.empty(max(G, 1), dtype=torch.float64, device=dev)
+        counts = torch.empty(max(G, 1), dtype=torch.int64, device=dev)
+        L.check(lib.pdx_dist_groupby_fetch(h, C.byref(m), first.data_ptr(), sums.data_ptr(), means.data_ptr(), counts.data_ptr(), K._stream()))
+        kcol._adopt(m)
+        _, kok = kcol.to_numpy()
+        records = int(lib.pdx_dist_groupby_num_records(h))
+    finally:
+        lib.pdx_dist_groupby_destroy(h)
+    ok_t = torch.ones(G, dtype=torch.bool, device=dev) if kok is None else torch.from_numpy(kok).to(dev)
+    return {"G": G, "keys": kcol.values[:G], "keys_ok": ok_t, "first_rows": first[:G], "kinds": [L.AGG_SUM, L.AGG_MEAN, L.AGG_COUNT],
+            "outs": [(sums[:G], None), (means[:G], None), (counts[:G], None)], "records": records}
+
+
+def groupby_sum_mean_count_chunked(keys, vals, chunk_rows=0):
+    """The headline query on one GPU for inputs beyond 2^31 - 1 rows (pdx_groupby_sum_mean_count_chunked): chunks of `chunk_rows` rows
+    (0 = the largest allowed) merged exactly through the partial-tree records.  Same result dict as the sharded entry points."""
+    import ctypes as C
+
+    from . import column as K
+
+    lib = L.load()
+    h = C.c_void_p()
+    ck, cv = keys.c(), vals.c()
+    L.check(lib.pdx_groupby_sum_mean_count_chunked(C.byref(ck), C.byref(cv), int(chunk_rows), K._stream(), C.byref(h)))
+    return _fetch_dist_result(lib, h, keys.dtype)
+
+
 class CDist:
     """Binding over the C ABI's sharded path: the orchestration, the glue kernels and the collectives all live in libpdx_hip.so
     (csrc/dist.hip); python only creates the communicator.
@@ -390,25 +430,7 @@ class CDist:
         h = C.c_void_p()
         ck, cv = keys.c(), vals.c()
         L.check(self.lib.pdx_dist_groupby_sum_mean_count(self._h, C.byref(ck), C.byref(cv), int(row_offset), K._stream(), C.byref(h)))
-        try:
-            G = int(self.lib.pdx_dist_groupby_num_groups(h))
-            kcol = K.Column.empty(keys.dtype, G, with_validity=True)
-            m = kcol.mut()
-            dev = K._device()
-            first = torch.empty(max(G, 1), dtype=torch.int64, device=dev)
-            sums = torch.empty(max(G, 1), dtype=torch.float64, device=dev)
-            means = torch.empty(max(G, 1), dtype=torch.float64, device=dev)
-            counts = torch.empty(max(G, 1), dtype=torch.int64, device=dev)
-            L.check(self.lib.pdx_dist_groupby_fetch(h, C.byref(m), first.data_ptr(), sums.data_ptr(), means.data_ptr(), counts.data_ptr(), K._stream()))
-            kcol._adopt(m)
-            kv, kok = kcol.to_numpy()
-            records = int(self.lib.pdx_dist_groupby_num_records(h))
-        finally:
-            self.lib.pdx_dist_groupby_destroy(h)
-        keys_t = kcol.values[:G]
-        ok_t = torch.ones(G, dtype=torch.bool, device=dev) if kok is None else torch.from_numpy(kok).to(dev)
-        return {"G": G, "keys": keys_t, "keys_ok": ok_t, "first_rows": first[:G], "kinds": [L.AGG_SUM, L.AGG_MEAN, L.AGG_COUNT],
-                "outs": [(sums[:G], None), (means[:G], None), (counts[:G], None)], "records": records}
+        return _fetch_dist_result(self.lib, h, keys.dtype)
 
     def concat(self, col):
         """all-gather(v) of one column's shards in rank order (pdx_dist_concat)."""

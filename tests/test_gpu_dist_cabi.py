@@ -151,3 +151,22 @@ def test_c_abi_sharded_three_ranks_one_gpu():
     ok[1:7003] = True
     cv, cok = got["concat"]
     assert np.array_equal(cok, ok) and np.array_equal(cv[ok].view(np.uint64), v[ok].view(np.uint64))
+
+
+@pytest.mark.parametrize("shape", ["four_chunks", "ragged_seven", "null_keys_bit_offsets", "one_chunk"])
+def test_chunked_groupby_beyond_the_row_limit_merge(shape):
+    """pdx_groupby_sum_mean_count_chunked: the path for inputs of more than 2^31 - 1 rows, exercised with small chunks -- every chunk
+    is a virtual rank on a host thread of its own, merged through the partial-tree records: bit-identical to ONE tree over the column"""
+    import torch
+
+    from pandasarrow_amd import _lib as L
+    from pandasarrow_amd import dist as pdist
+    from pandasarrow_amd.column import Column
+
+    L.check(L.load().pdx_init(0))
+    n, nk, chunk, nullk = {"four_chunks": (400_003, 3000, 100_001, False), "ragged_seven": (333_337, 50, 50_000, False),
+                           "null_keys_bit_offsets": (250_007, 700, 77_777, True), "one_chunk": (120_000, 900, 0, False)}[shape]
+    keys, vals, kvalid = _data(n, nk, nullk)
+    res = pdist.groupby_sum_mean_count_chunked(Column.from_numpy(keys, kvalid, offset=3 if nullk else 0), Column.from_numpy(vals), chunk)
+    _check(_to_host(res), keys, vals, kvalid)
+    torch.cuda.synchronize()
