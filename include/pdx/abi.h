@@ -314,6 +314,11 @@ int pdx_replay_partials(const int64_t* rec_key, const double* rec_val, int64_t m
  * buffer must stay alive and unchanged until pdx_groupby_destroy. */
 int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right, int label_right, int origin_type,
                         int64_t origin_custom_ns, int64_t offset_ns, void* stream, pdx_groupby** out);
+/* The grid alone (host arithmetic, no GPU): first bin edge and number of bins of an axis with extremes tmin / tmax -- adjustDatesAnchored
+ * + date_range (src/resample.cpp:85-178, src/core.cpp:308-331), with the reference's errors.  pdx_resample_create uses it; so does
+ * the sharded resample, where every rank must bin on the WHOLE axis' grid. */
+int pdx_resample_grid(int64_t tmin, int64_t tmax, int64_t freq_ns, int closed_right, int origin_type, int64_t origin_custom_ns, int64_t offset_ns,
+                      int64_t* first_edge, int64_t* num_bins);
 /* per-row labels (GroupInfo::downsample): device pointer to num_rows int64 */
 int pdx_resample_row_labels(pdx_groupby* gb, int64_t* out_labels, void* stream);
 
@@ -447,6 +452,16 @@ int pdx_dist_groupby_fetch(const pdx_dist_groupby* g, pdx_mut_column* keys, int6
                            void* stream);
 int pdx_dist_groupby_destroy(pdx_dist_groupby* g);
 int pdx_dist_concat(pdx_dist* d, const pdx_column* part, pdx_mut_column* out, void* stream);
+/* pd::resample(df, rule).{kinds}(col) over a sorted axis sharded by row ranges (src/resample.h:91-122, src/group_by.h:255-299): the
+ * leading rows of a shard whose bin opened on an earlier rank move there (one all-to-all(v)), every rank bins on the whole axis'
+ * grid (pdx_resample_grid of the all-gathered extremes), results are all-gathered in rank order == label order.  kinds:
+ * PDX_AGG_SUM .. PDX_AGG_LAST.  Every rank ends with the full result; the reference's whole-axis errors are raised on every rank. */
+typedef struct pdx_dist_resampled pdx_dist_resampled;
+int pdx_dist_resample(pdx_dist* d, const pdx_column* ts, const pdx_column* values, const int* kinds, int nk, int64_t freq_ns, int closed_right,
+                      int label_right, int origin_type, int64_t origin_custom_ns, int64_t offset_ns, void* stream, pdx_dist_resampled** out);
+int64_t pdx_dist_resampled_num_bins(const pdx_dist_resampled* g);
+int pdx_dist_resampled_fetch(const pdx_dist_resampled* g, pdx_mut_column* labels, pdx_mut_column* outs, void* stream);
+int pdx_dist_resampled_destroy(pdx_dist_resampled* g);
 /* The headline query on ONE GPU for inputs beyond the per-call limit of pdx_groupby_create (2^31 - 1 rows: the reference's own
  * Grouper::MakeGroupings breaks there): the rows are cut into chunks of chunk_rows (0 = the largest the limit allows; tests
  * pass small values), every chunk plays one rank of the exchange above on a host thread of its own, and the partial-tree records merge

@@ -111,6 +111,7 @@ ABI_SYMBOLS = {
     "pdx_grouped_partial_fill": (C.c_int, [_P, _P, _P, _P, _P]),
     "pdx_replay_partials": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "pdx_resample_create": (C.c_int, [_COL, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _P, C.POINTER(_P)]),
+    "pdx_resample_grid": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pdx_resample_row_labels": (C.c_int, [_P, _P, _P]),
     "pdx_round_temporal": (C.c_int, [C.c_int, _COL, C.c_int64, C.c_int, C.c_int, C.c_int, _MUT, _P]),
     "pdx_downsample_create": (C.c_int, [_COL, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P, C.POINTER(_P)]),
@@ -139,6 +140,10 @@ ABI_SYMBOLS = {
     "pdx_dist_groupby_fetch": (C.c_int, [_P, _MUT, _P, _P, _P, _P, _P]),
     "pdx_dist_groupby_destroy": (C.c_int, [_P]),
     "pdx_dist_concat": (C.c_int, [_P, _COL, _MUT, _P]),
+    "pdx_dist_resample": (C.c_int, [_P, _COL, _COL, C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _P, C.POINTER(_P)]),
+    "pdx_dist_resampled_num_bins": (C.c_int64, [_P]),
+    "pdx_dist_resampled_fetch": (C.c_int, [_P, _MUT, _MUT, _P]),
+    "pdx_dist_resampled_destroy": (C.c_int, [_P]),
     "pdx_groupby_sum_mean_count_chunked": (C.c_int, [_COL, _COL, C.c_int64, _P, C.POINTER(_P)]),
     "pdx_parquet_open": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
     "pdx_parquet_destroy": (C.c_int, [_P]),

@@ -1188,6 +1188,23 @@ inline DataFrame group_by_sum_mean_count(Communicator& comm, const DataFrame& sh
                                         static_cast<int64_t*>(counts.values->ptr), nullptr));
   return DataFrame({"sum", "mean", "count"}, {sums, means, counts}, keys);
 }
+// pd::resample(shard, rule).agg(kind)(col) over a sorted axis sharded by row ranges: a Series of the aggregate indexed by the labels of the
+// non-empty bins of the WHOLE axis (every rank gets all of it)
+inline Series resample_agg(Communicator& comm, const Array& ts_shard, const Array& values_shard, int kind, int64_t freq_ns, bool closed_right = false,
+                           bool label_right = false, int origin = PDX_ORIGIN_START_DAY, int64_t offset_ns = 0) {
+  auto ct = ts_shard.c(), cv = values_shard.c();
+  pdx_dist_resampled* raw = nullptr;
+  ThrowOnFailure(pdx_dist_resample(comm.h, &ct, &cv, &kind, 1, freq_ns, closed_right, label_right, origin, 0, offset_ns, nullptr, &raw));
+  std::shared_ptr<pdx_dist_resampled> g(raw, [](pdx_dist_resampled* p) { pdx_dist_resampled_destroy(p); });
+  const int64_t G = pdx_dist_resampled_num_bins(raw);
+  const int dt = (kind == PDX_AGG_MEAN || kind == PDX_AGG_VARIANCE || kind == PDX_AGG_STDDEV) ? PDX_FLOAT64 : kind == PDX_AGG_COUNT ? PDX_INT64 : values_shard.dtype;
+  Array labels = Array::Empty(PDX_TIMESTAMP_NS, G, false), out = Array::Empty(dt, G, true);
+  auto ml = labels.mut(), mo = out.mut();
+  ThrowOnFailure(pdx_dist_resampled_fetch(raw, &ml, &mo, nullptr));
+  out.null_count = mo.null_count;
+  if (mo.null_count == 0) out.validity.reset();
+  return Series(out, labels, "");
+}
 // pd::concat of the shards' columns in rank order (the all-gather(v) merge)
 inline Array concat(Communicator& comm, const Array& part, int64_t total_rows) {
   Array out = Array::Empty(part.dtype, total_rows, true);

@@ -196,6 +196,17 @@ __global__ void k_means(const double* __restrict__ sums, const int64_t* __restri
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) means[g] = sums[g] / (double)counts[g];
 }
+// rows of a sorted int64 axis below `edge` (<= edge when inclusive): one thread, binary search
+__global__ void k_count_below(const long long* __restrict__ t, int64_t n, long long edge, int inclusive, int64_t* __restrict__ out) {
+  if (blockIdx.x || threadIdx.x) return;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (inclusive ? t[mid] <= edge : t[mid] < edge) lo = mid + 1;
+    else hi = mid;
+  }
+  *out = lo;
+}
 struct InvPred {
   const int64_t* inv;
   __device__ bool operator()(int64_t g) const { return inv[g] >= 0; }
@@ -311,6 +322,27 @@ struct pdx_dist_groupby {
     return p;
   }
   ~pdx_dist_groupby() {
+    StreamNote note(stream);
+    pool_free_many(owned.data(), (int)owned.size());
+  }
+};
+
+struct pdx_dist_resampled {
+  int64_t G = 0;
+  int nk = 0;
+  int64_t* labels = nullptr;
+  std::vector<int> dtypes;
+  std::vector<uint64_t*> vals;
+  std::vector<int64_t*> oks;  // 0 / 1 per bin, or nullptr when no shard produced a null
+  hipStream_t stream = nullptr;
+  std::vector<void*> owned;
+  template <typename T>
+  T* own(size_t count) {
+    T* p = static_cast<T*>(pool_alloc((count ? count : 1) * sizeof(T)));
+    if (p) owned.push_back(p);
+    return p;
+  }
+  ~pdx_dist_resampled() {
     StreamNote note(stream);
     pool_free_many(owned.data(), (int)owned.size());
   }
@@ -697,6 +729,246 @@ int pdx_dist_concat(pdx_dist* d, const pdx_column* part, pdx_mut_column* out, vo
   return PDX_OK;
 }
 
+
+// pd::resample(df, rule).{kinds}(col) over an axis sharded by row ranges in rank order (src/resample.h:91-122, src/group_by.h:255-299).
+// Sorted timestamps make the shards time ranges.  Bins are made whole before any arithmetic: the leading rows of a shard that fall
+// into a bin already open on an earlier rank move to that bin's first rank (ONE all-to-all(v); usually a few hundred rows per cut),
+// every rank resamples its rows on the WHOLE axis' grid (pdx_resample_grid of the all-gathered extremes), and the (label, value)
+// rows are all-gathered in rank order == label order.  The reference's whole-axis errors (unsorted input, values outside the
+// bins, upsampling) are raised on every rank.
+int pdx_dist_resample(pdx_dist* d, const pdx_column* ts, const pdx_column* values, const int* kinds, int nk, int64_t freq_ns, int closed_right,
+                      int label_right, int origin_type, int64_t origin_custom_ns, int64_t offset_ns, void* stream, pdx_dist_resampled** out) {
+  if (!d || !out || !kinds || nk <= 0) return fail(PDX_INVALID, "pdx_dist_resample: null argument");
+  *out = nullptr;
+  PDX_TRY(check_column(ts, "pdx_dist_resample"));
+  PDX_TRY(check_column(values, "pdx_dist_resample"));
+  if (ts->dtype != PDX_TIMESTAMP_NS && ts->dtype != PDX_INT64) return fail(PDX_INVALID, "axis must be a TimestampArray");
+  if (validity_or_null(ts)) return fail(PDX_NOT_IMPLEMENTED, "pdx_dist_resample: null timestamps are not supported");
+  if (values->dtype != PDX_FLOAT64 && values->dtype != PDX_INT64) return fail(PDX_NOT_IMPLEMENTED, "pdx_dist_resample: values must be int64 or float64");
+  if (values->length != ts->length) return fail(PDX_INVALID, "pdx_dist_resample: axis and values differ in length");
+  hipStream_t st = as_stream(stream);
+  const int W = d->world, r = d->rank;
+  const bool solo = W == 1 && !d->force;
+  Scratch s;
+  const int64_t n_loc = ts->length;
+  const long long* tv = static_cast<const long long*>(ts->values) + ts->offset;
+  const uint64_t* vv = static_cast<const uint64_t*>(values->values) + values->offset;
+  // ---- every shard's (rows, first, last, has nulls): the whole axis' extremes and grid on every rank
+  int64_t mine[4] = {n_loc, 0, 0, validity_or_null(values) ? 1 : 0};
+  if (n_loc) {
+    PDX_HIP(hipMemcpyAsync(&mine[1], tv, 8, hipMemcpyDeviceToHost, st));
+    PDX_HIP(hipMemcpyAsync(&mine[2], tv + (n_loc - 1), 8, hipMemcpyDeviceToHost, st));
+    PDX_HIP(hipStreamSynchronize(st));
+  }
+  std::vector<int64_t> info;
+  PDX_TRY(gather_host(d, mine, 4, &info, s, st));
+  auto I = [&](int q, int k) { return info[(size_t)q * 4 + k]; };
+  std::vector<int> live;
+  int64_t N = 0;
+  bool any_nulls = false;
+  for (int q = 0; q < W; ++q) {
+    if (I(q, 0) > 0) live.push_back(q);
+    N += I(q, 0);
+    any_nulls = any_nulls || I(q, 3) != 0;
+  }
+  std::unique_ptr<pdx_dist_resampled> res(new pdx_dist_resampled());
+  res->stream = st;
+  res->nk = nk;
+  if (N == 0) {
+    res->labels = res->own<int64_t>(1);
+    for (int k = 0; k < nk; ++k) {
+      res->dtypes.push_back(PDX_FLOAT64);
+      res->vals.push_back(res->own<uint64_t>(1));
+      res->oks.push_back(nullptr);
+    }
+    *out = res.release();
+    return PDX_OK;
+  }
+  for (size_t i = 0; i + 1 < live.size(); ++i)
+    if (I(live[i], 2) > I(live[i + 1], 1)) return fail(PDX_INVALID, "pdx_resample_create: timestamps must be sorted ascending");
+  int64_t first_edge = 0, nbins = 0;
+  PDX_TRY(pdx_resample_grid(I(live.front(), 1), I(live.back(), 2), freq_ns, closed_right, origin_type, origin_custom_ns, offset_ns, &first_edge, &nbins));
+  if (N < nbins) return fail(PDX_INVALID, "upSampling is not implemented.");  // GroupInfo::upsampling on the whole axis (src/resample.h:14-17)
+  auto floor_div = [](int64_t a, int64_t b) { int64_t q = a / b, m = a % b; return (m != 0 && ((m < 0) != (b < 0))) ? q - 1 : q; };
+  auto bin_of = [&](int64_t t) { return floor_div(t - first_edge - (closed_right ? 1 : 0), freq_ns); };  // [e_k, e_k + f) or (e_k, e_k + f]
+  // ---- the first rank that holds rows of my leading bin; the rows of that bin move there
+  int send_to = r;
+  int64_t m = 0;
+  if (n_loc) {
+    const int64_t b0 = bin_of(I(r, 1));
+    for (int i = (int)live.size() - 1; i >= 0; --i) {
+      const int q = live[(size_t)i];
+      if (q >= r) continue;
+      if (bin_of(I(q, 2)) != b0) break;
+      send_to = q;
+      if (bin_of(I(q, 1)) != b0) break;
+    }
+    if (send_to != r) {
+      int64_t* dm = s.get<int64_t>(1);
+      PDX_SCRATCH_CHECK(s);
+      hipLaunchKernelGGL(k_count_below, dim3(1), dim3(1), 0, st, tv, n_loc, (long long)(first_edge + (b0 + 1) * freq_ns), closed_right ? 1 : 0, dm);
+      PDX_LAUNCH_CHECK();
+      PDX_HIP(hipMemcpyAsync(&m, dm, 8, hipMemcpyDeviceToHost, st));
+      PDX_HIP(hipStreamSynchronize(st));
+    }
+  }
+  // ---- the exchange of the moved rows (timestamps, values, validity words) and the shard as it is resampled
+  const long long* ts2 = tv;
+  const uint64_t* vals2 = vv;
+  const uint8_t* valid2 = validity_or_null(values);
+  int64_t valid2_off = values->offset, n2 = n_loc;
+  if (!solo) {
+    std::vector<int64_t> moves;  // moves[q] = (rows q sends, destination of q)
+    int64_t mv[2] = {m, send_to};
+    PDX_TRY(gather_host(d, mv, 2, &moves, s, st));
+    int64_t recv_rows = 0;
+    std::vector<size_t> so((size_t)W, 0), sb((size_t)W, 0), ro((size_t)W, 0), rb((size_t)W, 0);
+    for (int q = 0; q < W; ++q) {
+      if (q == r) continue;
+      if (moves[(size_t)q * 2 + 1] == r) {
+        ro[(size_t)q] = (size_t)recv_rows * 8;
+        rb[(size_t)q] = (size_t)moves[(size_t)q * 2] * 8;
+        recv_rows += moves[(size_t)q * 2];
+      }
+    }
+    if (send_to != r) sb[(size_t)send_to] = (size_t)m * 8;
+    n2 = n_loc - m + recv_rows;
+    long long* t2 = s.get<long long>((size_t)n2);
+    uint64_t* v2 = s.get<uint64_t>((size_t)n2);
+    int64_t* okw = any_nulls ? s.get<int64_t>((size_t)n_loc) : nullptr;
+    int64_t* ok2 = any_nulls ? s.get<int64_t>((size_t)n2) : nullptr;
+    uint8_t* bits2 = any_nulls ? s.get<uint8_t>((size_t)(n2 + 7) / 8 + 16) : nullptr;
+    PDX_SCRATCH_CHECK(s);
+    const int64_t keep = n_loc - m;
+    if (keep) {
+      PDX_HIP(hipMemcpyAsync(t2, tv + m, (size_t)keep * 8, hipMemcpyDeviceToDevice, st));
+      PDX_HIP(hipMemcpyAsync(v2, vv + m, (size_t)keep * 8, hipMemcpyDeviceToDevice, st));
+    }
+    PDX_TRY(d->tr.all_to_all_v(d->tr.ctx, tv, so.data(), sb.data(), t2 + keep, ro.data(), rb.data(), st));
+    PDX_TRY(d->tr.all_to_all_v(d->tr.ctx, vv, so.data(), sb.data(), v2 + keep, ro.data(), rb.data(), st));
+    if (any_nulls) {
+      if (n_loc) hipLaunchKernelGGL(k_bits_to_i64, dim3(grid_for(n_loc, 256)), dim3(256), 0, st, validity_or_null(values), values->offset, n_loc, okw);
+      PDX_LAUNCH_CHECK();
+      if (keep) PDX_HIP(hipMemcpyAsync(ok2, okw + m, (size_t)keep * 8, hipMemcpyDeviceToDevice, st));
+      PDX_TRY(d->tr.all_to_all_v(d->tr.ctx, okw, so.data(), sb.data(), ok2 + keep, ro.data(), rb.data(), st));
+      if (n2) hipLaunchKernelGGL(k_i64_to_bits, dim3(grid_for((n2 + 7) / 8, 256)), dim3(256), 0, st, ok2, n2, bits2);
+      PDX_LAUNCH_CHECK();
+    }
+    ts2 = t2;
+    vals2 = v2;
+    valid2 = bits2;
+    valid2_off = 0;
+  }
+  // ---- every shard bins on the whole axis' grid, anchored at its FIRST EDGE (with a negative first offset the reference's grid starts
+  // at the first timestamp itself, src/resample.cpp:85-178)
+  struct Handle {
+    pdx_groupby* gb = nullptr;
+    ~Handle() { if (gb) pdx_groupby_destroy(gb); }
+  } h;
+  pdx_column tc{};
+  tc.dtype = PDX_TIMESTAMP_NS;
+  tc.length = n2;
+  tc.values = ts2;
+  pdx_column vc{};
+  vc.dtype = values->dtype;
+  vc.length = n2;
+  vc.offset = solo ? values->offset : 0;
+  vc.values = solo ? values->values : (const void*)vals2;
+  vc.validity = valid2;
+  vc.null_count = valid2 ? -1 : 0;
+  (void)valid2_off;
+  int64_t Gl = 0;
+  if (n2) {
+    PDX_TRY(pdx_resample_create(&tc, freq_ns, closed_right, label_right, PDX_ORIGIN_CUSTOM | PDX_ORIGIN_SHARD, first_edge, 0, st, &h.gb));
+    Gl = pdx_groupby_num_groups(h.gb);
+  }
+  std::vector<int64_t> sizes;
+  PDX_TRY(gather_host(d, &Gl, 1, &sizes, s, st));
+  int64_t G = 0;
+  for (int q = 0; q < W; ++q) G += sizes[(size_t)q];
+  res->G = G;
+  res->labels = res->own<int64_t>((size_t)G);
+  if (!res->labels) return PDX_OOM;
+  int64_t* lab_l = s.get<int64_t>((size_t)Gl);
+  PDX_SCRATCH_CHECK(s);
+  std::vector<pdx_mut_column> outs((size_t)nk);
+  std::vector<uint8_t*> out_bits((size_t)nk, nullptr);
+  for (int k = 0; k < nk; ++k) {
+    const int kind = kinds[k];
+    if (kind < PDX_AGG_SUM || kind > PDX_AGG_LAST) return fail(PDX_NOT_IMPLEMENTED, "pdx_dist_resample: aggregate kind not supported on shards");
+    const int dt = (kind == PDX_AGG_MEAN || kind == PDX_AGG_VARIANCE || kind == PDX_AGG_STDDEV) ? PDX_FLOAT64 : kind == PDX_AGG_COUNT ? PDX_INT64 : values->dtype;
+    res->dtypes.push_back(dt);
+    res->vals.push_back(res->own<uint64_t>((size_t)G));
+    res->oks.push_back(any_nulls && kind != PDX_AGG_COUNT ? res->own<int64_t>((size_t)G) : nullptr);
+    if (!res->vals.back() || (any_nulls && kind != PDX_AGG_COUNT && !res->oks.back())) return PDX_OOM;
+    pdx_mut_column& mcol = outs[(size_t)k];
+    mcol = pdx_mut_column{};
+    mcol.dtype = dt;
+    mcol.length = Gl;
+    mcol.values = s.get<uint64_t>((size_t)Gl);
+    out_bits[(size_t)k] = valid2 ? s.get<uint8_t>((size_t)(Gl + 7) / 8 + 16) : nullptr;
+    mcol.validity = out_bits[(size_t)k];
+    PDX_SCRATCH_CHECK(s);
+  }
+  if (n2) {
+    pdx_mut_column lm{};
+    lm.dtype = PDX_TIMESTAMP_NS;
+    lm.length = Gl;
+    lm.values = lab_l;
+    PDX_TRY(pdx_groupby_unique_keys(h.gb, &lm, st));
+    PDX_TRY(pdx_groupby_agg(h.gb, &vc, kinds, nk, outs.data(), st));
+  }
+  PDX_TRY(all_gather_v(d, lab_l, sizes, 8, res->labels, st));
+  int64_t* okl = any_nulls ? s.get<int64_t>((size_t)Gl) : nullptr;
+  PDX_SCRATCH_CHECK(s);
+  for (int k = 0; k < nk; ++k) {
+    PDX_TRY(all_gather_v(d, outs[(size_t)k].values, sizes, 8, res->vals[(size_t)k], st));
+    if (res->oks[(size_t)k]) {
+      // (a shard without nulls contributes all-valid words)
+      if (Gl) hipLaunchKernelGGL(k_bits_to_i64, dim3(grid_for(Gl, 256)), dim3(256), 0, st, (const uint8_t*)out_bits[(size_t)k], (int64_t)0, Gl, okl);
+      PDX_LAUNCH_CHECK();
+      PDX_TRY(all_gather_v(d, okl, sizes, 8, res->oks[(size_t)k], st));
+    }
+  }
+  PDX_HIP(hipStreamSynchronize(st));
+  *out = res.release();
+  return PDX_OK;
+}
+int64_t pdx_dist_resampled_num_bins(const pdx_dist_resampled* g) { return g ? g->G : -1; }
+int pdx_dist_resampled_destroy(pdx_dist_resampled* g) {
+  delete g;
+  return PDX_OK;
+}
+// labels: PDX_TIMESTAMP_NS, capacity >= num_bins; outs[k]: the k-th aggregate (dtype as pdx_groupby_agg; a validity buffer is filled when given)
+int pdx_dist_resampled_fetch(const pdx_dist_resampled* g, pdx_mut_column* labels, pdx_mut_column* outs, void* stream) {
+  if (!g) return fail(PDX_INVALID, "pdx_dist_resampled_fetch: null handle");
+  hipStream_t st = as_stream(stream);
+  const size_t b = (size_t)g->G * 8;
+  if (labels) {
+    if (labels->length < g->G || (g->G && !labels->values)) return fail(PDX_INVALID, "pdx_dist_resampled_fetch: label output too small");
+    labels->length = g->G;
+    labels->null_count = 0;
+    if (b) PDX_HIP(hipMemcpyAsync(labels->values, g->labels, b, hipMemcpyDeviceToDevice, st));
+  }
+  for (int k = 0; outs && k < g->nk; ++k) {
+    pdx_mut_column& o = outs[k];
+    if (o.length < g->G || (g->G && !o.values)) return fail(PDX_INVALID, "pdx_dist_resampled_fetch: output too small");
+    if (o.dtype != g->dtypes[(size_t)k]) return fail(PDX_INVALID, "pdx_dist_resampled_fetch: output dtype does not match the aggregate's result type");
+    o.length = g->G;
+    if (b) PDX_HIP(hipMemcpyAsync(o.values, g->vals[(size_t)k], b, hipMemcpyDeviceToDevice, st));
+    if (g->oks[(size_t)k]) {
+      if (!o.validity) return fail(PDX_INVALID, "pdx_dist_resampled_fetch: the result carries nulls but an output has no validity buffer");
+      if (g->G) hipLaunchKernelGGL(k_i64_to_bits, dim3(grid_for((g->G + 7) / 8, 256)), dim3(256), 0, st, g->oks[(size_t)k], g->G, static_cast<uint8_t*>(o.validity));
+      o.null_count = -1;
+    } else {
+      if (o.validity && g->G) PDX_HIP(hipMemsetAsync(o.validity, 0xFF, (size_t)(g->G + 7) / 8, st));
+      o.null_count = 0;
+    }
+  }
+  PDX_LAUNCH_CHECK();
+  PDX_HIP(hipStreamSynchronize(st));
+  return PDX_OK;
+}
 
 // Inputs of more than 2^31 - 1 rows (the per-call limit of the 32-bit row ids inside pdx_groupby_create): the rows are cut into chunks,
 // every chunk plays one rank of the exchange above -- a host thread with its own stream on the SAME device, the collectives are

@@ -1133,6 +1133,43 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
 }
 
 
+// adjustDatesAnchored + date_range (src/resample.cpp:85-178, src/core.cpp:308-331), tz == "": the first bin edge and the number of bins
+// of an axis whose smallest / largest timestamps are tmin / tmax.  Host arithmetic only (also used by the sharded resample, where
+// every rank must bin on the WHOLE axis' grid).
+int pdx_resample_grid(int64_t tmin, int64_t tmax, int64_t freq_ns, int closed_right, int origin_type, int64_t origin_custom_ns, int64_t offset_ns,
+                      int64_t* first_edge, int64_t* num_bins) {
+  if (!first_edge || !num_bins) return fail(PDX_INVALID, "pdx_resample_grid: null output");
+  if (freq_ns <= 0) return fail(PDX_INVALID, "FREQ must be positive");
+  auto floor_div = [](long long a, long long b) { long long q = a / b, r = a % b; return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q; };
+  const long long day = 86400000000000LL;
+  long long first = tmin, last = tmax, origin = 0;
+  switch (origin_type & ~PDX_ORIGIN_SHARD) {
+    case PDX_ORIGIN_EPOCH: origin = 0; break;
+    case PDX_ORIGIN_START_DAY: origin = floor_div(first, day) * day; break;
+    case PDX_ORIGIN_START: origin = first; break;
+    case PDX_ORIGIN_END: origin = last; break;
+    case PDX_ORIGIN_END_DAY: origin = floor_div(last, day) * day; break;
+    default: origin = origin_custom_ns; break;
+  }
+  origin += offset_ns;
+  long long foffset = (first - origin) % freq_ns, loffset = (last - origin) % freq_ns;
+  if (closed_right) {
+    if (foffset > 0) first -= foffset; else first -= freq_ns;
+    if (loffset > 0) last += freq_ns - loffset;
+  } else {
+    if (foffset > 0) first -= foffset;
+    if (loffset > 0) last += freq_ns - loffset; else last += freq_ns;
+  }
+  if (first >= last) return fail(PDX_INVALID, "start date has to be less than end date");
+  long long nedges = (last - first) / freq_ns + 1;  // date_range: first + k*freq <= last (src/core.cpp:308-331)
+  long long last_edge = first + (nedges - 1) * freq_ns;
+  if (tmin < first) return fail(PDX_INVALID, "Values falls before first bin");
+  if (tmax > last_edge) return fail(PDX_INVALID, "Values falls after last bin");
+  *first_edge = first;
+  *num_bins = nedges - 1;
+  return PDX_OK;
+}
+
 int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right, int label_right, int origin_type,
                         int64_t origin_custom_ns, int64_t offset_ns, void* stream, pdx_groupby** out) {
   PDX_TRY(check_column(ts, "pdx_resample_create"));
@@ -1177,35 +1214,11 @@ int pdx_resample_create(const pdx_column* ts, int64_t freq_ns, int closed_right,
   }
   if (rc != PDX_OK) return rc;
   if (hbad) return fail(PDX_INVALID, "pdx_resample_create: timestamps must be sorted ascending");
-  // adjustDatesAnchored (src/resample.cpp:85-178), tz == ""
-  auto floor_div = [](long long a, long long b) { long long q = a / b, r = a % b; return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q; };
-  const long long day = 86400000000000LL;
-  long long first = mn, last = mx, origin = 0;
   const bool is_shard = (origin_type & PDX_ORIGIN_SHARD) != 0;
   origin_type &= ~PDX_ORIGIN_SHARD;
-  switch (origin_type) {
-    case PDX_ORIGIN_EPOCH: origin = 0; break;
-    case PDX_ORIGIN_START_DAY: origin = floor_div(first, day) * day; break;
-    case PDX_ORIGIN_START: origin = first; break;
-    case PDX_ORIGIN_END: origin = last; break;
-    case PDX_ORIGIN_END_DAY: origin = floor_div(last, day) * day; break;
-    default: origin = origin_custom_ns; break;
-  }
-  origin += offset_ns;
-  long long foffset = (first - origin) % freq_ns, loffset = (last - origin) % freq_ns;
-  if (closed_right) {
-    if (foffset > 0) first -= foffset; else first -= freq_ns;
-    if (loffset > 0) last += freq_ns - loffset;
-  } else {
-    if (foffset > 0) first -= foffset;
-    if (loffset > 0) last += freq_ns - loffset; else last += freq_ns;
-  }
-  if (first >= last) return fail(PDX_INVALID, "start date has to be less than end date");
-  long long nedges = (last - first) / freq_ns + 1;  // date_range: first + k*freq <= last (src/core.cpp:308-331)
-  long long last_edge = first + (nedges - 1) * freq_ns;
-  if (mn < first) return fail(PDX_INVALID, "Values falls before first bin");
-  if (mx > last_edge) return fail(PDX_INVALID, "Values falls after last bin");
-  long long nbins = nedges - 1;
+  int64_t first_edge = 0, num_bins = 0;
+  PDX_TRY(pdx_resample_grid(mn, mx, freq_ns, closed_right, origin_type, origin_custom_ns, offset_ns, &first_edge, &num_bins));
+  const long long first = first_edge, nbins = num_bins;
   if (n < nbins && !is_shard) return fail(PDX_INVALID, "upSampling is not implemented.");  // GroupInfo::upsampling, src/resample.h:14-17
   gb->bin = BinParams{t, first, freq_ns, 1.0 / (double)freq_ns, closed_right};
   gb->label_base = first + (label_right ? freq_ns : 0);

@@ -432,6 +432,36 @@ class CDist:
         L.check(self.lib.pdx_dist_groupby_sum_mean_count(self._h, C.byref(ck), C.byref(cv), int(row_offset), K._stream(), C.byref(h)))
         return _fetch_dist_result(self.lib, h, keys.dtype)
 
+    def resample(self, ts, vals, kinds, freq_ns, closed_right=False, label_right=False, origin=L.ORIGIN_START_DAY, origin_custom_ns=0, offset_ns=0):
+        """pd::resample(...).{kinds}(col) over a sorted axis sharded by row ranges, inside the library (pdx_dist_resample).
+        -> {"labels": int64 tensor, "outs": [(values tensor, valid bool tensor | None) per kind]} on every rank."""
+        import ctypes as C
+
+        from . import column as K
+
+        kinds = list(kinds)
+        h = C.c_void_p()
+        ct, cv = ts.c(), vals.c()
+        karr = (C.c_int * len(kinds))(*kinds)
+        L.check(self.lib.pdx_dist_resample(self._h, C.byref(ct), C.byref(cv), karr, len(kinds), int(freq_ns), int(bool(closed_right)), int(bool(label_right)),
+                                           int(origin), int(origin_custom_ns), int(offset_ns), K._stream(), C.byref(h)))
+        try:
+            G = int(self.lib.pdx_dist_resampled_num_bins(h))
+            labels = K.Column.empty(L.TIMESTAMP_NS, G)
+            outs = [K.Column.empty(K._AGG_OUT_DT[k](vals.dtype), G, with_validity=True) for k in kinds]
+            lm, marr = labels.mut(), K._mut_array(outs)
+            L.check(self.lib.pdx_dist_resampled_fetch(h, C.byref(lm), marr, K._stream()))
+            labels._adopt(lm)
+            for i, o in enumerate(outs):
+                o._adopt(marr[i])
+        finally:
+            self.lib.pdx_dist_resampled_destroy(h)
+        res = []
+        for o in outs:
+            _, ok = o.to_numpy() if o.null_count != 0 else (None, None)
+            res.append((o.values[:G], None if ok is None else torch.from_numpy(ok).to(K._device())))
+        return {"labels": labels.values[:G], "outs": res}
+
     def concat(self, col):
         """all-gather(v) of one column's shards in rank order (pdx_dist_concat)."""
         import ctypes as C

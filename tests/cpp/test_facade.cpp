@@ -402,6 +402,17 @@ static void test_sharded_groupby_from_cpp() {
   Series withnull(std::vector<double>{1.0, std::nan(""), 3.0});
   Array cn = dist::concat(comm, withnull.m_array, 3);
   REQUIRE((cn.valid_flags() == std::vector<bool>{true, false, true}));
+  // resample over the "sharded" axis == the single-GPU Resampler (tests/series_resample_test.cpp shape: 1-minute data, 5-minute bins)
+  std::vector<long> ts(600);
+  std::vector<double> tv(600);
+  for (int i = 0; i < 600; ++i) { ts[(size_t)i] = 946684800000000000L + (long)i * 60000000000L; tv[(size_t)i] = 0.5 * (i % 11) - 2.0; }
+  Array axis = Array::Make(ts);
+  axis.dtype = PDX_TIMESTAMP_NS;
+  Series rs = dist::resample_agg(comm, axis, Array::Make(tv), PDX_AGG_MEAN, 300000000000L);
+  DataFrame tdf({"v"}, {Array::Make(tv)}, axis);
+  DataFrame one = tdf.resample("5T").mean();
+  REQUIRE(rs.size() == 120 && (rs.values<double>() == one["v"].values<double>()));
+  REQUIRE((rs.m_index->values_as<long>() == one.m_index->values_as<long>()));
   unsetenv("PDX_DIST_FORCE_COLLECTIVES");
 }
 

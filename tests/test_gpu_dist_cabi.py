@@ -48,6 +48,49 @@ def _to_host(res):
             "outs": [v.cpu().numpy() for v, _ in res["outs"]], "records": res["records"]}
 
 
+def _resample_data():
+    rng = np.random.default_rng(3)
+    n = 200_003
+    minute = 60 * 10**9
+    ts = 1_600_000_000 * 10**9 + np.sort(rng.integers(0, 900 * minute, n)).astype(np.int64)
+    v = rng.standard_normal(n) * 10.0 ** rng.integers(-4, 7, n)
+    ok = rng.random(n) > 0.07
+    return ts, v, ok, minute
+
+
+RESAMPLE_CASES = (("plain", False, dict(closed_right=False, label_right=False, origin=1)),
+                  ("nulls_right", True, dict(closed_right=True, label_right=True, origin=2, offset_ns=7 * 10**9)))
+
+
+def _resample_cases(cd, rank, world, L, Column):
+    ts, v, ok, minute = _resample_data()
+    n = len(ts)
+    cuts = [n * q // world for q in range(world + 1)]
+    if world == 3:
+        cuts = [0, n * 30 // 100, n * 30 // 100 + 17, n]  # a 17-row shard: its rows all belong to a bin that opened on the rank before
+    lo, hi = cuts[rank], cuts[rank + 1]
+    out = {}
+    for name, nulls, kw in RESAMPLE_CASES:
+        res = cd.resample(Column.from_numpy(ts[lo:hi], dtype=L.TIMESTAMP_NS), Column.from_numpy(v[lo:hi], ok[lo:hi] if nulls else None), [0, 1, 2, 3, 4],
+                          5 * minute, **kw)
+        out[name] = {"labels": res["labels"].cpu().numpy(), "outs": [(a.cpu().numpy(), None if b is None else b.cpu().numpy()) for a, b in res["outs"]]}
+    return out
+
+
+def _check_resample(got):
+    ts, v, ok, minute = _resample_data()
+    for name, nulls, kw in RESAMPLE_CASES:
+        exp = [orc.resample_agg(k, ts, v, 5 * minute, valid=ok if nulls else None, **kw) for k in (0, 1, 2, 3, 4)]
+        assert np.array_equal(got[name]["labels"], exp[0][0]), name
+        for (gv, gok), (_, ev, eok) in zip(got[name]["outs"], exp):
+            eok = np.asarray(eok, bool)
+            assert (gok is None and eok.all()) or np.array_equal(gok, eok), name
+            if ev.dtype == np.float64:
+                assert np.array_equal(gv.view(np.uint64)[eok], ev.view(np.uint64)[eok]), name
+            else:
+                assert np.array_equal(gv[eok], ev[eok]), name
+
+
 def _rccl_worker(q):
     os.environ["PDX_DIST_FORCE_COLLECTIVES"] = "1"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -70,6 +113,7 @@ def _rccl_worker(q):
     ok = np.arange(1000) % 5 != 0
     c = cd.concat(Column.from_numpy(v, ok, offset=3))
     out["concat"] = c.to_numpy()
+    out["resample"] = _resample_cases(cd, 0, 1, L, Column)
     cd.close()
     q.put(out)
 
@@ -91,6 +135,7 @@ def test_c_abi_sharded_one_rank_rccl_on_the_wire():
         _check(got[name], keys, vals, kvalid)
     cv, cok = got["concat"]
     assert np.array_equal(cv, np.arange(1000, dtype=np.float64) / 7) and np.array_equal(cok, np.arange(1000) % 5 != 0)
+    _check_resample(got["resample"])
 
 
 def _gloo_worker(rank, world, port, q):
@@ -121,6 +166,7 @@ def _gloo_worker(rank, world, port, q):
         cuts = [0, 1, 7003, 10_000]
         lo, hi = cuts[rank], cuts[rank + 1]
         out["concat"] = cd.concat(Column.from_numpy(v[lo:hi], ok[lo:hi] if rank != 1 else None)).to_numpy()   # rank 1's shard has no bitmap
+        out["resample"] = _resample_cases(cd, rank, world, L, Column)
         cd.close()
         if rank == 0:
             q.put(out)
@@ -151,6 +197,7 @@ def test_c_abi_sharded_three_ranks_one_gpu():
     ok[1:7003] = True
     cv, cok = got["concat"]
     assert np.array_equal(cok, ok) and np.array_equal(cv[ok].view(np.uint64), v[ok].view(np.uint64))
+    _check_resample(got["resample"])
 
 
 @pytest.mark.parametrize("shape", ["four_chunks", "ragged_seven", "null_keys_bit_offsets", "one_chunk"])

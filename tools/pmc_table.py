@@ -7,7 +7,7 @@ cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            k = r["Kernel_Name"].split("(")[0][:60]
+            k = r["Kernel_Name"].split("(")[0][:150]
             tab[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[k][r["Counter_Name"]] += 1
 names = sorted({c for k in tab for c in tab[k]})
