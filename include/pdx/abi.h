@@ -130,6 +130,10 @@ typedef enum pdx_origin {
 
 /* ---------------------------------------------------------------- runtime */
 int pdx_abi_version(void);
+/* "pdx-hip abi <version> gfx950 sources <digest>": the digest (sha256 prefix over the .hip / .hpp files under csrc and this header, computed by
+ * __graft_entry__.build()) names the source tree the loaded library was compiled from; tests/test_abi_symbols.py compares it with the
+ * tree, so a stale in-tree .so cannot pass for a build of the current sources. */
+const char* pdx_build_info(void);
 /* Select the HIP device for the calling thread and create the scratch pool.  Idempotent. */
 int pdx_init(int device);
 int pdx_shutdown(void);

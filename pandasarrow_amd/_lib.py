@@ -63,6 +63,7 @@ _COL = C.POINTER(PdxColumn)
 _MUT = C.POINTER(PdxMutColumn)
 ABI_SYMBOLS = {
     "pdx_abi_version": (C.c_int, []),
+    "pdx_build_info": (C.c_char_p, []),
     "pdx_init": (C.c_int, [C.c_int]),
     "pdx_shutdown": (C.c_int, []),
     "pdx_last_error": (C.c_char_p, []),

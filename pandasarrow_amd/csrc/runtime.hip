@@ -280,6 +280,10 @@ using namespace pdx;
 extern "C" {
 
 int pdx_abi_version(void) { return PDX_ABI_VERSION; }
+#ifndef PDX_SOURCE_HASH
+#define PDX_SOURCE_HASH "unknown"
+#endif
+const char* pdx_build_info(void) { return "pdx-hip abi " "1" " gfx950 sources " PDX_SOURCE_HASH; }
 
 int pdx_init(int device) {
   int count = 0;

@@ -36,6 +36,17 @@ def test_library_exports_every_symbol(lib):
     assert lib.load().pdx_abi_version() == 1
 
 
+def test_loaded_library_was_built_from_these_sources(lib):
+    """pdx_build_info() carries the digest of the sources the library was compiled from (written into runtime.hip's object by
+    __graft_entry__.build_hip): the in-tree .so that the GPU tests load cannot be a leftover of older sources"""
+    import __graft_entry__ as ge
+    import bench
+
+    info = lib.load().pdx_build_info().decode()
+    assert info.startswith("pdx-hip abi 1 gfx950 sources "), info
+    assert info.split()[-1] == ge.source_hash() == bench.source_hash(), (info, ge.source_hash())
+
+
 def test_no_cpu_fallback(lib):
     import torch
 
