@@ -501,6 +501,14 @@ const char* pdx_parquet_metadata_key(const pdx_parquet_file* file, int i);
 const char* pdx_parquet_metadata_value(const pdx_parquet_file* file, int i);
 int pdx_parquet_load(pdx_parquet_file* file, void* stream);
 int pdx_parquet_column(const pdx_parquet_file* file, int i, pdx_column* out);
+/* DataFrame::toParquet (src/dataframe.cpp:685-724: one record batch through parquet::arrow::WriteTable with default properties): the
+ * equally long columns as ONE row group of uncompressed v1 data pages with PLAIN values; an OPTIONAL column's definition levels are one
+ * bit-packed run per page whose payload IS the Arrow validity bitmap of the page's rows.  Columns without a validity bitmap are
+ * REQUIRED; uint64 / timestamp[ns] carry their logical types.  Assembled on the host (columns_on_host != 0: the pdx_column pointers
+ * are host memory); *out_blob is malloc'ed by the library: release it with pdx_parquet_free_blob.  Readable by Arrow / pyarrow and by
+ * pdx_parquet_open. */
+int pdx_parquet_write(const pdx_column* cols, const char* const* names, int ncols, int columns_on_host, void* stream, void** out_blob, size_t* out_size);
+int pdx_parquet_free_blob(void* blob);
 
 #ifdef __cplusplus
 }

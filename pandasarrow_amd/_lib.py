@@ -156,6 +156,8 @@ ABI_SYMBOLS = {
     "pdx_parquet_metadata_value": (C.c_char_p, [_P, C.c_int]),
     "pdx_parquet_load": (C.c_int, [_P, _P]),
     "pdx_parquet_column": (C.c_int, [_P, C.c_int, _COL]),
+    "pdx_parquet_write": (C.c_int, [_COL, C.POINTER(C.c_char_p), C.c_int, C.c_int, _P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "pdx_parquet_free_blob": (C.c_int, [_P]),
     "pdx_index_union": (C.c_int, [_COL, _COL, C.c_int, _MUT, _P]),
     "pdx_index_intersection": (C.c_int, [_COL, _COL, _MUT, _P]),
     "pdx_argsort": (C.c_int, [_COL, C.c_int, _MUT, _P]),

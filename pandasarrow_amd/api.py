@@ -593,6 +593,19 @@ class DataFrame:
         df.metadata = frame.metadata
         return df
 
+    def toParquet(self, path, index_field=""):
+        """DataFrame::toParquet(filepath, indexField) (src/dataframe.cpp:685-724): the columns, and -- when `index_field` is given -- the
+        index as a last column of that name (concatenateArraysToRecordBatch), as one row group.  path=None returns the bytes."""
+        cols, names = list(self.cols), list(self.names)
+        if index_field:
+            cols.append(_frame_index(self))
+            names.append(index_field)
+        blob = K.parquet_write(cols, names)
+        if path is None:
+            return blob
+        with open(path, "wb") as fh:
+            fh.write(blob)
+
     @staticmethod
     def readParquet(path_or_bytes):
         """DataFrame::readParquet (src/dataframe.cpp:646-683): a Parquet file with ONE row group -> a frame on the device.  The

@@ -674,6 +674,19 @@ class ParquetFile:
         return cols
 
 
+def parquet_write(cols, names) -> bytes:
+    """pdx_parquet_write of device columns -> the bytes of a Parquet file (one row group, PLAIN pages)."""
+    lib = L.load()
+    arr = _col_array(cols)
+    cn = (C.c_char_p * len(names))(*[nm.encode() for nm in names])
+    out, size = C.c_void_p(), C.c_size_t()
+    L.check(lib.pdx_parquet_write(arr, cn, len(cols), 0, _stream(), C.byref(out), C.byref(size)))
+    try:
+        return C.string_at(out, size.value)
+    finally:
+        lib.pdx_parquet_free_blob(out)
+
+
 def ipc_write(cols, names, metadata=None) -> bytes:
     """One schema + one record batch (+ custom metadata) + end-of-stream, the layout DataFrame::toBinary produces."""
     lib = L.load()

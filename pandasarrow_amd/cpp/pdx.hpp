@@ -857,6 +857,34 @@ class DataFrame {
     }
     return DataFrame(names, cols, std::nullopt);
   }
+  // toParquet(filepath, indexField) (src/dataframe.cpp:685-724): the columns (+ the index as a last column named indexField) as one row group
+  void toParquet(const std::string& path, const std::string& indexField = "") const {
+    std::vector<Array> cols = m_columns;
+    std::vector<std::string> names = m_names;
+    if (!indexField.empty()) {
+      if (m_index) cols.push_back(*m_index);
+      else {
+        std::vector<int64_t> r((size_t)num_rows());
+        for (size_t i = 0; i < r.size(); ++i) r[i] = (int64_t)i;
+        cols.push_back(Array::Make(r));
+      }
+      names.push_back(indexField);
+    }
+    std::vector<pdx_column> cc;
+    std::vector<const char*> cn;
+    for (size_t i = 0; i < cols.size(); ++i) {
+      cc.push_back(cols[i].c());
+      cn.push_back(names[i].c_str());
+    }
+    void* blob = nullptr;
+    size_t size = 0;
+    ThrowOnFailure(pdx_parquet_write(cc.data(), cn.data(), (int)cc.size(), /*columns_on_host=*/0, nullptr, &blob, &size));
+    std::FILE* fh = std::fopen(path.c_str(), "wb");
+    const bool ok = fh && std::fwrite(blob, 1, size, fh) == size;
+    if (fh) std::fclose(fh);
+    pdx_parquet_free_blob(blob);
+    if (!ok) throw std::runtime_error("IOError: Failed to write '" + path + "'");
+  }
   static DataFrame readParquet(const std::string& path) {
     std::FILE* fh = std::fopen(path.c_str(), "rb");
     if (!fh) throw std::runtime_error("IOError: Failed to open local file '" + path + "'");

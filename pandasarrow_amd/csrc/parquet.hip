@@ -18,6 +18,7 @@
 // UNCOMPRESSED and SNAPPY, encodings PLAIN / PLAIN_DICTIONARY / RLE_DICTIONARY (+ RLE levels), data pages v1 and v2.
 // Everything else is refused by pdx_parquet_open with a message that names the column and the feature (strings, nested columns,
 // INT96, DATE / TIME / DECIMAL annotations, GZIP / ZSTD / LZ4 / BROTLI, DELTA_* and BYTE_STREAM_SPLIT encodings, encryption).
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <memory>
@@ -1086,6 +1087,247 @@ int pdx_parquet_column(const pdx_parquet_file* f, int i, pdx_column* out) {
     out->validity = c.null_count > 0 ? c.validity : nullptr;
     out->values = c.values;
   }
+  return PDX_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- writing (DataFrame::toParquet, reference src/dataframe.cpp:685-724)
+// The reference hands one record batch to parquet::arrow::WriteTable with default properties.  This writer emits the same logical
+// content in the simplest valid physical form: ONE row group, per column a chain of uncompressed v1 data pages with PLAIN values; an
+// OPTIONAL column's definition levels are ONE bit-packed run per page -- whose payload is, bit for bit, the Arrow validity bitmap of
+// the page's rows (LSB first, 1 = valid = level 1).  Assembly happens on the host (buffers are fetched once, like pdx_ipc_write).
+namespace pdx {
+namespace {
+struct ThriftOut {
+  std::vector<uint8_t> b;
+  std::vector<int16_t> last{0};
+  void varint(uint64_t v) {
+    while (v >= 0x80) {
+      b.push_back((uint8_t)(v | 0x80));
+      v >>= 7;
+    }
+    b.push_back((uint8_t)v);
+  }
+  void zigzag(int64_t v) { varint(((uint64_t)v << 1) ^ (uint64_t)(v >> 63)); }
+  void field(int16_t id, int type) {
+    const int delta = id - last.back();
+    if (delta > 0 && delta <= 15) b.push_back((uint8_t)((delta << 4) | type));
+    else {
+      b.push_back((uint8_t)type);
+      zigzag(id);
+    }
+    last.back() = id;
+  }
+  void i32(int16_t id, int32_t v) { field(id, 5); zigzag(v); }
+  void i64(int16_t id, int64_t v) { field(id, 6); zigzag(v); }
+  void i8(int16_t id, int8_t v) { field(id, 3); b.push_back((uint8_t)v); }
+  void boolean(int16_t id, bool v) { field(id, v ? 1 : 2); }
+  void str(int16_t id, const std::string& v) { field(id, 8); varint(v.size()); b.insert(b.end(), v.begin(), v.end()); }
+  void list(int16_t id, int elem_type, size_t n) {
+    field(id, 9);
+    if (n < 15) b.push_back((uint8_t)((n << 4) | elem_type));
+    else {
+      b.push_back((uint8_t)(0xF0 | elem_type));
+      varint(n);
+    }
+  }
+  void begin_field_struct(int16_t id) { field(id, 12); last.push_back(0); }
+  void begin_elem_struct() { last.push_back(0); }
+  void end_struct() { b.push_back(0); last.pop_back(); }
+};
+}  // namespace
+}  // namespace pdx
+
+extern "C" {
+
+int pdx_parquet_write(const pdx_column* cols, const char* const* names, int ncols, int columns_on_host, void* stream, void** out_blob, size_t* out_size) {
+  if ((ncols > 0 && (!cols || !names)) || ncols <= 0 || !out_blob || !out_size) return fail(PDX_INVALID, "pdx_parquet_write: bad argument");
+  hipStream_t st = as_stream(stream);
+  const int64_t n = cols[0].length;
+  constexpr int64_t kPageRows = 1 << 20;  // rows per data page (a multiple of 8: pages start on a byte of the validity bitmap)
+  std::vector<uint8_t> file{'P', 'A', 'R', '1'};
+  struct ChunkInfo {
+    int64_t first_page = 0, bytes = 0, nulls = 0;
+  };
+  std::vector<ChunkInfo> chunks((size_t)ncols);
+  auto fetch = [&](void* dst, const void* src, size_t bytes) -> int {
+    if (!bytes) return PDX_OK;
+    if (columns_on_host) memcpy(dst, src, bytes);
+    else {
+      PDX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+      PDX_HIP(hipStreamSynchronize(st));
+    }
+    return PDX_OK;
+  };
+  // bits [bit_off, bit_off + nbits) of a bitmap, re-based to bit 0
+  auto fetch_bits = [&](std::vector<uint8_t>& dst, const uint8_t* src, int64_t bit_off, int64_t nbits) -> int {
+    dst.assign((size_t)((nbits + 7) / 8) + 1, 0);
+    if (!nbits) return PDX_OK;
+    const int64_t b0 = bit_off >> 3, nb = ((bit_off + nbits + 7) >> 3) - b0;
+    const int sh = (int)(bit_off & 7);
+    std::vector<uint8_t> tmp((size_t)nb + 1, 0);
+    PDX_TRY(fetch(tmp.data(), src + b0, (size_t)nb));
+    for (int64_t k = 0; k < (nbits + 7) / 8; ++k) dst[(size_t)k] = sh ? (uint8_t)((tmp[(size_t)k] >> sh) | (tmp[(size_t)k + 1] << (8 - sh))) : tmp[(size_t)k];
+    if (nbits & 7) dst[(size_t)((nbits - 1) / 8)] &= (uint8_t)((1u << (nbits & 7)) - 1u);
+    return PDX_OK;
+  };
+  for (int c = 0; c < ncols; ++c) {
+    PDX_TRY(check_column(&cols[c], "pdx_parquet_write"));
+    if (cols[c].length != n) return fail(PDX_INVALID, "pdx_parquet_write: all columns must have the same length");
+    if (!names[c]) return fail(PDX_INVALID, "pdx_parquet_write: null column name");
+    const int dt = cols[c].dtype;
+    if (dt < PDX_INT64 || dt > PDX_TIMESTAMP_NS) return fail(PDX_INVALID, "pdx_parquet_write: unknown dtype");
+    const bool optional = validity_or_null(&cols[c]) != nullptr;
+    std::vector<uint8_t> valid, bits;
+    std::vector<uint64_t> vals;
+    if (optional) PDX_TRY(fetch_bits(valid, static_cast<const uint8_t*>(cols[c].validity), cols[c].offset, n));
+    if (dt == PDX_BOOL) PDX_TRY(fetch_bits(bits, static_cast<const uint8_t*>(cols[c].values), cols[c].offset, n));
+    else {
+      vals.resize((size_t)n);
+      PDX_TRY(fetch(vals.data(), static_cast<const uint64_t*>(cols[c].values) + cols[c].offset, (size_t)n * 8));
+    }
+    chunks[(size_t)c].first_page = (int64_t)file.size();
+    for (int64_t r0 = 0; r0 < n || (n == 0 && r0 == 0); r0 += kPageRows) {
+      const int64_t rows = std::min<int64_t>(kPageRows, n - r0);
+      std::vector<uint8_t> payload;
+      int64_t nonnull = rows;
+      if (optional) {
+        const int64_t groups = (rows + 7) / 8;
+        ThriftOut hv;
+        hv.varint(((uint64_t)groups << 1) | 1u);  // ONE bit-packed run: `groups` groups of 8 one-bit levels = the validity bytes
+        const uint32_t len = (uint32_t)(hv.b.size() + (size_t)groups);
+        payload.resize(4);
+        memcpy(payload.data(), &len, 4);
+        payload.insert(payload.end(), hv.b.begin(), hv.b.end());
+        const uint8_t* vb = valid.data() + r0 / 8;
+        payload.insert(payload.end(), vb, vb + groups);
+        if (rows & 7) payload.back() &= (uint8_t)((1u << (rows & 7)) - 1u);
+        nonnull = 0;
+        for (int64_t k = 0; k < groups; ++k) nonnull += __builtin_popcount(payload[payload.size() - (size_t)groups + (size_t)k]);
+        chunks[(size_t)c].nulls += rows - nonnull;
+      }
+      auto is_valid = [&](int64_t i) { return !optional || ((valid[(size_t)(i >> 3)] >> (i & 7)) & 1); };
+      if (dt == PDX_BOOL) {  // PLAIN booleans: the non-null values bit-packed, LSB first
+        const size_t at = payload.size();
+        payload.resize(at + (size_t)((nonnull + 7) / 8), 0);
+        int64_t j = 0;
+        for (int64_t i = r0; i < r0 + rows; ++i)
+          if (is_valid(i)) {
+            if ((bits[(size_t)(i >> 3)] >> (i & 7)) & 1) payload[at + (size_t)(j >> 3)] |= (uint8_t)(1u << (j & 7));
+            ++j;
+          }
+      } else {  // PLAIN 8-byte values of the non-null rows
+        const size_t at = payload.size();
+        payload.resize(at + (size_t)nonnull * 8);
+        if (nonnull == rows) memcpy(payload.data() + at, vals.data() + r0, (size_t)rows * 8);
+        else {
+          int64_t j = 0;
+          for (int64_t i = r0; i < r0 + rows; ++i)
+            if (is_valid(i)) memcpy(payload.data() + at + (size_t)(j++) * 8, &vals[(size_t)i], 8);
+        }
+      }
+      if (payload.size() > 0x7FFFFFF0u) return fail(PDX_INVALID, "pdx_parquet_write: page too large");
+      ThriftOut ph;  // PageHeader
+      ph.i32(1, 0);  // DATA_PAGE
+      ph.i32(2, (int32_t)payload.size());
+      ph.i32(3, (int32_t)payload.size());
+      ph.begin_field_struct(5);  // DataPageHeader
+      ph.i32(1, (int32_t)rows);
+      ph.i32(2, kEncPlain);
+      ph.i32(3, kEncRle);
+      ph.i32(4, kEncRle);
+      ph.end_struct();
+      ph.b.push_back(0);
+      file.insert(file.end(), ph.b.begin(), ph.b.end());
+      file.insert(file.end(), payload.begin(), payload.end());
+      if (n == 0) break;
+    }
+    chunks[(size_t)c].bytes = (int64_t)file.size() - chunks[(size_t)c].first_page;
+  }
+  // ---- footer
+  ThriftOut f;
+  f.i32(1, 2);  // version
+  f.list(2, 12, (size_t)ncols + 1);
+  f.begin_elem_struct();  // root
+  f.str(4, "schema");
+  f.i32(5, ncols);
+  f.end_struct();
+  for (int c = 0; c < ncols; ++c) {
+    const int dt = cols[c].dtype;
+    f.begin_elem_struct();
+    f.i32(1, dt == PDX_BOOL ? kPqBool : dt == PDX_FLOAT64 ? kPqDouble : kPqInt64);
+    f.i32(3, validity_or_null(&cols[c]) ? 1 : 0);  // OPTIONAL / REQUIRED
+    f.str(4, names[c]);
+    if (dt == PDX_UINT64) f.i32(6, 14);  // ConvertedType UINT_64
+    if (dt == PDX_UINT64) {
+      f.begin_field_struct(10);  // LogicalType
+      f.begin_field_struct(10);  // INTEGER
+      f.i8(1, 64);
+      f.boolean(2, false);
+      f.end_struct();
+      f.end_struct();
+    } else if (dt == PDX_TIMESTAMP_NS) {
+      f.begin_field_struct(10);
+      f.begin_field_struct(8);  // TIMESTAMP
+      f.boolean(1, false);      // isAdjustedToUTC
+      f.begin_field_struct(2);  // unit
+      f.begin_field_struct(3);  // NANOS
+      f.end_struct();
+      f.end_struct();
+      f.end_struct();
+      f.end_struct();
+    }
+    f.end_struct();
+  }
+  f.i64(3, n);
+  f.list(4, 12, 1);
+  f.begin_elem_struct();  // RowGroup
+  f.list(1, 12, (size_t)ncols);
+  int64_t total = 0;
+  for (int c = 0; c < ncols; ++c) {
+    const ChunkInfo& ci = chunks[(size_t)c];
+    const int dt = cols[c].dtype;
+    total += ci.bytes;
+    f.begin_elem_struct();  // ColumnChunk
+    f.i64(2, ci.first_page);
+    f.begin_field_struct(3);  // ColumnMetaData
+    f.i32(1, dt == PDX_BOOL ? kPqBool : dt == PDX_FLOAT64 ? kPqDouble : kPqInt64);
+    f.list(2, 5, 2);
+    f.zigzag(kEncPlain);
+    f.zigzag(kEncRle);
+    f.list(3, 8, 1);
+    f.varint(strlen(names[c]));
+    f.b.insert(f.b.end(), names[c], names[c] + strlen(names[c]));
+    f.i32(4, kCodecNone);
+    f.i64(5, n);
+    f.i64(6, ci.bytes);
+    f.i64(7, ci.bytes);
+    f.i64(9, ci.first_page);
+    f.begin_field_struct(12);  // Statistics
+    f.i64(3, ci.nulls);
+    f.end_struct();
+    f.end_struct();
+    f.end_struct();
+  }
+  f.i64(2, total);
+  f.i64(3, n);
+  f.end_struct();
+  f.str(6, "pdx-hip (PandasArrow MI355X backend)");
+  f.b.push_back(0);
+  file.insert(file.end(), f.b.begin(), f.b.end());
+  const uint32_t flen = (uint32_t)f.b.size();
+  file.insert(file.end(), reinterpret_cast<const uint8_t*>(&flen), reinterpret_cast<const uint8_t*>(&flen) + 4);
+  file.insert(file.end(), {'P', 'A', 'R', '1'});
+  void* blob = malloc(file.size());
+  if (!blob) return fail(PDX_OOM, "pdx_parquet_write: host allocation failed");
+  memcpy(blob, file.data(), file.size());
+  *out_blob = blob;
+  *out_size = file.size();
+  return PDX_OK;
+}
+int pdx_parquet_free_blob(void* blob) {
+  free(blob);
   return PDX_OK;
 }
 

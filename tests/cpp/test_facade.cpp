@@ -416,6 +416,26 @@ static void test_sharded_groupby_from_cpp() {
   unsetenv("PDX_DIST_FORCE_COLLECTIVES");
 }
 
+// DataFrame::toParquet / readParquet (src/dataframe.cpp:646-724) round trip through a file: device columns -> Parquet -> device columns
+static void test_parquet_round_trip() {
+  std::vector<bool> ok{true, false, true, true, false, true, true};
+  DataFrame df({"x", "y", "flag"}, {Array::Make(std::vector<long>{1, -2, 3, 1L << 40, 5, 6, -7}), Array::Make(std::vector<double>{0.5, 1.5, -2.5, 3.5, 4.5, -0.0, 6.5}, &ok),
+                                    Array::Make(std::vector<bool>{true, false, true, true, false, false, true})},
+               Array::Make(std::vector<long>{10, 11, 12, 13, 14, 15, 16}));
+  const std::string path = "/tmp/pdx_facade_test.parquet";
+  df.toParquet(path, "idx");
+  DataFrame back = DataFrame::readParquet(path);
+  REQUIRE((back.m_names == std::vector<std::string>{"x", "y", "flag", "idx"}));
+  REQUIRE((back["x"].values<long>() == std::vector<long>{1, -2, 3, 1L << 40, 5, 6, -7}));
+  REQUIRE((back["y"].m_array.valid_flags() == ok));
+  auto y = back["y"].values<double>();
+  REQUIRE(y[0] == 0.5 && y[2] == -2.5 && y[3] == 3.5 && std::signbit(y[5]) && y[6] == 6.5);
+  REQUIRE((back["flag"].values<int>() == std::vector<int>{1, 0, 1, 1, 0, 0, 1}));
+  REQUIRE((back["idx"].values<long>() == std::vector<long>{10, 11, 12, 13, 14, 15, 16}));
+  REQUIRE_THROWS(DataFrame::readParquet("/tmp/pdx_no_such_file.parquet"));
+  std::remove(path.c_str());
+}
+
 int main() {
   ThrowOnFailure(pdx_init(0));
   test_series_math();
@@ -429,6 +449,7 @@ int main() {
   test_frame_compare_logical_reindex();
   test_groupby_bound_columns();
   test_sharded_groupby_from_cpp();
+  test_parquet_round_trip();
   std::printf("%d checks, %d failed\n", g_checks, g_failed);
   return g_failed ? 1 : 0;
 }

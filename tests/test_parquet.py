@@ -80,6 +80,52 @@ def test_rejects_garbage_truncation_and_crafted_footers(lib):
             lib.load().pdx_parquet_destroy(h)
 
 
+def _bits(x):
+    return np.concatenate([np.packbits(np.asarray(x, bool), bitorder="little"), np.zeros(16, np.uint8)])
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 64, 1000, 1_048_576 + 13])
+def test_write_host_columns_read_by_pyarrow(lib, n):
+    """pdx_parquet_write (DataFrame::toParquet, src/dataframe.cpp:685-724) with host-resident columns: Arrow's own reader must give
+    back every value and null; our reader must open the file too.  The last size spans two data pages."""
+    pa = pytest.importorskip("pyarrow")
+    pq = pytest.importorskip("pyarrow.parquet")
+    import io
+
+    L = lib
+    rng = np.random.default_rng(n)
+    a, f = rng.integers(-2**62, 2**62, n + 5), rng.standard_normal(n + 5)
+    bv, vf, vb = rng.random(n + 5) < 0.5, rng.random(n + 5) > 0.2, rng.random(n + 5) > 0.3
+    ts, u = rng.integers(0, 10**18, n + 5), rng.integers(0, 2**63, n + 5).astype(np.uint64) * 2 + 1
+    if n > 3:
+        f[7], f[8] = np.nan, -0.0
+    bb, vfb, vbb = _bits(bv), _bits(vf), _bits(vb)
+    off = 5 if n else 0  # sliced columns: element / bit offset 5
+    cols = (L.PdxColumn * 5)(L.PdxColumn(L.INT64, 0, n, off, 0, None, a.ctypes.data), L.PdxColumn(L.FLOAT64, 0, n, off, -1, vfb.ctypes.data, f.ctypes.data),
+                             L.PdxColumn(L.BOOL, 0, n, off, -1, vbb.ctypes.data, bb.ctypes.data), L.PdxColumn(L.TIMESTAMP_NS, 0, n, off, 0, None, ts.ctypes.data),
+                             L.PdxColumn(L.UINT64, 0, n, off, 0, None, u.ctypes.data))
+    names = (C.c_char_p * 5)(b"a", b"f", b"flag", b"when", b"u")
+    out, sz = C.c_void_p(), C.c_size_t()
+    assert L.load().pdx_parquet_write(cols, names, 5, 1, None, C.byref(out), C.byref(sz)) == 0, L.load().pdx_last_error()
+    data = C.string_at(out, sz.value)
+    L.load().pdx_parquet_free_blob(out)
+    t = pq.read_table(io.BytesIO(data))
+    t.validate(full=True)
+    assert [str(x) for x in t.schema.types] == ["int64", "double", "bool", "timestamp[ns]", "uint64"] and t.schema.names == ["a", "f", "flag", "when", "u"]
+    assert t.num_rows == n and pq.ParquetFile(io.BytesIO(data)).metadata.num_row_groups == (1 if n else 1)
+    sl = slice(off, off + n)
+    col = [t.column(i).combine_chunks() for i in range(5)]
+    assert np.array_equal(col[0].to_numpy(zero_copy_only=False), a[sl]) and col[0].null_count == 0
+    assert col[1].null_count == int((~vf[sl]).sum()) and np.array_equal(np.asarray(col[1].is_valid()), vf[sl])
+    assert np.array_equal(col[1].to_numpy(zero_copy_only=False)[vf[sl]].view(np.uint64), f[sl][vf[sl]].view(np.uint64))
+    assert np.array_equal(np.asarray(col[2].is_valid()), vb[sl]) and np.array_equal(np.asarray(col[2].fill_null(False))[vb[sl]], bv[sl][vb[sl]])
+    assert np.array_equal(col[3].cast(pa.int64()).to_numpy(zero_copy_only=False), ts[sl]) and np.array_equal(col[4].to_numpy(zero_copy_only=False), u[sl])
+    if n:  # our own reader takes our own file (an empty table is refused, as by the reference)
+        rc, h, _keep = _open(L, data)
+        assert rc == 0 and L.load().pdx_parquet_num_rows(h) == n and L.load().pdx_parquet_num_columns(h) == 5
+        L.load().pdx_parquet_destroy(h)
+
+
 # ------------------------------------------------------------------ GPU
 @pytest.fixture(scope="module")
 def px():
@@ -159,3 +205,36 @@ def test_load_detects_corrupt_pages_on_the_device(px):
             failures += 1
             assert "pdx_parquet" in str(e)
     assert failures >= 1
+
+
+@pytest.mark.gpu
+def test_to_parquet_from_device_and_round_trip(px, tmp_path):
+    """DataFrame.toParquet from device columns (incl. a nullable int64, booleans, an index written as the named last column), read back by
+    pyarrow AND by readParquet on the device: every bit returns"""
+    pa = pytest.importorskip("pyarrow")
+    pq = pytest.importorskip("pyarrow.parquet")
+    api, K = px.api, px.K
+    rng = np.random.default_rng(21)
+    n = 300_007
+    v = rng.standard_normal(n)
+    vok = rng.random(n) > 0.1
+    i = rng.integers(-10**15, 10**15, n)
+    iok = rng.random(n) > 0.5
+    b = rng.random(n) > 0.3
+    ts = np.sort(rng.integers(0, 10**18, n))
+    df = api.DataFrame({"v": K.Column.from_numpy(v, vok), "i": K.Column.from_numpy(i, iok), "b": K.Column.from_numpy(b)},
+                       index=K.Column.from_numpy(ts, dtype=px.L.TIMESTAMP_NS))
+    path = tmp_path / "out.parquet"
+    df.toParquet(str(path), "when")
+    t = pq.read_table(str(path))
+    assert t.schema.names == ["v", "i", "b", "when"] and t.num_rows == n
+    assert np.array_equal(np.asarray(t["v"].combine_chunks().is_valid()), vok) and np.array_equal(np.asarray(t["i"].combine_chunks().is_valid()), iok)
+    assert np.array_equal(t["v"].combine_chunks().to_numpy(zero_copy_only=False)[vok].view(np.uint64), v[vok].view(np.uint64))
+    assert np.array_equal(t["when"].combine_chunks().cast(pa.int64()).to_numpy(), ts)
+    back = api.DataFrame.readParquet(str(path))
+    assert back.names == ["v", "i", "b", "when"]
+    for name, exp, ok in (("v", v, vok), ("i", i, iok), ("b", b, None), ("when", ts, None)):
+        got, gok = back[name].col.to_numpy()
+        assert (gok is None and ok is None) or np.array_equal(gok, ok), name
+        sel = slice(None) if ok is None else ok
+        assert np.array_equal(np.asarray(got)[sel], np.asarray(exp)[sel]), name
