@@ -110,6 +110,15 @@ struct pdx_groupby {
   BinParams bin{};
   long long label_base = 0;
   mutable hipStream_t stream = nullptr;  // the stream of the last call that used the handle (pool frees are ordered behind it)
+  // pdx_groupby_create returns without draining its stream (G is known from an earlier read-back; the last small kernels overlap with
+  // the caller's preparation of the first aggregation: ~80 us per step): calls on the SAME stream are ordered behind them by the
+  // stream, calls on another stream wait for this event first
+  hipStream_t create_stream = nullptr;
+  hipEvent_t ready = nullptr;
+  void use_on(hipStream_t st) const {
+    if (ready && st != create_stream) (void)hipStreamWaitEvent(st, ready, 0);
+    stream = st;
+  }
   // bound columns (pdx_groupby_bind): grouped layouts + cached results, least recently used first out when over the byte limit
   std::vector<std::unique_ptr<GroupedLayout>> bound;
   size_t bind_limit = 0;   // 0 = default (a quarter of the device's memory)
@@ -123,6 +132,7 @@ struct pdx_groupby {
     return p;
   }
   ~pdx_groupby() {
+    if (ready) (void)hipEventDestroy(ready);
     for (auto& b : bound) b->stream = stream;
     bound.clear();
     StreamNote note(stream);

@@ -246,7 +246,7 @@ int pdx_groupby_group_values(pdx_groupby* gb, const pdx_column* values, void* st
   if (values->dtype != PDX_FLOAT64 || validity_or_null(values)) return fail(PDX_NOT_IMPLEMENTED, "pdx_groupby_group_values: float64 values without nulls only");
   if (values->length != gb->n) return fail(PDX_INVALID, "pdx_groupby_group_values: values length differs from the grouped key length");
   hipStream_t st = as_stream(stream);
-  gb->stream = st;  // frees of the handle's blocks are ordered behind this stream
+  gb->use_on(st);  // ordered behind the handle's creation; frees of its blocks are ordered behind this stream
   std::unique_ptr<pdx_grouped> gowner(new pdx_grouped());
   gowner->stream = st;
   pdx_grouped* g = gowner.get();

@@ -664,8 +664,11 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
                        block_pre, null_slot, gb->uniques, gb->unique_ok, gb->first_rows, region, gb->gid_of_occ);
   }
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  // no drain of the stream: everything the caller can read on the host (G) is known; later calls are ordered by the stream / the event
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&gb->ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventRecord(gb->ready, st);
   if (e != hipSuccess) return hip_fail(e, "pdx_groupby_create");
+  gb->create_stream = st;
   *out = owner.release();
   return PDX_OK;
 }
@@ -681,7 +684,7 @@ int pdx_groupby_unique_keys(const pdx_groupby* gb, pdx_mut_column* out, void* st
   if (!gb || !out) return fail(PDX_INVALID, "pdx_groupby_unique_keys: null argument");
   if (out->length < gb->G) return fail(PDX_INVALID, "pdx_groupby_unique_keys: output too small");
   hipStream_t st = as_stream(stream);
-  gb->stream = st;  // frees of the handle's blocks are ordered behind this stream
+  gb->use_on(st);  // ordered behind the handle's creation; frees of its blocks are ordered behind this stream
   out->length = gb->G;
   out->null_count = -1;
   if (gb->G == 0) return PDX_OK;
@@ -698,7 +701,7 @@ int pdx_groupby_unique_keys(const pdx_groupby* gb, pdx_mut_column* out, void* st
 int pdx_groupby_first_rows(const pdx_groupby* gb, int64_t* out_rows, void* stream) {
   if (!gb || !out_rows) return fail(PDX_INVALID, "pdx_groupby_first_rows: null argument");
   hipStream_t st = as_stream(stream);
-  gb->stream = st;  // frees of the handle's blocks are ordered behind this stream
+  gb->use_on(st);  // ordered behind the handle's creation; frees of its blocks are ordered behind this stream
   if (gb->G) PDX_HIP(hipMemcpyAsync(out_rows, gb->first_rows, (size_t)gb->G * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
   PDX_HIP(hipStreamSynchronize(st));
   return PDX_OK;
@@ -707,7 +710,7 @@ int pdx_groupby_first_rows(const pdx_groupby* gb, int64_t* out_rows, void* strea
 int pdx_groupby_group_ids(pdx_groupby* gb, uint32_t* out_ids, void* stream) {
   if (!gb || !out_ids) return fail(PDX_INVALID, "pdx_groupby_group_ids: null argument");
   hipStream_t st = as_stream(stream);
-  gb->stream = st;  // frees of the handle's blocks are ordered behind this stream
+  gb->use_on(st);  // ordered behind the handle's creation; frees of its blocks are ordered behind this stream
   if (gb->n == 0) return PDX_OK;
   if (gb->mode == 0 && gb->slot_part)
     hipLaunchKernelGGL(k_part_row_gids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->gid_of_slot, gb->slot_part, gb->rows_part, gb->n,
@@ -724,7 +727,7 @@ int pdx_groupby_group_ids(pdx_groupby* gb, uint32_t* out_ids, void* stream) {
 int pdx_groupby_map_ids(pdx_groupby* gb, const int64_t* map, int64_t* out, void* stream) {
   if (!gb || !map || !out) return fail(PDX_INVALID, "pdx_groupby_map_ids: null argument");
   hipStream_t st = as_stream(stream);
-  gb->stream = st;  // frees of the handle's blocks are ordered behind this stream
+  gb->use_on(st);  // ordered behind the handle's creation; frees of its blocks are ordered behind this stream
   if (gb->n == 0) return PDX_OK;
   if (gb->mode == 0 && gb->slot_part)
     hipLaunchKernelGGL(k_part_row_gids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->gid_of_slot, gb->slot_part, gb->rows_part, gb->n, map,
@@ -890,7 +893,7 @@ int pdx_groupby_bind(pdx_groupby* gb, const pdx_column* values, void* stream) {
   if (values->dtype != PDX_FLOAT64 && values->dtype != PDX_INT64)
     return fail(PDX_NOT_IMPLEMENTED, "pdx_groupby_bind: values must be int64 or float64 (boolean columns are order-free: nothing to keep)");
   hipStream_t st = as_stream(stream);
-  gb->stream = st;
+  gb->use_on(st);
   if (find_bound(gb, values)) return PDX_OK;
   std::unique_ptr<GroupedLayout> L(new GroupedLayout());
   L->bound = true;
@@ -953,7 +956,7 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   const bool is_f = values->dtype == PDX_FLOAT64;
   if (!is_f && values->dtype != PDX_INT64) return fail(PDX_NOT_IMPLEMENTED, "pdx_groupby_agg: values must be int64 or float64");
   hipStream_t st = as_stream(stream);
-  gb->stream = st;  // frees of the handle's blocks are ordered behind this stream
+  gb->use_on(st);  // ordered behind the handle's creation; frees of its blocks are ordered behind this stream
   const int64_t n = gb->n, G = gb->G;
   const uint8_t* vvalid = validity_or_null(values);
   AggRequest rq;
@@ -1349,7 +1352,7 @@ int pdx_resample_row_labels(pdx_groupby* gb, int64_t* out_labels, void* stream) 
   if (!gb || !out_labels) return fail(PDX_INVALID, "pdx_resample_row_labels: null argument");
   if (!gb->resample) return fail(PDX_INVALID, "pdx_resample_row_labels: handle was not created by pdx_resample_create");
   hipStream_t st = as_stream(stream);
-  gb->stream = st;  // frees of the handle's blocks are ordered behind this stream
+  gb->use_on(st);  // ordered behind the handle's creation; frees of its blocks are ordered behind this stream
   if (gb->n) hipLaunchKernelGGL(k_row_labels, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->bin, gb->label_base, gb->n, out_labels);
   PDX_LAUNCH_CHECK();
   PDX_HIP(hipStreamSynchronize(st));
