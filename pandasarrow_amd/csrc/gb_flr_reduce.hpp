@@ -12,7 +12,14 @@
 constexpr int kFlrBits = 6;
 constexpr int kFlrLevels = 20;  // a group lies inside one run, a run is <= 2^19 rows (checked by the host), and with nulls a leaf can
                                 // be a single row: <= 2^19 leaves
-constexpr int kFlrItems = 10;   // rows per thread and tile: 3072-row tiles (measured best: 4096 -> 5.6 ms, 3072 -> 4.2 ms, 2048 -> 4.5 ms per 1e9 rows)
+#ifndef PDX_FLR_ITEMS
+#define PDX_FLR_ITEMS 10
+#endif
+#ifndef PDX_FLR_DENSE_WAVES
+#define PDX_FLR_DENSE_WAVES 1
+#endif
+constexpr int kFlrDenseWaves = PDX_FLR_DENSE_WAVES;  // diagnostic: minimum waves per SIMD the dense instantiation is compiled for
+constexpr int kFlrItems = PDX_FLR_ITEMS;   // rows per thread and tile: 3072-row tiles (measured best: 4096 -> 5.6 ms, 3072 -> 4.2 ms, 2048 -> 4.5 ms per 1e9 rows)
 constexpr int kFlrTile = kSortBlock * kFlrItems;
 __global__ void k_run_starts(const uint32_t* __restrict__ sorted_keys, int64_t n, int low_bits, int64_t nruns, uint32_t* __restrict__ run_start,
                              unsigned int* __restrict__ max_len) {
@@ -88,7 +95,7 @@ struct RunStateOp {
 // byte in place, then one lane per group walks its leaves in order for the counter pushes (instead of one lane per group adding
 // up all of its rows one by one).  Bit-exact, but not faster yet (11.3 vs 10.7 ms per 1e9 rows at 5 % nulls): opt-in.
 template <typename T, bool DENSE_PW, typename KT = uint32_t, bool NULL_PW = false>
-__global__ void __launch_bounds__(kSortBlock) k_flr_reduce(const KT* __restrict__ keys, const T* __restrict__ vals,
+__global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k_flr_reduce(const KT* __restrict__ keys, const T* __restrict__ vals,
                                                            const uint32_t* __restrict__ run_start, int64_t nruns, int low_bits,
                                                            const uint32_t* __restrict__ gid_of_slot, SegOut out, uint8_t* __restrict__ ok,
                                                            int want_pw, int want_mm, int want_is, int nullable,
