@@ -58,7 +58,7 @@ for k, t in traffic.items():
         continue
     out[k] = {"launches_in_profiled_run": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
 # bench.py tags -> kernels (large-payload instantiations only)
-TAGS = {"radix_scatter": r"k_radix_scatter<\d+, unsigned long", "radix_hist": r"k_radix_hist<", "dense_slots": r"k_dense_slots_tail", "hash_insert": r"k_hash_insert",
+TAGS = {"radix_scatter": r"k_radix_scatter(_occ4)?<\d+, unsigned long", "radix_hist": r"k_radix_hist<", "dense_slots": r"k_dense_slots_tail", "hash_insert": r"k_hash_insert",
         "seg_reduce": r"k_seg_reduce<", "key_minmax": r"k_minmax_partial<long long>", "fused_last_digit_reduce": r"k_flr_(reduce|wave)<",
         "hash_probe_lds": r"k_hash_probe_lds", "hash_bucket_hist": r"k_hash_bucket_hist"}
 by_tag = {}
