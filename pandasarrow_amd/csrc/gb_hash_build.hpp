@@ -256,13 +256,17 @@ __global__ void __launch_bounds__(256) k_hash_probe_part(const long long* __rest
 // streams the bucket's rows once and writes the region back.  Random probes hit LDS banks instead of the L2/TA path, which
 // tops out near 70 G random accesses/s chip-wide however local the table is (measured: profiles/ notes in DESIGN.md).
 constexpr int kLdsRegionMax = 8192;
+#ifndef PDX_HASH_PAIR
+#define PDX_HASH_PAIR 1  // (compile-time diagnostic: 0 = one slot per LDS read in k_hash_probe_lds, probe sequences start on any slot)
+#endif
+constexpr unsigned int kProbeStartMask = PDX_HASH_PAIR ? ~1u : ~0u;
 constexpr int kProbeBlock = 1024;
 __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long* __restrict__ keys_part, const uint32_t* __restrict__ rows_part,
                                                                 const uint32_t* __restrict__ bucket_off,
                                                                 int64_t n, Slot* table, unsigned int cap, unsigned int region,
                                                                 uint32_t* __restrict__ slot_part, HashCtl* ctl, unsigned int pb, int64_t head_rows,
                                                                 uint16_t* __restrict__ idx16 /* slot index inside the bucket's region, or null */) {
-  __shared__ unsigned long long lkeys[kLdsRegionMax];
+  __shared__ __attribute__((aligned(16))) unsigned long long lkeys[kLdsRegionMax];
   __shared__ unsigned int lfirst[kLdsRegionMax];
   __shared__ unsigned int linserted;
   __shared__ unsigned int lspecial[2];
@@ -328,8 +332,43 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
         if (r < lspecial[sp - cap]) atomicMin(&lspecial[sp - cap], r);
         logical = sp;
       } else {
-        unsigned int idx = (h[u] >> pb) & rmask, probes = 0;
+        // The probe sequence starts on an EVEN slot and one 16-byte LDS read looks at two slots: the divergent chain loop of the wave
+        // (it runs to the longest chain among its 64 x 4 rows) makes about half as many trips.  Still plain linear probing over slots
+        // -- a key sits in the first slot of its sequence that was empty when it arrived -- so the chunked tail kernel, which walks
+        // the same sequence slot by slot (same even start), finds every key where this kernel put it.
+        unsigned int idx = (h[u] >> pb) & rmask & kProbeStartMask, probes = 0;
         for (;;) {
+#if PDX_HASH_PAIR
+          const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(&lkeys[idx]);
+          unsigned long long c0 = pr.x, c1 = pr.y;
+          if (c0 == (unsigned long long)key[u]) break;
+          if (c1 == (unsigned long long)key[u]) { idx += 1; break; }
+          if (c0 == (unsigned long long)kEmptyKey) {
+            unsigned long long old = atomicCAS(&lkeys[idx], (unsigned long long)kEmptyKey, (unsigned long long)key[u]);
+            if (old == (unsigned long long)kEmptyKey) {
+              atomicAdd(&linserted, 1u);
+              break;
+            }
+            if (old == (unsigned long long)key[u]) break;
+            c1 = lkeys[idx + 1];  // the slot went to another key in the meantime: the second one may have changed as well
+            if (c1 == (unsigned long long)key[u]) { idx += 1; break; }
+          }
+          if (c1 == (unsigned long long)kEmptyKey) {
+            unsigned long long old = atomicCAS(&lkeys[idx + 1], (unsigned long long)kEmptyKey, (unsigned long long)key[u]);
+            if (old == (unsigned long long)kEmptyKey) {
+              atomicAdd(&linserted, 1u);
+              idx += 1;
+              break;
+            }
+            if (old == (unsigned long long)key[u]) { idx += 1; break; }
+          }
+          idx = (idx + 2) & rmask;
+          probes += 2;
+          if (probes > 512) {  // pathologically long probe chain: the host retries with a larger table (L2 path)
+            atomicExch(&ctl->overflow, 1u);
+            break;
+          }
+#else
           unsigned long long cur = lkeys[idx];
           if (cur == (unsigned long long)key[u]) break;
           if (cur == (unsigned long long)kEmptyKey) {
@@ -345,6 +384,7 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
             atomicExch(&ctl->overflow, 1u);
             break;
           }
+#endif
         }
         if (r < lfirst[idx]) atomicMin(&lfirst[idx], r);
         logical = (idx << pb) | b;
@@ -432,7 +472,7 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds_tail(const long 
         if (r < lspecial[sp - cap]) atomicMin(&lspecial[sp - cap], r);
         logical = sp;
       } else {
-        unsigned int idx = (key_hash32(key[u], false) >> pb) & rmask, probes = 0;
+        unsigned int idx = (key_hash32(key[u], false) >> pb) & rmask & kProbeStartMask, probes = 0;  // (the head kernel's sequence: even start)
         bool found = false, dead = false;
         for (;;) {  // the snapshot
           unsigned long long cur = lkeys[idx];

@@ -424,7 +424,7 @@ template <int BITS, typename V, bool WRITE_KEYS, bool IOTA = false, typename K =
           bool PAYLOAD_DIGIT = false>
 inline void launch_radix_scatter(int64_t ntiles, hipStream_t st, const K* kin, const V* vin, KO* kout, V* vout, int64_t n, int shift, const uint32_t* offsets,
                                  int swz, IotaSrc iota = IotaSrc{nullptr, 0}, int drop = 0, uint32_t* rows_out = nullptr) {
-  if constexpr (sizeof(V) == 8 && !IOTA) {
+  if constexpr (sizeof(V) == 8 && !IOTA && BITS <= 8) {  // (wider digits: the counter arrays alone keep the kernel at 3 workgroups per CU)
     if (scatter_occ4()) {
       hipLaunchKernelGGL((k_radix_scatter_occ4<BITS, V, WRITE_KEYS, IOTA, K, KO, FLAGS, EMIT_ROWS, PAYLOAD_DIGIT>), dim3((unsigned)ntiles), dim3(kScatBlock), 0, st,
                          kin, vin, kout, vout, n, shift, offsets, swz, iota, drop, rows_out);
