@@ -87,3 +87,45 @@ def test_groupby_fuzz(px, monkeypatch, seed, mode):
             pass
         assert (ok is None and eok.all()) or np.array_equal(ok, eok), (seed, mode, kind)
         assert _bits_equal(got, exp, eok), (seed, mode, kind)
+
+
+@pytest.mark.parametrize("mode", ["bound", "bound_fused", "bound_hash_fused"])
+@pytest.mark.parametrize("seed", range(60))
+def test_groupby_fuzz_bound_columns(px, monkeypatch, seed, mode):
+    """the same generator through a BOUND column (pdx_groupby_bind): the kinds one call at a time in the case's random order, then all of
+    them in one call, then each once more -- layouts (fused, full, both) and cached per-group results must serve every request
+    bit-identically to the oracle, whatever was asked before"""
+    if mode == "bound_hash_fused":
+        monkeypatch.setenv("PDX_GROUPBY_DENSE", "0")
+        monkeypatch.setenv("PDX_HASH_PARTITION", "2")
+    if mode.endswith("fused"):
+        monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_MIN_ROWS", "0")
+        monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS", "4")
+        monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_MIN_RUN", "0")
+        monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_HASH", "1")
+    keys, kvalid, vals, vvalid, kinds = _make_case(seed * 104_729 + 7)
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys, kvalid, offset=int(seed % 3)))
+    ids, uniq, isnull, first = orc.group_ids(keys, kvalid)
+    G = len(uniq)
+    assert gb.num_groups == G
+    vcol = px.Column.from_numpy(vals, vvalid, offset=int(seed % 5))
+    gb.bind(vcol)
+    expected = {k: orc.groupby_agg(k, ids, G, vals, vvalid, nthreads=4) for k in set(kinds)}
+
+    def check(kind, out, what):
+        got, ok = out.to_numpy()
+        exp, eok = expected[kind]
+        assert (ok is None and eok.all()) or np.array_equal(ok, eok), (seed, mode, kind, what)
+        assert _bits_equal(got, exp, eok), (seed, mode, kind, what)
+
+    for k in kinds:
+        check(k, gb.agg(vcol, [k])[0], "single")
+        assert gb.last_plan()["bound"] == "1"
+    for k, out in zip(kinds, gb.agg(vcol, kinds)):
+        check(k, out, "together")
+    for k in reversed(kinds):
+        check(k, gb.agg(vcol, [k])[0], "again")
+    other = px.Column.from_numpy(np.arange(len(keys), dtype=np.float64))   # an unbound column on the same handle is never served from the cache
+    got, _ = gb.agg(other, [0])[0].to_numpy()
+    exp, eok = orc.groupby_agg(0, ids, G, np.arange(len(keys), dtype=np.float64), None, nthreads=4)
+    assert _bits_equal(got, exp, eok) and gb.last_plan()["bound"] == "0"
