@@ -41,7 +41,7 @@ struct GroupedLayout {
   void* c_max = nullptr;
   uint8_t* c_ok = nullptr;
   bool have_pw = false, have_is = false, have_mm = false, have_count = false;
-  std::string plan;  // how the layout was built (pdx_groupby_last_plan)
+  std::string plan_fused, plan_full;  // how each form was built (pdx_groupby_last_plan reports the one a call used)
   hipStream_t stream = nullptr;
   std::vector<void*> owned;
   std::vector<size_t> owned_bytes;

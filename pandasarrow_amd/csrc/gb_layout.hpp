@@ -113,7 +113,7 @@ static int build_layout(pdx_groupby* gb, const pdx_column* values, bool allow_fu
     L.vals_sorted = static_cast<const uint64_t*>(values->values) + values->offset;
     L.seg_start = gb->seg_start;
     L.row_valid = vvalid;
-    L.plan = slots + " sort=none layout=full";
+    L.plan_full = slots + " sort=none layout=full";
     return PDX_OK;
   }
   Scratch s;
@@ -271,7 +271,7 @@ static int build_layout(pdx_groupby* gb, const pdx_column* values, bool allow_fu
       L.nruns = nruns;
       L.hmax = hmax;
       L.run_start = run_start;
-      L.plan = slots + " sort=" + sort_desc + " layout=fused";
+      L.plan_fused = slots + " sort=" + sort_desc + " layout=fused";
       return PDX_OK;
     }
   }
@@ -321,6 +321,6 @@ static int build_layout(pdx_groupby* gb, const pdx_column* values, bool allow_fu
     L.seg_start = ss;
     L.out_index = gb->gid_of_occ;
   }
-  L.plan = slots + " sort=" + sort_desc + " layout=full" + (fp.flr ? " skew=1" : "");
+  L.plan_full = slots + " sort=" + sort_desc + " layout=full" + (fp.flr ? " skew=1" : "");
   return PDX_OK;
 }

@@ -1129,7 +1129,7 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
     PDX_LAUNCH_CHECK();
     if (reducer.empty() || reducer == "none") reducer = "seg_product_first_last";
   }
-  gb->last_plan = L.plan + " reducer=" + reducer + (bound ? " bound=1" : " bound=0") + cache_note;
+  gb->last_plan = (use_fused ? L.plan_fused : L.plan_full) + " reducer=" + reducer + (bound ? " bound=1" : " bound=0") + cache_note;
   if (bound && L.bytes != bytes_before) enforce_bind_limit(gb, &L);
   PDX_HIP(hipStreamSynchronize(st));  // outputs are valid on return; scratch and a local layout go back to the pool on exit
   return PDX_OK;
