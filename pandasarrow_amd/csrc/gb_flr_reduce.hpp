@@ -21,6 +21,26 @@ constexpr int kFlrLevels = 20;  // a group lies inside one run, a run is <= 2^19
 constexpr int kFlrDenseWaves = PDX_FLR_DENSE_WAVES;  // diagnostic: minimum waves per SIMD the dense instantiation is compiled for
 constexpr int kFlrItems = PDX_FLR_ITEMS;   // rows per thread and tile: 3072-row tiles (measured best: 4096 -> 5.6 ms, 3072 -> 4.2 ms, 2048 -> 4.5 ms per 1e9 rows)
 constexpr int kFlrTile = kSortBlock * kFlrItems;
+// Dense path: the staged rows are laid out BY LEAF, element pair e of leaf f at doubles [e][f][2] -- the 64 lanes of the leaf phase (one
+// leaf each) read 16 consecutive bytes per lane and instruction, free of bank conflicts, where rows staged in rank order put the lanes
+// 128 bytes apart (two bank groups for 64 lanes).  A tile touches at most tile / 16 + 64 * 30 / 16 leaves (every group may continue an
+// open leaf and leave one open).
+#ifdef PDX_FLR_TIMING  // diagnostic build only (tools/): cycles per phase of the dense kernel, wave 0 and wave 1, summed over all workgroups
+__device__ unsigned long long g_flr_cycles[2][12];
+#define FLR_T(slot)                                                                                     \
+  do {                                                                                                  \
+    if (DENSE_PW && wave < 2) {                                                                         \
+      const unsigned long long now_ = __builtin_readcyclecounter();                                     \
+      tacc_[slot] += now_ - tmark_;                                                                     \
+      tmark_ = now_;                                                                                    \
+    }                                                                                                   \
+  } while (0)
+#else
+#define FLR_T(slot) do { } while (0)
+#endif
+constexpr int kFlrMaxLeaves = kFlrTile / 16 + ((1 << kFlrBits) * 30) / 16;
+constexpr int kFlrLeafStride = kFlrMaxLeaves + 1;
+constexpr int kFlrDenseLevels = 16;  // the dense path has no nulls: a run of <= 2^19 rows (kFlrMaxRun) holds <= 2^15 leaves
 __global__ void k_run_starts(const uint32_t* __restrict__ sorted_keys, int64_t n, int low_bits, int64_t nruns, uint32_t* __restrict__ run_start,
                              unsigned int* __restrict__ max_len) {
   const uint32_t lmask = (1u << low_bits) - 1u;
@@ -105,18 +125,23 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
   constexpr int R = 1 << kFlrBits;
   // staged rows of digit d start at dstart[d] + d: the digits' regions are ~64 rows = 512 B apart, so without the skew the 64
   // lanes of the replay (one digit each) would hit the same LDS bank on every read (measured: 3x slower)
-  __shared__ T svals[kFlrTile + R];
+  __shared__ __attribute__((aligned(16))) T svals[DENSE_PW ? 16 * kFlrLeafStride : kFlrTile + R];
   __shared__ __attribute__((aligned(8))) uint8_t snull[kFlrTile + R];
   __shared__ uint32_t cnt[kSortWaves][R];
   __shared__ unsigned long long match[kSortWaves][R];  // match-any words of the ranking (wave_match_rank)
   __shared__ uint32_t dstart[R + 1];
-  __shared__ double csum[kFlrLevels][R];
+  constexpr int kLevels = DENSE_PW ? kFlrDenseLevels : kFlrLevels;
+  __shared__ double csum[kLevels][R];
   // dense sum/mean/count fast path (no nulls, no min/max/int sum): one THREAD per 16-value leaf, then one lane per group for the
   // few counter pushes -- the open leaf of every group (rows so far + their sequential sum) lives in LDS between tiles
   __shared__ int open_pos[R];
   __shared__ double open_acc[R];
   __shared__ double mu_s[R];
   __shared__ int lp[R + 1];
+  // dense path: digit of every leaf of the tile (written by the digit's lane for its first leaf and by the row that opens any later one)
+  // and, per digit, first leaf | rows in the open leaf << 12 | rows in this tile << 16 -- one read each in the leaf phase
+  __shared__ uint8_t leaf_d[DENSE_PW ? kFlrLeafStride + 3 : 4];
+  __shared__ uint32_t dinfo[R];
   __shared__ uint32_t run_smem[8];
   double* leafsum = reinterpret_cast<double*>(snull);  // (the null flags are unused on this path: room for (tile + 64) / 8 leaf sums)
   constexpr bool dense_pw = DENSE_PW;  // host: want_pw && !want_mm && !want_is && !nullable (a separate instantiation: fewer live registers)
@@ -130,6 +155,9 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
     (&match[0][0])[d] = 0;
   }
   __syncthreads();
+#ifdef PDX_FLR_TIMING
+  unsigned long long tacc_[9] = {};
+#endif
   for (int64_t run = blockIdx.x; run < nruns; run += gridDim.x) {
     const int64_t s = run_start[run], e = run_start[run + 1];
     if (s == e) continue;
@@ -143,13 +171,14 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
     // per-group state (wave 0, lane = top digit)
     double acc = 0.0;
     int pos = 0, root = 0;
+    int tile_c = 0, tile_lp = 0;  // dense path, wave 0: this digit's rows and first leaf in the current tile
     unsigned long long cmask = 0, isum = 0;
     long long nvalid = 0, nrows = 0;
     T vmn = T(0), vmx = T(0);
     int zneg = -1;  // sign of the last zero-valued valid row (-1: none)
     bool has = false;
     if (wave == 0)
-      for (int l = 0; l < kFlrLevels; ++l) csum[l][lane] = 0.0;
+      for (int l = 0; l < kLevels; ++l) csum[l][lane] = 0.0;
     uint32_t key[kFlrItems];
     T val[kFlrItems];
     auto load_tile = [&](int64_t t0) {
@@ -167,9 +196,13 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
       }
     };
     load_tile(s);
+#ifdef PDX_FLR_TIMING
+    unsigned long long tmark_ = __builtin_readcyclecounter();
+#endif
     for (int64_t t0 = s; t0 < e; t0 += kFlrTile) {
       const int rows = (int)(e - t0 < kFlrTile ? e - t0 : kFlrTile);
       uint32_t rank[kFlrItems];
+      FLR_T(0);  // wave 0: the previous tile's pushes; others: nothing
 #pragma unroll
       for (int q = 0; q < kFlrItems; ++q) {
         const int r = wave * (64 * kFlrItems) + q * 64 + lane;
@@ -177,21 +210,56 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
         const uint32_t d = sizeof(KT) == 4 ? ((key[q] & kSortKeyMask) >> low_bits) & (R - 1) : key[q] & (R - 1);
         rank[q] = wave_match_rank(match[wave], cnt[wave], d, active, lane, lt_mask);
       }
+      FLR_T(1);  // ranking (includes waiting for this tile's loads)
       __syncthreads();
+      FLR_T(2);
       if (tid < R) {  // exclusive prefix over waves per digit, then over digits (64 values: one wave)
+        // (the four counters are read in one batch and written once: every dependent LDS round trip here is time the other three
+        //  waves spend at the barrier)
+        uint32_t cw[kSortWaves];
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) cw[w] = cnt[w][tid];
         uint32_t tot = 0;
 #pragma unroll
         for (int w = 0; w < kSortWaves; ++w) {
-          const uint32_t c = cnt[w][tid];
-          cnt[w][tid] = tot;
+          const uint32_t c = cw[w];
+          cw[w] = tot;
           tot += c;
         }
-        const uint32_t inc = wave_inclusive_scan(tot, SumOp());
-        const uint32_t ex = inc - tot;
+        uint32_t base, inc, ex;
+        if (dense_pw) {
+          // leaves touched by this tile, per group: the first one may continue the open leaf, the last one may stay open.  Rows and
+          // leaves are scanned in one word (<= 2560 rows, <= 280 leaves)
+          const int c = (int)tot;
+          const uint32_t nl = c > 0 ? (uint32_t)(pos + c + 15) >> 4 : 0u;
+          const uint32_t both = wave_inclusive_scan(tot | (nl << 16), SumOp());
+          inc = both & 0xFFFFu;
+          ex = inc - tot;
+          const uint32_t lincl = both >> 16, lex = lincl - nl;
+          // the staging base of a digit is its "leaf coordinate": 16 x first leaf + rows already in the open leaf, so base + rank =
+          // 16 x leaf + element
+          base = 16u * lex + (uint32_t)pos;
+          tile_c = c;
+          tile_lp = (int)lex;
+          dinfo[tid] = lex | ((uint32_t)pos << 12) | ((uint32_t)c << 16);
+          if (c > 0) leaf_d[lex] = (uint8_t)tid;
+          if (tid == R - 1) lp[R] = (int)lincl;
+          if (sqdev_mean && c > 0 && !mu_known) {
+            mu = sqdev_mean[gid_of_slot[((uint32_t)lane << low_bits) | (uint32_t)run]];
+            mu_s[lane] = mu;
+            mu_known = true;
+          }
+          nrows += c;
+          nvalid += c;
+        } else {
+          inc = wave_inclusive_scan(tot, SumOp());
+          ex = inc - tot;
+          base = ex;
+          dstart[tid] = ex;
+          if (tid == R - 1) dstart[R] = inc;
+        }
 #pragma unroll
-        for (int w = 0; w < kSortWaves; ++w) cnt[w][tid] += ex;
-        dstart[tid] = ex;
-        if (tid == R - 1) dstart[R] = inc;
+        for (int w = 0; w < kSortWaves; ++w) cnt[w][tid] = cw[w] + base;
         if (NULL_PW) {
           snull[inc + tid] = 2;  // the unused slot behind this group's staged rows: a group boundary for the scan below
           const int c = (int)tot;
@@ -202,85 +270,125 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
           }
           nrows += c;
         }
-        if (dense_pw) {
-          // leaves touched by this tile, per group: the first one may continue the open leaf, the last one may stay open
-          const int c = (int)tot;
-          if (sqdev_mean && c > 0 && !mu_known) {
-            mu = sqdev_mean[gid_of_slot[((uint32_t)lane << low_bits) | (uint32_t)run]];
-            mu_s[lane] = mu;
-            mu_known = true;
-          }
-          const int nl = c > 0 ? (open_pos[lane] + c + 15) >> 4 : 0;
-          const int incl = wave_inclusive_scan(nl, SumOp());
-          lp[lane] = incl - nl;
-          if (lane == R - 1) lp[R] = incl;
-          nrows += c;
-          nvalid += c;
-        }
       }
+      FLR_T(3);  // prefix
       __syncthreads();
+      FLR_T(4);
 #pragma unroll
       for (int q = 0; q < kFlrItems; ++q) {
         const int r = wave * (64 * kFlrItems) + q * 64 + lane;
         if (r < rows) {
           const uint32_t d = sizeof(KT) == 4 ? ((key[q] & kSortKeyMask) >> low_bits) & (R - 1) : key[q] & (R - 1);
-          const uint32_t p = cnt[wave][d] + rank[q] + d;
+          uint32_t p = cnt[wave][d] + rank[q];
+          if (dense_pw) {
+            if ((p & 15u) == 0) leaf_d[p >> 4] = (uint8_t)d;  // this row opens a leaf
+            p = ((p & 14u) >> 1) * (2 * kFlrLeafStride) + (p >> 4) * 2 + (p & 1u);
+          } else {
+            p += d;
+          }
           svals[p] = val[q];
           if (nullable) snull[p] = (uint8_t)(key[q] >> (8 * (int)sizeof(KT) - 1));
         }
       }
       if (t0 + kFlrTile < e) load_tile(t0 + kFlrTile);  // in flight while wave 0 replays this tile
+      FLR_T(5);  // staging + issuing the next tile's loads
       __syncthreads();
+      FLR_T(6);
       for (int d = tid; d < kSortWaves * R; d += kSortBlock) (&cnt[0][0])[d] = 0;  // (free again: the bases were consumed above)
       if (dense_pw) {
         const int NL = lp[R];
         for (int Lf = tid; Lf < NL; Lf += kSortBlock) {
-          int lo = 0, hi = R - 1;
-          while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (lp[mid] <= Lf) lo = mid;
-            else hi = mid - 1;
-          }
-          const int d = lo, j = Lf - lp[d];
-          const int p0 = open_pos[d], c = (int)(dstart[d + 1] - dstart[d]);
-          const int r0 = j == 0 ? 0 : 16 * j - p0;
-          int r1 = 16 * (j + 1) - p0;
-          r1 = r1 < c ? r1 : c;
-          double a = (j == 0 && p0 > 0) ? open_acc[d] : 0.0;
-          const T* v = svals + dstart[d] + d;
-          // all (<= 16) values of the leaf are requested before the first add: a loop that loads, waits and adds row by row pays
-          // one LDS round trip per row on the critical path of the tile
+          // element q of this leaf sits at [q >> 1][Lf][q & 1]; elements in front of q0 (summed into open_acc by an earlier tile) and
+          // behind the leaf's last row are read and ignored.  All values are requested before the first add.
+          const int d = leaf_d[Lf];
           double xs[16];
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const int r = r0 + q < r1 ? r0 + q : r1 - 1;
-            xs[q] = seg_to_f64(v[r]);
+          for (int e = 0; e < 8; ++e) {
+            struct alignas(16) Pair { T x, y; };
+            const Pair pr = *reinterpret_cast<const Pair*>(svals + e * (2 * kFlrLeafStride) + 2 * Lf);
+            xs[2 * e] = seg_to_f64(pr.x);
+            xs[2 * e + 1] = seg_to_f64(pr.y);
           }
+          const uint32_t di = dinfo[d];
+          const double oa = open_acc[d];
+          const int j = Lf - (int)(di & 0xFFFu), p0 = (int)((di >> 12) & 15u), c = (int)(di >> 16);
+          const int q0 = j == 0 ? p0 : 0;
+          int q1 = p0 + c - 16 * j;  // elements of the leaf filled so far
+          q1 = q1 < 16 ? q1 : 16;
+          double a = (j == 0 && p0 > 0) ? oa : 0.0;
           if (sqdev_mean) {
             const double m = mu_s[d];
 #pragma unroll
             for (int q = 0; q < 16; ++q)
-              if (r0 + q < r1) a += flr_sqdev(xs[q], m);
+              if (q >= q0 && q < q1) a += flr_sqdev(xs[q], m);
           } else {
 #pragma unroll
             for (int q = 0; q < 16; ++q)
-              if (r0 + q < r1) a += xs[q];
+              if (q >= q0 && q < q1) a += xs[q];
           }
           leafsum[Lf] = a;
         }
+        FLR_T(7);  // leaf sums
         __syncthreads();
-        if (wave == 0) {
-          const int c = (int)(dstart[lane + 1] - dstart[lane]);
-          if (c > 0) {
-            const int p0 = open_pos[lane];
-            const int nl = (p0 + c + 15) >> 4, nfull = (p0 + c) >> 4;
-            for (int j = 0; j < nfull; ++j) flr_counter_push(csum, lane, cmask, root, leafsum[lp[lane] + j]);
-            const int rem = (p0 + c) & 15;
-            open_pos[lane] = rem;
-            if (rem) open_acc[lane] = leafsum[lp[lane] + nl - 1];
-            pos = rem;
-            acc = rem ? leafsum[lp[lane] + nl - 1] : 0.0;
+        FLR_T(8);
+        if (wave == 0 && tile_c > 0) {
+          // Arrow's binary counter over this tile's finished leaves.  Levels 0-2 live in registers for the duration (one batch of
+          // reads, one of writes); a carry beyond them walks the LDS column as before (one leaf in eight).
+          const int p0 = pos, c = tile_c;
+          const int nl = (p0 + c + 15) >> 4, nfull = (p0 + c) >> 4;
+          const double* lf = leafsum + tile_lp;
+          const double last = lf[nl - 1];
+          if (nfull > 0) {
+            double c0 = csum[0][lane], c1 = csum[1][lane], c2 = csum[2][lane];
+            double nxt = lf[0];
+            for (int j = 0; j < nfull; ++j) {
+              double v = nxt;
+              if (j + 1 < nfull) nxt = lf[j + 1];
+              v = c0 + v;
+              cmask ^= 1ull;
+              if (cmask & 1ull) {
+                c0 = v;
+              } else {
+                c0 = 0.0;
+                v = c1 + v;
+                cmask ^= 2ull;
+                if (cmask & 2ull) {
+                  c1 = v;
+                  root = root > 1 ? root : 1;
+                } else {
+                  c1 = 0.0;
+                  v = c2 + v;
+                  cmask ^= 4ull;
+                  if (cmask & 4ull) {
+                    c2 = v;
+                    root = root > 2 ? root : 2;
+                  } else {
+                    c2 = 0.0;
+                    int cur = 3;
+                    unsigned long long m = 8ull;
+                    v = csum[3][lane] + v;
+                    cmask ^= m;
+                    while ((cmask & m) == 0) {
+                      csum[cur][lane] = 0.0;
+                      ++cur;
+                      m <<= 1;
+                      v = csum[cur][lane] + v;
+                      cmask ^= m;
+                    }
+                    csum[cur][lane] = v;
+                    root = cur > root ? cur : root;
+                  }
+                }
+              }
+            }
+            csum[0][lane] = c0;
+            csum[1][lane] = c1;
+            csum[2][lane] = c2;
           }
+          const int rem = (p0 + c) & 15;
+          pos = rem;
+          acc = rem ? last : 0.0;
+          if (rem) open_acc[lane] = last;
         }
       } else if (NULL_PW) {
         constexpr int CH = (kFlrTile + R + kSortBlock - 1) / kSortBlock;  // staged slots per thread
@@ -488,4 +596,8 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
     }
     __syncthreads();
   }
+#ifdef PDX_FLR_TIMING
+  if (DENSE_PW && wave < 2 && lane == 0)
+    for (int i = 0; i < 9; ++i) atomicAdd(&g_flr_cycles[wave][i], tacc_[i]);
+#endif
 }

@@ -1362,3 +1362,15 @@ int pdx_resample_row_labels(pdx_groupby* gb, int64_t* out_labels, void* stream) 
 }  // extern "C"
 
 #include "gb_partial_tree.hpp"
+
+#ifdef PDX_FLR_TIMING
+// diagnostic build only: read (and clear) the dense fused kernel's per-phase cycle sums
+extern "C" int pdx_debug_flr_cycles(unsigned long long* out24, int reset) {
+  if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(pdx::g_flr_cycles), sizeof(unsigned long long) * 24) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[24] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(pdx::g_flr_cycles), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
