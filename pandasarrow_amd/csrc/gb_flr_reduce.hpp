@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
   }
   __syncthreads();
 #ifdef PDX_FLR_TIMING
-  unsigned long long tacc_[9] = {};
+  unsigned long long tacc_[10] = {};
 #endif
   for (int64_t run = blockIdx.x; run < nruns; run += gridDim.x) {
     const int64_t s = run_start[run], e = run_start[run + 1];
@@ -185,14 +185,11 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
       const int rows = (int)(e - t0 < kFlrTile ? e - t0 : kFlrTile);
 #pragma unroll
       for (int q = 0; q < kFlrItems; ++q) {
+        // (rows behind the tile's end read its last row instead of branching around the load: they are never ranked or staged)
         const int r = wave * (64 * kFlrItems) + q * 64 + lane;
-        if (r < rows) {
-          key[q] = keys[t0 + r];
-          val[q] = vals[t0 + r];
-        } else {
-          key[q] = 0;
-          val[q] = T(0);
-        }
+        const int rr = r < rows ? r : rows - 1;
+        key[q] = keys[t0 + rr];
+        val[q] = vals[t0 + rr];
       }
     };
     load_tile(s);
@@ -274,12 +271,18 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
       FLR_T(3);  // prefix
       __syncthreads();
       FLR_T(4);
+      // (all bases are requested before the first staged write: reads behind a byte store would wait for it)
+#pragma unroll
+      for (int q = 0; q < kFlrItems; ++q) {
+        const uint32_t d = sizeof(KT) == 4 ? ((key[q] & kSortKeyMask) >> low_bits) & (R - 1) : key[q] & (R - 1);
+        rank[q] += cnt[wave][d];
+      }
 #pragma unroll
       for (int q = 0; q < kFlrItems; ++q) {
         const int r = wave * (64 * kFlrItems) + q * 64 + lane;
         if (r < rows) {
           const uint32_t d = sizeof(KT) == 4 ? ((key[q] & kSortKeyMask) >> low_bits) & (R - 1) : key[q] & (R - 1);
-          uint32_t p = cnt[wave][d] + rank[q];
+          uint32_t p = rank[q];
           if (dense_pw) {
             if ((p & 15u) == 0) leaf_d[p >> 4] = (uint8_t)d;  // this row opens a leaf
             p = ((p & 14u) >> 1) * (2 * kFlrLeafStride) + (p >> 4) * 2 + (p & 1u);
@@ -290,8 +293,9 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
           if (nullable) snull[p] = (uint8_t)(key[q] >> (8 * (int)sizeof(KT) - 1));
         }
       }
+      FLR_T(5);  // staging
       if (t0 + kFlrTile < e) load_tile(t0 + kFlrTile);  // in flight while wave 0 replays this tile
-      FLR_T(5);  // staging + issuing the next tile's loads
+      FLR_T(9);  // issuing the next tile's loads
       __syncthreads();
       FLR_T(6);
       for (int d = tid; d < kSortWaves * R; d += kSortBlock) (&cnt[0][0])[d] = 0;  // (free again: the bases were consumed above)
@@ -598,6 +602,6 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
   }
 #ifdef PDX_FLR_TIMING
   if (DENSE_PW && wave < 2 && lane == 0)
-    for (int i = 0; i < 9; ++i) atomicAdd(&g_flr_cycles[wave][i], tacc_[i]);
+    for (int i = 0; i < 10; ++i) atomicAdd(&g_flr_cycles[wave][i], tacc_[i]);
 #endif
 }
