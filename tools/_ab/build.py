@@ -1,0 +1,9 @@
+import sys, os, subprocess
+sys.path.insert(0, '/root/repo')
+import __graft_entry__ as g
+name, flags = sys.argv[1], sys.argv[2:]
+objs=[os.path.join(g.CSRC,s.replace('.hip','.o')) for s in g.HIP_SOURCES if s!='groupby.hip']
+o=f'/root/repo/tools/_ab/groupby_{name}.o'
+subprocess.check_call(['/opt/rocm/bin/hipcc',*g.HIPCC_FLAGS,*flags,'-c',os.path.join(g.CSRC,'groupby.hip'),'-o',o],stderr=subprocess.DEVNULL)
+subprocess.check_call(['/opt/rocm/bin/hipcc','--offload-arch=gfx950','-shared','-fPIC','-o',f'/root/repo/tools/_ab/libpdx_{name}.so',*objs,o,'-ldl'])
+print('built', name)
