@@ -1,3 +1,6 @@
+"""Cycles per phase of the dense fused last-digit reduce.  Needs a -DPDX_FLR_TIMING build:
+   python tools/build_variant.py tm -DPDX_FLR_TIMING=1
+   gpurun -- 'PDX_LIB_PATH=$PWD/tools/_ab/libpdx_tm.so python tools/flr_phase_timing.py'"""
 import ctypes, os, sys
 sys.path.insert(0, os.getcwd())
 import torch
