@@ -6,6 +6,7 @@
 // (see pairwise.hpp); integer sum wraps; integer mean sums the values converted to double with the same tree
 // (Arrow 25.0.0 behaviour, pinned by tests/golden agg_i64_*); min/max skip NaN unless all values are NaN and keep
 // the FIRST of tied values (0.0 vs -0.0), implemented as an order-independent (value, row) reduction.
+#include <string.h>
 #include "minmax.hpp"
 #include "pairwise.hpp"
 #include "scan.hpp"
@@ -18,6 +19,15 @@ constexpr int kLeafPad = 17;                    // LDS stride per leaf (doubles)
 
 template <typename T>
 __device__ __forceinline__ double to_f64(T x) { return (double)x; }
+
+// small device-to-host read (<= 64 bytes) through this thread's pinned slot: a copy into pageable memory is staged by the runtime
+static int read_back(void* dst, const void* dev, size_t bytes, hipStream_t st) {
+  void* pin = bytes <= 64 ? pinned_slot() : nullptr;
+  PDX_HIP(hipMemcpyAsync(pin ? pin : dst, dev, bytes, hipMemcpyDeviceToHost, st));
+  PDX_HIP(hipStreamSynchronize(st));
+  if (pin) memcpy(dst, pin, bytes);
+  return PDX_OK;
+}
 
 // ---------------------------------------------------------------- dense path, level 0
 // block b: values [4096b, 4096b+4096) -> 256 leaf sums -> full block: one level-8 node, ragged last block: raw leaves
@@ -401,8 +411,7 @@ static int sum_nullable(const T* v, const uint8_t* valid, int64_t off, int64_t n
   hipLaunchKernelGGL(k_null_seg_count, dim3(grid), dim3(kNullTileWaves * 64), 0, st, valid, off, n, ntiles, z, lc);
   PDX_TRY((device_exclusive_scan<int64_t, SumOp>(lc, lc, nseg, total, s, st)));
   int64_t m = 0;
-  PDX_HIP(hipMemcpyAsync(&m, total, sizeof(m), hipMemcpyDeviceToHost, st));
-  PDX_HIP(hipStreamSynchronize(st));
+  PDX_TRY(read_back(&m, total, sizeof(m), st));
   double* leaves = s.get<double>((size_t)(m ? m : 1));
   PDX_SCRATCH_CHECK(s);
   // persistent waves: launch exactly what is resident at once (146 VGPRs -> 3 waves per SIMD = 6 two-wave workgroups per CU; a grid sized
@@ -499,16 +508,24 @@ static int minmax_impl(const T* v, const uint8_t* valid, int64_t off, int64_t n,
   int grid = grid_for(n, 256, 8);
   MinMaxPartial<T>* partials = s.get<MinMaxPartial<T>>((size_t)grid + 1);
   PDX_SCRATCH_CHECK(s);
+  // the final kernel writes its one record into this thread's pinned slot when it fits
+  MinMaxPartial<T>* pin = sizeof(MinMaxPartial<T>) <= 64 ? static_cast<MinMaxPartial<T>*>(pinned_slot()) : nullptr;
+  MinMaxPartial<T>* fin = pin ? pin : partials + grid;
   if (max_last) {
     hipLaunchKernelGGL((k_minmax_partial<T, true>), dim3(grid), dim3(256), 0, st, v, valid, off, n, partials);
-    hipLaunchKernelGGL((k_minmax_final<T, true>), dim3(1), dim3(256), 0, st, partials, grid, partials + grid);
+    hipLaunchKernelGGL((k_minmax_final<T, true>), dim3(1), dim3(256), 0, st, partials, grid, fin);
   } else {
     hipLaunchKernelGGL((k_minmax_partial<T, false>), dim3(grid), dim3(256), 0, st, v, valid, off, n, partials);
-    hipLaunchKernelGGL((k_minmax_final<T, false>), dim3(1), dim3(256), 0, st, partials, grid, partials + grid);
+    hipLaunchKernelGGL((k_minmax_final<T, false>), dim3(1), dim3(256), 0, st, partials, grid, fin);
   }
   PDX_LAUNCH_CHECK();
-  PDX_HIP(hipMemcpyAsync(host_out, partials + grid, sizeof(*host_out), hipMemcpyDeviceToHost, st));
-  PDX_HIP(hipStreamSynchronize(st));
+  if (pin) {
+    PDX_HIP(hipStreamSynchronize(st));
+    memcpy(host_out, pin, sizeof(*host_out));
+  } else {
+    PDX_HIP(hipMemcpyAsync(host_out, partials + grid, sizeof(*host_out), hipMemcpyDeviceToHost, st));
+    PDX_HIP(hipStreamSynchronize(st));
+  }
   return PDX_OK;
 }
 
@@ -540,8 +557,7 @@ int count_valid_host(const pdx_column* a, int64_t* out, Scratch& s, hipStream_t 
   hipLaunchKernelGGL(k_count_valid, dim3(grid_for(nwords, 256)), dim3(256), 0, st, valid, a->offset, a->length, total);
   PDX_LAUNCH_CHECK();
   unsigned long long h = 0;
-  PDX_HIP(hipMemcpyAsync(&h, total, sizeof(h), hipMemcpyDeviceToHost, st));
-  PDX_HIP(hipStreamSynchronize(st));
+  PDX_TRY(read_back(&h, total, sizeof(h), st));
   *out = (int64_t)h;
   return PDX_OK;
 }
@@ -552,27 +568,44 @@ static int pairwise_sum_host(const pdx_column* a, double* sum_out, int64_t* coun
   const T* v = static_cast<const T*>(a->values) + a->offset;
   const uint8_t* valid = validity_or_null(a);
   int64_t n = a->length;
-  double* res = s.get<double>(1);
-  unsigned long long* vt = s.get<unsigned long long>(1);
-  PDX_SCRATCH_CHECK(s);
-  PDX_HIP(hipMemsetAsync(vt, 0, sizeof(*vt), st));
   if (n == 0) {
     *sum_out = 0.0;
     *count_out = 0;
     return PDX_OK;
   }
+  // the finish kernel writes the scalar straight into this thread's pinned slot: no copy command between the kernel and the host
+  double* pinned = static_cast<double*>(pinned_slot());
+  double* res = pinned ? pinned : s.get<double>(1);
+  PDX_SCRATCH_CHECK(s);
   if (!valid) {
     PDX_TRY(sum_dense<T>(v, n, res, s, st));
     *count_out = n;
   } else {
+    unsigned long long* vt = s.get<unsigned long long>(1);
+    PDX_SCRATCH_CHECK(s);
+    PDX_HIP(hipMemsetAsync(vt, 0, sizeof(*vt), st));
     PDX_TRY(sum_nullable<T>(v, valid, a->offset, n, res, vt, s, st));
     unsigned long long h = 0;
-    PDX_HIP(hipMemcpyAsync(&h, vt, sizeof(h), hipMemcpyDeviceToHost, st));
+    if (pinned) {
+      PDX_HIP(hipMemcpyAsync(pinned + 1, vt, sizeof(h), hipMemcpyDeviceToHost, st));
+    } else {
+      PDX_HIP(hipMemcpyAsync(&h, vt, sizeof(h), hipMemcpyDeviceToHost, st));
+    }
     PDX_HIP(hipStreamSynchronize(st));
+    if (pinned) h = *reinterpret_cast<volatile unsigned long long*>(pinned + 1);
     *count_out = (int64_t)h;
+    if (pinned) {
+      *sum_out = *reinterpret_cast<volatile double*>(pinned);
+      return PDX_OK;
+    }
   }
-  PDX_HIP(hipMemcpyAsync(sum_out, res, sizeof(double), hipMemcpyDeviceToHost, st));
-  PDX_HIP(hipStreamSynchronize(st));
+  if (pinned) {
+    PDX_HIP(hipStreamSynchronize(st));
+    *sum_out = *reinterpret_cast<volatile double*>(pinned);
+  } else {
+    PDX_HIP(hipMemcpyAsync(sum_out, res, sizeof(double), hipMemcpyDeviceToHost, st));
+    PDX_HIP(hipStreamSynchronize(st));
+  }
   return PDX_OK;
 }
 
@@ -625,8 +658,7 @@ extern "C" int pdx_aggregate(int kind, const pdx_column* a, pdx_scalar* out, voi
                          validity_or_null(a), a->offset, n, total);
     PDX_LAUNCH_CHECK();
     unsigned long long h = 0;
-    PDX_HIP(hipMemcpyAsync(&h, total, sizeof(h), hipMemcpyDeviceToHost, st));
-    PDX_HIP(hipStreamSynchronize(st));
+    PDX_TRY(read_back(&h, total, sizeof(h), st));
     out->dtype = PDX_INT64;
     out->count = cnt;
     out->is_valid = cnt > 0;

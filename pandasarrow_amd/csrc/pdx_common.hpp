@@ -37,6 +37,7 @@ void pool_free_many(void* const* ptrs, int n);  // one event for the whole batch
 void pool_trim();
 void note_stream(hipStream_t s);  // thread-local: the stream whose queued kernels may still use blocks this thread frees
 hipStream_t current_stream();
+void* pinned_slot();  // 64 pinned bytes of this host thread (or nullptr)
 
 struct Scratch {  // RAII: everything allocated through it is returned to the pool on scope exit
   static constexpr int kMax = 64;

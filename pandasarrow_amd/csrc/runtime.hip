@@ -117,6 +117,21 @@ bool block_ready(const FreeBlock& b, hipStream_t want) {
 void note_stream(hipStream_t s) { t_stream = s; }
 hipStream_t current_stream() { return t_stream; }
 
+// 64 bytes of pinned, device-visible host memory per host thread (never freed): kernels write small results straight into it and
+// small device-to-host copies land in it without the staging a pageable target needs.  nullptr when the allocation fails.
+void* pinned_slot() {
+  static thread_local void* p = nullptr;
+  static thread_local bool tried = false;
+  if (!tried) {
+    tried = true;
+    if (hipHostMalloc(&p, 64, hipHostMallocPortable) != hipSuccess) {
+      (void)hipGetLastError();
+      p = nullptr;
+    }
+  }
+  return p;
+}
+
 void* pool_alloc(size_t bytes) {
   size_t sz = bucket(bytes);
   Pool& p = pool();
