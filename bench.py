@@ -212,8 +212,10 @@ def secondary_runs(torch, L, K, api, keys, vals, kinds, n_total, nkeys, steps):
     # (c) C1: Series<double> add + sum at 1e6 rows (plumbing) and at the headline's row count
     for n in (1_000_000, n_total):
         x, y = K.synth_vals(0, n, 1), K.synth_vals(0, n, 2)
-        put(f"C1_add_f64[{n:.0e}]", n, 24.0 * n, timeit(lambda: K.binary(L.ADD, x, y)))
-        put(f"C1_sum_f64[{n:.0e}]", n, 8.0 * n, timeit(lambda: K.aggregate(L.AGG_SUM, x)))
+        # (at 1e6 rows a call is tens of microseconds of launch / sync latency: median of 200 calls, not of 3)
+        reps, warm = (200, 20) if n <= 1e7 else (3, 1)
+        put(f"C1_add_f64[{n:.0e}]", n, 24.0 * n, timeit(lambda: K.binary(L.ADD, x, y), reps, warm))
+        put(f"C1_sum_f64[{n:.0e}]", n, 8.0 * n, timeit(lambda: K.aggregate(L.AGG_SUM, x), reps, warm))
         del x, y
     # (d) C2: DataFrame boolean-mask filter + take, 1e8 rows x 8 fp64 cols (+ index)
     n = min(100_000_000, n_total)
@@ -415,6 +417,16 @@ def main():
             check = {"groups": G, "counts_sum_to_rows": ok_counts, "mean_is_sum_over_count": ok_mean, "first_occurrence_order": ok_order}
         else:
             check = pdist.check_result(res, n_total)
+            if cd is not None:
+                # the library's orchestration (raw RCCL calls) against the older one over torch.distributed's collectives, same shards:
+                # keys, first rows, sums, means and counts bit for bit, on every rank (outside the timed region)
+                ref = pdist.groupby_sum_mean_count_sharded(pdist.HipEngine(), keys, vals, row_offset=lo)
+                same = (int(ref["G"]) == int(res["G"]) and torch.equal(ref["keys"], res["keys"]) and torch.equal(ref["first_rows"], res["first_rows"])
+                        and all(torch.equal(a[0].view(torch.int64), b[0].view(torch.int64)) for a, b in zip(ref["outs"], res["outs"])))
+                flag = torch.tensor([1 if same else 0], dtype=torch.int64, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                check["c_abi_matches_torch_orchestration_all_ranks"] = bool(flag.item())
+                ref = None
         if rank == 0 and not all(v for k, v in check.items() if isinstance(v, bool)):
             raise SystemExit(f"result check failed: {check}")
     res = None

@@ -62,3 +62,4 @@ def test_bench_two_rank_rehearsal():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rows_per_gpu"] == 2_000_000 and d["cpu_baseline"] is None
     assert d["check"]["groups"] == 20_000 and all(v for v in d["check"].values() if isinstance(v, bool))
     assert d["config"]["path"] == "sharded-c-abi"  # pdx_dist_* inside the library; the custom transport rides on the gloo group here
+    assert d["check"]["c_abi_matches_torch_orchestration_all_ranks"] is True  # both orchestrations, same shards, bit for bit
