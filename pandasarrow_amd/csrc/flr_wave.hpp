@@ -58,7 +58,7 @@ template <typename T, typename KT, bool NULLABLE, bool PW_ONLY>
 __global__ void __launch_bounds__(64) k_flr_wave(const KT* __restrict__ keys, const T* __restrict__ vals, int64_t n, const uint32_t* __restrict__ run_start,
                                                  int64_t nruns, int low_bits, const uint32_t* __restrict__ gid_of_slot, SegOut out,
                                                  uint8_t* __restrict__ ok, int want_pw, int want_mm, int want_is,
-                                                 const double* __restrict__ sqdev_mean, int levels) {
+                                                 const double* __restrict__ sqdev_mean, int levels, unsigned int max_run) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fw_lds[];
   unsigned long long* const match = reinterpret_cast<unsigned long long*>(fw_lds);  // [kFwItems][64]: both half-step words of a digit
   uint32_t* const match32 = reinterpret_cast<uint32_t*>(fw_lds);                    // [kFwItems][64][2]
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(64) k_flr_wave(const KT* __restrict__ keys, co
 
   for (int64_t run = blockIdx.x; run < nruns; run += gridDim.x) {
     const int64_t rs = run_start[run], re = run_start[run + 1];
-    if (rs == re) continue;
+    if (rs == re || re - rs > (int64_t)max_run) continue;  // (longer runs: the layout's side form)
     // per-group state (lane = top digit)
     double acc = 0.0, mu = 0.0;
     int pos = 0, root = 0;

@@ -60,18 +60,101 @@ __global__ void k_run_starts(const uint32_t* __restrict__ sorted_keys, int64_t n
   }
   (void)max_len;
 }
-__global__ void k_run_max_len(const uint32_t* __restrict__ run_start, int64_t nruns, unsigned int* __restrict__ max_len) {
+// out[0] = rows of the longest run, out[1] = runs longer than `limit`, out[2] = their rows together
+__global__ void k_run_max_len(const uint32_t* __restrict__ run_start, int64_t nruns, unsigned int* __restrict__ out, unsigned int limit) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  unsigned int m = 0;
+  unsigned int m = 0, nl = 0, rl = 0;
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nruns; r += stride) {
     unsigned int len = run_start[r + 1] - run_start[r];
     m = len > m ? len : m;
+    if (len > limit) {
+      ++nl;
+      rl += len;
+    }
   }
   for (int d = 32; d >= 1; d >>= 1) {
     unsigned int o = __shfl_xor(m, d, 64);
     m = o > m ? o : m;
+    nl += __shfl_xor(nl, d, 64);
+    rl += __shfl_xor(rl, d, 64);
   }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(max_len, m);
+  if ((threadIdx.x & 63) == 0) {
+    if (m) atomicMax(&out[0], m);
+    if (nl) {
+      atomicAdd(&out[1], nl);
+      atomicAdd(&out[2], rl);
+    }
+  }
+}
+// the long runs, unordered (at most `cap` are kept; the host has the count already)
+__global__ void k_long_runs_append(const uint32_t* __restrict__ run_start, int64_t nruns, unsigned int limit, unsigned int cap,
+                                   uint32_t* __restrict__ list, unsigned int* __restrict__ count) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nruns; r += stride)
+    if (run_start[r + 1] - run_start[r] > limit) {
+      const unsigned int i = atomicAdd(count, 1u);
+      if (i < cap) list[i] = (uint32_t)r;
+    }
+}
+// ... in ascending run order, with the start of every run's rows in the side array (off[nl] = all of them); one workgroup of 256
+constexpr int kMaxLongRuns = 256;
+__global__ void __launch_bounds__(256) k_long_runs_order(const uint32_t* __restrict__ unordered, int nl, const uint32_t* __restrict__ run_start,
+                                                         uint32_t* __restrict__ list, uint32_t* __restrict__ off) {
+  __shared__ uint32_t a[kMaxLongRuns], b[kMaxLongRuns], len[kMaxLongRuns];
+  const int t = threadIdx.x;
+  if (t < nl) a[t] = unordered[t];
+  __syncthreads();
+  if (t < nl) {
+    int rank = 0;
+    for (int j = 0; j < nl; ++j) rank += a[j] < a[t];
+    b[rank] = a[t];
+  }
+  __syncthreads();
+  if (t < nl) {
+    list[t] = b[t];
+    len[t] = run_start[b[t] + 1] - run_start[b[t]];
+  }
+  __syncthreads();
+  if (t == 0) {
+    uint32_t acc = 0;
+    for (int j = 0; j < nl; ++j) {
+      off[j] = acc;
+      acc += len[j];
+    }
+    off[nl] = acc;
+  }
+}
+// side_key[t] = the full slot of the t-th row of the long runs (| bit 31: null value), side_val[t] = its value.  KT = uint8: the top
+// digit alone (bit 7 = null flag) after a narrowing sort; uint32: the slot itself (bit 31 = null flag)
+template <typename KT>
+__global__ void __launch_bounds__(256) k_side_gather(const KT* __restrict__ keys, const uint64_t* __restrict__ vals, const uint32_t* __restrict__ run_start,
+                                                     const uint32_t* __restrict__ list, const uint32_t* __restrict__ off, int nl, int low_bits, int64_t m,
+                                                     uint32_t* __restrict__ side_key, uint64_t* __restrict__ side_val) {
+  __shared__ uint32_t soff[kMaxLongRuns + 1], srun[kMaxLongRuns], sstart[kMaxLongRuns];
+  for (int j = threadIdx.x; j <= nl; j += 256) {
+    soff[j] = off[j];
+    if (j < nl) {
+      srun[j] = list[j];
+      sstart[j] = run_start[list[j]];
+    }
+  }
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < m; t += stride) {
+    int lo = 0, hi = nl - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if ((int64_t)soff[mid] <= t) lo = mid;
+      else hi = mid - 1;
+    }
+    const int64_t src = (int64_t)sstart[lo] + (t - (int64_t)soff[lo]);
+    const uint32_t k = keys[src];
+    uint32_t slot;
+    if (sizeof(KT) == 1) slot = (((k & ((1u << kFlrBits) - 1u)) << low_bits) | srun[lo]) | ((k >> 7) << 31);
+    else slot = k;
+    side_key[t] = slot;
+    side_val[t] = vals[src];
+  }
 }
 // (x - mean)^2 with x86 NaN operand propagation (k_seg_sqdev)
 __device__ __forceinline__ double flr_sqdev(double v, double mu) {
@@ -119,7 +202,8 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
                                                            const uint32_t* __restrict__ run_start, int64_t nruns, int low_bits,
                                                            const uint32_t* __restrict__ gid_of_slot, SegOut out, uint8_t* __restrict__ ok,
                                                            int want_pw, int want_mm, int want_is, int nullable,
-                                                           const double* __restrict__ sqdev_mean) {
+                                                           const double* __restrict__ sqdev_mean, unsigned int max_run) {
+  // max_run: runs longer than this are not this kernel's (the layout's side form holds their rows)
   // sqdev_mean != nullptr (second pass of variance): every value x of group g enters the sum as (x - sqdev_mean[g])^2, with the
   // reference's x86 NaN propagation (see k_seg_sqdev)
   constexpr int R = 1 << kFlrBits;
@@ -160,7 +244,7 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
 #endif
   for (int64_t run = blockIdx.x; run < nruns; run += gridDim.x) {
     const int64_t s = run_start[run], e = run_start[run + 1];
-    if (s == e) continue;
+    if (s == e || e - s > (int64_t)max_run) continue;
     if (tid < R) {
       open_pos[tid] = 0;
       open_acc[tid] = 0.0;

@@ -26,6 +26,15 @@ struct GroupedLayout {
   const uint32_t* fkeys = nullptr;
   const uint64_t* fvals = nullptr;
   const uint32_t* run_start = nullptr;
+  // (A') runs longer than max_run rows (a key holding a large share of the rows drags its run along) are skipped by the fused kernels:
+  // their rows live once more in a SIDE full form -- (slot, value) of those rows sorted by slot, segment starts for all G groups
+  // (empty for every group outside the long runs) -- reduced by the classic kernels BEFORE the fused kernel writes its groups
+  unsigned int max_run = 0;             // the limit the layout was built with (0: no run is skipped)
+  int64_t side_rows = 0;
+  int side_runs = 0;
+  const uint64_t* side_vals = nullptr;
+  const uint32_t* side_keys = nullptr;  // nullable values: bit 31 = null (as flag_keys)
+  const uint32_t* side_seg = nullptr;   // G + 1
   // (B) full form: every group's values contiguous in row order (classic reducers, product / first / last, skewed keys)
   bool full = false;
   const void* vals_sorted = nullptr;

@@ -19,6 +19,8 @@ struct AggTuning {
   int flr_wgs_per_cu = 24;  // PDX_FLR_WGS_PER_CU
   int fw_wgs_per_cu = 48;   // PDX_FLR_WAVE_WGS_PER_CU
   int wave_force = -1;      // PDX_FLR_WAVE=0 / 1: force the workgroup / wave form of the fused kernel
+  bool hybrid = true;       // PDX_FLR_HYBRID=0: any run over the limit sends the whole column down the classic path
+  unsigned int max_run = 1u << 19;  // PDX_FLR_MAX_RUN (<= 2^19): rows of the longest run the fused kernels take
   static AggTuning read() {
     AggTuning t;
     auto off = [](const char* name) { const char* e = getenv(name); return e && e[0] == '0'; };
@@ -33,11 +35,52 @@ struct AggTuning {
     if (const char* e = getenv("PDX_FLR_WGS_PER_CU")) if (atoi(e) > 0) t.flr_wgs_per_cu = atoi(e);
     if (const char* e = getenv("PDX_FLR_WAVE_WGS_PER_CU")) if (atoi(e) > 0) t.fw_wgs_per_cu = atoi(e);
     if (const char* e = getenv("PDX_FLR_WAVE")) t.wave_force = e[0] != '0' ? 1 : 0;
+    t.hybrid = !off("PDX_FLR_HYBRID");
+    if (const char* e = getenv("PDX_FLR_MAX_RUN")) if (atoll(e) >= 64 && atoll(e) <= (1ll << 19)) t.max_run = (unsigned int)atoll(e);
     return t;
   }
 };
 
-constexpr unsigned int kFlrMaxRun = 1u << 19;  // a run is walked by ONE workgroup / wave: longer runs (skewed keys) take the classic path
+constexpr unsigned int kFlrMaxRun = 1u << 19;  // a run is walked by ONE workgroup / wave (and sizes their counter levels): longer runs
+                                               // (skewed keys) go through the side form below, or the whole column takes the classic path
+
+// The side form of a fused layout: the rows of the (few) runs longer than t.max_run, gathered with their full slots, sorted by the top
+// digit (one pass: within a digit they are in run order already, so the result is in slot order) and cut into segments for all G
+// groups.  `keys` = the layout's top-digit bytes or 4-byte slots, `vals` its values, both sorted by the low slot bits.
+template <typename KT>
+static int build_side(pdx_groupby* gb, GroupedLayout& L, const KT* keys, const uint64_t* vals, const uint32_t* run_start, int64_t nruns, int low_bits,
+                      unsigned int limit, int n_long, int64_t rows_long, bool nullable, Scratch& s, hipStream_t st) {
+  PDX_PROFILE("side_layout", st);
+  const int64_t G = gb->G, m = rows_long;
+  uint32_t* unordered = s.get<uint32_t>(kMaxLongRuns);
+  uint32_t* list = s.get<uint32_t>(kMaxLongRuns);
+  uint32_t* off = s.get<uint32_t>(kMaxLongRuns + 1);
+  unsigned int* cnt = s.get<unsigned int>(1);
+  uint32_t* k_in = s.get<uint32_t>((size_t)m);
+  uint64_t* v_in = s.get<uint64_t>((size_t)m);
+  PDX_SCRATCH_CHECK(s);
+  uint32_t* k_out = L.own<uint32_t>((size_t)m);
+  uint64_t* v_out = L.own<uint64_t>((size_t)m);
+  uint32_t* seg = L.own<uint32_t>((size_t)G + 1);
+  if (!k_out || !v_out || !seg) return PDX_OOM;
+  PDX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int), st));
+  hipLaunchKernelGGL(k_long_runs_append, dim3(grid_for(nruns, 256)), dim3(256), 0, st, run_start, nruns, limit, (unsigned int)kMaxLongRuns, unordered, cnt);
+  hipLaunchKernelGGL(k_long_runs_order, dim3(1), dim3(256), 0, st, unordered, n_long, run_start, list, off);
+  hipLaunchKernelGGL((k_side_gather<KT>), dim3(grid_for(m, 256, 4)), dim3(256), 0, st, keys, vals, run_start, list, off, n_long, low_bits, m, k_in, v_in);
+  PDX_LAUNCH_CHECK();
+  const uint32_t* ks = nullptr;
+  const uint64_t* vs = nullptr;
+  PDX_TRY((radix_sort_pairs<uint64_t>(k_in, v_in, k_out, v_out, k_out, v_out, m, kFlrBits, &ks, &vs, true, s, st, low_bits)));
+  hipLaunchKernelGGL(k_seg_starts, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, ks, m, gb->occ_slot, G, seg);
+  PDX_LAUNCH_CHECK();
+  L.side_rows = m;
+  L.side_runs = n_long;
+  L.side_vals = vs;
+  L.side_seg = seg;
+  if (nullable) L.side_keys = ks;
+  else L.disown(k_out);
+  return PDX_OK;
+}
 
 // Which sort feeds the fused last digit on this handle (all false: full sort + classic reducers)
 struct FusedPlan {
@@ -128,10 +171,14 @@ static int build_layout(pdx_groupby* gb, const pdx_column* values, bool allow_fu
   if (fp.flr) {
     const int64_t nruns = (int64_t)1 << low_bits;
     uint32_t* run_start = L.own<uint32_t>((size_t)nruns + 1);
-    unsigned int* dmax = s.get<unsigned int>(1);
+    unsigned int* dmax = s.get<unsigned int>(3);  // longest run, runs over the limit, their rows
     if (!run_start) return PDX_OOM;
     PDX_SCRATCH_CHECK(s);
-    unsigned int hmax = 0;
+    unsigned int hmax = 0, n_long = 0, rows_long = 0;
+    const unsigned int max_run = std::min(t.max_run, kFlrMaxRun);
+    // a few long runs (one key with a large share of the rows is enough to make one) are reduced from a side form, the rest by the
+    // fused kernels; many or very long ones: the whole column takes the classic path
+    auto side_ok = [&] { return t.hybrid && n_long > 0 && n_long <= (unsigned int)kMaxLongRuns && (int64_t)rows_long <= n / 4; };
     const size_t mark = L.owned.size();
     if (fp.narrow || fp.narrow_part) {
       const int b0 = fp.narrow ? fp.low_plan.bits[0] : kPartBits, b1 = fp.narrow ? fp.low_plan.bits[1] : fp.mid_bits;
@@ -181,10 +228,10 @@ static int build_layout(pdx_groupby* gb, const pdx_column* values, bool allow_fu
         PDX_PROFILE("run_starts", st);
         // (row 0 of the pass-0 offsets = where every first digit's rows begin in the input of pass 1)
         hipLaunchKernelGGL((k_level_starts<uint16_t>), dim3(1u << b0), dim3(256), 0, st, k16, n, prev_off, (int64_t)1 << b0, b0, b1, nhist, run_start);
-        PDX_HIP(hipMemsetAsync(dmax, 0, sizeof(unsigned int), st));
-        hipLaunchKernelGGL(k_run_max_len, dim3(grid_for(nruns, 256)), dim3(256), 0, st, run_start, nruns, dmax);
+        PDX_HIP(hipMemsetAsync(dmax, 0, 3 * sizeof(unsigned int), st));
+        hipLaunchKernelGGL(k_run_max_len, dim3(grid_for(nruns, 256)), dim3(256), 0, st, run_start, nruns, dmax, max_run);
         PDX_LAUNCH_CHECK();
-        PDX_HIP(hipMemcpyAsync(hmax_pinned(), dmax, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+        PDX_HIP(hipMemcpyAsync(hmax_pinned(), dmax, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
         PDX_HIP(hipEventCreateWithFlags(&hmax_ready.ev, hipEventDisableTiming));
         PDX_HIP(hipEventRecord(hmax_ready.ev, st));
       }
@@ -203,9 +250,17 @@ static int build_layout(pdx_groupby* gb, const pdx_column* values, bool allow_fu
       {
         const hipError_t ew = hipEventSynchronize(hmax_ready.ev);
         if (ew != hipSuccess) return hip_fail(ew, "pdx_groupby_agg");
-        hmax = *hmax_pinned();
+        hmax = hmax_pinned()[0];
+        n_long = hmax_pinned()[1];
+        rows_long = hmax_pinned()[2];
       }
-      if (hmax > kFlrMaxRun) {
+      if (hmax > max_run && side_ok()) {
+        PDX_TRY((build_side<uint8_t>(gb, L, k8, nv1, run_start, nruns, low_bits, max_run, (int)n_long, (int64_t)rows_long, vvalid != nullptr, s, st)));
+        L.fused = true;
+        L.keys8 = k8;
+        L.fvals = nv1;
+        L.disown(nv0);
+      } else if (hmax > max_run) {
         // skewed keys: the fused kernel is skipped.  Finish the sort with the one pass that is left (on the byte digits) and take the
         // group offsets from its scatter offsets: one more level of k_level_starts gives the start of every slot's rows
         uint32_t* ss_narrow = L.own<uint32_t>((size_t)G + 1);
@@ -250,14 +305,20 @@ static int build_layout(pdx_groupby* gb, const pdx_column* values, bool allow_fu
       keep_only(L, mark, {keys_sorted, vs});
       {
         PDX_PROFILE("run_starts", st);
-        PDX_HIP(hipMemsetAsync(dmax, 0, sizeof(unsigned int), st));
+        PDX_HIP(hipMemsetAsync(dmax, 0, 3 * sizeof(unsigned int), st));
         hipLaunchKernelGGL(k_run_starts, dim3(grid_for(nruns + 1, 256)), dim3(256), 0, st, keys_sorted, n, low_bits, nruns, run_start, dmax);
-        hipLaunchKernelGGL(k_run_max_len, dim3(grid_for(nruns, 256)), dim3(256), 0, st, run_start, nruns, dmax);
+        hipLaunchKernelGGL(k_run_max_len, dim3(grid_for(nruns, 256)), dim3(256), 0, st, run_start, nruns, dmax, max_run);
         PDX_LAUNCH_CHECK();
-        PDX_HIP(hipMemcpyAsync(&hmax, dmax, sizeof(hmax), hipMemcpyDeviceToHost, st));
+        unsigned int h3[3] = {0, 0, 0};
+        PDX_HIP(hipMemcpyAsync(h3, dmax, sizeof(h3), hipMemcpyDeviceToHost, st));
         PDX_HIP(hipStreamSynchronize(st));
+        hmax = h3[0];
+        n_long = h3[1];
+        rows_long = h3[2];
       }
-      if (hmax <= kFlrMaxRun) {
+      if (hmax > max_run && side_ok())
+        PDX_TRY((build_side<uint32_t>(gb, L, keys_sorted, vs, run_start, nruns, low_bits, max_run, (int)n_long, (int64_t)rows_long, vvalid != nullptr, s, st)));
+      if (hmax <= max_run || L.side_rows) {
         L.fused = true;
         L.fkeys = keys_sorted;
         L.fvals = vs;
@@ -269,9 +330,10 @@ static int build_layout(pdx_groupby* gb, const pdx_column* values, bool allow_fu
     if (L.fused) {
       L.low_bits = low_bits;
       L.nruns = nruns;
-      L.hmax = hmax;
+      L.hmax = std::min(hmax, max_run);  // (rows of the longest run the fused kernels walk)
+      L.max_run = max_run;
       L.run_start = run_start;
-      L.plan_fused = slots + " sort=" + sort_desc + " layout=fused";
+      L.plan_fused = slots + " sort=" + sort_desc + " layout=fused" + (L.side_rows ? " side=" + std::to_string(L.side_runs) : std::string());
       return PDX_OK;
     }
   }

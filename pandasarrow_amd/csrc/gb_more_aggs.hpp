@@ -10,12 +10,14 @@ __device__ __forceinline__ bool seg_row_is_null(const uint32_t* sorted_keys, con
 // d[i] = (x[i] - mean of x's segment)^2: the second pass of Arrow's variance.  One wave per segment, coalesced.
 template <typename T>
 __global__ void __launch_bounds__(256) k_seg_sqdev(const T* __restrict__ vals, const uint32_t* __restrict__ seg_start, int64_t nseg,
-                                                   const double* __restrict__ mean_seg, double* __restrict__ d) {
+                                                   const double* __restrict__ mean_seg, double* __restrict__ d,
+                                                   const uint32_t* __restrict__ mean_index = nullptr) {
   const int lane = threadIdx.x & 63;
   const int64_t nw = (int64_t)gridDim.x * 4;
   for (int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); k < nseg; k += nw) {
     const int64_t s = seg_start[k], e = seg_start[k + 1];
-    const double mu = mean_seg[k];
+    if (s == e) continue;
+    const double mu = mean_seg[mean_index ? mean_index[k] : k];  // (mean_index: the means are in group-id order, the segments are not)
     for (int64_t i = s + lane; i < e; i += 64) {
       // NaN operands: x86 SUBSD/MULSD hand back the first NaN operand unchanged, v_add_f64 with a negated source flips its sign;
       // spell the x86 result out so the NaN bits agree too

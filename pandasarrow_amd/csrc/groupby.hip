@@ -754,10 +754,59 @@ struct AggRequest {
   bool std_only() const { return (want_std5 || var_out || std_out) && !prod_out && !first_out && !last_out; }  // (variance: two more fused passes)
 };
 
+// one segmented reduce of `vals` (float64 or int64 per f64) over `G` segments of `nrows` grouped rows into `oo`; nullable: the null flag of
+// every grouped row is bit 31 of flag_keys (or read in place from row_valid, segments mode); ok_bytes: 1 = the group has a valid value
+static int reduce_segments(bool nullable, const uint32_t* flag_keys, const uint8_t* row_valid, int64_t valid_off, const uint32_t* seg_start, int64_t G,
+                           int64_t nrows, const void* vals, bool f64, const SegOut& oo, bool pw, bool mm, bool is, const uint32_t* oidx, uint8_t* ok_bytes,
+                           Scratch& s, hipStream_t st) {
+  PDX_PROFILE("seg_reduce", st);
+  const int64_t n = nrows;
+  if (!nullable) {
+    if (f64) return launch_seg_reduce_dense<double>(static_cast<const double*>(vals), seg_start, G, oidx, oo, pw, mm, is, n, s, st);
+    return launch_seg_reduce_dense<long long>(static_cast<const long long*>(vals), seg_start, G, oidx, oo, pw, mm, is, n, s, st);
+  }
+  const int grid = (int)std::min<int64_t>(ceil_div(G, kSegWaves), (int64_t)kCUs * 8);
+  if (f64)
+    hipLaunchKernelGGL((k_seg_reduce_nullable<double>), dim3(grid), dim3(kSegWaves * 64), 0, st, static_cast<const double*>(vals), flag_keys, row_valid,
+                       valid_off, seg_start, G, oidx, oo, ok_bytes);
+  else
+    hipLaunchKernelGGL((k_seg_reduce_nullable<long long>), dim3(grid), dim3(kSegWaves * 64), 0, st, static_cast<const long long*>(vals), flag_keys,
+                       row_valid, valid_off, seg_start, G, oidx, oo, ok_bytes);
+  PDX_LAUNCH_CHECK();
+  return reduce_huge_nullable_groups(vals, f64 ? PDX_FLOAT64 : PDX_INT64, flag_keys, row_valid, valid_off, seg_start, G, oidx, n, oo, ok_bytes, s, st);
+}
+// ... over a full layout; vals == the layout's own values or an array in the same order
+static int reduce_full(const pdx_groupby* gb, const GroupedLayout& L, const void* vals, bool f64, const SegOut& oo, bool pw, bool mm, bool is,
+                       const uint32_t* oidx, uint8_t* ok_bytes, Scratch& s, hipStream_t st) {
+  return reduce_segments(L.validity != nullptr, L.flag_keys, L.row_valid, L.offset, L.seg_start, gb->G, gb->n, vals, f64, oo, pw, mm, is, oidx, ok_bytes, s, st);
+}
+// ... over the side form of a fused layout (the rows of its long runs): EVERY group's outputs are written -- zeros / nulls for the groups
+// outside the long runs -- so it runs before the fused kernel, which then writes the groups of the runs it walks
+static int reduce_side(const pdx_groupby* gb, const GroupedLayout& L, const SegOut& oo, bool pw, bool mm, bool is, uint8_t* ok_bytes, const double* sqmean,
+                       Scratch& s, hipStream_t st) {
+  const bool is_f = L.dtype == PDX_FLOAT64, nullable = L.validity != nullptr;
+  const void* vals = L.side_vals;
+  bool f64 = is_f;
+  if (sqmean) {  // second pass of variance: (x - mean of x's group)^2, summed over the same valid runs
+    double* d = s.get<double>((size_t)L.side_rows);
+    PDX_SCRATCH_CHECK(s);
+    PDX_PROFILE("seg_sqdev", st);
+    const int grid = (int)std::min<int64_t>(ceil_div(gb->G, 4), (int64_t)kCUs * 16);
+    if (is_f) hipLaunchKernelGGL((k_seg_sqdev<double>), dim3(grid), dim3(256), 0, st, reinterpret_cast<const double*>(L.side_vals), L.side_seg, gb->G, sqmean, d, gb->gid_of_occ);
+    else hipLaunchKernelGGL((k_seg_sqdev<long long>), dim3(grid), dim3(256), 0, st, reinterpret_cast<const long long*>(L.side_vals), L.side_seg, gb->G, sqmean, d, gb->gid_of_occ);
+    PDX_LAUNCH_CHECK();
+    vals = d;
+    f64 = true;
+  }
+  return reduce_segments(nullable, L.side_keys, nullptr, 0, L.side_seg, gb->G, L.side_rows, vals, f64, oo, pw, mm, is, gb->gid_of_occ, ok_bytes, s, st);
+}
+
 // The fused last digit: rank by the top 6 slot bits + Arrow's leaf / counter recurrence in one pass over a fused layout.
 // ok_bytes (nullable values): 1 = the group has a valid value; sqmean: second pass of variance.
 static int reduce_fused(const pdx_groupby* gb, const GroupedLayout& L, const AggTuning& t, const SegOut& oo, bool pw, bool mm, bool is, uint8_t* okbytes,
-                        const double* sqmean, hipStream_t st, std::string* reducer) {
+                        const double* sqmean, Scratch& s, hipStream_t st, std::string* reducer) {
+  if (L.side_rows) PDX_TRY(reduce_side(gb, L, oo, pw, mm, is, okbytes, sqmean, s, st));
+  const unsigned int max_run = L.max_run ? L.max_run : 0xFFFFFFFFu;
   PDX_PROFILE("fused_last_digit_reduce", st);
   const bool nullable = L.validity != nullptr, is_f = L.dtype == PDX_FLOAT64;
   const int64_t nruns = L.nruns, n = gb->n;
@@ -774,16 +823,16 @@ static int reduce_fused(const pdx_groupby* gb, const GroupedLayout& L, const Agg
 #define FLR_LAUNCH(TT, DD)                                                                                                                       \
   if (keys8 && nullpw)                                                                                                                           \
     hipLaunchKernelGGL((k_flr_reduce<TT, false, uint8_t, true>), dim3(grid), dim3(kSortBlock), 0, st, keys8, reinterpret_cast<const TT*>(vs), run_start, \
-                       nruns, low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, 1, sqmean);                                       \
+                       nruns, low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, 1, sqmean, max_run);                              \
   else if (nullpw)                                                                                                                               \
     hipLaunchKernelGGL((k_flr_reduce<TT, false, uint32_t, true>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const TT*>(vs),   \
-                       run_start, nruns, low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, 1, sqmean);                            \
+                       run_start, nruns, low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, 1, sqmean, max_run);                   \
   else if (keys8)                                                                                                                                \
     hipLaunchKernelGGL((k_flr_reduce<TT, DD, uint8_t>), dim3(grid), dim3(kSortBlock), 0, st, keys8, reinterpret_cast<const TT*>(vs), run_start, nruns, \
-                       low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, nullable ? 1 : 0, sqmean);                               \
+                       low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, nullable ? 1 : 0, sqmean, max_run);                      \
   else                                                                                                                                           \
     hipLaunchKernelGGL((k_flr_reduce<TT, DD>), dim3(grid), dim3(kSortBlock), 0, st, keys_sorted, reinterpret_cast<const TT*>(vs), run_start, nruns, \
-                       low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, nullable ? 1 : 0, sqmean)
+                       low_bits, gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, nullable ? 1 : 0, sqmean, max_run)
   // one WAVE per run (flr_wave.hpp) for everything but the dense sum / mean / count: nullable values, min / max and int64 sums
   // were a per-lane replay by wave 0 alone in the workgroup-per-run kernel (5 % nulls: 10.7 -> 4.9 ms per 1e9 rows); the dense
   // fast path of k_flr_reduce (thread per leaf) is still ahead of the wave form (3.0 vs 3.3 ms).  PDX_FLR_WAVE=1 / 0 force either.
@@ -798,7 +847,7 @@ static int reduce_fused(const pdx_groupby* gb, const GroupedLayout& L, const Agg
     const size_t fw_lds = (size_t)fw_lds_bytes(nullable, fw_levels);
 #define FW_LAUNCH(TT, KK, KPTR, NN, PP)                                                                                                  \
   hipLaunchKernelGGL((k_flr_wave<TT, KK, NN, PP>), dim3(wgrid), dim3(64), fw_lds, st, KPTR, reinterpret_cast<const TT*>(vs), n, run_start, nruns, low_bits, \
-                     gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, sqmean, fw_levels)
+                     gb->gid_of_slot, oo, okbytes, (int)pw, (int)mm, (int)is, sqmean, fw_levels, max_run)
 #define FW_DISPATCH(TT)                                                                        \
   if (keys8) {                                                                                 \
     if (nullable) { if (pw_only) FW_LAUNCH(TT, uint8_t, keys8, true, true); else FW_LAUNCH(TT, uint8_t, keys8, true, false); }          \
@@ -820,27 +869,6 @@ static int reduce_fused(const pdx_groupby* gb, const GroupedLayout& L, const Agg
 #undef FLR_LAUNCH
   PDX_LAUNCH_CHECK();
   return PDX_OK;
-}
-
-// one segmented reduce of `vals` (float64 or int64 per f64) over a full layout into `oo`; ok_bytes (nullable values only): 1 = the
-// group has a valid value.  vals == nullptr: the layout's own values.
-static int reduce_full(const pdx_groupby* gb, const GroupedLayout& L, const void* vals, bool f64, const SegOut& oo, bool pw, bool mm, bool is,
-                       const uint32_t* oidx, uint8_t* ok_bytes, Scratch& s, hipStream_t st) {
-  PDX_PROFILE("seg_reduce", st);
-  const int64_t n = gb->n, G = gb->G;
-  if (!L.validity) {
-    if (f64) return launch_seg_reduce_dense<double>(static_cast<const double*>(vals), L.seg_start, G, oidx, oo, pw, mm, is, n, s, st);
-    return launch_seg_reduce_dense<long long>(static_cast<const long long*>(vals), L.seg_start, G, oidx, oo, pw, mm, is, n, s, st);
-  }
-  const int grid = (int)std::min<int64_t>(ceil_div(G, kSegWaves), (int64_t)kCUs * 8);
-  if (f64)
-    hipLaunchKernelGGL((k_seg_reduce_nullable<double>), dim3(grid), dim3(kSegWaves * 64), 0, st, static_cast<const double*>(vals), L.flag_keys, L.row_valid,
-                       L.offset, L.seg_start, G, oidx, oo, ok_bytes);
-  else
-    hipLaunchKernelGGL((k_seg_reduce_nullable<long long>), dim3(grid), dim3(kSegWaves * 64), 0, st, static_cast<const long long*>(vals), L.flag_keys,
-                       L.row_valid, L.offset, L.seg_start, G, oidx, oo, ok_bytes);
-  PDX_LAUNCH_CHECK();
-  return reduce_huge_nullable_groups(vals, f64 ? PDX_FLOAT64 : PDX_INT64, L.flag_keys, L.row_valid, L.offset, L.seg_start, G, oidx, n, oo, ok_bytes, s, st);
 }
 
 __global__ void k_mean_from_cache(const double* __restrict__ sum, const long long* __restrict__ cnt, int64_t G, double* __restrict__ out) {
@@ -1013,7 +1041,7 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   };
   // the five standard kinds from one reduce into `oo`
   auto reduce_std = [&](const SegOut& oo, bool pw, bool mm, bool is, uint8_t* okb) -> int {
-    if (use_fused) return reduce_fused(gb, L, t, oo, pw, mm, is, okb, nullptr, st, &reducer);
+    if (use_fused) return reduce_fused(gb, L, t, oo, pw, mm, is, okb, nullptr, s, st, &reducer);
     reducer = vvalid ? "seg_reduce_nullable" : "seg_reduce";
     return reduce_full(gb, L, L.vals_sorted, is_f, oo, pw, mm, is, L.out_index, okb, s, st);
   };
@@ -1083,8 +1111,8 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
     o2.count = cnt_g;
     if (use_fused) {
       // on the same partially sorted rows: per-group mean (group-id order), then the squared deviations formed inside the kernel
-      PDX_TRY(reduce_fused(gb, L, t, o1, true, false, false, ok1, nullptr, st, &reducer));
-      PDX_TRY(reduce_fused(gb, L, t, o2, true, false, false, ok2, mean_g, st, nullptr));
+      PDX_TRY(reduce_fused(gb, L, t, o1, true, false, false, ok1, nullptr, s, st, &reducer));
+      PDX_TRY(reduce_fused(gb, L, t, o2, true, false, false, ok2, mean_g, s, st, nullptr));
     } else {
       if (reducer.empty()) reducer = vvalid ? "seg_reduce_nullable" : "seg_reduce";
       double* d = s.get<double>((size_t)n);

@@ -1,5 +1,7 @@
 """GPU: seeded differential fuzz of the group-by path against the oracle -- random sizes, cardinalities, key distributions
 (uniform / zipf-like / sorted / runs), key and value nulls, value dtype and aggregate sets, through every key->slot path."""
+import os
+
 import numpy as np
 import pytest
 
@@ -59,12 +61,14 @@ def _make_case(seed):
     return keys, kvalid, vals, vvalid, kinds
 
 
-@pytest.mark.parametrize("mode", ["default", "hash", "hash_global", "fused_dense", "fused_hash"])
+@pytest.mark.parametrize("mode", ["default", "hash", "hash_global", "fused_dense", "fused_hash", "fused_side"])
 @pytest.mark.parametrize("seed", range(160))
 def test_groupby_fuzz(px, monkeypatch, seed, mode):
     if mode in ("hash", "hash_global", "fused_hash"):
         monkeypatch.setenv("PDX_GROUPBY_DENSE", "0")
         monkeypatch.setenv("PDX_HASH_PARTITION", "0" if mode == "hash_global" else "2")
+    if mode == "fused_side":  # runs over 1500 rows count as long: a few of them -> side form, many -> classic path; either way the oracle's bits
+        monkeypatch.setenv("PDX_FLR_MAX_RUN", "1500")
     if mode.startswith("fused"):  # the fused last-digit reduce at any size (product default: >= 2^22 rows and >= 2^10 runs)
         monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_MIN_ROWS", "0")
         monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS", "4")
@@ -129,3 +133,54 @@ def test_groupby_fuzz_bound_columns(px, monkeypatch, seed, mode):
     got, _ = gb.agg(other, [0])[0].to_numpy()
     exp, eok = orc.groupby_agg(0, ids, G, np.arange(len(keys), dtype=np.float64), None, nthreads=4)
     assert _bits_equal(got, exp, eok) and gb.last_plan()["bound"] == "0"
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_groupby_fuzz_side_form(px, monkeypatch, seed):
+    """hot keys: 1-4 keys hold 1-6 % of the rows each, so their runs are far longer than the limit (lowered to 20 000 rows here) while the
+    others stay below it -- the fused kernels skip those runs and the side form reduces them.  Random value dtype, nulls, kinds (variance
+    included), dense / hash slots, narrow / 4-byte sort keys, bound or not; the plan must say `side`, the bits must be the oracle's."""
+    rng = np.random.default_rng(seed * 1009 + 5)
+    monkeypatch.setenv("PDX_FLR_MAX_RUN", "20000")
+    monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_MIN_ROWS", "0")
+    monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_MIN_RUN", "0")
+    monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS", "4")
+    hashed = seed % 4 == 3
+    if hashed:
+        monkeypatch.setenv("PDX_GROUPBY_DENSE", "0")
+    if seed % 5 == 4:
+        monkeypatch.setenv("PDX_SORT_NARROW", "0")
+    n = int(rng.integers(600_000, 3_000_000))
+    card = int(rng.choice([20_000, 60_000, 150_000]))
+    keys = rng.integers(0, card, n).astype(np.int64)
+    u = rng.random(n)
+    lo = 0.0
+    for h in range(int(rng.integers(1, 5))):
+        share = float(rng.uniform(0.01, 0.06))
+        keys[(u >= lo) & (u < lo + share)] = int(rng.integers(0, card))
+        lo += share
+    kvalid = (rng.random(n) > 0.02) if seed % 7 == 6 and not hashed else None
+    if rng.random() < 0.6:
+        vals = rng.standard_normal(n) * 10.0 ** rng.integers(-3, 6, n)
+    else:
+        vals = rng.integers(-10**12, 10**12, n).astype(np.int64)
+    vvalid = (rng.random(n) > rng.choice([0.03, 0.4])) if rng.random() < 0.4 else None
+    kinds = [int(k) for k in rng.permutation([0, 1, 2, 3, 4, 5, 6])[: int(rng.integers(1, 5))]]
+    ids, uniq, isnull, first = orc.group_ids(keys, kvalid)
+    G = len(uniq)
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys, kvalid))
+    assert gb.num_groups == G
+    vcol = px.Column.from_numpy(vals, vvalid, offset=int(seed % 3))
+    if seed % 3 == 0:
+        gb.bind(vcol)
+    outs = gb.agg(vcol, kinds)
+    plan = gb.last_plan()
+    if os.environ.get("PDX_TEST_PRINT_PLAN"):
+        print("PLAN", plan["layout"], "side=" + plan.get("side", "0"))
+    if plan["layout"] == "fused":   # (a hash table with the null / INT64_MIN slots, or too few slot bits, keeps the classic path)
+        assert "side" in plan, (seed, plan)
+    for kind, out in zip(kinds, outs):
+        got, ok = out.to_numpy()
+        exp, eok = orc.groupby_agg(kind, ids, G, vals, vvalid, nthreads=4)
+        assert (ok is None and eok.all()) or np.array_equal(ok, eok), (seed, kind, plan)
+        assert _bits_equal(got, exp, eok), (seed, kind, plan)

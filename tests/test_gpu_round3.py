@@ -408,3 +408,79 @@ def test_group_order_is_first_occurrence_where_arrow_differs(px, monkeypatch, na
     assert np.array_equal(uk, uniq) and np.array_equal(gb.first_rows().cpu().numpy(), first)
     arrow_order = z[f"{name}/arrow_order"]
     assert np.array_equal(np.sort(arrow_order), np.sort(uk)) and int((arrow_order != uk).sum()) == info["positions_that_differ"]
+
+
+# ------------------------------------------------------------------ hot keys: long runs through the side form
+@pytest.mark.parametrize("case", ["f64_sum_mean_count", "f64_five_kinds", "f64_nulls", "i64_five_kinds", "f64_variance_std", "bound_three_calls",
+                                  "wide_slots", "hash_slots"])
+def test_hot_keys_take_the_side_form(px, monkeypatch, case):
+    """A key that holds a few per cent of the rows makes its run longer than 2^19 rows.  That used to send the WHOLE column down the classic
+    path (one more sort pass + segmented reduce: +5 ms per 1e9 rows for a key with 0.06 % of them); now the fused kernels skip the few long
+    runs, whose rows are reduced from a side form (gathered with their slots, one sort pass, classic reducers).  Three hot keys: two in
+    runs of their own, the third sharing its run with the first.  Everything must equal the oracle bit for bit; the plan says side=<runs>."""
+    if case == "wide_slots":
+        monkeypatch.setenv("PDX_SORT_NARROW", "0")   # 4-byte slots through the passes: the side rows come from the sorted slots
+    if case == "hash_slots":   # (at this size a hash table's runs are below the default threshold: 2^18 slots, 4150 rows per run)
+        monkeypatch.setenv("PDX_GROUPBY_DENSE", "0")
+        monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_MIN_RUN", "0")
+    n = PROD_N
+    rng = np.random.default_rng(77)
+    keys = orc.synth_keys(0, n, PROD_KEYS)
+    u = rng.random(n)
+    low = (1 << 11) if case != "hash_slots" else 0
+    keys[u < 0.04] = 4242
+    keys[(u >= 0.04) & (u < 0.075)] = 77_001
+    if low:
+        keys[(u >= 0.075) & (u < 0.08)] = 4242 + 16 * low   # same low 11 slot bits as 4242: the same run
+    ids, uniq, _, _ = orc.group_ids(keys)
+    vvalid = None
+    if case.startswith("i64"):
+        vals = rng.integers(-10**15, 10**15, n).astype(np.int64)
+    else:
+        vals = orc.synth_vals(0, n) - 0.25
+    if case == "f64_nulls":
+        vvalid = rng.random(n) > 0.05
+    kinds = {"f64_sum_mean_count": [SUM, MEAN, COUNT], "f64_five_kinds": [SUM, MEAN, COUNT, MIN, MAX], "f64_nulls": [SUM, MEAN, COUNT, MIN, MAX],
+             "i64_five_kinds": [SUM, MEAN, COUNT, MIN, MAX], "f64_variance_std": [VAR, STD, MEAN], "bound_three_calls": [SUM, MEAN, COUNT],
+             "wide_slots": [SUM, MEAN, COUNT], "hash_slots": [SUM, MEAN, COUNT]}[case]
+    kcol, vcol = px.Column.from_numpy(keys), px.Column.from_numpy(vals, vvalid)
+    gb = px.K.GroupByHandle.create(kcol)
+    assert gb.num_groups == len(uniq)
+    if case == "bound_three_calls":
+        gb.bind(vcol)
+        outs = [gb.agg(vcol, [k])[0] for k in kinds]
+        assert gb.last_plan()["cache"] == "hit"
+    else:
+        outs = gb.agg(vcol, kinds)
+    plan = gb.last_plan()
+    assert plan["layout"] == "fused" and int(plan.get("side", 0)) in (2, 3), plan   # (hash slots: the three keys may lie in three runs)
+    _check_outs(kinds, outs, ids, len(uniq), vals, vvalid, case)
+    # the switch back: the whole column through the classic path, same answers
+    monkeypatch.setenv("PDX_FLR_HYBRID", "0")
+    gb2 = px.K.GroupByHandle.create(kcol)
+    outs2 = gb2.agg(vcol, kinds)
+    assert gb2.last_plan()["layout"] == "full" and gb2.last_plan().get("skew") == "1", gb2.last_plan()
+    _check_outs(kinds, outs2, ids, len(uniq), vals, vvalid, case + " hybrid off")
+
+
+def test_many_or_heavy_long_runs_keep_the_classic_path(px, monkeypatch):
+    """more long runs than the side form takes, or long runs holding more than a quarter of the rows: the whole column is finished by the
+    classic path as before"""
+    n = PROD_N
+    rng = np.random.default_rng(78)
+    keys = orc.synth_keys(0, n, PROD_KEYS)
+    keys[rng.random(n) < 0.3] = 4242
+    vals = orc.synth_vals(0, n) - 0.25
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys))
+    outs = gb.agg(px.Column.from_numpy(vals), [SUM, MEAN, COUNT])
+    assert gb.last_plan()["layout"] == "full" and gb.last_plan().get("skew") == "1", gb.last_plan()
+    ids, uniq, _, _ = orc.group_ids(keys)
+    _check_outs([SUM, MEAN, COUNT], outs, ids, len(uniq), vals, None, "heavy")
+    # a low limit makes most runs "long": far more than 256 of them
+    monkeypatch.setenv("PDX_FLR_MAX_RUN", "4096")
+    keys = orc.synth_keys(0, n, PROD_KEYS)
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys))
+    outs = gb.agg(px.Column.from_numpy(vals), [SUM, MEAN, COUNT])
+    assert gb.last_plan()["layout"] == "full" and gb.last_plan().get("skew") == "1", gb.last_plan()
+    ids, uniq, _, _ = orc.group_ids(keys)
+    _check_outs([SUM, MEAN, COUNT], outs, ids, len(uniq), vals, None, "many")
