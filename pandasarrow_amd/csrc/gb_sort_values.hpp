@@ -175,7 +175,11 @@ static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int
   const int64_t min_len = -1;
   if (nrows / nseg < mid_max) {
     const int64_t nwaves = (int64_t)kCUs * seg_wgs_per_cu * kSegWaves;
-    const int64_t gpw = std::max<int64_t>(64, ceil_div(nseg, nwaves));
+    // groups per wave: at least a batch of short groups (64), but with long groups few of them are a wave's worth of rows already -- a
+    // thousand 1000-row groups are a thousand waves, not sixteen
+    const int64_t avg_rows = std::max<int64_t>(1, nrows / nseg);
+    const int64_t min_gpw = std::max<int64_t>(1, std::min<int64_t>(64, 4096 / avg_rows));
+    const int64_t gpw = std::max<int64_t>(min_gpw, ceil_div(nseg, nwaves));
     const int grid_mid = (int)ceil_div(ceil_div(nseg, gpw), kSegWaves);
 #define SEG_MID(PW, MM, IS) \
   hipLaunchKernelGGL((k_seg_reduce_mid<T, PW, MM, IS>), dim3(grid_mid), b, 0, st, vals, seg_start, nseg, out_index, o, gpw)

@@ -80,12 +80,27 @@ template <int BITS>
 __global__ void __launch_bounds__(256) k_col_chunk_sums(const uint32_t* __restrict__ hist, int64_t ntiles,
                                                         uint32_t* __restrict__ chunk_sum /* [chunks][R] */) {
   constexpr int R = 1 << BITS;
+  constexpr int T = R >= 256 ? 1 : 256 / R;  // narrow digits: T threads share a digit's column (the tiles of the chunk dealt round-robin)
   int64_t t0 = (int64_t)blockIdx.x * kColChunk;
   int64_t t1 = t0 + kColChunk < ntiles ? t0 + kColChunk : ntiles;
-  for (int d = threadIdx.x; d < R; d += 256) {
+  if constexpr (T == 1) {
+    for (int d = threadIdx.x; d < R; d += 256) {
+      uint32_t acc = 0;
+      for (int64_t t = t0; t < t1; ++t) acc += hist[t * R + d];
+      chunk_sum[(int64_t)blockIdx.x * R + d] = acc;
+    }
+  } else {
+    __shared__ uint32_t part[256];
+    const int tl = threadIdx.x / R, d = threadIdx.x % R;
     uint32_t acc = 0;
-    for (int64_t t = t0; t < t1; ++t) acc += hist[t * R + d];
-    chunk_sum[(int64_t)blockIdx.x * R + d] = acc;
+    for (int64_t t = t0 + tl; t < t1; t += T) acc += hist[t * R + d];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (tl == 0) {
+#pragma unroll
+      for (int j = 1; j < T; ++j) acc += part[j * R + d];
+      chunk_sum[(int64_t)blockIdx.x * R + d] = acc;
+    }
   }
 }
 // one workgroup per digit: exclusive scan of the digit's column of chunk sums; digit_total[d] = rows with that digit
@@ -133,9 +148,28 @@ __global__ void __launch_bounds__(256) k_col_apply(uint32_t* __restrict__ hist, 
   }
   int64_t t0 = (int64_t)blockIdx.x * kColChunk;
   int64_t t1 = t0 + kColChunk < ntiles ? t0 + kColChunk : ntiles;
-  for (int d = threadIdx.x; d < R; d += 256) {
+  constexpr int T = R >= 256 ? 1 : 256 / R;  // narrow digits: T threads per column, each a contiguous share of the chunk's tiles
+  if constexpr (T == 1) {
+    for (int d = threadIdx.x; d < R; d += 256) {
+      uint32_t off = chunk_off[(int64_t)blockIdx.x * R + d] + dpre[d];
+      for (int64_t t = t0; t < t1; ++t) {
+        uint32_t v = hist[t * R + d];
+        hist[t * R + d] = off;
+        off += v;
+      }
+    }
+  } else {
+    __shared__ uint32_t part[256];
+    const int tl = threadIdx.x / R, d = threadIdx.x % R;
+    const int64_t sub = (t1 - t0 + T - 1) / T;
+    const int64_t ts = t0 + tl * sub, te = ts + sub < t1 ? ts + sub : t1;
+    uint32_t acc = 0;
+    for (int64_t t = ts; t < te; ++t) acc += hist[t * R + d];
+    part[threadIdx.x] = acc;
+    __syncthreads();
     uint32_t off = chunk_off[(int64_t)blockIdx.x * R + d] + dpre[d];
-    for (int64_t t = t0; t < t1; ++t) {
+    for (int j = 0; j < tl; ++j) off += part[j * R + d];
+    for (int64_t t = ts; t < te; ++t) {
       uint32_t v = hist[t * R + d];
       hist[t * R + d] = off;
       off += v;
