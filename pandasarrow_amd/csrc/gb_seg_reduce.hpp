@@ -483,18 +483,18 @@ struct SubState {
   T vmin, vmax;
   long long rmin, rmax;
 };
-struct BigPred {
-  const uint32_t* seg_start;
-  __device__ bool operator()(int64_t k) const { return (int64_t)seg_start[k + 1] - (int64_t)seg_start[k] > kBigSeg; }
-};
-struct BigEmit {
-  uint32_t* big_idx;
-  __device__ void operator()(int64_t pos, int64_t k) const { big_idx[pos] = (uint32_t)k; }
-};
+// The long groups, in no particular order (each is reduced on its own, so the order is immaterial): *count of them.  The kernels below read
+// the count from the device -- their launches are sized for the most long groups `nrows` rows can hold -- so the host never waits for it.
+__global__ void k_big_append(const uint32_t* __restrict__ seg_start, int64_t nseg, uint32_t* __restrict__ big_idx, int64_t* __restrict__ count) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += stride)
+    if ((int64_t)seg_start[k + 1] - (int64_t)seg_start[k] > kBigSeg) big_idx[atomicAdd(reinterpret_cast<unsigned long long*>(count), 1ull)] = (uint32_t)k;
+}
 // item_off[b] = first work item (sub-segment) of long group b; item_off[B] = number of items.  One workgroup.
-__global__ void __launch_bounds__(256) k_big_offsets(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ big_idx, int64_t B,
-                                                     int64_t* __restrict__ item_off) {
+__global__ void __launch_bounds__(256) k_big_offsets(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ big_idx,
+                                                     const int64_t* __restrict__ count, int64_t* __restrict__ item_off) {
   __shared__ int64_t smem[8];
+  const int64_t B = *count;
   int64_t carry = 0;
   for (int64_t b0 = 0; b0 < B; b0 += 256) {
     int64_t b = b0 + threadIdx.x;
@@ -514,12 +514,14 @@ __global__ void __launch_bounds__(256) k_big_offsets(const uint32_t* __restrict_
 template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM>
 __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_sub(const T* __restrict__ vals, const uint32_t* __restrict__ seg_start,
                                                                    const uint32_t* __restrict__ big_idx, const int64_t* __restrict__ item_off,
-                                                                   int64_t B, SubState<T>* __restrict__ state) {
+                                                                   const int64_t* __restrict__ count, SubState<T>* __restrict__ state) {
   __shared__ double stage[kSegWaves][64 * 17];
   __shared__ double csum_all[kSegWaves][48];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double* lds = stage[wave];
   double* csum = csum_all[wave];
+  const int64_t B = *count;
+  if (B == 0) return;
   const int64_t nitems = item_off[B];
   const int64_t nw = (int64_t)gridDim.x * kSegWaves;
   for (int64_t t = (int64_t)blockIdx.x * kSegWaves + wave; t < nitems; t += nw) {
@@ -554,11 +556,12 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_sub(const T* __re
 }
 template <typename T, bool WANT_PAIRWISE, bool WANT_MINMAX, bool WANT_ISUM>
 __global__ void __launch_bounds__(64) k_seg_combine_big(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ big_idx,
-                                                        const int64_t* __restrict__ item_off, int64_t B, const SubState<T>* __restrict__ state,
-                                                        const uint32_t* __restrict__ out_index, SegOut out) {
+                                                        const int64_t* __restrict__ item_off, const int64_t* __restrict__ count,
+                                                        const SubState<T>* __restrict__ state, const uint32_t* __restrict__ out_index, SegOut out) {
   // one wave per long group.  64 consecutive FULL sub-segments (64-aligned within the group) are a perfect subtree of level-12
   // nodes: one butterfly makes their level-18 node; everything else is replayed by lane 0.
   const int64_t b = blockIdx.x;
+  if (b >= *count) return;
   const int lane = threadIdx.x;
   const uint32_t k = big_idx[b];
   const uint32_t oi = out_index ? out_index[k] : k;

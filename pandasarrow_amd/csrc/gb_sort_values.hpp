@@ -144,26 +144,23 @@ static int launch_seg_reduce_dense(const T* vals, const uint32_t* seg_start, int
   }
   // ---- long groups first (their outputs are skipped by the per-group kernels below)
   if (nrows > kBigSeg) {
-    const int64_t maxB = nrows / kBigSeg + 1;  // a long group has more than kBigSeg rows
-    uint32_t* big_idx = s.get<uint32_t>((size_t)std::min<int64_t>(nseg, maxB));
+    const int64_t maxB = std::min<int64_t>(nseg, nrows / kBigSeg + 1);  // a long group has more than kBigSeg rows
+    const int64_t max_items = nrows / kBigSeg + maxB;
+    uint32_t* big_idx = s.get<uint32_t>((size_t)maxB);
+    int64_t* nbig = s.get<int64_t>(1);
+    int64_t* item_off = s.get<int64_t>((size_t)maxB + 1);
+    SubState<T>* state = s.get<SubState<T>>((size_t)max_items);
     PDX_SCRATCH_CHECK(s);
-    int64_t B = 0;
-    PDX_TRY(compact_indices(nseg, BigPred{seg_start}, BigEmit{big_idx}, &B, s, st));
-    if (B > 0) {
-      const int64_t max_items = nrows / kBigSeg + B;
-      int64_t* item_off = s.get<int64_t>((size_t)B + 1);
-      SubState<T>* state = s.get<SubState<T>>((size_t)max_items);
-      PDX_SCRATCH_CHECK(s);
-      hipLaunchKernelGGL(k_big_offsets, dim3(1), dim3(256), 0, st, seg_start, big_idx, B, item_off);
-      const int grid_sub = (int)std::min<int64_t>(ceil_div(max_items, kSegWaves), (int64_t)kCUs * 8);
-#define SEG_SUB(PW, MM, IS)                                                                                                                   \
-  hipLaunchKernelGGL((k_seg_reduce_sub<T, PW, MM, IS>), dim3(grid_sub), dim3(kSegWaves * 64), 0, st, vals, seg_start, big_idx, item_off, B, state); \
-  hipLaunchKernelGGL((k_seg_combine_big<T, PW, MM, IS>), dim3((unsigned)B), dim3(64), 0, st, seg_start, big_idx, item_off, B, state, \
-                     out_index, o)
-      SEG_DISPATCH(SEG_SUB)
+    PDX_HIP(hipMemsetAsync(nbig, 0, sizeof(int64_t), st));
+    hipLaunchKernelGGL(k_big_append, dim3(grid_for(nseg, 256)), dim3(256), 0, st, seg_start, nseg, big_idx, nbig);
+    hipLaunchKernelGGL(k_big_offsets, dim3(1), dim3(256), 0, st, seg_start, big_idx, nbig, item_off);
+    const int grid_sub = (int)std::min<int64_t>(ceil_div(max_items, kSegWaves), (int64_t)kCUs * 8);
+#define SEG_SUB(PW, MM, IS)                                                                                                                      \
+  hipLaunchKernelGGL((k_seg_reduce_sub<T, PW, MM, IS>), dim3(grid_sub), dim3(kSegWaves * 64), 0, st, vals, seg_start, big_idx, item_off, nbig, state); \
+  hipLaunchKernelGGL((k_seg_combine_big<T, PW, MM, IS>), dim3((unsigned)maxB), dim3(64), 0, st, seg_start, big_idx, item_off, nbig, state, out_index, o)
+    SEG_DISPATCH(SEG_SUB)
 #undef SEG_SUB
-      PDX_LAUNCH_CHECK();
-    }
+    PDX_LAUNCH_CHECK();
   }
   // workgroups per CU: a multiple of what is resident at once (the 4-wave workgroups hold ~44 KB of LDS: 3 per CU), so that the waves'
   // static shares of the groups run in full rounds (8 per CU meant 3 + 3 + 2).  PDX_SEG_WGS_PER_CU: diagnostic.
