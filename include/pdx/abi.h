@@ -252,6 +252,10 @@ int pdx_groupby_group_ids(pdx_groupby* gb, uint32_t* out_ids, void* stream);
 int pdx_groupby_map_ids(pdx_groupby* gb, const int64_t* map, int64_t* out, void* stream);
 /* first_row[g] = index of the first row of group g (device pointer to G int64) */
 int pdx_groupby_first_rows(const pdx_groupby* gb, int64_t* out_rows, void* stream);
+/* Grouper::MakeGroupings (src/dataframe.cpp:1546, 1562; what GroupBy::group / MakeSubDataFrame / apply walk, src/group_by.h:39-77):
+ * out_rows (n int64, device) = the rows of group 0, then of group 1, ... each ascending; out_offsets (G + 1 int64, device): group g
+ * owns out_rows[out_offsets[g] .. out_offsets[g + 1]).  Not part of pdx_groupby_create: only callers that walk groups pay for it. */
+int pdx_groupby_groupings(pdx_groupby* gb, int64_t* out_rows, int64_t* out_offsets, void* stream);
 /* Replaces GROUPBY_AGG(sum|min|max) and GROUPBY_NUMERIC_AGG(mean|count) (src/pd_core_macros.h:5-147, instantiated
  * src/dataframe.cpp:1512-1534): for every group, the scalar aggregate over the group's rows IN ROW ORDER.
  * `kinds`/`outs` have nk entries and are all computed from one grouped pass over `values` (sum/mean/count of the

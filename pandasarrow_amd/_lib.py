@@ -99,6 +99,7 @@ ABI_SYMBOLS = {
     "pdx_groupby_group_ids": (C.c_int, [_P, _P, _P]),
     "pdx_groupby_map_ids": (C.c_int, [_P, _P, _P, _P]),
     "pdx_groupby_first_rows": (C.c_int, [_P, _P, _P]),
+    "pdx_groupby_groupings": (C.c_int, [_P, _P, _P, _P]),
     "pdx_groupby_agg": (C.c_int, [_P, _COL, C.POINTER(C.c_int), C.c_int, _MUT, _P]),
     "pdx_groupby_bind": (C.c_int, [_P, _COL, _P]),
     "pdx_groupby_unbind": (C.c_int, [_P, _COL]),

@@ -692,6 +692,89 @@ class GroupBy:
         self.key = key
         self._h = _handle if _handle is not None else K.GroupByHandle.create(df[key].col)
         self._bound_names = set()
+        self._groupings_cache = None
+        self._keys_host = None
+
+    # ---- walking the groups (src/group_by.h:39-77; dataframe.cpp:1354-1510).  The reference materialises every group's arrays in the
+    # constructor; here the groupings (pdx_groupby_groupings) are built on first use and a group's frame is one take.
+    def _groupings(self):
+        if self._groupings_cache is None:
+            rows, off = self._h.groupings()
+            self._groupings_cache = (rows, off.cpu().numpy())
+        return self._groupings_cache
+
+    def _keys(self):
+        if self._keys_host is None:
+            vals, ok = self.unique().to_numpy()
+            self._keys_host = (vals, ok)
+        return self._keys_host
+
+    def GetKeyByIndex(self, i):
+        """uniqueKeys->GetScalar(i) (group_by.h:57-60): the key of group i as a python scalar, None for the null key"""
+        vals, ok = self._keys()
+        if not 0 <= i < len(vals):
+            raise L.PdxError(L.INDEX_ERROR, f"Index {i} out of bounds")
+        return None if ok is not None and not ok[i] else vals[i].item()
+
+    def _group_index(self, key):
+        vals, ok = self._keys()
+        if key is None:
+            hit = np.flatnonzero(~ok) if ok is not None else np.array([], dtype=np.int64)
+        else:
+            hit = np.flatnonzero((vals == key) & (ok if ok is not None else True))
+        if len(hit) == 0:
+            raise KeyError(f"{key} is an invalid key")   # group_by.h:45-49
+        return int(hit[0])
+
+    def MakeSubDataFrame(self, groupIndex=None, key=None):
+        """MakeSubDataFrame(groupIndex) / MakeSubDataFrame(key) (group_by.h:62-73; python has no overloads, so the key form is spelled
+        key=...): the rows of one group, every column and the index, in row order"""
+        i = self._group_index(key) if groupIndex is None else int(groupIndex)
+        if not 0 <= i < self.groupSize():
+            raise L.PdxError(L.INDEX_ERROR, f"Index {i} out of bounds")
+        rows, off = self._groupings()
+        sel = rows[int(off[i]):int(off[i + 1])]
+        idx = Column(L.INT64, int(sel.numel()), sel, None)
+        outs = K.take(self.df.cols + [_frame_index(self.df)], idx)
+        return self.df._like(outs[:-1], index=outs[-1])
+
+    def group(self, key):
+        """GroupBy::group(value) (group_by.h:38-50): the group's column arrays"""
+        return self.MakeSubDataFrame(key=key).cols
+
+    def apply(self, fn, per_column=False, _index_keys=False):
+        """GroupBy::apply (dataframe.cpp:1430-1510).  fn(DataFrame) -> scalar: Series indexed by the unique keys; fn(DataFrame) -> array of
+        the group's length: the arrays concatenated in GROUP order under the frame's own index (as the reference does);
+        per_column=True: fn(Series) -> scalar for every column of every group -> DataFrame with one row per group."""
+        G = self.groupSize()
+        if per_column:
+            subs = [self.MakeSubDataFrame(i) for i in range(G)]
+            cols = {}
+            for nm in self.df.names:
+                cols[nm] = _scalars_to_column([fn(Series(sub.cols[sub.names.index(nm)], index=sub.index, name=nm)) for sub in subs])
+            return DataFrame(cols, index=self.unique() if _index_keys else None)
+        results = [fn(self.MakeSubDataFrame(i)) for i in range(G)]
+        if results and isinstance(results[0], (Series, Column, np.ndarray, list)):
+            parts = []
+            for i, r in enumerate(results):
+                c = r.col if isinstance(r, Series) else (r if isinstance(r, Column) else Column.from_numpy(np.asarray(r)))
+                rows, off = self._groupings()
+                if c.length != int(off[i + 1] - off[i]):
+                    raise L.PdxError(L.INVALID, f"Failed to Merge Apply::Functor due to inconsistent Row Length\n{c.length} != {int(off[i + 1] - off[i])}")
+                parts.append(c)
+            return Series(K.concat(parts), index=self.df.index)
+        return Series(_scalars_to_column(results), index=self.unique())
+
+    def apply_async(self, fn, per_column=False):
+        """apply_async (dataframe.cpp:1354-1408): the same results (the per-column form is indexed by the unique keys)"""
+        return self.apply(fn, per_column, _index_keys=True)
+
+    def apply_chunk(self, fn):
+        """apply_chunk (dataframe.cpp:1411-1428): fn(DataFrame) -> DataFrame per group, concatenated along the index"""
+        return concat([fn(self.MakeSubDataFrame(i)) for i in range(self.groupSize())], axis="index")
+
+    def getDF(self):
+        return self.df
 
     def groupSize(self):
         return self._h.num_groups
@@ -827,6 +910,17 @@ def concat(frames, axis="index", join="outer", ignore_index=False, sort=False):
     df = DataFrame.__new__(DataFrame)
     df.names, df.cols, df.index = list(names), cols, index
     return df
+
+
+def _scalars_to_column(vals):
+    """buildArray(ScalarVector): Scalars / python scalars (None = null) -> one column; ints stay int64 unless a float is among them"""
+    vals = [v.value if isinstance(v, Scalar) else v for v in vals]
+    ok = np.array([v is not None for v in vals], dtype=bool)
+    isf = any(isinstance(v, (float, np.floating)) for v in vals)
+    isb = bool(vals) and all(isinstance(v, (bool, np.bool_)) or v is None for v in vals)
+    dt = bool if isb else (np.float64 if isf else np.int64)
+    arr = np.array([dt(0) if v is None else v for v in vals], dtype=dt)
+    return Column.from_numpy(arr, None if ok.all() else ok)
 
 
 def _frame_index(f):

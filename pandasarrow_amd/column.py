@@ -439,6 +439,13 @@ class GroupByHandle:
         L.check(L.load().pdx_groupby_first_rows(self._h, out.data_ptr(), _stream()))
         return out[: self.num_groups]
 
+    def groupings(self):
+        """Grouper::MakeGroupings: (rows int64 [n]: the rows of group 0, then group 1, ..., each ascending; offsets int64 [G + 1])."""
+        rows = torch.empty(max(self.num_rows, 1), dtype=torch.int64, device=_device())
+        off = torch.empty(self.num_groups + 1, dtype=torch.int64, device=_device())
+        L.check(L.load().pdx_groupby_groupings(self._h, rows.data_ptr(), off.data_ptr(), _stream()))
+        return rows[: self.num_rows], off
+
     def row_labels(self) -> torch.Tensor:
         out = torch.empty(max(self.num_rows, 1), dtype=torch.int64, device=_device())
         L.check(L.load().pdx_resample_row_labels(self._h, out.data_ptr(), _stream()))

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <algorithm>
 #include <cstdio>
+#include <functional>
 #include <map>
 #include <memory>
 #include <array>
@@ -1004,6 +1005,114 @@ struct GroupBy {
   DataFrame product(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_PRODUCT); }
   DataFrame first(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_FIRST); }
   DataFrame last(const std::vector<std::string>& a) const { return agg(a, PDX_AGG_LAST); }
+
+  // ---- walking the groups (src/group_by.h:39-77; src/dataframe.cpp:1354-1510).  The reference materialises every group's arrays in
+  // the constructor (Grouper::MakeGroupings + ApplyGroupings); here the groupings are built on first use (pdx_groupby_groupings) and a
+  // group's frame is one take of its rows.
+  struct Groupings {
+    Array rows;                    // int64, device: the rows of group 0, then of group 1, ..., each ascending
+    std::vector<int64_t> offsets;  // G + 1
+  };
+  const Groupings& groupings() const {
+    if (!m_groupings) {
+      auto g = std::make_shared<Groupings>();
+      const int64_t n = pdx_groupby_num_rows(handle->h), G = (int64_t)groupSize();
+      g->rows = Array::Empty(PDX_INT64, n, false);
+      DeviceBuffer off((size_t)(G + 1) * 8);
+      ThrowOnFailure(pdx_groupby_groupings(handle->h, static_cast<int64_t*>(g->rows.values->ptr), static_cast<int64_t*>(off.ptr), nullptr));
+      g->offsets.resize((size_t)G + 1);
+      ThrowOnFailure(pdx_to_host(g->offsets.data(), off.ptr, (size_t)(G + 1) * 8, nullptr));
+      m_groupings = g;
+    }
+    return *m_groupings;
+  }
+  Scalar GetKeyByIndex(int64_t i) const {  // uniqueKeys->GetScalar(i) (group_by.h:57-60)
+    if (!m_keys) {
+      Array u = unique();
+      m_keys = std::make_shared<std::pair<std::vector<int64_t>, std::vector<bool>>>(u.values_as<int64_t>(), u.valid_flags());
+      if (u.dtype == PDX_FLOAT64) m_keys_f = std::make_shared<std::vector<double>>(u.values_as<double>());
+    }
+    if (i < 0 || i >= (int64_t)m_keys->first.size()) throw std::runtime_error("Index " + std::to_string(i) + " out of bounds");
+    if (!m_keys->second[(size_t)i]) return Scalar();
+    return m_keys_f ? Scalar((*m_keys_f)[(size_t)i]) : Scalar(m_keys->first[(size_t)i]);
+  }
+  int64_t index_of_key(const Scalar& key) const {
+    for (int64_t i = 0; i < (int64_t)groupSize(); ++i) {
+      const Scalar k = GetKeyByIndex(i);
+      if (k.isValid() != key.isValid()) continue;
+      if (!k.isValid() || k.as<double>() == key.as<double>()) return i;
+    }
+    throw std::out_of_range("invalid key");  // groups.at(key) (group_by.h:41-49)
+  }
+  DataFrame MakeSubDataFrame(int64_t groupIndex) const {  // (group_by.h:62-73; the schema argument is the frame's own here)
+    const Groupings& g = groupings();
+    if (groupIndex < 0 || groupIndex >= (int64_t)groupSize()) throw std::runtime_error("Index " + std::to_string(groupIndex) + " out of bounds");
+    Array idx = g.rows;
+    idx.offset = g.offsets[(size_t)groupIndex];
+    idx.length = g.offsets[(size_t)groupIndex + 1] - idx.offset;
+    std::vector<Array> cols = df.m_columns;
+    cols.push_back(df.m_index ? *df.m_index : row_numbers());
+    auto outs = Series::run_take(cols, idx);
+    Array index = outs.back();
+    outs.pop_back();
+    return DataFrame(df.m_names, outs, index);
+  }
+  DataFrame MakeSubDataFrame(const Scalar& key) const { return MakeSubDataFrame(index_of_key(key)); }
+  template <typename T>
+  std::vector<Array> group(T value) const { return MakeSubDataFrame(Scalar(value)).m_columns; }  // GroupBy::group (group_by.h:38-50)
+  const DataFrame& getDF() const { return df; }
+
+  // apply (src/dataframe.cpp:1430-1510): one call per group over its sub-frame; scalars -> Series indexed by the unique keys, arrays of
+  // the groups' lengths -> concatenated in group order under the frame's own index; per column: Series -> scalar for every column
+  Series apply(const std::function<Scalar(DataFrame const&)>& fn) const {
+    std::vector<Scalar> r;
+    for (int64_t i = 0; i < (int64_t)groupSize(); ++i) r.push_back(fn(MakeSubDataFrame(i)));
+    return Series(build_array(r), unique());
+  }
+  inline Series apply(const std::function<Array(DataFrame const&)>& fn) const;
+  DataFrame apply(const std::function<Scalar(Series const&)>& fn, bool index_keys = false) const {
+    const int64_t G = (int64_t)groupSize();
+    std::vector<DataFrame> subs;
+    for (int64_t i = 0; i < G; ++i) subs.push_back(MakeSubDataFrame(i));
+    std::vector<Array> cols;
+    for (size_t c = 0; c < df.m_names.size(); ++c) {
+      std::vector<Scalar> r;
+      for (auto& sub : subs) r.push_back(fn(Series(sub.m_columns[c], sub.m_index, df.m_names[c])));
+      cols.push_back(build_array(r));
+    }
+    return index_keys ? DataFrame(df.m_names, cols, unique()) : DataFrame(df.m_names, cols);
+  }
+  // apply_async (src/dataframe.cpp:1354-1408): the same results; the per-column form is indexed by the unique keys
+  Series apply_async(const std::function<Scalar(DataFrame const&)>& fn) const { return apply(fn); }
+  DataFrame apply_async(const std::function<Scalar(Series const&)>& fn) const { return apply(fn, true); }
+  inline DataFrame apply_chunk(const std::function<DataFrame(DataFrame const&)>& fn) const;  // (src/dataframe.cpp:1411-1428)
+
+  static Array build_array(const std::vector<Scalar>& r) {  // buildArray(ScalarVector): int64 unless a double is among the scalars
+    bool any_f = false;
+    for (auto& x : r) any_f = any_f || (x.isValid() && x.s.dtype == PDX_FLOAT64);
+    std::vector<bool> valid;
+    for (auto& x : r) valid.push_back(x.isValid());
+    if (any_f) {
+      std::vector<double> v;
+      for (auto& x : r) v.push_back(x.isValid() ? x.as<double>() : 0.0);
+      return Array::Make(v, &valid);
+    }
+    std::vector<int64_t> v;
+    for (auto& x : r) v.push_back(x.isValid() ? x.as<int64_t>() : 0);
+    return Array::Make(v, &valid);
+  }
+
+ private:
+  Array row_numbers() const {  // the implicit index: uint64 0 .. n-1 (uint_range, src/ndframe.cpp:100-107)
+    std::vector<int64_t> v((size_t)df.num_rows());
+    for (size_t i = 0; i < v.size(); ++i) v[i] = (int64_t)i;
+    Array a = Array::Make(v);
+    a.dtype = PDX_UINT64;
+    return a;
+  }
+  mutable std::shared_ptr<Groupings> m_groupings;
+  mutable std::shared_ptr<std::pair<std::vector<int64_t>, std::vector<bool>>> m_keys;
+  mutable std::shared_ptr<std::vector<double>> m_keys_f;
 };
 
 // ---------------------------------------------------------------- pd::Resampler (src/group_by.h:255-299)
@@ -1245,5 +1354,23 @@ inline Array concat(Communicator& comm, const Array& part, int64_t total_rows) {
   return out;
 }
 }  // namespace dist
+
+// GroupBy::apply(fn -> Array) and apply_chunk need concat: defined here
+inline Series GroupBy::apply(const std::function<Array(DataFrame const&)>& fn) const {
+  std::vector<Array> parts;
+  for (int64_t i = 0; i < (int64_t)groupSize(); ++i) {
+    DataFrame sub = MakeSubDataFrame(i);
+    Array r = fn(sub);
+    if (r.length != sub.num_rows())
+      throw std::runtime_error("Failed to Merge Apply::Functor due to inconsistent Row Length\n" + std::to_string(r.length) + " != " + std::to_string(sub.num_rows()));
+    parts.push_back(r);
+  }
+  return Series(concat_arrays(parts), df.m_index);
+}
+inline DataFrame GroupBy::apply_chunk(const std::function<DataFrame(DataFrame const&)>& fn) const {
+  std::vector<DataFrame> parts;
+  for (int64_t i = 0; i < (int64_t)groupSize(); ++i) parts.push_back(fn(MakeSubDataFrame(i)));
+  return concat(parts);
+}
 
 }  // namespace pd

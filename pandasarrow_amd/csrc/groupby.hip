@@ -740,6 +740,69 @@ int pdx_groupby_map_ids(pdx_groupby* gb, const int64_t* map, int64_t* out, void*
   return PDX_OK;
 }
 
+}  // extern "C"
+
+namespace pdx {
+// offsets[g] = first position of group id g in the sorted ids (g = G: n); rows[i] widened to int64
+__global__ void k_groupings_finish(const uint32_t* __restrict__ sorted_ids, const uint32_t* __restrict__ rows32, int64_t n, int64_t G,
+                                   int64_t* __restrict__ out_rows, int64_t* __restrict__ out_offsets) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n + G + 1; i += stride) {
+    if (i < n) {
+      out_rows[i] = (int64_t)rows32[i];
+      continue;
+    }
+    const int64_t g = i - n;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)sorted_ids[mid] < g) lo = mid + 1;
+      else hi = mid;
+    }
+    out_offsets[g] = lo;
+  }
+}
+__global__ void k_iota_rows(uint32_t* __restrict__ p, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = (uint32_t)i;
+}
+}  // namespace pdx
+
+extern "C" {
+// Grouper::MakeGroupings (src/dataframe.cpp:1546, 1562): the rows of every group, ascending, groups in group-id order
+int pdx_groupby_groupings(pdx_groupby* gb, int64_t* out_rows, int64_t* out_offsets, void* stream) {
+  if (!gb || !out_rows || !out_offsets) return fail(PDX_INVALID, "pdx_groupby_groupings: null argument");
+  hipStream_t st = as_stream(stream);
+  gb->use_on(st);
+  const int64_t n = gb->n, G = gb->G;
+  if (n == 0) {
+    PDX_HIP(hipMemsetAsync(out_offsets, 0, sizeof(int64_t) * (size_t)(G + 1), st));
+    PDX_HIP(hipStreamSynchronize(st));
+    return PDX_OK;
+  }
+  Scratch s;
+  uint32_t* ids = s.get<uint32_t>((size_t)n);
+  uint32_t* rows = s.get<uint32_t>((size_t)n);
+  uint32_t* k0 = s.get<uint32_t>((size_t)n);
+  uint32_t* k1 = s.get<uint32_t>((size_t)n);
+  uint32_t* v0 = s.get<uint32_t>((size_t)n);
+  uint32_t* v1 = s.get<uint32_t>((size_t)n);
+  PDX_SCRATCH_CHECK(s);
+  PDX_TRY(pdx_groupby_group_ids(gb, ids, stream));
+  hipLaunchKernelGGL(k_iota_rows, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, rows, n);
+  PDX_LAUNCH_CHECK();
+  const uint32_t* ks = ids;
+  const uint32_t* vs = rows;
+  if (gb->mode == 0 && G > 1) {  // (segments mode: the rows are grouped as they stand)
+    const int bits = std::max(1, ilog2((uint64_t)G));
+    PDX_TRY((radix_sort_pairs<uint32_t>(ids, rows, k0, v0, k1, v1, n, bits, &ks, &vs, true, s, st)));
+  }
+  hipLaunchKernelGGL(k_groupings_finish, dim3(grid_for(n + G + 1, 256, 4)), dim3(256), 0, st, ks, vs, n, G, out_rows, out_offsets);
+  PDX_LAUNCH_CHECK();
+  PDX_HIP(hipStreamSynchronize(st));
+  return PDX_OK;
+}
+
 // ---------------------------------------------------------------- stage 2 of pdx_groupby_agg: reducers over a GroupedLayout
 }  // extern "C"
 

@@ -436,6 +436,39 @@ static void test_parquet_round_trip() {
   std::remove(path.c_str());
 }
 
+// GroupBy::group / GetKeyByIndex / MakeSubDataFrame / apply / apply_chunk (src/group_by.h:39-77, src/dataframe.cpp:1354-1510) over
+// pdx_groupby_groupings; the frame of tests/dataframe_iterator_test.cpp:11-44 (keys 1,3,8,2; sums of b 37,12,3,3)
+static void test_groupby_walkers() {
+  DataFrame df({"a", "b"}, {Array::Make(std::vector<long>{1, 1, 3, 1, 1, 1, 3, 8, 2, 2}), Array::Make(std::vector<double>{10, 9, 8, 7, 6, 5, 4, 3, 2, 1})});
+  auto gb = df.group_by("a");
+  REQUIRE(gb.groupSize() == 4);
+  REQUIRE(gb.GetKeyByIndex(0).as<long>() == 1 && gb.GetKeyByIndex(1).as<long>() == 3 && gb.GetKeyByIndex(2).as<long>() == 8 && gb.GetKeyByIndex(3).as<long>() == 2);
+  REQUIRE((gb.groupings().offsets == std::vector<int64_t>{0, 5, 7, 8, 10}));
+  REQUIRE((gb.groupings().rows.values_as<int64_t>() == std::vector<int64_t>{0, 1, 3, 4, 5, 2, 6, 7, 8, 9}));
+  DataFrame sub = gb.MakeSubDataFrame(1);
+  REQUIRE((sub["b"].values<double>() == std::vector<double>{8, 4}));
+  REQUIRE((sub.m_index->values_as<int64_t>() == std::vector<int64_t>{2, 6}));   // the group's rows of the (implicit) index
+  REQUIRE((gb.group(8L)[1].values_as<double>() == std::vector<double>{3}));
+  {  // groups.at(key) (group_by.h:41-49): std::out_of_range
+    bool oor = false;
+    try { (void)gb.group(99L); } catch (const std::out_of_range&) { oor = true; }
+    REQUIRE(oor);
+  }
+  Series s = gb.apply([](DataFrame const& f) { return f["b"].sum(); });
+  REQUIRE((s.values<double>() == std::vector<double>{37, 12, 3, 3}));
+  REQUIRE((s.m_index->values_as<int64_t>() == std::vector<int64_t>{1, 3, 8, 2}));
+  Series arr = gb.apply([](DataFrame const& f) { return (f["b"] * Scalar(2.0)).m_array; });
+  REQUIRE((arr.values<double>() == std::vector<double>{20, 18, 14, 12, 10, 16, 8, 6, 4, 2}));
+  REQUIRE_THROWS(gb.apply([](DataFrame const& f) { return Array::Make(std::vector<double>((size_t)f.num_rows() + 1, 0.0)); }));
+  DataFrame pc = gb.apply([](Series const& c) { return c.max(); });
+  REQUIRE((pc["b"].values<double>() == std::vector<double>{10, 8, 3, 2}));
+  REQUIRE(!pc.m_index);
+  DataFrame pa = gb.apply_async([](Series const& c) { return c.max(); });
+  REQUIRE((pa.m_index->values_as<int64_t>() == std::vector<int64_t>{1, 3, 8, 2}));
+  DataFrame ch = gb.apply_chunk([](DataFrame const& f) { return f * Scalar(1.0); });
+  REQUIRE((ch["b"].values<double>() == std::vector<double>{10, 9, 7, 6, 5, 8, 4, 3, 2, 1}));
+}
+
 int main() {
   ThrowOnFailure(pdx_init(0));
   test_series_math();
@@ -448,6 +481,7 @@ int main() {
   test_sort();
   test_frame_compare_logical_reindex();
   test_groupby_bound_columns();
+  test_groupby_walkers();
   test_sharded_groupby_from_cpp();
   test_parquet_round_trip();
   std::printf("%d checks, %d failed\n", g_checks, g_failed);

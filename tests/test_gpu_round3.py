@@ -484,3 +484,49 @@ def test_many_or_heavy_long_runs_keep_the_classic_path(px, monkeypatch):
     assert gb.last_plan()["layout"] == "full" and gb.last_plan().get("skew") == "1", gb.last_plan()
     ids, uniq, _, _ = orc.group_ids(keys)
     _check_outs([SUM, MEAN, COUNT], outs, ids, len(uniq), vals, None, "many")
+
+
+# ------------------------------------------------------------------ walking the groups (GroupBy::group / MakeSubDataFrame / apply)
+def test_groupings_and_apply_family(px):
+    """pdx_groupby_groupings == Grouper::MakeGroupings (rows of every group ascending, groups in first-occurrence order), and the
+    reference's group walkers on top of it: GetKeyByIndex, MakeSubDataFrame, group, apply (scalar / array / per column), apply_chunk.
+    Known answers from tests/dataframe_iterator_test.cpp:11-44 (keys 1,3,8,2 -> sums 37,12,3,3) plus a larger random case against numpy."""
+    api, L = px.api, px.L
+    df = api.DataFrame({"id": np.array([1, 3, 8, 1, 2, 3], dtype=np.int64), "v": np.array([30.0, 5.0, 3.0, 7.0, 3.0, 7.0])})
+    gb = df.group_by("id")
+    assert gb.groupSize() == 4 and [gb.GetKeyByIndex(i) for i in range(4)] == [1, 3, 8, 2]
+    rows, off = gb._h.groupings()
+    assert rows.cpu().tolist() == [0, 3, 1, 5, 2, 4] and off.cpu().tolist() == [0, 2, 4, 5, 6]
+    sub = gb.MakeSubDataFrame(1)
+    assert sub.cols[1].to_numpy()[0].tolist() == [5.0, 7.0] and sub.index.to_numpy()[0].tolist() == [1, 5]
+    assert gb.group(8)[1].to_numpy()[0].tolist() == [3.0]
+    with pytest.raises(KeyError):
+        gb.group(99)
+    s = gb.apply(lambda f: f["v"].sum())              # fn returns a Scalar, as the reference's ScalarPtr
+    assert s.col.to_numpy()[0].tolist() == [37.0, 12.0, 3.0, 3.0] and s.index.to_numpy()[0].tolist() == [1, 3, 8, 2]
+    a = gb.apply(lambda f: (f["v"] * 2.0))      # arrays of the groups' lengths: concatenated in group order
+    assert a.col.to_numpy()[0].tolist() == [60.0, 14.0, 10.0, 14.0, 6.0, 6.0]
+    with pytest.raises(L.PdxError, match="inconsistent Row Length"):
+        gb.apply(lambda f: np.zeros(f.num_rows() + 1))
+    pc = gb.apply(lambda c: c.max(), per_column=True)
+    assert pc.cols[pc.names.index("v")].to_numpy()[0].tolist() == [30.0, 7.0, 3.0, 3.0] and pc.cols[pc.names.index("id")].to_numpy()[0].tolist() == [1, 3, 8, 2]
+    assert gb.apply_async(lambda c: c.max(), per_column=True).index.to_numpy()[0].tolist() == [1, 3, 8, 2]
+    ch = gb.apply_chunk(lambda f: f * 1.0)
+    assert ch.cols[ch.names.index("v")].to_numpy()[0].tolist() == [30.0, 7.0, 5.0, 7.0, 3.0, 3.0]
+    # larger: every path of the key -> slot machinery must hand back the same groupings as a stable argsort of the oracle's ids
+    rng = np.random.default_rng(12)
+    for n, card, spread in ((200_000, 5_000, False), (300_000, 40_000, True), (70_000, 3, False)):
+        keys = rng.integers(0, card, n).astype(np.int64) * (1_000_003_019 if spread else 1)
+        kvalid = rng.random(n) > 0.01
+        gbh = px.K.GroupByHandle.create(px.Column.from_numpy(keys, kvalid))
+        ids, uniq, _, _ = orc.group_ids(keys, kvalid)
+        rows, off = gbh.groupings()
+        order = np.argsort(ids, kind="stable")
+        assert np.array_equal(rows.cpu().numpy(), order)
+        assert np.array_equal(off.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(ids, minlength=len(uniq)))]))
+    # segments mode (resample bins): groups are runs, the groupings are the identity
+    ts = np.arange(0, 1000, dtype=np.int64) * 100_000_000 + 946_684_800_000_000_000
+    rs = px.K.GroupByHandle.resample(px.Column.from_numpy(ts, dtype=L.TIMESTAMP_NS), 60_000_000_000) if hasattr(px.K.GroupByHandle, "resample") else None
+    if rs is not None:
+        rows, off = rs.groupings()
+        assert np.array_equal(rows.cpu().numpy(), np.arange(1000)) and off.cpu().numpy()[-1] == 1000
