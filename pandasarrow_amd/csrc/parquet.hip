@@ -1220,8 +1220,9 @@ int pdx_parquet_write(const pdx_column* cols, const char* const* names, int ncol
       } else {  // PLAIN 8-byte values of the non-null rows
         const size_t at = payload.size();
         payload.resize(at + (size_t)nonnull * 8);
-        if (nonnull == rows) memcpy(payload.data() + at, vals.data() + r0, (size_t)rows * 8);
-        else {
+        if (nonnull == rows) {
+          if (rows) memcpy(payload.data() + at, vals.data() + r0, (size_t)rows * 8);  // (an empty page: both pointers may be null)
+        } else {
           int64_t j = 0;
           for (int64_t i = r0; i < r0 + rows; ++i)
             if (is_valid(i)) memcpy(payload.data() + at + (size_t)(j++) * 8, &vals[(size_t)i], 8);
