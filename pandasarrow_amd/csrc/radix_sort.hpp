@@ -29,6 +29,22 @@ constexpr int kScatBlock = 256;
 constexpr int kScatItems = kSortTile / kScatBlock;
 constexpr int kScatWaves = kScatBlock / 64;      // bit 31 of a key is a caller flag and never sorted on
 
+// One histogram increment per lane -- unless many lanes of the wave hold the same digit (a key with a large share of the rows): LDS
+// atomics on one word serialise, so the lanes that share the wave's current CANDIDATE digit are counted by their first lane alone.
+// The candidate is the digit of the wave's first lane at the last step where fewer than eight lanes shared it (it settles on a hot
+// digit within a few steps and costs a compare + ballot per step otherwise).
+__device__ __forceinline__ void wave_hist_add(uint32_t* h, uint32_t d, uint32_t& cand) {
+  const unsigned long long m = __ballot(d == cand);
+  const int shared = __popcll(m);
+  if (shared >= 8) {
+    if (d != cand) atomicAdd(&h[d], 1u);
+    else if ((int)__lane_id() == __ffsll((long long)m) - 1) atomicAdd(&h[d], (uint32_t)shared);
+  } else {
+    atomicAdd(&h[d], 1u);
+    cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+  }
+}
+
 template <int BITS, typename K = uint32_t>
 __global__ void __launch_bounds__(kSortBlock) k_radix_hist(const K* __restrict__ keys, int64_t n, int shift,
                                                            uint32_t* __restrict__ hist /* [tiles][1<<BITS] */) {
@@ -38,6 +54,7 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_hist(const K* __restrict__
   __shared__ uint32_t h[R];
   for (int d = threadIdx.x; d < R; d += kSortBlock) h[d] = 0;
   __syncthreads();
+  uint32_t cand = 0xFFFFFFFFu;
   int64_t base = (int64_t)blockIdx.x * kSortTile;
   if (base + kSortTile <= n && (reinterpret_cast<uintptr_t>(keys) & 15) == 0) {
     // full tile: 16-byte loads, all of them in flight before the LDS atomics
@@ -53,13 +70,13 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_hist(const K* __restrict__
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if constexpr (sizeof(K) == 4) {
-          atomicAdd(&h[(w[j] >> shift) & (R - 1)], 1u);
+          wave_hist_add(h, (w[j] >> shift) & (R - 1), cand);
         } else if constexpr (sizeof(K) == 2) {
-          atomicAdd(&h[((w[j] & 0xFFFFu) >> shift) & (R - 1)], 1u);
-          atomicAdd(&h[((w[j] >> 16) >> shift) & (R - 1)], 1u);
+          wave_hist_add(h, ((w[j] & 0xFFFFu) >> shift) & (R - 1), cand);
+          wave_hist_add(h, ((w[j] >> 16) >> shift) & (R - 1), cand);
         } else {
 #pragma unroll
-          for (int b = 0; b < 4; ++b) atomicAdd(&h[(((w[j] >> (8 * b)) & 0xFFu) >> shift) & (R - 1)], 1u);
+          for (int b = 0; b < 4; ++b) wave_hist_add(h, (((w[j] >> (8 * b)) & 0xFFu) >> shift) & (R - 1), cand);
         }
       }
     }
@@ -67,7 +84,7 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_hist(const K* __restrict__
 #pragma unroll
     for (int k = 0; k < kSortItems; ++k) {
       int64_t i = base + k * kSortBlock + threadIdx.x;
-      if (i < n) atomicAdd(&h[((uint32_t)keys[i] >> shift) & (R - 1)], 1u);
+      if (i < n) wave_hist_add(h, ((uint32_t)keys[i] >> shift) & (R - 1), cand);
     }
   }
   __syncthreads();
@@ -191,6 +208,28 @@ __device__ __forceinline__ uint32_t wave_match_rank(unsigned long long* match, u
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (active && (peers & lt_mask) == 0) {  // the lowest lane of the digit
     __hip_atomic_store(&match[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __hip_atomic_store(&cnt[d], base + (uint32_t)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  return base + (uint32_t)__popcll(peers & lt_mask);
+}
+
+// wave_match_rank for the scatter kernels, with the same shortcut as wave_hist_add: the lanes that hold the wave's candidate digit take
+// their peers from one ballot instead of the LDS exchange (19 of 64 lanes ORing into one word cost 19 turns).  Ranks are the same.
+__device__ __forceinline__ uint32_t wave_match_rank_hot(unsigned long long* match, uint32_t* cnt, uint32_t d, bool active, int lane, uint64_t lt_mask,
+                                                        uint32_t& cand) {
+  const unsigned long long hot = __ballot(active && d == cand);
+  const bool many = __popcll(hot) >= 8;
+  const bool mine = many && active && d == cand;
+  if (!many) cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+  if (active && !mine) __hip_atomic_fetch_or(&match[d], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  unsigned long long peers = __hip_atomic_load(&match[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  const uint32_t base = __hip_atomic_load(&cnt[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (mine) peers = hot;
+  if (active && (peers & lt_mask) == 0) {  // the lowest lane of the digit
+    if (!mine) __hip_atomic_store(&match[d], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     __hip_atomic_store(&cnt[d], base + (uint32_t)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -330,12 +369,13 @@ __device__ __forceinline__ void radix_scatter_body(const K* __restrict__ keys_in
       key[s] = (key[s] & 0xFFu) | ((uint32_t)r << 8) | (isnull ? 0x80000000u : 0u);
     }
   }
+  uint32_t cand = 0xFFFFFFFFu;
 #pragma unroll
   for (int s = 0; s < kScatItems; ++s) {
     int r = wave * (64 * kScatItems) + s * 64 + lane;
     bool active = r < tile_rows;
     uint32_t d = (key[s] >> shift) & (R - 1);
-    rank[s] = wave_match_rank(match + wave * R, cnt[wave], d, active, lane, lt_mask);
+    rank[s] = wave_match_rank_hot(match + wave * R, cnt[wave], d, active, lane, lt_mask, cand);
   }
   __syncthreads();
   // per digit: exclusive prefix over waves, tile totals, exclusive scan over digits
