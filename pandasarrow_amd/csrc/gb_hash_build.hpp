@@ -260,6 +260,9 @@ constexpr int kLdsRegionMax = 8192;
 #define PDX_HASH_PAIR 1  // (compile-time diagnostic: 0 = one slot per LDS read in k_hash_probe_lds, probe sequences start on any slot)
 #endif
 constexpr unsigned int kProbeStartMask = PDX_HASH_PAIR ? ~1u : ~0u;
+#ifndef PDX_HASH_U
+#define PDX_HASH_U 4  // rows per thread and trip of k_hash_probe_lds (the next trip's rows are in flight during this one's probes)
+#endif
 constexpr int kProbeBlock = 1024;
 __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long* __restrict__ keys_part, const uint32_t* __restrict__ rows_part,
                                                                 const uint32_t* __restrict__ bucket_off,
@@ -285,7 +288,7 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
     lspecial[0] = lspecial[1] = kNoRow;
   }
   __syncthreads();
-  constexpr int U = 4;
+  constexpr int U = PDX_HASH_U;
   const unsigned int dense_limit = region - (region >> 2);  // 75 % full: give up early, the host retries with a larger table
   bool sampled = false;
   // (the trip count is uniform over the workgroup -- rows are masked by act[] -- so the barrier after the first trip is safe)
