@@ -281,7 +281,9 @@ int64_t pdx_groupby_bound_bytes(const pdx_groupby* gb);
  * threshold fails a test instead of silently changing which kernels run):
  *   slots=dense|hash_lds|hash_part|hash_part2|hash_global|runs|bins   how keys became slots (pdx_groupby_create)
  *   sort=narrow:7+7|narrow_part:8+6|lsd:skip6|lsd|none[+finish]       the value sort (narrowing 4->2->1 byte keys, ...)
- *   layout=fused|full [skew=1]                                        fused last digit vs fully sorted (skew: a run > 2^19 rows)
+ *   layout=fused [side=<runs>] | full [skew=1]                        fused last digit vs fully sorted.  side: that many runs longer than
+ *                                                                     2^19 rows (hot keys) were reduced from a side copy of their rows;
+ *                                                                     skew: too many / too heavy long runs, the whole column was sorted on
  *   reducer=flr_reduce_dense|flr_reduce|flr_wave|seg_reduce|seg_reduce_nullable|none
  *   bound=0|1 [cache=fill|hit] */
 int pdx_groupby_last_plan(const pdx_groupby* gb, char* buf, size_t buf_len);

@@ -5,6 +5,7 @@
 //   processIndex/processEach (MakeGroupings + ApplyGroupings of every column, 1539-1569)  -> deferred, per aggregated
 //                                                                                            column, to pdx_groupby_agg
 //   GROUPBY_AGG / GROUPBY_NUMERIC_AGG  src/pd_core_macros.h:5-147 (one CallFunction per group)  -> pdx_groupby_agg
+//   GroupBy::group / MakeSubDataFrame / apply (src/group_by.h:38-77: walk the per-group arrays)  -> pdx_groupby_groupings
 //   pd::resample / makeGroupInfo / generate_bins_dt64 / GroupInfo::downsample
 //        src/resample.h:19-43,91-122  src/resample.cpp:11-83,85-178,202-295               -> pdx_resample_create
 //
@@ -19,9 +20,11 @@
 //   2. occupied slots are compacted (slot order) and sorted by first_row -> dense gid in FIRST-OCCURRENCE order.
 //   3. per aggregated column: stable LSD radix sort of (slot, value) by slot (radix_sort.hpp) -> every group's values
 //      contiguous IN ROW ORDER.  For sum/mean/min/max/count (and variance) the last 6 slot bits are not sorted: k_flr_reduce
-//      ranks each 2560-row tile by them in LDS and replays Arrow's leaf / binary-counter recurrence with one lane per group.
+//      ranks each 2560-row tile by them in LDS, stages the rows by 16-value leaf, sums one leaf per thread and pushes the leaves
+//      through Arrow's binary counter with one lane per group (k_flr_wave: one wave per run, for nullable values / min / max).
 //      Dense slots + values without nulls: narrowing sort (the key shrinks 4 -> 2 -> 1 byte as digits are consumed; run and
-//      group starts come from the scatter offsets, k_level_starts).
+//      group starts come from the scatter offsets, k_level_starts).  Runs longer than 2^19 rows (hot keys) are skipped by the
+//      fused kernels and reduced from a side form of the layout (build_side, gb_layout.hpp).
 //   4. classic reducers on fully sorted values (skewed keys, small inputs, resample, product/first/last): k_seg_reduce (one wave
 //      per group, 16-value leaves + shuffle tree + counter), k_seg_reduce_mid (batches of short groups per wave),
 //      k_seg_reduce_sub + k_seg_combine_big (many waves per long group), k_seg_reduce_nullable.
