@@ -14,9 +14,12 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 MODES = {"default": {}, "fused_dense": {"PDX_FUSED_LAST_DIGIT_MIN_ROWS": "0", "PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS": "4", "PDX_FUSED_LAST_DIGIT_MIN_RUN": "0"},
          "hash_tail": {"PDX_GROUPBY_DENSE": "0", "PDX_HASH_HEAD_ROWS": "4096"}, "null_pw": {"PDX_FLR_NULL_PW": "1", "PDX_FUSED_LAST_DIGIT_MIN_ROWS": "0",
-         "PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS": "4", "PDX_FUSED_LAST_DIGIT_MIN_RUN": "0"}}
+         "PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS": "4", "PDX_FUSED_LAST_DIGIT_MIN_RUN": "0"},
+         # hot keys: runs over 20 000 rows are "long" -> the side form of the fused layout (or the classic route when there are too many)
+         "side": {"PDX_FLR_MAX_RUN": "20000", "PDX_FUSED_LAST_DIGIT_MIN_ROWS": "0", "PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS": "4", "PDX_FUSED_LAST_DIGIT_MIN_RUN": "0"}}
 ALL_ENV = sorted({k for m in MODES.values() for k in m})
 bad = 0
+plans = {}
 for i in range(count):
     seed = first + i
     rng = np.random.default_rng(seed)
@@ -27,6 +30,13 @@ for i in range(count):
         keys = rng.integers(0, card, n).astype(np.int64) + int(rng.integers(-5, 5)) * 1000
         if rng.random() < 0.3:
             keys[rng.random(n) < 0.2] = 77
+        elif rng.random() < 0.4:  # a few keys with a few per cent each
+            u = rng.random(n)
+            lo = 0.0
+            for _ in range(int(rng.integers(1, 4))):
+                share = float(rng.uniform(0.01, 0.05))
+                keys[(u >= lo) & (u < lo + share)] = int(rng.integers(0, card))
+                lo += share
         kvalid = (rng.random(n) > 0.03) if rng.random() < 0.3 else None
         vals = rng.standard_normal(n) if rng.random() < 0.6 else rng.integers(-50, 50, n).astype(np.int64)
         vvalid = (rng.random(n) > rng.choice([0.02, 0.5])) if rng.random() < 0.5 else None
@@ -40,7 +50,13 @@ for i in range(count):
     ids, uniq, isnull, frst = orc.group_ids(keys, kvalid)
     G = len(uniq)
     ok_all = gb.num_groups == G and np.array_equal(gb.group_ids().cpu().numpy().astype(np.uint32), ids) and np.array_equal(gb.first_rows().cpu().numpy(), frst)
+    if seed % 3 == 0:  # Grouper::MakeGroupings: a stable argsort of the ids
+        rows, off = gb.groupings()
+        ok_all = ok_all and np.array_equal(rows.cpu().numpy(), np.argsort(ids, kind="stable")) and np.array_equal(
+            off.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(ids, minlength=G))]))
     outs = gb.agg(K.Column.from_numpy(vals, vvalid, offset=seed % 5), kinds)
+    plans[(mode, gb.last_plan().get("layout"), "side" if "side" in gb.last_plan() else gb.last_plan().get("skew", ""))] = plans.get(
+        (mode, gb.last_plan().get("layout"), "side" if "side" in gb.last_plan() else gb.last_plan().get("skew", "")), 0) + 1
     for kind, out in zip(kinds, outs):
         got, ok = out.to_numpy()
         exp, eok = orc.groupby_agg(kind, ids, G, vals, vvalid, nthreads=8)
@@ -50,5 +66,6 @@ for i in range(count):
         print("MISMATCH seed", seed, "mode", mode, "n", len(keys), "G", G, "kinds", kinds, flush=True)
     if i % 25 == 24:
         print(f"{i + 1} cases, {bad} mismatches", flush=True)
+print("paths:", sorted(plans.items()))
 print("done:", count, "cases,", bad, "mismatches")
 sys.exit(1 if bad else 0)
