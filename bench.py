@@ -209,6 +209,25 @@ def secondary_runs(torch, L, K, api, keys, vals, kinds, n_total, nkeys, steps):
 
     put("groupby_5pct_null_values", n_total, (ALGO_BYTES_PER_ROW + 0.125) * n_total, timeit(gb_nulls, reps=2))
     del vn, vmask
+    # (b2) skewed keys: one key holds 5 % of the rows (its run of the fused layout is far over the kernels' limit: side form)
+    hot = K.Column(keys.dtype, n_total, keys.values.clone(), None, 0, 0)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    for s0 in range(0, n_total, 1 << 27):
+        e0 = min(n_total, s0 + (1 << 27))
+        hot.values[s0:e0][torch.rand(e0 - s0, device="cuda", generator=gen) < 0.05] = 12345
+    plan_hot = {}
+
+    def gb_hot():
+        gb = K.GroupByHandle.create(hot)
+        r = gb.agg(vals, kinds)
+        plan_hot.update(gb.last_plan())
+        return r
+
+    dth = timeit(gb_hot, reps=2)
+    put("groupby_one_hot_key_5pct", n_total, ALGO_BYTES_PER_ROW * n_total, dth, plan=dict(plan_hot),
+        workload="the headline's keys with 5 % of the rows moved to one key")
+    del hot
     # (c) C1: Series<double> add + sum at 1e6 rows (plumbing) and at the headline's row count
     for n in (1_000_000, n_total):
         x, y = K.synth_vals(0, n, 1), K.synth_vals(0, n, 2)

@@ -44,7 +44,7 @@ def test_bench_single_gpu_contract():
     sec = d["secondary"]
     t3 = sec["groupby_reference_api_three_calls"]
     assert t3["ms"] > 0 and t3["ratio_to_fused_call"] < 1.6  # (small workload: launch overheads weigh more than at 1e9 rows)
-    for k in ("groupby_general_keys_hash_path", "groupby_5pct_null_values", "C1_add_f64[1e+06]", "C2_filter_8cols+index", "C2_take_8cols+index",
+    for k in ("groupby_general_keys_hash_path", "groupby_5pct_null_values", "groupby_one_hot_key_5pct", "C1_add_f64[1e+06]", "C2_filter_8cols+index", "C2_take_8cols+index",
               "C5_resample_1min_mean", "a12_round_temporal_minute", "a12_downsample_1T_mean", "groupby_sorted_keys", "8f3_argsort_f64"):
         assert sec[k]["ms"] > 0 and 0 < sec[k]["frac"] < 1, k
 
