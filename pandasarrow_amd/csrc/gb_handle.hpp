@@ -114,6 +114,8 @@ struct pdx_groupby {
   int64_t* uniques = nullptr;      // G (labels in resample mode)
   uint8_t* unique_ok = nullptr;    // G bytes
   int64_t* first_rows = nullptr;   // G
+  long long* sizes = nullptr;      // G: rows per group = count of any column without nulls (gb_acc.hpp fills it on first use)
+  bool sizes_ready = false;
   // segments mode
   uint32_t* seg_start = nullptr;   // G + 1
   BinParams bin{};

@@ -137,6 +137,7 @@ static unsigned int* hmax_pinned() {
 
 namespace pdx {
 #include "gb_layout.hpp"
+#include "gb_acc.hpp"
 }  // namespace pdx
 
 extern "C" {
@@ -1096,10 +1097,18 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   GroupedLayout& L = *Lp;
   const bool std_only = rq.std_only();
   const size_t bytes_before = L.bytes;
-  if ((!L.fused && !L.full) || (!std_only && !L.full)) PDX_TRY(build_layout(gb, values, std_only, t, L, st));
+  // count / min / max / int64 sum do not depend on the order of a group's rows: when nothing else is asked for and no sorted layout of
+  // the column exists yet, they skip the value sort (gb_acc.hpp: one partition pass + accumulators in LDS)
+  const AccTuning at = AccTuning::read();
+  const bool order_free = rq.want_std5 && !rq.want_pw && !rq.var_out && !rq.std_out && !rq.prod_out && !rq.first_out && !rq.last_out;
+  AccGeom ag;
+  if (order_free && !L.fused && !L.full)
+    ag = acc_geometry(gb, vvalid != nullptr, (o.vmin ? kAccMin : 0u) | (o.vmax ? kAccMax : 0u) | (o.sum_i ? kAccSum : 0u) | (o.count ? kAccCnt : 0u), is_f, at);
+  const bool use_acc = ag.ok;
+  if (!use_acc && ((!L.fused && !L.full) || (!std_only && !L.full))) PDX_TRY(build_layout(gb, values, std_only, t, L, st));
   const bool use_fused = std_only && L.fused;
   Scratch s;
-  std::string reducer;
+  std::string reducer, acc_plan;
   auto pack_validity = [&](uint8_t* bits, const uint8_t* ok_bytes) {
     if (!bits) return;
     if (!ok_bytes) hipMemsetAsync(bits, 0xFF, (size_t)((G + 7) / 8), st);
@@ -1107,6 +1116,10 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   };
   // the five standard kinds from one reduce into `oo`
   auto reduce_std = [&](const SegOut& oo, bool pw, bool mm, bool is, uint8_t* okb) -> int {
+    if (use_acc) {
+      reducer = "lds_acc";
+      return reduce_acc(gb, ag, values, oo, okb, at, s, st, &acc_plan);
+    }
     if (use_fused) return reduce_fused(gb, L, t, oo, pw, mm, is, okb, nullptr, s, st, &reducer);
     reducer = vvalid ? "seg_reduce_nullable" : "seg_reduce";
     return reduce_full(gb, L, L.vals_sorted, is_f, oo, pw, mm, is, L.out_index, okb, s, st);
@@ -1114,9 +1127,32 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   std::string cache_note;
   if (rq.want_std5 && bound) {
     // a bound column keeps its per-group sum / count (/ min / max): sum(); mean(); count() as three calls cost one reduce
-    const bool want_sumfam = rq.want_pw || rq.want_is || o.count;
-    const bool need_sumfam = want_sumfam && !L.have_pw, need_mm = rq.want_mm && !L.have_mm;
-    if (need_sumfam || need_mm) {
+    const bool have_cnt = L.have_pw || L.have_count, have_isum = L.have_pw || L.have_is;
+    const bool need_sumfam = (rq.want_pw && !L.have_pw) || (rq.want_is && !have_isum) || (o.count && !have_cnt), need_mm = rq.want_mm && !L.have_mm;
+    if (use_acc && (need_sumfam || need_mm)) {
+      // order-free kinds of a bound column: only what is asked for is computed and kept
+      const bool need_is = rq.want_is && !have_isum, need_cnt = o.count && !have_cnt;
+      if (need_cnt && !L.c_count) L.c_count = L.own<long long>((size_t)G);
+      if (vvalid && !L.c_ok) L.c_ok = L.own<uint8_t>((size_t)G);
+      if (need_is && !L.c_isum) L.c_isum = L.own<long long>((size_t)G);
+      if (need_mm && !L.c_min) {
+        L.c_min = L.own<uint64_t>((size_t)G);
+        L.c_max = L.own<uint64_t>((size_t)G);
+      }
+      if ((need_cnt && !L.c_count) || (vvalid && !L.c_ok) || (need_is && !L.c_isum) || (need_mm && (!L.c_min || !L.c_max))) return PDX_OOM;
+      SegOut c{};
+      if (need_cnt) c.count = L.c_count;
+      if (need_is) c.sum_i = L.c_isum;
+      if (need_mm) {
+        c.vmin = L.c_min;
+        c.vmax = L.c_max;
+      }
+      PDX_TRY(reduce_std(c, false, need_mm, need_is, L.c_ok));
+      L.have_count = L.have_count || need_cnt;
+      L.have_is = L.have_is || need_is;
+      L.have_mm = L.have_mm || need_mm;
+      cache_note = " cache=fill";
+    } else if (need_sumfam || need_mm) {
       if (!L.c_count) L.c_count = L.own<long long>((size_t)G);
       if (vvalid && !L.c_ok) L.c_ok = L.own<uint8_t>((size_t)G);
       if (need_sumfam && !L.c_sum) L.c_sum = L.own<double>((size_t)G);
@@ -1223,7 +1259,10 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
     PDX_LAUNCH_CHECK();
     if (reducer.empty() || reducer == "none") reducer = "seg_product_first_last";
   }
-  gb->last_plan = (use_fused ? L.plan_fused : L.plan_full) + " reducer=" + reducer + (bound ? " bound=1" : " bound=0") + cache_note;
+  if (use_acc)
+    gb->last_plan = (acc_plan.empty() ? std::string("slots=") + slots_name(gb) + " sort=none layout=none reducer=none" : acc_plan) + (bound ? " bound=1" : " bound=0") + cache_note;
+  else
+    gb->last_plan = (use_fused ? L.plan_fused : L.plan_full) + " reducer=" + reducer + (bound ? " bound=1" : " bound=0") + cache_note;
   if (bound && L.bytes != bytes_before) enforce_bind_limit(gb, &L);
   PDX_HIP(hipStreamSynchronize(st));  // outputs are valid on return; scratch and a local layout go back to the pool on exit
   return PDX_OK;
