@@ -199,6 +199,21 @@ def secondary_runs(torch, L, K, api, keys, vals, kinds, n_total, nkeys, steps):
     dt1 = timeit(gb_step, reps=max(2, min(steps, 3)))
     put("groupby_reference_api_three_calls", n_total, ALGO_BYTES_PER_ROW * n_total, dt3, fused_call_ms=round(dt1 * 1e3, 3),
         ratio_to_fused_call=round(dt3 / dt1, 3), workload="create + bind + sum(); mean(); count() as three pdx_groupby_agg calls")
+    # (a3) the order-free kinds north_star names beside sum / mean -- min / max / count (and int64 sum) -- on an EXISTING handle (the
+    # reference constructs the GroupBy once, then calls gb.min(c), gb.max(c), gb.count(c): src/group_by.h:85-139): no value sort, one
+    # partition pass + accumulators in LDS (gb_acc.hpp).  Algorithmic bytes: 4 B slot id + 8 B value per row (count: the slot ids alone).
+    gb0 = K.GroupByHandle.create(keys)
+    ikeys = K.Column(L.INT64, n_total, keys.values, None, 0, 0)  # an int64 value column that is already resident: the keys themselves
+    os.environ["PDX_ACC_SIZES_CACHE"] = "0"  # (count of a column without nulls is otherwise served from the handle after the first call)
+    try:
+        for name, col, kk, bpr in (("groupby_min_max", vals, [L.AGG_MIN, L.AGG_MAX], 12.0), ("groupby_count", vals, [L.AGG_COUNT], 4.0),
+                                   ("groupby_int64_sum", ikeys, [L.AGG_SUM], 12.0)):
+            dta = timeit(lambda: gb0.agg(col, kk), reps=3)
+            put(name, n_total, bpr * n_total, dta, plan=gb0.last_plan(), algo_bytes_per_row=bpr,
+                workload=f"pdx_groupby_agg({name.split('_', 1)[1]}) on an existing handle, {n_total:.3g} rows / {nkeys:.3g} keys")
+    finally:
+        del os.environ["PDX_ACC_SIZES_CACHE"]
+    del gb0, ikeys
     # (b) 5 % null values (SURVEY 8d secondary run)
     vmask = K.compare(L.NE, K.synth_keys(3, n_total, 20), 0)
     vn = K.Column(L.FLOAT64, n_total, vals.values, vmask.values, 0, -1)
