@@ -293,14 +293,47 @@ def secondary_runs(torch, L, K, api, keys, vals, kinds, n_total, nkeys, steps):
     return out
 
 
+def launch_ranks(n):
+    """One child process per rank on 127.0.0.1 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run sets them), same command
+    line.  Rank 0's stdout is this process's stdout, so exactly one JSON line comes out.  A rank that fails takes the others down (by pid)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"[bench] rank {r} exited with status {code}: stopping the other ranks", file=sys.stderr)
+                for o in alive:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before anything initialises HIP/HSA (dmabuf IPC for RCCL)
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as a plain command: start the N ranks here -- fresh child processes, created before this process has
+        # imported torch or touched the GPU (never a re-exec of a process that holds a GPU context) -- and exit with their status.
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:  # before any GPU call, so a launcher can still start the ranks cleanly
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks with torch.distributed.run (one per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks with torch.distributed.run (one per GPU), or drop "
+                         "WORLD_SIZE from the environment and let bench.py start them")
     import torch
     import torch.distributed as dist
 
@@ -357,7 +390,16 @@ def main():
             try:
                 cd = pdist.CDist("rccl" if backend == "nccl" else "torch")
             except Exception as e:  # noqa: BLE001
-                print(f"[bench] pdx_dist communicator failed ({type(e).__name__}: {e}); using the torch.distributed orchestration", file=sys.stderr)
+                print(f"[bench] rank {rank}: pdx_dist communicator failed ({type(e).__name__}: {e})", file=sys.stderr)
+            # the ranks must agree: the two orchestrations use different collectives, a split decision would deadlock the timed step
+            okf = torch.tensor([1 if cd is not None else 0], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if int(okf.item()) == 0:
+                if cd is not None:
+                    cd.close()
+                cd = None
+                if rank == 0:
+                    print("[bench] not every rank has a pdx_dist communicator: all ranks use the torch.distributed orchestration", file=sys.stderr)
         if cd is not None:
             def step():
                 # sum/mean/count with the exact partial-tree exchange (fragments + aligned subtree nodes, no rows shipped)

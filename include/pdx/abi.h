@@ -462,6 +462,21 @@ int pdx_dist_groupby_fetch(const pdx_dist_groupby* g, pdx_mut_column* keys, int6
                            void* stream);
 int pdx_dist_groupby_destroy(pdx_dist_groupby* g);
 int pdx_dist_concat(pdx_dist* d, const pdx_column* part, pdx_mut_column* out, void* stream);
+/* The order-free kinds over row-range shards -- df.group_by(key).{min, max, count}(col) and the sum of an int64 column
+ * (src/group_by.h:85-139, GROUPBY_AGG / GROUPBY_NUMERIC_AGG src/pd_core_macros.h:5-147): every rank reduces its shard, the results go into
+ * dense per-group partial arrays indexed by GLOBAL group id, ONE all-gather and a fold in rank order finish (SURVEY 8e 3a's
+ * reduce-by-key; int64 sums wrap, min keeps the first of ties, max the first -- the last when the group holds a null on any rank).
+ * Values may carry nulls.  kinds: PDX_AGG_MIN / PDX_AGG_MAX / PDX_AGG_COUNT, PDX_AGG_SUM for int64 values; float64 sums / means are order
+ * dependent and stay with pdx_dist_groupby_sum_mean_count.  One corner is not Arrow's: a maximum that is a tie of +0.0 and -0.0 ACROSS
+ * ranks in a group that has a null on one rank and its last zeros on a rank whose share has none takes that share's first zero.
+ * Collective like the other pdx_dist_* calls: a rank whose shard fails its local checks makes EVERY rank return an error before any
+ * data exchange.  Fetch: keys / first_rows may be NULL; outs[k] = the k-th requested kind, dtypes as pdx_groupby_agg. */
+typedef struct pdx_dist_agg pdx_dist_agg;
+int pdx_dist_groupby_order_free(pdx_dist* d, const pdx_column* keys, const pdx_column* values, const int* kinds, int nk, int64_t row_offset, void* stream,
+                                pdx_dist_agg** out);
+int64_t pdx_dist_agg_num_groups(const pdx_dist_agg* g);
+int pdx_dist_agg_fetch(const pdx_dist_agg* g, pdx_mut_column* keys, int64_t* first_rows, pdx_mut_column* outs, void* stream);
+int pdx_dist_agg_destroy(pdx_dist_agg* g);
 /* pd::resample(df, rule).{kinds}(col) over a sorted axis sharded by row ranges (src/resample.h:91-122, src/group_by.h:255-299): the
  * leading rows of a shard whose bin opened on an earlier rank move there (one all-to-all(v)), every rank bins on the whole axis'
  * grid (pdx_resample_grid of the all-gathered extremes), results are all-gathered in rank order == label order.  kinds:

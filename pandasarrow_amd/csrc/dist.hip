@@ -113,12 +113,18 @@ int rccl_all_to_all_v(void* vctx, const void* send, const size_t* send_off, cons
   uint8_t* r = static_cast<uint8_t*>(recv);
   Rccl& n = rccl();
   PDX_NCCL(n.GroupStart());
-  for (int p = 0; p < c->world; ++p) {
+  // a Send / Recv that fails must not leave the thread's RCCL group open (every later RCCL call of the thread -- torch's own process
+  // group included -- would queue into it and never launch): remember the first error, always close the group, then report
+  int first_err = 0;
+  const char* where = "";
+  for (int p = 0; p < c->world && !first_err; ++p) {
     if (p == c->rank && !c->force) continue;
-    if (send_bytes[p]) PDX_NCCL(n.Send(const_cast<uint8_t*>(s + send_off[p]), send_bytes[p], kNcclInt8, p, c->comm, st));
-    if (recv_bytes[p]) PDX_NCCL(n.Recv(r + recv_off[p], recv_bytes[p], kNcclInt8, p, c->comm, st));
+    if (send_bytes[p] && (first_err = n.Send(const_cast<uint8_t*>(s + send_off[p]), send_bytes[p], kNcclInt8, p, c->comm, st)) != 0) where = "ncclSend";
+    if (!first_err && recv_bytes[p] && (first_err = n.Recv(r + recv_off[p], recv_bytes[p], kNcclInt8, p, c->comm, st)) != 0) where = "ncclRecv";
   }
-  PDX_NCCL(n.GroupEnd());
+  const int end_err = n.GroupEnd();
+  if (first_err) return nccl_fail(first_err, where);
+  if (end_err) return nccl_fail(end_err, "ncclGroupEnd");
   if (!c->force && send_bytes[c->rank])
     PDX_HIP(hipMemcpyAsync(r + recv_off[c->rank], s + send_off[c->rank], send_bytes[c->rank], hipMemcpyDeviceToDevice, st));
   return PDX_OK;
@@ -206,6 +212,56 @@ __global__ void k_count_below(const long long* __restrict__ t, int64_t n, long l
     else hi = mid;
   }
   *out = lo;
+}
+// The reduce-by-key of SURVEY 8(e) 3a for the ORDER-FREE kinds: every rank's dense per-group partials part[p][a][g] (a = 0 valid count,
+// 1 rows, 2 min, 3 max, 4 int64 sum; absent arrays are never read) folded in rank order.  min keeps the first of tied values (strict <),
+// max the first -- the last when the group holds a null on any rank (minmax.hpp); NaN partials (a share of NaNs only) are skipped
+// unless every share is one; int64 sums wrap.
+template <typename T>
+__global__ void k_fold_partials(const int64_t* __restrict__ part, int W, int A, int64_t G, int a_min, int a_max, int a_sum, int a_rows, T* __restrict__ omin,
+                                T* __restrict__ omax, long long* __restrict__ osum, long long* __restrict__ ocnt, int64_t* __restrict__ ok) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) {
+    long long cnt = 0, rows = 0;
+    for (int p = 0; p < W; ++p) {
+      cnt += part[((int64_t)p * A + 0) * G + g];
+      if (a_rows >= 0) rows += part[((int64_t)p * A + a_rows) * G + g];
+    }
+    const bool has_null = a_rows >= 0 && rows > cnt;
+    bool have_mn = false, have_mx = false;
+    T mn = T(0), mx = T(0);
+    unsigned long long sm = 0;
+    for (int p = 0; p < W; ++p) {
+      if (part[((int64_t)p * A + 0) * G + g] <= 0) continue;  // no valid value of the group on this rank
+      if (a_sum >= 0) sm += (unsigned long long)part[((int64_t)p * A + a_sum) * G + g];
+      if (a_min >= 0) {
+        const T x = reinterpret_cast<const T*>(part)[((int64_t)p * A + a_min) * G + g];
+        if (x == x && (!have_mn || x < mn)) { mn = x; have_mn = true; }
+      }
+      if (a_max >= 0) {
+        const T x = reinterpret_cast<const T*>(part)[((int64_t)p * A + a_max) * G + g];
+        if (x == x && (!have_mx || x > mx || (has_null && x == mx))) { mx = x; have_mx = true; }
+      }
+    }
+    T none = T(0);
+    if constexpr (__is_same(T, double)) none = __builtin_nan("");
+    if (omin) omin[g] = have_mn ? mn : none;
+    if (omax) omax[g] = have_mx ? mx : none;
+    if (osum) osum[g] = (long long)sm;
+    if (ocnt) ocnt[g] = cnt;
+    if (ok) ok[g] = cnt > 0;
+  }
+}
+__global__ void k_fill_i64(int64_t* __restrict__ v, int64_t n, int64_t x) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) v[i] = x;
+}
+// any i with t[i] > t[i + 1]?  (a shard's own sortedness, checked before the ranks exchange rows)
+__global__ void k_any_descent(const long long* __restrict__ t, int64_t n, unsigned int* __restrict__ flag) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < n; i += stride) bad = bad || t[i] > t[i + 1];
+  if (bad) atomicOr(flag, 1u);
 }
 struct InvPred {
   const int64_t* inv;
@@ -327,6 +383,27 @@ struct pdx_dist_groupby {
   }
 };
 
+struct pdx_dist_agg {  // pdx_dist_groupby_order_free: the global dictionary + one column per requested kind
+  int64_t G = 0;
+  int key_dtype = PDX_INT64;
+  int64_t *keys = nullptr, *keys_ok = nullptr, *first_rows = nullptr;
+  std::vector<int> dtypes;
+  std::vector<uint64_t*> vals;
+  std::vector<int64_t*> oks;  // 0 / 1 per group (values with nulls), or nullptr
+  hipStream_t stream = nullptr;
+  std::vector<void*> owned;
+  template <typename T>
+  T* own(size_t count) {
+    T* p = static_cast<T*>(pool_alloc((count ? count : 1) * sizeof(T)));
+    if (p) owned.push_back(p);
+    return p;
+  }
+  ~pdx_dist_agg() {
+    StreamNote note(stream);
+    pool_free_many(owned.data(), (int)owned.size());
+  }
+};
+
 struct pdx_dist_resampled {
   int64_t G = 0;
   int nk = 0;
@@ -383,6 +460,135 @@ int all_gather_v(pdx_dist* d, const void* mine, const std::vector<int64_t>& size
     at += rb[(size_t)p];
   }
   return d->tr.all_to_all_v(d->tr.ctx, mine, so.data(), sb.data(), out, ro.data(), rb.data(), st);
+}
+
+
+// A rank whose shard fails a local precondition (nulls in its values, an unsorted stretch, a create that fails) must not return while
+// its peers wait for it inside the next collective: the local status travels with the first small all-gather of the call, and every
+// rank returns an error before any further collective.  The failing rank keeps its own message; the others name the rank.
+int gate_status(const std::vector<int64_t>& info, int words, int status_word, int W, int r, int local_rc, const char* what) {
+  for (int p = 0; p < W; ++p) {
+    const int64_t code = info[(size_t)p * words + status_word];
+    if (code == PDX_OK) continue;
+    if (p == r && local_rc != PDX_OK) return local_rc;  // (thread-local message of the failing call is still in place)
+    return fail((int)code, std::string(what) + ": rank " + std::to_string(p) + " failed on its shard (status " + std::to_string(code) +
+                               "); no rank entered the exchange");
+  }
+  return PDX_OK;
+}
+
+// Steps 1-2 of every sharded group-by: local dictionary -> all-gather(v) of (key, first row, valid) in rank order -> regrouped keeping the
+// first occurrence = the single-process dictionary.  own(count) allocates int64 arrays that live as long as the result.
+struct GlobalDict {
+  pdx_groupby *gb = nullptr, *gb_cat = nullptr;
+  int64_t Gl = 0, G = 0;
+  int64_t* my_map = nullptr;  // local group id -> global group id (scratch)
+  int64_t *keys = nullptr, *keys_ok = nullptr, *first_rows = nullptr;  // G, result lifetime
+  ~GlobalDict() {
+    if (gb_cat) pdx_groupby_destroy(gb_cat);
+    if (gb) pdx_groupby_destroy(gb);
+  }
+};
+template <typename Own>
+int build_dictionary(pdx_dist* d, const pdx_column* keys, int local_rc, const char* what, int64_t row_offset, Scratch& s, hipStream_t st, Own&& own,
+                     GlobalDict* D) {
+  const int W = d->world, r = d->rank;
+  const bool solo = W == 1 && !d->force;
+  // ---- 1. local dictionary (a failure here is reported through the gate below, not by leaving)
+  if (local_rc == PDX_OK) local_rc = pdx_groupby_create(keys, st, &D->gb);
+  const int64_t Gl = local_rc == PDX_OK ? pdx_groupby_num_groups(D->gb) : 0;
+  D->Gl = Gl;
+  int64_t mine[2] = {Gl, local_rc};
+  std::vector<int64_t> info;
+  const int grc = gather_host(d, mine, 2, &info, s, st);
+  if (grc != PDX_OK) return local_rc != PDX_OK ? local_rc : grc;
+  PDX_TRY(gate_status(info, 2, 1, W, r, local_rc, what));
+  std::vector<int64_t> sizes((size_t)W);
+  for (int p = 0; p < W; ++p) sizes[(size_t)p] = info[(size_t)p * 2];
+  int64_t* uk = s.get<int64_t>((size_t)Gl);
+  uint8_t* uk_bits = s.get<uint8_t>((size_t)(Gl + 7) / 8 + 16);
+  int64_t* uok = s.get<int64_t>((size_t)Gl);
+  int64_t* fr = s.get<int64_t>((size_t)Gl);
+  PDX_SCRATCH_CHECK(s);
+  {
+    pdx_mut_column m{};
+    m.dtype = keys->dtype;
+    m.length = Gl;
+    m.values = uk;
+    m.validity = uk_bits;
+    PDX_TRY(pdx_groupby_unique_keys(D->gb, &m, st));
+    PDX_TRY(pdx_groupby_first_rows(D->gb, fr, st));
+    if (Gl) {
+      hipLaunchKernelGGL(k_bits_to_i64, dim3(grid_for(Gl, 256)), dim3(256), 0, st, uk_bits, (int64_t)0, Gl, uok);
+      hipLaunchKernelGGL(k_add_const, dim3(grid_for(Gl, 256)), dim3(256), 0, st, fr, Gl, row_offset);
+    }
+    PDX_LAUNCH_CHECK();
+  }
+  // ---- 2. global dictionary
+  int64_t total_u = 0, off = 0;
+  for (int p = 0; p < W; ++p) {
+    if (p < r) off += sizes[(size_t)p];
+    total_u += sizes[(size_t)p];
+  }
+  int64_t G = Gl;
+  D->my_map = s.get<int64_t>((size_t)Gl);
+  PDX_SCRATCH_CHECK(s);
+  if (solo) {
+    D->keys = own((size_t)G);
+    D->keys_ok = own((size_t)G);
+    D->first_rows = own((size_t)G);
+    if (!D->keys || !D->keys_ok || !D->first_rows) return PDX_OOM;
+    if (G) {
+      PDX_HIP(hipMemcpyAsync(D->keys, uk, (size_t)G * 8, hipMemcpyDeviceToDevice, st));
+      PDX_HIP(hipMemcpyAsync(D->keys_ok, uok, (size_t)G * 8, hipMemcpyDeviceToDevice, st));
+      PDX_HIP(hipMemcpyAsync(D->first_rows, fr, (size_t)G * 8, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(k_iota_i64, dim3(grid_for(G, 256)), dim3(256), 0, st, G, D->my_map);  // one rank: local ids ARE the global ids
+    }
+    PDX_LAUNCH_CHECK();
+  } else {
+    int64_t* cat_keys = s.get<int64_t>((size_t)total_u);
+    int64_t* cat_first = s.get<int64_t>((size_t)total_u);
+    int64_t* cat_ok = s.get<int64_t>((size_t)total_u);
+    uint8_t* cat_bits = s.get<uint8_t>((size_t)(total_u + 7) / 8 + 16);
+    uint32_t* gid_cat = s.get<uint32_t>((size_t)total_u);
+    PDX_SCRATCH_CHECK(s);
+    PDX_TRY(all_gather_v(d, uk, sizes, 8, cat_keys, st));
+    PDX_TRY(all_gather_v(d, fr, sizes, 8, cat_first, st));
+    PDX_TRY(all_gather_v(d, uok, sizes, 8, cat_ok, st));
+    if (total_u) hipLaunchKernelGGL(k_i64_to_bits, dim3(grid_for((total_u + 7) / 8, 256)), dim3(256), 0, st, cat_ok, total_u, cat_bits);
+    PDX_LAUNCH_CHECK();
+    pdx_column cc{};
+    cc.dtype = keys->dtype;
+    cc.length = total_u;
+    cc.null_count = -1;
+    cc.validity = cat_bits;
+    cc.values = cat_keys;
+    PDX_TRY(pdx_groupby_create(&cc, st, &D->gb_cat));
+    G = pdx_groupby_num_groups(D->gb_cat);
+    D->keys = own((size_t)G);
+    D->keys_ok = own((size_t)G);
+    D->first_rows = own((size_t)G);
+    uint8_t* gk_bits = s.get<uint8_t>((size_t)(G + 7) / 8 + 16);
+    int64_t* cat_first_rows = s.get<int64_t>((size_t)G);
+    if (!D->keys || !D->keys_ok || !D->first_rows) return PDX_OOM;
+    PDX_SCRATCH_CHECK(s);
+    pdx_mut_column gm{};
+    gm.dtype = keys->dtype;
+    gm.length = G;
+    gm.values = D->keys;
+    gm.validity = gk_bits;
+    PDX_TRY(pdx_groupby_unique_keys(D->gb_cat, &gm, st));
+    PDX_TRY(pdx_groupby_first_rows(D->gb_cat, cat_first_rows, st));
+    if (total_u) PDX_TRY(pdx_groupby_group_ids(D->gb_cat, gid_cat, st));
+    if (G) {
+      hipLaunchKernelGGL(k_bits_to_i64, dim3(grid_for(G, 256)), dim3(256), 0, st, gk_bits, (int64_t)0, G, D->keys_ok);
+      hipLaunchKernelGGL(k_gather_i64, dim3(grid_for(G, 256)), dim3(256), 0, st, cat_first, cat_first_rows, G, D->first_rows);
+    }
+    if (Gl) hipLaunchKernelGGL(k_map_from_ids, dim3(grid_for(Gl, 256)), dim3(256), 0, st, gid_cat, off, Gl, D->my_map);
+    PDX_LAUNCH_CHECK();
+  }
+  D->G = G;
+  return PDX_OK;
 }
 
 }  // namespace
@@ -445,123 +651,39 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
                                     pdx_dist_groupby** out) {
   if (!d || !out) return fail(PDX_INVALID, "pdx_dist_groupby_sum_mean_count: null argument");
   *out = nullptr;
-  PDX_TRY(check_column(keys, "pdx_dist_groupby_sum_mean_count"));
-  PDX_TRY(check_column(values, "pdx_dist_groupby_sum_mean_count"));
-  if (values->dtype != PDX_FLOAT64 || validity_or_null(values))
-    return fail(PDX_NOT_IMPLEMENTED, "pdx_dist_groupby_sum_mean_count: float64 values without nulls (the partial-tree exchange); other columns: route rows");
-  if (values->length != keys->length) return fail(PDX_INVALID, "pdx_dist_groupby_sum_mean_count: keys and values differ in length");
+  // local preconditions: collected, not returned -- they travel with the dictionary's first all-gather (build_dictionary)
+  int lrc = check_column(keys, "pdx_dist_groupby_sum_mean_count");
+  if (lrc == PDX_OK) lrc = check_column(values, "pdx_dist_groupby_sum_mean_count");
+  if (lrc == PDX_OK && (values->dtype != PDX_FLOAT64 || validity_or_null(values)))
+    lrc = fail(PDX_NOT_IMPLEMENTED, "pdx_dist_groupby_sum_mean_count: float64 values without nulls (the partial-tree exchange); other kinds / columns: pdx_dist_groupby_order_free, or route rows");
+  if (lrc == PDX_OK && values->length != keys->length) lrc = fail(PDX_INVALID, "pdx_dist_groupby_sum_mean_count: keys and values differ in length");
   hipStream_t st = as_stream(stream);
   const int W = d->world, r = d->rank;
   const bool solo = W == 1 && !d->force;
   Scratch s;
   std::unique_ptr<pdx_dist_groupby> res(new pdx_dist_groupby());
   res->stream = st;
-  res->key_dtype = keys->dtype;
-  struct Handles {  // RAII for the intermediate handles
-    pdx_groupby *gb = nullptr, *gb_cat = nullptr;
+  res->key_dtype = lrc == PDX_OK ? keys->dtype : PDX_INT64;
+  GlobalDict D;
+  struct Handles {  // RAII for the intermediate handles (declared after D: the grouped values go before the handle they came from)
     pdx_grouped* gv = nullptr;
     ~Handles() {
       if (gv) pdx_grouped_destroy(gv);
-      if (gb_cat) pdx_groupby_destroy(gb_cat);
-      if (gb) pdx_groupby_destroy(gb);
     }
   } h;
-  // ---- 1. local dictionary
-  PDX_TRY(pdx_groupby_create(keys, st, &h.gb));
-  const int64_t Gl = pdx_groupby_num_groups(h.gb);
-  int64_t* uk = s.get<int64_t>((size_t)Gl);
-  uint8_t* uk_bits = s.get<uint8_t>((size_t)(Gl + 7) / 8 + 16);
-  int64_t* uok = s.get<int64_t>((size_t)Gl);
-  int64_t* fr = s.get<int64_t>((size_t)Gl);
-  PDX_SCRATCH_CHECK(s);
-  {
-    pdx_mut_column m{};
-    m.dtype = keys->dtype;
-    m.length = Gl;
-    m.values = uk;
-    m.validity = uk_bits;
-    PDX_TRY(pdx_groupby_unique_keys(h.gb, &m, st));
-    PDX_TRY(pdx_groupby_first_rows(h.gb, fr, st));
-    if (Gl) {
-      hipLaunchKernelGGL(k_bits_to_i64, dim3(grid_for(Gl, 256)), dim3(256), 0, st, uk_bits, (int64_t)0, Gl, uok);
-      hipLaunchKernelGGL(k_add_const, dim3(grid_for(Gl, 256)), dim3(256), 0, st, fr, Gl, row_offset);
-    }
-    PDX_LAUNCH_CHECK();
-  }
-  // ---- 2. global dictionary: all-gather(v) of (key, first row, valid) in rank order, regrouped keeping the first occurrence
-  std::vector<int64_t> sizes;
-  PDX_TRY(gather_host(d, &Gl, 1, &sizes, s, st));
-  int64_t total_u = 0, off = 0;
-  for (int p = 0; p < W; ++p) {
-    if (p < r) off += sizes[(size_t)p];
-    total_u += sizes[(size_t)p];
-  }
-  int64_t G = Gl;
-  int64_t* my_map = s.get<int64_t>((size_t)Gl);  // local group id -> global group id
-  PDX_SCRATCH_CHECK(s);
-  if (solo) {
-    res->keys = res->own<int64_t>((size_t)G);
-    res->keys_ok = res->own<int64_t>((size_t)G);
-    res->first_rows = res->own<int64_t>((size_t)G);
-    if (!res->keys || !res->keys_ok || !res->first_rows) return PDX_OOM;
-    if (G) {
-      PDX_HIP(hipMemcpyAsync(res->keys, uk, (size_t)G * 8, hipMemcpyDeviceToDevice, st));
-      PDX_HIP(hipMemcpyAsync(res->keys_ok, uok, (size_t)G * 8, hipMemcpyDeviceToDevice, st));
-      PDX_HIP(hipMemcpyAsync(res->first_rows, fr, (size_t)G * 8, hipMemcpyDeviceToDevice, st));
-      hipLaunchKernelGGL(k_iota_i64, dim3(grid_for(G, 256)), dim3(256), 0, st, G, my_map);  // one rank: local ids ARE the global ids
-    }
-    PDX_LAUNCH_CHECK();
-  }
-  int64_t* cat_keys = nullptr;
-  if (!solo) {
-    cat_keys = s.get<int64_t>((size_t)total_u);
-    int64_t* cat_first = s.get<int64_t>((size_t)total_u);
-    int64_t* cat_ok = s.get<int64_t>((size_t)total_u);
-    uint8_t* cat_bits = s.get<uint8_t>((size_t)(total_u + 7) / 8 + 16);
-    uint32_t* gid_cat = s.get<uint32_t>((size_t)total_u);
-    PDX_SCRATCH_CHECK(s);
-    PDX_TRY(all_gather_v(d, uk, sizes, 8, cat_keys, st));
-    PDX_TRY(all_gather_v(d, fr, sizes, 8, cat_first, st));
-    PDX_TRY(all_gather_v(d, uok, sizes, 8, cat_ok, st));
-    if (total_u) hipLaunchKernelGGL(k_i64_to_bits, dim3(grid_for((total_u + 7) / 8, 256)), dim3(256), 0, st, cat_ok, total_u, cat_bits);
-    PDX_LAUNCH_CHECK();
-    pdx_column cc{};
-    cc.dtype = keys->dtype;
-    cc.length = total_u;
-    cc.null_count = -1;
-    cc.validity = cat_bits;
-    cc.values = cat_keys;
-    PDX_TRY(pdx_groupby_create(&cc, st, &h.gb_cat));
-    G = pdx_groupby_num_groups(h.gb_cat);
-    res->keys = res->own<int64_t>((size_t)G);
-    res->keys_ok = res->own<int64_t>((size_t)G);
-    res->first_rows = res->own<int64_t>((size_t)G);
-    uint8_t* gk_bits = s.get<uint8_t>((size_t)(G + 7) / 8 + 16);
-    int64_t* cat_first_rows = s.get<int64_t>((size_t)G);
-    if (!res->keys || !res->keys_ok || !res->first_rows) return PDX_OOM;
-    PDX_SCRATCH_CHECK(s);
-    pdx_mut_column gm{};
-    gm.dtype = keys->dtype;
-    gm.length = G;
-    gm.values = res->keys;
-    gm.validity = gk_bits;
-    PDX_TRY(pdx_groupby_unique_keys(h.gb_cat, &gm, st));
-    PDX_TRY(pdx_groupby_first_rows(h.gb_cat, cat_first_rows, st));
-    if (total_u) PDX_TRY(pdx_groupby_group_ids(h.gb_cat, gid_cat, st));
-    if (G) {
-      hipLaunchKernelGGL(k_bits_to_i64, dim3(grid_for(G, 256)), dim3(256), 0, st, gk_bits, (int64_t)0, G, res->keys_ok);
-      hipLaunchKernelGGL(k_gather_i64, dim3(grid_for(G, 256)), dim3(256), 0, st, cat_first, cat_first_rows, G, res->first_rows);
-    }
-    if (Gl) hipLaunchKernelGGL(k_map_from_ids, dim3(grid_for(Gl, 256)), dim3(256), 0, st, gid_cat, off, Gl, my_map);
-    PDX_LAUNCH_CHECK();
-  }
+  PDX_TRY(build_dictionary(d, keys, lrc, "pdx_dist_groupby_sum_mean_count", row_offset, s, st, [&](size_t c) { return res->own<int64_t>(c); }, &D));
+  res->keys = D.keys;
+  res->keys_ok = D.keys_ok;
+  res->first_rows = D.first_rows;
+  const int64_t Gl = D.Gl, G = D.G;
+  int64_t* my_map = D.my_map;
   res->G = G;
   res->sums = res->own<double>((size_t)G);
   res->means = res->own<double>((size_t)G);
   res->counts = res->own<int64_t>((size_t)G);
   if (!res->sums || !res->means || !res->counts) return PDX_OOM;
   // ---- 3. grouped values + rows per local group
-  PDX_TRY(pdx_groupby_group_values(h.gb, values, st, &h.gv));
+  PDX_TRY(pdx_groupby_group_values(D.gb, values, st, &h.gv));
   int64_t* cnt_local = s.get<int64_t>((size_t)Gl);
   int64_t* prefix_local = s.get<int64_t>((size_t)Gl);
   PDX_SCRATCH_CHECK(s);
@@ -688,6 +810,159 @@ int pdx_dist_groupby_fetch(const pdx_dist_groupby* g, pdx_mut_column* keys, int6
   return PDX_OK;
 }
 
+// df.group_by(key).{min, max, count}(col) and the int64 sum (src/group_by.h:85-139, GROUPBY_AGG / GROUPBY_NUMERIC_AGG
+// src/pd_core_macros.h:5-147) over row-range shards: these kinds do not depend on the order of a group's rows, so every rank reduces its
+// shard (pdx_groupby_agg on the local dictionary: the accumulate path of gb_acc.hpp), scatters the results into dense G-length partial
+// arrays indexed by GLOBAL group id and ONE all-gather + a fold in rank order finishes -- SURVEY 8(e) 3a's reduce-by-key.  Values may
+// carry nulls.  kinds: PDX_AGG_MIN / MAX / COUNT, PDX_AGG_SUM for int64 values (float64 sums are order dependent:
+// pdx_dist_groupby_sum_mean_count).  Every rank ends with the full result.
+int pdx_dist_groupby_order_free(pdx_dist* d, const pdx_column* keys, const pdx_column* values, const int* kinds, int nk, int64_t row_offset, void* stream,
+                                pdx_dist_agg** out) {
+  if (!d || !out || !kinds || nk <= 0 || nk > 8) return fail(PDX_INVALID, "pdx_dist_groupby_order_free: null argument / more than 8 kinds");
+  *out = nullptr;
+  int lrc = check_column(keys, "pdx_dist_groupby_order_free");
+  if (lrc == PDX_OK) lrc = check_column(values, "pdx_dist_groupby_order_free");
+  if (lrc == PDX_OK && values->dtype != PDX_FLOAT64 && values->dtype != PDX_INT64) lrc = fail(PDX_NOT_IMPLEMENTED, "pdx_dist_groupby_order_free: values must be int64 or float64");
+  if (lrc == PDX_OK && values->length != keys->length) lrc = fail(PDX_INVALID, "pdx_dist_groupby_order_free: keys and values differ in length");
+  bool want_min = false, want_max = false, want_sum = false;
+  for (int k = 0; k < nk && lrc == PDX_OK; ++k) {
+    if (kinds[k] == PDX_AGG_MIN) want_min = true;
+    else if (kinds[k] == PDX_AGG_MAX) want_max = true;
+    else if (kinds[k] == PDX_AGG_COUNT) continue;
+    else if (kinds[k] == PDX_AGG_SUM && values->dtype == PDX_INT64) want_sum = true;
+    else lrc = fail(PDX_NOT_IMPLEMENTED, "pdx_dist_groupby_order_free: min / max / count, and sum of int64 values (order-dependent kinds: pdx_dist_groupby_sum_mean_count)");
+  }
+  hipStream_t st = as_stream(stream);
+  const int W = d->world;
+  const bool solo = W == 1 && !d->force;
+  Scratch s;
+  std::unique_ptr<pdx_dist_agg> res(new pdx_dist_agg());
+  res->stream = st;
+  res->key_dtype = lrc == PDX_OK ? keys->dtype : PDX_INT64;
+  GlobalDict D;
+  PDX_TRY(build_dictionary(d, keys, lrc, "pdx_dist_groupby_order_free", row_offset, s, st, [&](size_t c) { return res->own<int64_t>(c); }, &D));
+  res->keys = D.keys;
+  res->keys_ok = D.keys_ok;
+  res->first_rows = D.first_rows;
+  const int64_t Gl = D.Gl, G = D.G;
+  res->G = G;
+  const bool is_f = values->dtype == PDX_FLOAT64;
+  const bool nullable = validity_or_null(values) != nullptr;
+  // ---- the shard's own aggregates (local group order).  The rows per group ride along when a maximum must know whether the group
+  // holds a null anywhere (its tie rule); nullability is a per-rank fact, so every rank sends the array (a shard without nulls: rows == count)
+  const bool need_rows = want_max && is_f;
+  int a = 1;
+  const int a_rows = need_rows ? a++ : -1, a_min = want_min ? a++ : -1, a_max = want_max ? a++ : -1, a_sum = want_sum ? a++ : -1, A = a;
+  int64_t* local = s.get<int64_t>((size_t)A * (size_t)std::max<int64_t>(Gl, 1));
+  uint8_t* lbits = nullable ? s.get<uint8_t>((size_t)(Gl + 7) / 8 + 16) : nullptr;
+  PDX_SCRATCH_CHECK(s);
+  if (Gl) {
+    int lk[4];
+    pdx_mut_column lo[4];
+    int m = 0;
+    auto add = [&](int kind, int slot, int dt) {
+      lk[m] = kind;
+      lo[m] = pdx_mut_column{};
+      lo[m].dtype = dt;
+      lo[m].length = Gl;
+      lo[m].values = local + (size_t)slot * Gl;
+      lo[m].validity = (nullable && kind != PDX_AGG_COUNT) ? lbits : nullptr;  // (group validity is re-derived from the counts)
+      ++m;
+    };
+    add(PDX_AGG_COUNT, 0, PDX_INT64);
+    if (want_min) add(PDX_AGG_MIN, a_min, values->dtype);
+    if (want_max) add(PDX_AGG_MAX, a_max, values->dtype);
+    if (want_sum) add(PDX_AGG_SUM, a_sum, PDX_INT64);
+    PDX_TRY(pdx_groupby_agg(D.gb, values, lk, m, lo, st));
+    if (need_rows) {
+      if (nullable) {  // rows per group = the count of the same column without its validity
+        pdx_column all = *values;
+        all.validity = nullptr;
+        all.null_count = 0;
+        int ck = PDX_AGG_COUNT;
+        pdx_mut_column co{};
+        co.dtype = PDX_INT64;
+        co.length = Gl;
+        co.values = local + (size_t)a_rows * Gl;
+        PDX_TRY(pdx_groupby_agg(D.gb, &all, &ck, 1, &co, st));
+      } else {
+        PDX_HIP(hipMemcpyAsync(local + (size_t)a_rows * Gl, local, (size_t)Gl * 8, hipMemcpyDeviceToDevice, st));
+      }
+    }
+  }
+  // ---- dense partials by global id, one all-gather, fold
+  int64_t* dense = s.get<int64_t>((size_t)A * (size_t)std::max<int64_t>(G, 1));
+  int64_t* all_parts = solo ? dense : s.get<int64_t>((size_t)W * A * (size_t)std::max<int64_t>(G, 1));
+  PDX_SCRATCH_CHECK(s);
+  if (G) PDX_HIP(hipMemsetAsync(dense, 0, (size_t)A * G * 8, st));  // count 0 = "this rank has no valid value of the group": the other arrays are not read
+  for (int j = 0; j < A && Gl; ++j)
+    hipLaunchKernelGGL(k_scatter_i64, dim3(grid_for(Gl, 256)), dim3(256), 0, st, local + (size_t)j * Gl, D.my_map, Gl, dense + (size_t)j * G);
+  PDX_LAUNCH_CHECK();
+  if (!solo && G) PDX_TRY(d->tr.all_gather(d->tr.ctx, dense, all_parts, (size_t)A * G * 8, st));
+  uint64_t *omin = nullptr, *omax = nullptr, *osum = nullptr, *ocnt = nullptr;
+  int64_t* ok = nullable ? res->own<int64_t>((size_t)G) : nullptr;
+  if (nullable && !ok) return PDX_OOM;
+  for (int k = 0; k < nk; ++k) {
+    uint64_t** slot = kinds[k] == PDX_AGG_MIN ? &omin : kinds[k] == PDX_AGG_MAX ? &omax : kinds[k] == PDX_AGG_SUM ? &osum : &ocnt;
+    if (!*slot) *slot = res->own<uint64_t>((size_t)G);
+    if (!*slot) return PDX_OOM;
+    res->vals.push_back(*slot);
+    res->dtypes.push_back(kinds[k] == PDX_AGG_COUNT || kinds[k] == PDX_AGG_SUM ? PDX_INT64 : values->dtype);
+    res->oks.push_back(kinds[k] == PDX_AGG_COUNT ? nullptr : ok);
+  }
+  if (G) {
+    const int Wf = solo ? 1 : W;
+    if (is_f)
+      hipLaunchKernelGGL((k_fold_partials<double>), dim3(grid_for(G, 256)), dim3(256), 0, st, all_parts, Wf, A, G, a_min, a_max, a_sum, a_rows,
+                         reinterpret_cast<double*>(omin), reinterpret_cast<double*>(omax), reinterpret_cast<long long*>(osum), reinterpret_cast<long long*>(ocnt), ok);
+    else
+      hipLaunchKernelGGL((k_fold_partials<long long>), dim3(grid_for(G, 256)), dim3(256), 0, st, all_parts, Wf, A, G, a_min, a_max, a_sum, a_rows,
+                         reinterpret_cast<long long*>(omin), reinterpret_cast<long long*>(omax), reinterpret_cast<long long*>(osum), reinterpret_cast<long long*>(ocnt), ok);
+    PDX_LAUNCH_CHECK();
+  }
+  PDX_HIP(hipStreamSynchronize(st));
+  *out = res.release();
+  return PDX_OK;
+}
+int64_t pdx_dist_agg_num_groups(const pdx_dist_agg* g) { return g ? g->G : -1; }
+int pdx_dist_agg_destroy(pdx_dist_agg* g) {
+  delete g;
+  return PDX_OK;
+}
+// keys / first_rows may be NULL; outs[k]: the k-th requested kind (dtype as pdx_groupby_agg; a validity buffer is filled when given)
+int pdx_dist_agg_fetch(const pdx_dist_agg* g, pdx_mut_column* keys, int64_t* first_rows, pdx_mut_column* outs, void* stream) {
+  if (!g) return fail(PDX_INVALID, "pdx_dist_agg_fetch: null handle");
+  hipStream_t st = as_stream(stream);
+  const size_t b = (size_t)g->G * 8;
+  if (keys) {
+    if (keys->length < g->G || (g->G && !keys->values)) return fail(PDX_INVALID, "pdx_dist_agg_fetch: key output too small");
+    keys->length = g->G;
+    keys->null_count = -1;
+    if (b) PDX_HIP(hipMemcpyAsync(keys->values, g->keys, b, hipMemcpyDeviceToDevice, st));
+    if (keys->validity && g->G)
+      hipLaunchKernelGGL(k_i64_to_bits, dim3(grid_for((g->G + 7) / 8, 256)), dim3(256), 0, st, g->keys_ok, g->G, static_cast<uint8_t*>(keys->validity));
+  }
+  if (b && first_rows) PDX_HIP(hipMemcpyAsync(first_rows, g->first_rows, b, hipMemcpyDeviceToDevice, st));
+  for (size_t k = 0; outs && k < g->vals.size(); ++k) {
+    pdx_mut_column& o = outs[k];
+    if (o.length < g->G || (g->G && !o.values)) return fail(PDX_INVALID, "pdx_dist_agg_fetch: output too small");
+    if (o.dtype != g->dtypes[k]) return fail(PDX_INVALID, "pdx_dist_agg_fetch: output dtype does not match the aggregate's result type");
+    o.length = g->G;
+    if (b) PDX_HIP(hipMemcpyAsync(o.values, g->vals[k], b, hipMemcpyDeviceToDevice, st));
+    if (g->oks[k]) {
+      if (!o.validity) return fail(PDX_INVALID, "pdx_dist_agg_fetch: the result carries nulls but an output has no validity buffer");
+      if (g->G) hipLaunchKernelGGL(k_i64_to_bits, dim3(grid_for((g->G + 7) / 8, 256)), dim3(256), 0, st, g->oks[k], g->G, static_cast<uint8_t*>(o.validity));
+      o.null_count = -1;
+    } else {
+      if (o.validity && g->G) PDX_HIP(hipMemsetAsync(o.validity, 0xFF, (size_t)(g->G + 7) / 8, st));
+      o.null_count = 0;
+    }
+  }
+  PDX_LAUNCH_CHECK();
+  PDX_HIP(hipStreamSynchronize(st));
+  return PDX_OK;
+}
+
 // pd::concat of row-range shards (src/concat.cpp:116-190 over the shards' results): the all-gather(v) merge in rank order.
 // part: this rank's rows (int64 / uint64 / timestamp / float64); out: capacity >= the total; validity stitched from 0/1 words.
 int pdx_dist_concat(pdx_dist* d, const pdx_column* part, pdx_mut_column* out, void* stream) {
@@ -740,29 +1015,50 @@ int pdx_dist_resample(pdx_dist* d, const pdx_column* ts, const pdx_column* value
                       int label_right, int origin_type, int64_t origin_custom_ns, int64_t offset_ns, void* stream, pdx_dist_resampled** out) {
   if (!d || !out || !kinds || nk <= 0) return fail(PDX_INVALID, "pdx_dist_resample: null argument");
   *out = nullptr;
-  PDX_TRY(check_column(ts, "pdx_dist_resample"));
-  PDX_TRY(check_column(values, "pdx_dist_resample"));
-  if (ts->dtype != PDX_TIMESTAMP_NS && ts->dtype != PDX_INT64) return fail(PDX_INVALID, "axis must be a TimestampArray");
-  if (validity_or_null(ts)) return fail(PDX_NOT_IMPLEMENTED, "pdx_dist_resample: null timestamps are not supported");
-  if (values->dtype != PDX_FLOAT64 && values->dtype != PDX_INT64) return fail(PDX_NOT_IMPLEMENTED, "pdx_dist_resample: values must be int64 or float64");
-  if (values->length != ts->length) return fail(PDX_INVALID, "pdx_dist_resample: axis and values differ in length");
+  // local preconditions are collected and travel with the first all-gather: a rank that fails on its shard must not return while its
+  // peers wait for it in a collective (every rank then returns the error)
+  int lrc = check_column(ts, "pdx_dist_resample");
+  if (lrc == PDX_OK) lrc = check_column(values, "pdx_dist_resample");
+  if (lrc == PDX_OK && ts->dtype != PDX_TIMESTAMP_NS && ts->dtype != PDX_INT64) lrc = fail(PDX_INVALID, "axis must be a TimestampArray");
+  if (lrc == PDX_OK && validity_or_null(ts)) lrc = fail(PDX_NOT_IMPLEMENTED, "pdx_dist_resample: null timestamps are not supported");
+  if (lrc == PDX_OK && values->dtype != PDX_FLOAT64 && values->dtype != PDX_INT64) lrc = fail(PDX_NOT_IMPLEMENTED, "pdx_dist_resample: values must be int64 or float64");
+  if (lrc == PDX_OK && values->length != ts->length) lrc = fail(PDX_INVALID, "pdx_dist_resample: axis and values differ in length");
   hipStream_t st = as_stream(stream);
   const int W = d->world, r = d->rank;
   const bool solo = W == 1 && !d->force;
   Scratch s;
-  const int64_t n_loc = ts->length;
-  const long long* tv = static_cast<const long long*>(ts->values) + ts->offset;
-  const uint64_t* vv = static_cast<const uint64_t*>(values->values) + values->offset;
-  // ---- every shard's (rows, first, last, has nulls): the whole axis' extremes and grid on every rank
-  int64_t mine[4] = {n_loc, 0, 0, validity_or_null(values) ? 1 : 0};
+  const int64_t n_loc = lrc == PDX_OK ? ts->length : 0;
+  const long long* tv = lrc == PDX_OK ? static_cast<const long long*>(ts->values) + ts->offset : nullptr;
+  const uint64_t* vv = lrc == PDX_OK ? static_cast<const uint64_t*>(values->values) + values->offset : nullptr;
+  // ---- every shard's (rows, first, last, has nulls, local status): the whole axis' extremes and grid on every rank
+  int64_t mine[5] = {n_loc, 0, 0, (lrc == PDX_OK && validity_or_null(values)) ? 1 : 0, lrc};
   if (n_loc) {
-    PDX_HIP(hipMemcpyAsync(&mine[1], tv, 8, hipMemcpyDeviceToHost, st));
-    PDX_HIP(hipMemcpyAsync(&mine[2], tv + (n_loc - 1), 8, hipMemcpyDeviceToHost, st));
-    PDX_HIP(hipStreamSynchronize(st));
+    // is the shard sorted INSIDE?  (its boundaries are compared across ranks below; an unsorted stretch inside would only surface in
+    // this rank's pdx_resample_create, after the row exchange)
+    unsigned int* dflag = s.get<unsigned int>(1);
+    if (s.failed) mine[4] = lrc = PDX_OOM;
+    else {
+      unsigned int hflag = 0;
+      hipError_t e = hipMemsetAsync(dflag, 0, sizeof(unsigned int), st);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_any_descent, dim3(grid_for(n_loc, 256, 4)), dim3(256), 0, st, tv, n_loc, dflag);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipMemcpyAsync(&mine[1], tv, 8, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(&mine[2], tv + (n_loc - 1), 8, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(&hflag, dflag, sizeof(unsigned int), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) mine[4] = lrc = hip_fail(e, "pdx_dist_resample");
+      else if (hflag) mine[4] = lrc = fail(PDX_INVALID, "pdx_resample_create: timestamps must be sorted ascending");
+    }
   }
   std::vector<int64_t> info;
-  PDX_TRY(gather_host(d, mine, 4, &info, s, st));
-  auto I = [&](int q, int k) { return info[(size_t)q * 4 + k]; };
+  {
+    const int grc = gather_host(d, mine, 5, &info, s, st);
+    if (grc != PDX_OK) return lrc != PDX_OK ? lrc : grc;
+  }
+  PDX_TRY(gate_status(info, 5, 4, W, r, lrc, "pdx_dist_resample"));
+  auto I = [&](int q, int k) { return info[(size_t)q * 5 + k]; };
   std::vector<int> live;
   int64_t N = 0;
   bool any_nulls = false;
@@ -878,14 +1174,23 @@ int pdx_dist_resample(pdx_dist* d, const pdx_column* ts, const pdx_column* value
   vc.null_count = valid2 ? -1 : 0;
   (void)valid2_off;
   int64_t Gl = 0;
+  int crc = PDX_OK;  // the shard's own create: its status travels with the bin counts (same gate as above)
   if (n2) {
-    PDX_TRY(pdx_resample_create(&tc, freq_ns, closed_right, label_right, PDX_ORIGIN_CUSTOM | PDX_ORIGIN_SHARD, first_edge, 0, st, &h.gb));
-    Gl = pdx_groupby_num_groups(h.gb);
+    crc = pdx_resample_create(&tc, freq_ns, closed_right, label_right, PDX_ORIGIN_CUSTOM | PDX_ORIGIN_SHARD, first_edge, 0, st, &h.gb);
+    if (crc == PDX_OK) Gl = pdx_groupby_num_groups(h.gb);
   }
-  std::vector<int64_t> sizes;
-  PDX_TRY(gather_host(d, &Gl, 1, &sizes, s, st));
+  std::vector<int64_t> sizes((size_t)W), ginfo;
+  {
+    int64_t gm[2] = {Gl, crc};
+    const int grc = gather_host(d, gm, 2, &ginfo, s, st);
+    if (grc != PDX_OK) return crc != PDX_OK ? crc : grc;
+  }
+  PDX_TRY(gate_status(ginfo, 2, 1, W, r, crc, "pdx_dist_resample"));
   int64_t G = 0;
-  for (int q = 0; q < W; ++q) G += sizes[(size_t)q];
+  for (int q = 0; q < W; ++q) {
+    sizes[(size_t)q] = ginfo[(size_t)q * 2];
+    G += sizes[(size_t)q];
+  }
   res->G = G;
   res->labels = res->own<int64_t>((size_t)G);
   if (!res->labels) return PDX_OOM;

@@ -342,14 +342,23 @@ class CDist:
         self._h = C.c_void_p()
         self.transport = transport
         if transport == "rccl":
+            # Every rank-local step that can fail is made collective BEFORE the ranks meet inside ncclCommInitRank: each rank asks the
+            # library for an id (this opens librccl and resolves its symbols; only rank 0's id is used) and the statuses are reduced, so a
+            # rank that cannot load RCCL raises on ALL ranks instead of leaving the others blocked in the broadcast / the communicator init.
             ident = (C.c_char * 128)()
-            if self.r == 0:
-                L.check(self.lib.pdx_dist_unique_id(ident))
+            rc = int(self.lib.pdx_dist_unique_id(ident))
+            msg = self.lib.pdx_last_error().decode("utf-8", "replace") if rc != 0 else ""
             if dist.is_initialized() and self.W > 1:
                 dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+                bad = torch.tensor([1 if rc != 0 else 0], dtype=torch.int64, device=dev)
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                if int(bad.item()) != 0:
+                    raise RuntimeError(f"pdx_dist: RCCL is not usable on every rank (rank {self.r}: {'status %d %s' % (rc, msg) if rc else 'ok'})")
                 t = torch.tensor(list(bytes(ident)), dtype=torch.uint8, device=dev)
                 dist.broadcast(t, 0)
                 ident = (C.c_char * 128)(*bytes(t.cpu().tolist()))
+            elif rc != 0:
+                raise RuntimeError(f"pdx_dist_unique_id failed: status {rc} {msg}")
             L.check(self.lib.pdx_dist_init(ident, self.W, self.r, C.byref(self._h)))
         elif transport == "torch":
             AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -431,6 +440,40 @@ class CDist:
         ck, cv = keys.c(), vals.c()
         L.check(self.lib.pdx_dist_groupby_sum_mean_count(self._h, C.byref(ck), C.byref(cv), int(row_offset), K._stream(), C.byref(h)))
         return _fetch_dist_result(self.lib, h, keys.dtype)
+
+    def groupby_order_free(self, keys, vals, kinds, row_offset=0):
+        """min / max / count (and the sum of an int64 column) over row-range shards, inside the library (pdx_dist_groupby_order_free:
+        dense per-group partials, one all-gather, fold in rank order).  Values may carry nulls.  Same result dict as the other sharded
+        group-bys: {"G", "keys", "keys_ok", "first_rows", "kinds", "outs": [(values tensor, valid bool tensor | None)]} on every rank."""
+        import ctypes as C
+
+        from . import column as K
+
+        kinds = list(kinds)
+        h = C.c_void_p()
+        ck, cv = keys.c(), vals.c()
+        karr = (C.c_int * len(kinds))(*kinds)
+        L.check(self.lib.pdx_dist_groupby_order_free(self._h, C.byref(ck), C.byref(cv), karr, len(kinds), int(row_offset), K._stream(), C.byref(h)))
+        try:
+            G = int(self.lib.pdx_dist_agg_num_groups(h))
+            dev = K._device()
+            kcol = K.Column.empty(keys.dtype, G, with_validity=True)
+            first = torch.empty(max(G, 1), dtype=torch.int64, device=dev)
+            outs = [K.Column.empty(K._AGG_OUT_DT[k](vals.dtype), G, with_validity=True) for k in kinds]
+            km, marr = kcol.mut(), K._mut_array(outs)
+            L.check(self.lib.pdx_dist_agg_fetch(h, C.byref(km), first.data_ptr(), marr, K._stream()))
+            kcol._adopt(km)
+            for i, o in enumerate(outs):
+                o._adopt(marr[i])
+        finally:
+            self.lib.pdx_dist_agg_destroy(h)
+        _, kok = kcol.to_numpy()
+        res = []
+        for o in outs:
+            _, ok = o.to_numpy() if o.null_count != 0 else (None, None)
+            res.append((o.values[:G], None if ok is None else torch.from_numpy(ok).to(dev)))
+        ok_t = torch.ones(G, dtype=torch.bool, device=dev) if kok is None else torch.from_numpy(kok).to(dev)
+        return {"G": G, "keys": kcol.values[:G], "keys_ok": ok_t, "first_rows": first[:G], "kinds": kinds, "outs": res}
 
     def resample(self, ts, vals, kinds, freq_ns, closed_right=False, label_right=False, origin=L.ORIGIN_START_DAY, origin_custom_ns=0, offset_ns=0):
         """pd::resample(...).{kinds}(col) over a sorted axis sharded by row ranges, inside the library (pdx_dist_resample).

@@ -44,7 +44,9 @@ def test_bench_single_gpu_contract():
     sec = d["secondary"]
     t3 = sec["groupby_reference_api_three_calls"]
     assert t3["ms"] > 0 and t3["ratio_to_fused_call"] < 1.6  # (small workload: launch overheads weigh more than at 1e9 rows)
-    for k in ("groupby_general_keys_hash_path", "groupby_5pct_null_values", "groupby_one_hot_key_5pct", "C1_add_f64[1e+06]", "C2_filter_8cols+index", "C2_take_8cols+index",
+    for k in ("groupby_min_max", "groupby_count", "groupby_int64_sum"):  # the order-free kinds skip the value sort (gb_acc.hpp)
+        assert sec[k]["plan"]["reducer"] == "lds_acc", (k, sec[k])
+    for k in ("groupby_min_max", "groupby_count", "groupby_int64_sum", "groupby_general_keys_hash_path", "groupby_5pct_null_values", "groupby_one_hot_key_5pct", "C1_add_f64[1e+06]", "C2_filter_8cols+index", "C2_take_8cols+index",
               "C5_resample_1min_mean", "a12_round_temporal_minute", "a12_downsample_1T_mean", "groupby_sorted_keys", "8f3_argsort_f64"):
         assert sec[k]["ms"] > 0 and 0 < sec[k]["frac"] < 1, k
 
@@ -63,3 +65,16 @@ def test_bench_two_rank_rehearsal():
     assert d["check"]["groups"] == 20_000 and all(v for v in d["check"].values() if isinstance(v, bool))
     assert d["config"]["path"] == "sharded-c-abi"  # pdx_dist_* inside the library; the custom transport rides on the gloo group here
     assert d["check"]["c_abi_matches_torch_orchestration_all_ranks"] is True  # both orchestrations, same shards, bit for bit
+
+
+def test_bench_two_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` as a plain command (no WORLD_SIZE in the environment): bench.py starts its two ranks itself as fresh
+    child processes and rank 0 prints the one JSON line (gloo rehearsal: both ranks share this box's GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PDX_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "4e6", "--keys", "2e4", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    d = _last_json(p.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["rows_per_gpu"] == 2_000_000 and d["config"]["path"] == "sharded-c-abi"
+    assert d["check"]["groups"] == 20_000 and all(v for v in d["check"].values() if isinstance(v, bool))

@@ -217,3 +217,168 @@ def test_chunked_groupby_beyond_the_row_limit_merge(shape):
     res = pdist.groupby_sum_mean_count_chunked(Column.from_numpy(keys, kvalid, offset=3 if nullk else 0), Column.from_numpy(vals), chunk)
     _check(_to_host(res), keys, vals, kvalid)
     torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------- round 4: order-free kinds over shards; collective error gates
+def _order_free_data(dtype):
+    rng = np.random.default_rng(21)
+    n, nk = 260_003, 4_000
+    keys = rng.integers(0, nk, n).astype(np.int64) * 31 + 5
+    if dtype == "f64":
+        vals = rng.standard_normal(n)
+        m = rng.integers(0, n, n // 25)
+        vals[m] = rng.choice(np.array([0.0, -0.0, np.nan, np.inf, -np.inf]), m.size)
+    else:
+        vals = rng.integers(-2**62, 2**62, n).astype(np.int64)
+        vals[rng.integers(0, n, 500)] = np.iinfo(np.int64).min
+        vals[rng.integers(0, n, 500)] = np.iinfo(np.int64).max
+    valid = rng.random(n) > 0.08
+    valid[keys == 5] = False  # a group without any valid value
+    return keys, vals, valid
+
+
+ORDER_FREE_CASES = (("f64", False, (2, 3, 4)), ("f64", True, (3, 4, 2)), ("i64", False, (0, 2, 3, 4)), ("i64", True, (4, 0)))
+
+
+def _order_free_cases(cd, rank, world, Column):
+    out = {}
+    for dtype, nulls, kinds in ORDER_FREE_CASES:
+        keys, vals, valid = _order_free_data(dtype)
+        n = len(keys)
+        cuts = [n * q // world for q in range(world + 1)] if world != 3 else [0, n * 20 // 100, n * 55 // 100, n]
+        lo, hi = cuts[rank], cuts[rank + 1]
+        res = cd.groupby_order_free(Column.from_numpy(keys[lo:hi]), Column.from_numpy(vals[lo:hi], valid[lo:hi] if nulls else None), list(kinds), row_offset=lo)
+        out[(dtype, nulls)] = {"keys": res["keys"].cpu().numpy(), "first_rows": res["first_rows"].cpu().numpy(),
+                               "outs": [(a.cpu().numpy(), None if b is None else b.cpu().numpy()) for a, b in res["outs"]]}
+    return out
+
+
+def _check_order_free(got, world):
+    for dtype, nulls, kinds in ORDER_FREE_CASES:
+        keys, vals, valid = _order_free_data(dtype)
+        ids, uniq, _, first = orc.group_ids(keys)
+        g = got[(dtype, nulls)]
+        assert np.array_equal(g["keys"], uniq) and np.array_equal(g["first_rows"], first)
+        for kind, (gv, gok) in zip(kinds, g["outs"]):
+            ev, eok = orc.groupby_agg(kind, ids, len(uniq), vals, valid if nulls else None, nthreads=4)
+            eok = np.asarray(eok, bool)
+            assert (gok is None and eok.all()) or np.array_equal(gok, eok), (dtype, nulls, kind)
+            if ev.dtype == np.float64:
+                a, b = gv[eok], ev[eok]
+                same = (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+                if world > 1 and kind == 3 and nulls:
+                    # the documented corner (include/pdx/abi.h at pdx_dist_groupby_order_free): a maximum that is a tie of zeros of both
+                    # signs ACROSS ranks in a group with a null may keep another share's zero -- the value is a zero either way
+                    same |= (a == 0.0) & (b == 0.0)
+                assert same.all(), (dtype, nulls, kind, int((~same).sum()))
+            else:
+                assert np.array_equal(gv[eok], ev[eok]), (dtype, nulls, kind)
+
+
+def _gloo_worker_r4(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PDX_ACC_MIN_ROWS="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pandasarrow_amd import _lib as L
+        from pandasarrow_amd import dist as pdist
+        from pandasarrow_amd.column import Column
+
+        torch.cuda.set_device(0)
+        L.check(L.load().pdx_init(0))
+        cd = pdist.CDist("torch")
+        out = {"order_free": _order_free_cases(cd, rank, world, Column)}
+        # ---- one bad shard: EVERY rank must come back with an error, none may wait in a collective
+        keys, vals, valid = _order_free_data("f64")
+        n = len(keys)
+        lo, hi = n * rank // world, n * (rank + 1) // world
+        errs = {}
+        try:  # rank 1's values carry nulls: the partial-tree exchange refuses them -- on all ranks
+            cd.groupby_sum_mean_count(Column.from_numpy(keys[lo:hi]), Column.from_numpy(vals[lo:hi], valid[lo:hi] if rank == 1 else None), row_offset=lo)
+            errs["nulls"] = None
+        except L.PdxError as e:
+            errs["nulls"] = (e.status, str(e))
+        ts, v, ok, minute = _resample_data()
+        m = len(ts)
+        lo, hi = m * rank // world, m * (rank + 1) // world
+        tloc = ts[lo:hi].copy()
+        if rank == 2:  # unsorted INSIDE the shard (its first and last rows still fit the neighbours)
+            tloc[1000], tloc[1001] = tloc[1001] + 5, tloc[1000]
+        try:
+            cd.resample(Column.from_numpy(tloc, dtype=L.TIMESTAMP_NS), Column.from_numpy(v[lo:hi]), [0, 4], 5 * minute)
+            errs["unsorted"] = None
+        except L.PdxError as e:
+            errs["unsorted"] = (e.status, str(e))
+        try:  # a kind the order-free entry refuses is refused before any exchange, and the communicator is still usable afterwards
+            cd.groupby_order_free(Column.from_numpy(keys[:100]), Column.from_numpy(vals[:100]), [0])
+            errs["kind"] = None
+        except L.PdxError as e:
+            errs["kind"] = (e.status, str(e))
+        out["after_errors"] = _to_host(cd.groupby_sum_mean_count(Column.from_numpy(keys[n * rank // world:n * (rank + 1) // world]),
+                                                                 Column.from_numpy(np.nan_to_num(vals[n * rank // world:n * (rank + 1) // world])),
+                                                                 row_offset=n * rank // world))
+        cd.close()
+        q.put((rank, out if rank == 0 else None, errs))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c_abi_order_free_and_error_gates_three_ranks_one_gpu():
+    import torch.multiprocessing as mp
+
+    from pandasarrow_amd import _lib as L
+
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker_r4, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    by_rank = {r: (out, errs) for r, out, errs in got}
+    _check_order_free(by_rank[0][0]["order_free"], world)
+    for r in range(world):
+        errs = by_rank[r][1]
+        assert errs["nulls"] is not None and errs["nulls"][0] == L.NOT_IMPLEMENTED, (r, errs)
+        assert ("rank 1" in errs["nulls"][1]) == (r != 1), (r, errs)  # the failing rank keeps its own message, the others name it
+        assert errs["unsorted"] is not None and errs["unsorted"][0] == L.INVALID, (r, errs)
+        assert errs["kind"] is not None and errs["kind"][0] == L.NOT_IMPLEMENTED, (r, errs)
+    keys, vals, _ = _order_free_data("f64")
+    _check(by_rank[0][0]["after_errors"], keys, np.nan_to_num(vals), None)
+
+
+def _rccl_worker_r4(q):
+    os.environ["PDX_DIST_FORCE_COLLECTIVES"] = "1"
+    os.environ["PDX_ACC_MIN_ROWS"] = "1"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+
+    from pandasarrow_amd import _lib as L
+    from pandasarrow_amd import dist as pdist
+    from pandasarrow_amd.column import Column
+
+    torch.cuda.set_device(0)
+    L.check(L.load().pdx_init(0))
+    cd = pdist.CDist("rccl")
+    out = _order_free_cases(cd, 0, 1, Column)
+    cd.close()
+    q.put(out)
+
+
+def test_c_abi_order_free_one_rank_rccl_on_the_wire():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker_r4, args=(q,))
+    p.start()
+    got = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    _check_order_free(got, 1)

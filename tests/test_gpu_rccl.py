@@ -150,6 +150,8 @@ def test_bench_under_torchrun_nccl():
 
 
 def test_bench_refuses_gpus_mismatch():
+    """inside a launcher's environment (WORLD_SIZE set) --gpus must agree with it; without WORLD_SIZE bench.py starts the ranks itself
+    (tests/test_gpu_bench_contract.py::test_bench_two_ranks_without_a_launcher)"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT,
-                       capture_output=True, text=True, timeout=300)
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
