@@ -103,7 +103,8 @@ struct pdx_groupby {
   int digit2_bits = 0;
   uint8_t* bucket8 = nullptr;          // n, row order: low kPartBits = partition
   uint32_t* part_off = nullptr;     // [tiles][256] scatter offsets of the partition pass
-  uint32_t* slot_part = nullptr;    // n, logical slot per partitioned position
+  uint32_t* slot_part = nullptr;    // n, logical slot per partitioned position (non-null = the rows are hash partitioned)
+  bool slot_part_ready = true;      // false: the LDS build wrote idx16_part only; ensure_slot_part (groupby.hip) fills slot_part on demand
   uint16_t* idx16_part = nullptr;   // n, slot index inside the bucket's region (LDS build, one partition level): the narrowing sort's key
   uint32_t* rows_part = nullptr;    // n, original row (bit 31: key is null)
   uint32_t* pass0_off = nullptr;    // row-order slots: scanned offsets of the first sort pass (fused into the slot kernel)

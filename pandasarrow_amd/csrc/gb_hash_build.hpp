@@ -264,6 +264,12 @@ constexpr unsigned int kProbeStartMask = PDX_HASH_PAIR ? ~1u : ~0u;
 #define PDX_HASH_U 4  // rows per thread and trip of k_hash_probe_lds (the next trip's rows are in flight during this one's probes)
 #endif
 constexpr int kProbeBlock = 1024;
+// ROWS = true: the keys may be null (bit 31 of rows_part) -- every row's original index is read with its key and the first row of a slot is
+// tracked as that index.  ROWS = false (no null keys): rows_part is NOT read per row; a slot's first row is tracked as the smallest
+// POSITION inside the bucket (the partition is stable, so positions order a bucket's rows as their row numbers do) and turned into a row
+// number once per slot when the region is written back: 4 B/row less to read.  With idx16 the 4-byte logical slot is not written either
+// (slot = idx16 << pb | bucket; ensure_slot_part rebuilds it for the few callers that want it): 8 + 2 instead of 12 + 6 bytes per row.
+template <bool ROWS>
 __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long* __restrict__ keys_part, const uint32_t* __restrict__ rows_part,
                                                                 const uint32_t* __restrict__ bucket_off,
                                                                 int64_t n, Slot* table, unsigned int cap, unsigned int region,
@@ -301,7 +307,7 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t p = base0 + tid + (int64_t)u * kProbeBlock;
-      nrow[u] = p < end ? rows_part[p] : 0u;
+      nrow[u] = ROWS ? (p < end ? rows_part[p] : 0u) : (uint32_t)(p - start);
       nkey[u] = p < end ? keys_part[p] : 0;
     }
   };
@@ -392,8 +398,8 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
         if (r < lfirst[idx]) atomicMin(&lfirst[idx], r);
         logical = (idx << pb) | b;
       }
-      slot_part[p0 + (int64_t)u * kProbeBlock] = logical;
       if (idx16) idx16[p0 + (int64_t)u * kProbeBlock] = (uint16_t)((logical >> pb) & 0xFFFFu);
+      else slot_part[p0 + (int64_t)u * kProbeBlock] = logical;
     }
     if (!sampled) {
       // cardinality sample: after the bucket's first U*kProbeBlock rows every thread has inserted its rows, so (rows, distinct)
@@ -412,11 +418,16 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds(const long long*
     Slot sl;
     sl.key = (long long)lkeys[i];
     sl.first = lfirst[i];
+    if (!ROWS && sl.first != kNoRow) sl.first = rows_part[start + sl.first] & 0x7FFFFFFFu;  // position inside the bucket -> row number
     sl.gid = kNoRow;
     table[(int64_t)b * region + i] = sl;
   }
   if (tid == 0 && linserted) atomicAdd(&ctl->inserted, linserted);
-  if (tid < 2 && lspecial[tid] != kNoRow) atomicMin(&table[cap + tid].first, lspecial[tid]);
+  if (tid < 2 && lspecial[tid] != kNoRow) {
+    unsigned int sp = lspecial[tid];
+    if (!ROWS) sp = rows_part[start + sp] & 0x7FFFFFFFu;  // (the INT64_MIN key; null keys take the ROWS form)
+    atomicMin(&table[cap + tid].first, sp);
+  }
 }
 
 // Skewed buckets (a hot key, or half of the keys null: all of those rows share one bucket): the workgroup above only builds the
@@ -507,8 +518,8 @@ __global__ void __launch_bounds__(kProbeBlock) k_hash_probe_lds_tail(const long 
         }
         logical = (idx << pb) | b;
       }
-      slot_part[p0 + (int64_t)u * kProbeBlock] = logical;
       if (idx16) idx16[p0 + (int64_t)u * kProbeBlock] = (uint16_t)((logical >> pb) & 0xFFFFu);
+      else slot_part[p0 + (int64_t)u * kProbeBlock] = logical;
     }
   }
   __syncthreads();
@@ -520,6 +531,25 @@ __device__ __forceinline__ int64_t phys_slot(int64_t logical, unsigned int regio
   if (region == 0 || logical >= (int64_t)cap) return logical;
   const int pb = (__ffs((int)cap) - 1) - (__ffs((int)region) - 1);  // cap = region << pb, both powers of two
   return (logical & ((1 << pb) - 1)) * (int64_t)region + (logical >> pb);
+}
+// the 4-byte logical slot of every partitioned position from its 2-byte region index: slot = idx16 << kPartBits | bucket, the bucket of a
+// position found in the 257 bucket starts (LDS).  Only the callers that sort 4-byte slots or map rows back want it.
+__global__ void __launch_bounds__(256) k_slot_part_from_idx16(const uint16_t* __restrict__ idx16, const uint32_t* __restrict__ bucket_off, int64_t n,
+                                                              uint32_t* __restrict__ slot_part) {
+  constexpr int R = 1 << kPartBits;
+  __shared__ uint32_t st[R + 1];
+  for (int d = threadIdx.x; d <= R; d += 256) st[d] = d < R ? bucket_off[d] : (uint32_t)n;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+    int lo = 0, hi = R;  // the last bucket that starts at or before p
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int64_t)st[mid] <= p) lo = mid;
+      else hi = mid;
+    }
+    slot_part[p] = ((uint32_t)idx16[p] << kPartBits) | (uint32_t)lo;
+  }
 }
 // row-order views from the partitioned arrays (on demand: group ids / mapped ids)
 __global__ void k_part_row_gids(const uint32_t* __restrict__ gid_of_slot, const uint32_t* __restrict__ slot_part,

@@ -33,6 +33,7 @@ static int sort_values_by_slot(pdx_groupby* gb, const uint64_t* vals, const uint
   uint64_t* v1 = static_cast<uint64_t*>(alloc((size_t)n * 8));
   if (!k0 || !k1 || !v0 || !v1) return PDX_OOM;
   if (gb->slot_part) {
+    PDX_TRY(ensure_slot_part(gb, st));
     uint64_t* vals_part = static_cast<uint64_t*>(alloc((size_t)n * 8));
     if (!vals_part) return PDX_OOM;
     PDX_TRY((radix_scatter_only<kPartBits, uint64_t, uint8_t>(gb->bucket8, vals, nullptr, vals_part, n, 0, false, gb->part_off, st)));

@@ -55,6 +55,15 @@ using namespace pdx;
 
 #include "gb_handle.hpp"
 
+// the 4-byte logical slots of a hash-partitioned handle, rebuilt from the 2-byte region indexes the LDS build wrote (on demand)
+static int ensure_slot_part(pdx_groupby* gb, hipStream_t st) {
+  if (!gb->slot_part || gb->slot_part_ready) return PDX_OK;
+  hipLaunchKernelGGL(k_slot_part_from_idx16, dim3(grid_for(gb->n, 256, 8)), dim3(256), 0, st, gb->idx16_part, gb->part_off, gb->n, gb->slot_part);
+  PDX_LAUNCH_CHECK();
+  gb->slot_part_ready = true;
+  return PDX_OK;
+}
+
 namespace pdx {
 #include "gb_sort_values.hpp"
 #include "gb_flr_reduce.hpp"
@@ -459,8 +468,12 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
         }
         uint16_t* idx16 = pb == (unsigned)kPartBits ? gb->idx16_part : nullptr;
         idx16_written = idx16 != nullptr;
-        hipLaunchKernelGGL(k_hash_probe_lds, dim3(1u << pb), dim3(kProbeBlock), 0, st, keys_part, gb->rows_part, boff, n,
-                           table, cap, region, gb->slot_part, ctl, pb, head_rows, idx16);
+        if (valid)
+          hipLaunchKernelGGL((k_hash_probe_lds<true>), dim3(1u << pb), dim3(kProbeBlock), 0, st, keys_part, gb->rows_part, boff, n, table, cap, region,
+                             gb->slot_part, ctl, pb, head_rows, idx16);
+        else  // no null keys: rows_part is not read per row (first rows as positions), and with idx16 the 4-byte slot is not written
+          hipLaunchKernelGGL((k_hash_probe_lds<false>), dim3(1u << pb), dim3(kProbeBlock), 0, st, keys_part, gb->rows_part, boff, n, table, cap, region,
+                             gb->slot_part, ctl, pb, head_rows, idx16);
         if (!chunks.empty()) {
           TailChunk* dchunks = s.get<TailChunk>(chunks.size());
           if (s.failed) {
@@ -575,6 +588,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     }
     gb->part_bits = (int)pb;
     if (!idx16_written) gb->idx16_part = nullptr;  // (the block stays owned by the handle; nothing reads it)
+    gb->slot_part_ready = !idx16_written;          // the LDS build at the first level writes the 2-byte region indexes only
     gb->owned.push_back(table);
     {
       Slot sp[2];
@@ -716,6 +730,7 @@ int pdx_groupby_group_ids(pdx_groupby* gb, uint32_t* out_ids, void* stream) {
   hipStream_t st = as_stream(stream);
   gb->use_on(st);  // ordered behind the handle's creation; frees of its blocks are ordered behind this stream
   if (gb->n == 0) return PDX_OK;
+  if (gb->mode == 0 && gb->slot_part) PDX_TRY(ensure_slot_part(gb, st));
   if (gb->mode == 0 && gb->slot_part)
     hipLaunchKernelGGL(k_part_row_gids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->gid_of_slot, gb->slot_part, gb->rows_part, gb->n,
                        (const int64_t*)nullptr, out_ids, (int64_t*)nullptr);
@@ -733,6 +748,7 @@ int pdx_groupby_map_ids(pdx_groupby* gb, const int64_t* map, int64_t* out, void*
   hipStream_t st = as_stream(stream);
   gb->use_on(st);  // ordered behind the handle's creation; frees of its blocks are ordered behind this stream
   if (gb->n == 0) return PDX_OK;
+  if (gb->mode == 0 && gb->slot_part) PDX_TRY(ensure_slot_part(gb, st));
   if (gb->mode == 0 && gb->slot_part)
     hipLaunchKernelGGL(k_part_row_gids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->gid_of_slot, gb->slot_part, gb->rows_part, gb->n, map,
                        (uint32_t*)nullptr, out);
@@ -1102,7 +1118,9 @@ int pdx_groupby_agg(pdx_groupby* gb, const pdx_column* values, const int* kinds,
   const AccTuning at = AccTuning::read();
   const bool order_free = rq.want_std5 && !rq.want_pw && !rq.var_out && !rq.std_out && !rq.prod_out && !rq.first_out && !rq.last_out;
   AccGeom ag;
-  if (order_free && !L.fused && !L.full)
+  // (a BOUND column's int64 sum keeps the sorted layout: gb.sum(c) is usually followed by gb.mean(c), which needs it -- Arrow's int64 mean
+  //  is the pairwise sum of the doubles -- and the layout then serves both; min / max / count of a bound column do skip the sort)
+  if (order_free && !(bound && rq.want_is) && !L.fused && !L.full)
     ag = acc_geometry(gb, vvalid != nullptr, (o.vmin ? kAccMin : 0u) | (o.vmax ? kAccMax : 0u) | (o.sum_i ? kAccSum : 0u) | (o.count ? kAccCnt : 0u), is_f, at);
   const bool use_acc = ag.ok;
   if (!use_acc && ((!L.fused && !L.full) || (!std_only && !L.full))) PDX_TRY(build_layout(gb, values, std_only, t, L, st));
