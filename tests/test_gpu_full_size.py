@@ -114,3 +114,45 @@ def test_c5_resample_full_size_two_paths(px):
     assert torch.equal(_bits(r["v"].col.values[:nb]), _bits(d["v"].col.values[:nb]))
     cnt = ser.resample("1min").count()
     assert int(cnt["v"].col.values[:nb].sum().item()) == n
+
+
+@pytest.mark.parametrize("dense", ["1", "0"])
+def test_c3_against_the_oracle_at_1e8_rows(px, monkeypatch, dense):
+    """SURVEY 8(d)'s CPU-comparison size -- 1e8 rows / 1e6 keys -- through the HIP path and the C oracle (OpenMP over groups, ~5 s), bit for
+    bit, for the default dense plan AND with every key through the hash table; the plan is asserted, so the kernels compared are the ones
+    the bench times.  The order-free kinds (min / max / count without the value sort, gb_acc.hpp) ride on the same handle."""
+    import os
+
+    import oracle as orc
+
+    monkeypatch.setenv("PDX_GROUPBY_DENSE", dense)
+    K, L = px.K, px.L
+    n, nk = 100_000_000, 1_000_000
+    threads = min(64, os.cpu_count() or 1)
+    keys, vals = K.synth_keys(0, n, nk), K.synth_vals(0, n)
+    gb = K.GroupByHandle.create(keys)
+    s, m, c = gb.agg(vals, [SUM, MEAN, COUNT])
+    plan = gb.last_plan()
+    hk, hv = orc.synth_keys(0, n, nk), orc.synth_vals(0, n)
+    ek, es, em, ec = orc.groupby_sum_mean_count(hk, hv, nthreads=threads)
+    # (100 rows per group: 6103 rows per run of the fused layout is under its 8192-row threshold, so the DEFAULT plan at this size is the
+    #  full sort + the classic segment reducers; the narrowing sort + fused last digit the bench times is held to the oracle at 1.35e8 /
+    #  2.7e8 rows by tests/test_gpu_round3.py::test_production_chain_headline_geometry / _hash_path)
+    if dense == "1":
+        assert plan["slots"] == "dense" and plan["layout"] == "full" and plan["reducer"] == "seg_reduce", plan
+    else:
+        assert plan["slots"] == "hash_lds" and plan["layout"] == "full" and plan["reducer"] == "seg_reduce", plan
+    assert np.array_equal(gb.unique_keys().to_numpy()[0], ek)
+    assert np.array_equal(s.to_numpy()[0].view(np.uint64), es.view(np.uint64))
+    assert np.array_equal(m.to_numpy()[0].view(np.uint64), em.view(np.uint64))
+    assert np.array_equal(c.to_numpy()[0], ec)
+    # order-free kinds on the same handle: no value sort
+    ids = orc.group_ids(hk)[0]
+    mn, mx = gb.agg(vals, [2, 3])
+    assert gb.last_plan()["reducer"] == "lds_acc", gb.last_plan()
+    for kind, got in ((2, mn), (3, mx)):
+        exp = orc.groupby_agg(kind, ids, len(ek), hv, None, nthreads=threads)[0]
+        assert np.array_equal(got.to_numpy()[0].view(np.uint64), exp.view(np.uint64)), kind
+    cnt = gb.agg(vals, [COUNT])[0]
+    assert gb.last_plan()["reducer"] in ("lds_acc", "sizes_cache") and np.array_equal(cnt.to_numpy()[0], ec)
+    del gb
