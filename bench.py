@@ -290,6 +290,46 @@ def secondary_runs(torch, L, K, api, keys, vals, kinds, n_total, nkeys, steps):
     sv = K.synth_vals(5, m, 77)
     put("8f3_argsort_f64", m, 16.0 * m, timeit(lambda: K.argsort(sv), reps=2))
     del sv
+    # (i) SURVEY 8(f)-4: Parquet / Arrow IPC ingest straight into device columns (DataFrame::readParquet / readBinary,
+    # src/dataframe.cpp:646-683, 754-791): host bytes of a pyarrow-written file -> pdx_parquet_load / pdx_ipc_load -> resident columns.
+    # Rate = DECODED bytes (16 B/row: int64 key + fp64 value) per second, the host->device copy of the file included (PCIe bound, not HBM).
+    try:
+        import io
+
+        import pyarrow as pa
+        import pyarrow.parquet as pq
+
+        m = min(20_000_000, n_total)
+        hk, hv = keys.values[:m].cpu().numpy(), vals.values[:m].cpu().numpy()
+        tbl = pa.table({"k": hk, "v": hv})
+        sink = io.BytesIO()
+        pq.write_table(tbl, sink, compression="snappy", use_dictionary=True, row_group_size=m)
+        pq_blob = sink.getvalue()
+        sink = pa.BufferOutputStream()
+        with pa.ipc.new_stream(sink, tbl.schema) as w:
+            w.write_table(tbl, max_chunksize=m)
+        ipc_blob = sink.getvalue().to_pybytes()
+        del tbl, sink
+
+        def load_parquet():
+            return K.ParquetFile(pq_blob).load()
+
+        def load_ipc():
+            return K.IpcFrame(ipc_blob).load()
+
+        cols = load_parquet()
+        same = bool(torch.equal(cols[0][1].values[:m], keys.values[:m]) and torch.equal(cols[1][1].values[:m].view(torch.int64), vals.values[:m].view(torch.int64)))
+        del cols
+        put("8f4_parquet_ingest_snappy_dict", m, 16.0 * m, timeit(load_parquet, reps=3), file_bytes=len(pq_blob), decoded_equals_source=same, bound="pcie + decode",
+            note="pyarrow-written file (Snappy, dictionary with PLAIN fallback, one row group) -> device columns; frac is against HBM and not the bound here")
+        cols = load_ipc()
+        same = bool(torch.equal(cols[0][1].values[:m], keys.values[:m]) and torch.equal(cols[1][1].values[:m].view(torch.int64), vals.values[:m].view(torch.int64)))
+        del cols
+        put("8f4_ipc_ingest", m, 16.0 * m, timeit(load_ipc, reps=3), file_bytes=len(ipc_blob), decoded_equals_source=same, bound="pcie",
+            note="Arrow IPC stream of one record batch: one host->device copy of the body, columns alias it")
+        del pq_blob, ipc_blob, hk, hv
+    except ImportError as e:  # no pyarrow on this box: nothing can write the files
+        out["8f4_ingest_skipped"] = str(e)
     return out
 
 

@@ -198,6 +198,12 @@ int pdx_if_else(const pdx_column* cond, const pdx_column* a, const pdx_column* b
  *                 differ from the reference's host libm in the last place (the reference's own result depends on its glibc
  *                 build): the only element-wise result on this path that is not bit-reproducible. */
 int pdx_unary(int op, const pdx_column* a, pdx_mut_column* out, void* stream);
+/* Replaces arrow::compute::Cast(column, float64()): the promotion of same-named int64 / float64 columns in pd::concat (src/concat.cpp:116-132:
+ * default CastOptions = the SAFE cast: checked = 1, a valid int64 value outside +-2^53 fails the call with PDX_INVALID "Integer value ... not in
+ * range: -9007199254740992 to 9007199254740992" -- the same check Arrow's DispatchBest applies when pdx_binary / pdx_compare / pdx_if_else
+ * meet an int64 and a float64 operand) and the value-by-value static_cast<double> of Arrow's `mean` over int64 input (checked = 0: the
+ * frame-level DataFrame::mean sums int64 chunks as doubles, src/ndframe.h:329-335).  a: PDX_INT64 (or PDX_FLOAT64: a copy); nulls carried over. */
+int pdx_cast_f64(const pdx_column* a, int checked, pdx_mut_column* out, void* stream);
 /* Replaces CallFunction("power", {array, Datum(double)}): Series::pow / DataFrame::pow (src/dataframe.cpp:267-270).  Integer input
  * is cast to float64 as in pdx_unary(SQRT); out: PDX_FLOAT64 = pow(a, exponent), last-place caveat as for EXP. */
 int pdx_power(const pdx_column* a, double exponent, pdx_mut_column* out, void* stream);
@@ -230,11 +236,16 @@ int pdx_scatter(const pdx_column* cols, int ncols, const pdx_column* indices, pd
  * pdx_groupby_create replaces GroupBy::makeGroups (src/dataframe.cpp:1571-1600): Grouper::Make + Consume
  * (dense group ids in FIRST-OCCURRENCE order, a null key is its own group) + GetUniques.  The reference's eager
  * MakeGroupings/ApplyGroupings of every column (src/dataframe.cpp:1539-1569) is deferred to pdx_groupby_agg.
- * GROUP ORDER: exactly first occurrence (group g's first row precedes group g+1's).  Arrow's Grouper is first-occurrence on the
- * reference's own tests and on any input with few new keys per 1024-row mini-batch of its swiss table, but only approximately so
- * when many new keys meet in one mini-batch (Arrow 25.0.0: 13 286 of 43 183 result rows sit elsewhere at 1e5 rows / 5e4 uniform
- * keys); per key every aggregate is bit-identical.  The deviation is frozen in tests/golden/group_order_arrow25.npz and asserted by
- * tests/test_oracle_golden_r3.py / tests/test_gpu_round3.py.
+ * GROUP ORDER: exactly first occurrence (group g's first row precedes group g+1's).  Arrow's Grouper::Consume (Arrow C++ 25.0.0, one
+ * call over the column, as src/dataframe.cpp:1580 makes it) differs from that by a BOUNDED permutation, and only so: it walks the batch
+ * in mini-batches of 128, 256, 512 and then 1024 rows (row boundaries 128, 384, 896, 1920, 2944, ...); the keys first seen in a
+ * mini-batch receive ONE CONTIGUOUS BLOCK of ids -- the same block first-occurrence numbering gives them -- permuted inside the block
+ * (the insertion rounds of its swiss table).  So: the reference's own tests (<= 17 rows) and any input with at most one new key per
+ * mini-batch are exactly first occurrence; group g here and group g there first appear in the same mini-batch, always; per key every
+ * aggregate is bit-identical; DataFrame::sort_index (src/dataframe.cpp:1062-1071; both facades) makes two results row-identical.
+ * Held against live Arrow on inputs spanning thousands of mini-batches by tests/test_oracle_golden_r4.py (oracle/arrow_order.cpp) and,
+ * with this library's own ids, by tests/cpp/arrow_bridge_test.cpp; measured sizes of the permutation: 51 of 97 groups at 1e5 rows / 97
+ * keys, 10 145 of 43 107 at 1e5 / 5e4, 23 825 of 993 353 at 5e6 / 1e6 (tests/golden/group_order_arrow25.npz freezes two such cases).
  * key: PDX_INT64 / PDX_TIMESTAMP_NS / PDX_UINT64.  Limits: length < 2^31 rows per call (row ids are 32 bits wide inside the handle;
  * pdx_groupby_sum_mean_count_chunked serves longer inputs for the headline query by an exact merge of chunks); keys that do not span a dense integer
  * range go through a hash table of at most 2^30 slots (about 7e8 distinct keys; the LDS-resident build covers 2.7e8). */

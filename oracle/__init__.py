@@ -163,6 +163,15 @@ def _binary_like(fn_f64, fn_i64, op, a, b, va, vb, offset, out_dtype, bits):
     isf = a.dtype == np.float64 or b.dtype == np.float64  # implicit promotion int64 (+) double -> double
     dt = np.float64 if isf else np.int64
     n = len(b) if sa else len(a)
+    if isf and a.dtype != b.dtype:
+        # the promotion is Arrow's CHECKED cast: a valid int64 value outside +-2^53 fails the call (pinned live against Arrow C++ 25 by
+        # tests/cpp/arrow_bridge_test.cpp and tests/test_oracle_golden_r4.py)
+        iv, ivalid = (a, va) if a.dtype != np.float64 else (b, vb)
+        sel = iv.astype(np.int64)
+        ok = np.ones(len(sel), bool) if ivalid is None else np.asarray(ivalid, bool)[:len(sel)]
+        bad = ok & ((sel > 2**53) | (sel < -2**53))
+        if bad.any():
+            raise OracleError(INVALID, f"Integer value {int(sel[np.flatnonzero(bad)[0]])} not in range: -9007199254740992 to 9007199254740992")
     A = a.astype(dt) if sa else _shift(a.astype(dt), offset)
     B = b.astype(dt) if sb else _shift(b.astype(dt), offset)
     VA = pack_bits(va, 0 if sa else offset)
@@ -562,6 +571,34 @@ def arrow_seq_build(force: bool = False):
            f"-Wl,-rpath,{libdir}", "-o", _ARROW_SEQ]
     subprocess.check_call(cmd)
     return _ARROW_SEQ
+
+
+def arrow_order_run(rows, nkeys, seed=1, timeout=600):
+    """oracle/arrow_order.cpp: (keys int64[n], ids uint32[n]) -- the group ids Arrow C++'s Grouper::Consume hands out for a seeded key
+    column (one Consume call over the whole column, as GroupBy::makeGroups does).  Raises when the pyarrow wheel is not on this box."""
+    import glob
+    import tempfile
+
+    import pyarrow as pa
+
+    src, exe = os.path.join(_HERE, "arrow_order.cpp"), os.path.join(_HERE, "_build", "arrow_order")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        inc = pa.get_include()
+        libdir = next(d for d in pa.get_library_dirs() if glob.glob(os.path.join(d, "libarrow.so*")))
+
+        def so(name):
+            return "-l:" + os.path.basename(sorted(glob.glob(os.path.join(libdir, name + ".so.*")) or glob.glob(os.path.join(libdir, name + ".so")))[0])
+
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["g++", "-std=c++20", "-O2", f"-I{inc}", src, f"-L{libdir}", so("libarrow_compute"), so("libarrow"), f"-Wl,-rpath,{libdir}", "-o", exe])
+    with tempfile.NamedTemporaryFile(suffix=".bin") as tf:
+        r = subprocess.run([exe, "--rows", str(int(rows)), "--keys", str(int(nkeys)), "--seed", str(int(seed)), "--out", tf.name], capture_output=True, text=True,
+                           timeout=timeout)
+        if r.returncode != 0:
+            raise RuntimeError("arrow_order failed: " + r.stderr[-500:])
+        raw = np.fromfile(tf.name, dtype=np.uint8)
+    n = int(rows)
+    return raw[:n * 8].view(np.int64).copy(), raw[n * 8:n * 12].view(np.uint32).copy()
 
 
 def arrow_seq_run(rows, nkeys, threads, timeout=1800):

@@ -85,6 +85,7 @@ ABI_SYMBOLS = {
     "pdx_invert": (C.c_int, [_COL, _MUT, _P]),
     "pdx_if_else": (C.c_int, [_COL, _COL, _COL, C.c_int, _MUT, _P]),
     "pdx_unary": (C.c_int, [C.c_int, _COL, _MUT, _P]),
+    "pdx_cast_f64": (C.c_int, [_COL, C.c_int, _MUT, _P]),
     "pdx_power": (C.c_int, [_COL, C.c_double, _MUT, _P]),
     "pdx_aggregate": (C.c_int, [C.c_int, _COL, C.POINTER(PdxScalar), _P]),
     "pdx_filter_count": (C.c_int, [_COL, C.c_int, C.POINTER(C.c_int64), _P]),

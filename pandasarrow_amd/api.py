@@ -356,6 +356,14 @@ class Series:
         outs = K.take(cols, idx)
         return Series(outs[0], index=outs[1], name=self.name)
 
+    def sort_index(self, ascending=True):
+        """values and index ordered by the INDEX (the Series form of DataFrame::sort_index, src/dataframe.cpp:1062-1071): a group-by result
+        sorted by key compares equal with the reference's whatever order its Grouper numbered the groups in"""
+        ix = self._explicit_index()
+        idx = K.argsort(ix, ascending)
+        outs = K.take([self.col, ix], idx)
+        return Series(outs[0], index=outs[1], name=self.name)
+
     def n_largest(self, n):
         s = self.sort(False)
         return s if s.size() < n else Series(s.col.slice(0, n), index=s.index.slice(0, n), name=self.name)
@@ -515,7 +523,7 @@ class DataFrame:
         self._check_one_dtype()
         tot, cnt = 0.0, 0
         for c in self.cols:
-            v, k = K.aggregate(L.AGG_SUM, c if c.dtype == L.FLOAT64 else K.binary(L.MUL, c, 1.0))
+            v, k = K.aggregate(L.AGG_SUM, c if c.dtype == L.FLOAT64 else K.cast_f64(c, checked=False))  # (Arrow's mean: static_cast<double> per value)
             if v is None:
                 continue
             tot, cnt = tot + v, cnt + k
@@ -549,6 +557,15 @@ class DataFrame:
         cols = self.cols + ([self.index] if self.index is not None else [])
         outs = K.take(cols, idx.col)
         return self._like(outs[: len(self.cols)], index=outs[-1] if self.index is not None else None)
+
+    def sort_index(self, ascending=True, ignore_index=False):
+        """DataFrame::sort_index (src/dataframe.cpp:1062-1071): the index sorted (Series::sort: array_sort_indices + take), the frame taken
+        by the same indices.  Also the order-independent view of a group-by result: group ORDER is first occurrence here and a bounded
+        permutation of it in Arrow's Grouper (include/pdx/abi.h at pdx_groupby_create), sorted by key both frames are identical."""
+        ix = _frame_index(self)
+        idx = K.argsort(ix, ascending)
+        outs = K.take(self.cols + [ix], idx)
+        return self._like(outs[:-1], index=None if ignore_index else outs[-1])
 
     def reindex(self, new_index, fill_value=None):
         """DataFrame::reindex / reindexAsync (src/dataframe.cpp:1139-1186, src/dataframe.h:403-406): every column at the LAST position
@@ -896,8 +913,8 @@ def concat(frames, axis="index", join="outer", ignore_index=False, sort=False):
         for f, c in zip(frames, have):
             if c is None:
                 c = K.null_column(dt, f.num_rows())
-            elif c.dtype != dt:  # Cast(int64 -> double): value by value, as x * 1.0
-                c = K.binary(L.MUL, c, 1.0, True)
+            elif c.dtype != dt:  # arrow::compute::Cast(column, double) with default (safe) options, src/concat.cpp:127
+                c = K.cast_f64(c, checked=True)
             parts.append(c)
         cols.append(K.concat(parts))
     if join == "inner":

@@ -228,6 +228,14 @@ def unary(op, a: Column) -> Column:
     return out._adopt(m)
 
 
+def cast_f64(a: Column, checked=True) -> Column:
+    """Cast(int64 -> float64) (pdx_cast_f64): checked = Arrow's safe cast (pd::concat's promotion), unchecked = static_cast per value."""
+    out = Column.empty(L.FLOAT64, a.length, with_validity=a.has_nulls())
+    ca, m = a.c(), out.mut()
+    L.check(L.load().pdx_cast_f64(C.byref(ca), int(bool(checked)), C.byref(m), _stream()))
+    return out._adopt(m)
+
+
 def power(a: Column, exponent: float) -> Column:
     lib = L.load()
     out = Column.empty(L.FLOAT64, a.length, with_validity=a.has_nulls())

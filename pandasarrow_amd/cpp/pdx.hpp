@@ -460,6 +460,16 @@ class Series {
     out.null_count = m.null_count;
     return out;
   }
+  // arrow::compute::Cast(column, float64()): checked = the default safe cast (pd::concat, src/concat.cpp:127), unchecked = static_cast per
+  // value (Arrow's mean over int64 input)
+  static Array run_cast_f64(const Array& a, bool checked) {
+    Array out = Array::Empty(PDX_FLOAT64, a.length, a.has_nulls());
+    auto ca = a.c();
+    auto m = out.mut();
+    ThrowOnFailure(pdx_cast_f64(&ca, checked ? 1 : 0, &m, nullptr));
+    out.null_count = m.null_count;
+    return out;
+  }
   static Array run_if_else(const Array& cond, const Array& a, const Array& b, int side) {
     const bool is_f = a.dtype == PDX_FLOAT64 || b.dtype == PDX_FLOAT64;
     Array out = Array::Empty(is_f ? PDX_FLOAT64 : PDX_INT64, cond.length, cond.has_nulls() || a.has_nulls() || b.has_nulls());
@@ -738,7 +748,7 @@ class DataFrame {
     double tot = 0.0;
     int64_t cnt = 0;
     for (auto& c : m_columns) {
-      Series col(c.dtype == PDX_FLOAT64 ? c : Series::run_binary(PDX_MUL, c, Scalar(1.0).to_array(), true));  // int64 chunks sum as doubles
+      Series col(c.dtype == PDX_FLOAT64 ? c : Series::run_cast_f64(c, false));  // int64 chunks sum as doubles (static_cast per value)
       Scalar s = col.sum();
       if (!s.isValid()) continue;
       tot += s.s.v.f64;
@@ -773,6 +783,22 @@ class DataFrame {
     if (idx.dtype() == PDX_BOOL) throw std::runtime_error("take indices must be integers, not boolean");
     auto outs = Series::run_take(columns_with_index(), idx.m_array);
     return rebuild(outs);
+  }
+  // DataFrame::sort_index (src/dataframe.cpp:1062-1071): the index sorted (array_sort_indices), the frame taken by the same indices.
+  // Also the order-independent view of a group-by result: group ORDER is first occurrence here and a bounded permutation of it in
+  // Arrow's Grouper (pdx/abi.h at pdx_groupby_create); sorted by key both frames are identical.
+  DataFrame sort_index(bool ascending = true, bool ignore_index = false) const {
+    DataFrame explicit_ix = *this;
+    if (!explicit_ix.m_index) {  // the implicit range index, materialised (uint_range, src/ndframe.cpp:100-107)
+      std::vector<int64_t> r((size_t)num_rows());
+      for (size_t i = 0; i < r.size(); ++i) r[i] = (int64_t)i;
+      explicit_ix.m_index = Array::Make(r);
+    }
+    const Series order = Series(*explicit_ix.m_index).argsort(ascending);
+    auto outs = Series::run_take(explicit_ix.columns_with_index(), order.m_array);
+    DataFrame r = explicit_ix.rebuild(outs);
+    if (ignore_index) r.m_index.reset();
+    return r;
   }
 
   // ---- Arrow IPC (src/dataframe.cpp:726-791).  toBinary: schema + ONE record batch + custom metadata; every column is written
@@ -1264,7 +1290,7 @@ inline DataFrame concat(const std::vector<DataFrame>& dfs, bool ignore_index = f
         parts.push_back(nul);
       } else {
         Array c = d.m_columns[(size_t)(it - d.m_names.begin())];
-        if (c.dtype != dt) c = Series::run_binary(PDX_MUL, c, Scalar(1.0).to_array(), true);  // Cast(int64 -> double)
+        if (c.dtype != dt) c = Series::run_cast_f64(c, true);  // arrow::compute::Cast(column, double), default (safe) options
         parts.push_back(c);
       }
     }

@@ -331,6 +331,40 @@ static int check_numeric_pair(const pdx_column* a, const pdx_column* b, int scal
 
 using namespace pdx;
 
+// ---------------------------------------------------------------- the implicit int64 -> float64 promotion is a CHECKED cast
+// Arrow's DispatchBest inserts a safe cast when an int64 operand meets a float64 one (add ... divide, the comparisons, if_else): a VALID
+// value outside +-2^53 fails the whole call with "Integer value ... not in range" (pinned against Arrow C++ 25 by
+// tests/cpp/arrow_bridge_test.cpp; null slots are not looked at, +-2^53 themselves pass).  One pass over the int64 operand, mixed-type
+// calls only.
+__global__ void __launch_bounds__(256) k_int_fits_f64(const long long* __restrict__ v, const uint8_t* __restrict__ valid, int64_t voff, int64_t n,
+                                                      unsigned long long* __restrict__ err /* [0] flag, [1] an offending value */) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const long long x = v[i];
+    if ((x > 9007199254740992ll || x < -9007199254740992ll) && (!valid || bit_get(valid, voff + i))) {
+      err[1] = (unsigned long long)x;
+      err[0] = 1ull;
+    }
+  }
+}
+static int check_promotion(const pdx_column* a, const pdx_column* b, hipStream_t st) {
+  if (a->dtype == b->dtype) return PDX_OK;
+  const pdx_column* c = a->dtype == PDX_INT64 ? a : b;  // the operand that is cast
+  if (c->dtype != PDX_INT64 || c->length == 0) return PDX_OK;
+  Scratch s;
+  unsigned long long* err = s.get<unsigned long long>(2);
+  PDX_SCRATCH_CHECK(s);
+  PDX_HIP(hipMemsetAsync(err, 0, 2 * sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(k_int_fits_f64, dim3(grid_for(c->length, 256, 8)), dim3(256), 0, st, static_cast<const long long*>(c->values) + c->offset, validity_or_null(c),
+                     c->offset, c->length, err);
+  PDX_LAUNCH_CHECK();
+  unsigned long long h[2] = {0, 0};
+  PDX_HIP(hipMemcpyAsync(h, err, sizeof(h), hipMemcpyDeviceToHost, st));
+  PDX_HIP(hipStreamSynchronize(st));
+  if (h[0]) return fail(PDX_INVALID, "Integer value " + std::to_string((long long)h[1]) + " not in range: -9007199254740992 to 9007199254740992");
+  return PDX_OK;
+}
+
 // ---------------------------------------------------------------- functions of one column
 constexpr int kPowerOp = 100;  // internal op code of pdx_power
 template <int OP, typename TI, typename TO>
@@ -520,12 +554,46 @@ int pdx_if_else(const pdx_column* cond, const pdx_column* a, const pdx_column* b
   out->null_count = has_nulls ? -1 : 0;
   if (n == 0) return PDX_OK;
   if (!out->values) return fail(PDX_INVALID, "pdx_if_else: null output buffer");
+  PDX_TRY(check_promotion(a, b, st));
   pdx_mut_column o = *out;
   if (!is_f) launch_if_else<int64_t, int64_t, int64_t>(cond, a, b, scalar_side, &o, n, st);
   else if (a->dtype == PDX_FLOAT64 && b->dtype == PDX_FLOAT64) launch_if_else<double, double, double>(cond, a, b, scalar_side, &o, n, st);
   else if (a->dtype == PDX_FLOAT64) launch_if_else<double, int64_t, double>(cond, a, b, scalar_side, &o, n, st);
   else launch_if_else<int64_t, double, double>(cond, a, b, scalar_side, &o, n, st);
   PDX_LAUNCH_CHECK();
+  return PDX_OK;
+}
+
+// Cast(int64 -> float64): value by value (static_cast<double>), nulls carried over
+__global__ void __launch_bounds__(256) k_cast_i64_f64(const long long* __restrict__ a, int64_t n, double* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (double)a[i];
+}
+int pdx_cast_f64(const pdx_column* a, int checked, pdx_mut_column* out, void* stream) {
+  PDX_TRY(check_column(a, "pdx_cast_f64"));
+  if (a->dtype != PDX_INT64 && a->dtype != PDX_FLOAT64) return fail(PDX_NOT_IMPLEMENTED, "pdx_cast_f64: input must be int64 or float64");
+  if (!out || out->length < a->length || out->dtype != PDX_FLOAT64) return fail(PDX_INVALID, "pdx_cast_f64: output must be PDX_FLOAT64 of the input length");
+  const bool has_nulls = validity_or_null(a) != nullptr;
+  if (has_nulls && !out->validity) return fail(PDX_INVALID, "pdx_cast_f64: input carries nulls but output has no validity buffer");
+  hipStream_t st = as_stream(stream);
+  const int64_t n = a->length;
+  out->length = n;
+  out->null_count = has_nulls ? -1 : 0;
+  if (n == 0) return PDX_OK;
+  if (!out->values) return fail(PDX_INVALID, "pdx_cast_f64: null output buffer");
+  if (a->dtype == PDX_FLOAT64) {
+    PDX_HIP(hipMemcpyAsync(out->values, static_cast<const double*>(a->values) + a->offset, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+  } else {
+    if (checked) {
+      pdx_column as_f = *a;  // (check_promotion looks at the int64 operand of a mixed pair)
+      as_f.dtype = PDX_FLOAT64;
+      PDX_TRY(check_promotion(a, &as_f, st));
+    }
+    hipLaunchKernelGGL(k_cast_i64_f64, dim3(grid_for(n, 256, 8)), dim3(256), 0, st, static_cast<const long long*>(a->values) + a->offset, n,
+                       static_cast<double*>(out->values));
+    PDX_LAUNCH_CHECK();
+  }
+  if (out->validity) PDX_TRY(launch_validity_and(a, nullptr, 0, n, static_cast<uint8_t*>(out->validity), st));
   return PDX_OK;
 }
 
@@ -550,6 +618,7 @@ int pdx_binary(int op, const pdx_column* a, const pdx_column* b, int b_is_scalar
   out->null_count = has_nulls ? -1 : 0;
   if (n == 0) return PDX_OK;
   if (!out->values) return fail(PDX_INVALID, "pdx_binary: null output buffer");
+  PDX_TRY(check_promotion(a, b, st));
   const bool need_err = (op == PDX_DIV) && !is_f;
   Scratch scratch;
   unsigned long long* err = nullptr;
@@ -601,6 +670,7 @@ int pdx_compare(int op, const pdx_column* a, const pdx_column* b, int b_is_scala
   out->null_count = has_nulls ? -1 : 0;
   if (n == 0) return PDX_OK;
   if (!out->values) return fail(PDX_INVALID, "pdx_compare: null output buffer");
+  PDX_TRY(check_promotion(a, b, st));
   uint8_t* o = static_cast<uint8_t*>(out->values);
   if (a->dtype == PDX_FLOAT64 && b->dtype == PDX_FLOAT64) launch_compare_op<double, double, double>(op, a, b, b_is_scalar, o, st);
   else if (a->dtype == PDX_FLOAT64) launch_compare_op<double, int64_t, double>(op, a, b, b_is_scalar, o, st);

@@ -1070,6 +1070,20 @@ int pdx_parquet_load(pdx_parquet_file* f, void* stream) {
     for (size_t k = 0; k < plans[ci].pages.size(); ++k) nulls += all_pages[p0 + k].num_values - all_pages[p0 + k].nonnull;
     c.null_count = c.repetition == 1 ? nulls : 0;
   }
+  // the staging blocks -- the uploaded file range, the decompressed pages, one byte per row of validity, dictionaries, page tables, the
+  // 8-byte form of boolean values -- go back to the pool now: the handle lives as long as the frame that aliases its columns, and must
+  // not pin file size + uncompressed size + a byte per nullable row of HBM beside them.  Only the columns' own buffers stay.
+  {
+    std::vector<void*> keep, drop;
+    for (void* q : f->owned) {
+      bool k = false;
+      for (const PqColumn& c : f->cols) k = k || q == c.values || q == c.validity;
+      (k ? keep : drop).push_back(q);
+    }
+    StreamNote note(f->stream);
+    pool_free_many(drop.data(), (int)drop.size());
+    f->owned.swap(keep);
+  }
   f->blob = nullptr;  // the caller may free the file bytes once this returns
   f->loaded = true;
   return PDX_OK;

@@ -259,7 +259,7 @@ class HipEngine:
         return self.K.aggregate(kind, col)
 
     def to_f64(self, col):
-        return self.K.binary(L.MUL, col, 1.0)  # int64 * float64 -> float64 (Arrow's implicit cast)
+        return self.K.cast_f64(col, checked=False)  # Arrow's mean over int64 input: static_cast<double> per value
 
     def count_below(self, ts_col, edge, inclusive):
         """rows with ts < edge (<= when inclusive)."""

@@ -146,6 +146,12 @@ static void test_groupby() {
   REQUIRE(result.num_rows() == 4 && result.num_columns() == 2);
   REQUIRE((result["a"].values<int64_t>() == std::vector<int64_t>{5, 6, 8, 4}));
   REQUIRE((result["b"].values<int64_t>() == std::vector<int64_t>{37, 12, 3, 3}));
+  // DataFrame::sort_index (src/dataframe.cpp:1062-1071): the key-sorted view of a result compares equal whatever order the groups came in
+  auto by_key = result.sort_index();
+  REQUIRE((by_key.m_index->values_as<long>() == std::vector<long>{1, 2, 3, 8}));
+  REQUIRE((by_key["b"].values<int64_t>() == std::vector<int64_t>{37, 3, 12, 3}));
+  REQUIRE((result.sort_index(false)["a"].values<int64_t>() == std::vector<int64_t>{8, 6, 4, 5}));
+  REQUIRE(!result.sort_index(true, true).m_index.has_value());
   // tests/cudf_examples/dataframe_resample_test.cpp:71-248 (gender male=0 female=1)
   DataFrame people({"gender", "age", "height"},
                    {Array::Make(std::vector<long>{0, 1, 0, 0, 1, 0, 0, 1, 0, 0}), Array::Make(std::vector<int>{16, 10, 10, 20, 30, 40, 15, 25, 35, 45}),

@@ -91,7 +91,12 @@ def test_elementwise_fuzz(px, seed):
             got, ok = px.K.binary(op, A, rhs_col, is_scalar).to_numpy()
             assert _same_valid(ok, eok, n) and _eq(got, exp, None if eok is None else eok), (seed, op, is_scalar)
     for op in range(6):  # eq ne lt le gt ge
-        exp, eok = orc.compare(op, a, b, va, vb)
+        try:
+            exp, eok = orc.compare(op, a, b, va, vb)
+        except orc.OracleError:  # int64 against float64 with a valid value outside +-2^53: Arrow's checked promotion fails the call
+            with pytest.raises(px.L.PdxError, match="not in range"):
+                px.K.compare(op, A, B)
+            continue
         got, ok = px.K.compare(op, A, B).to_numpy()
         assert _same_valid(ok, eok, n) and _eq(got, exp, None if eok is None else eok), (seed, "cmp", op)
     m1, m2 = rng.random(n) < 0.5, rng.random(n) < 0.5

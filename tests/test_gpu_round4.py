@@ -269,3 +269,52 @@ def test_order_free_fuzz(px, monkeypatch, seed):
     kinds = [k for k in pool if rng.random() < 0.6] or [MIN]
     outs = gb.agg(vcol, kinds)
     _check(kinds, outs, ids, len(uniq), vals[off:], None if vvalid is None else vvalid[off:], f"fuzz seed={seed} plan={gb.last_plan()}")
+
+
+def test_mixed_type_promotion_is_arrows_checked_cast(px):
+    """int64 (op) float64 promotes through Arrow's CHECKED cast (DispatchBest; pinned live by tests/cpp/arrow_bridge_test.cpp and
+    tests/test_oracle_golden_r4.py): a valid int64 outside +-2^53 fails add / compare / if_else with Arrow's message; a null slot is not
+    looked at; +-2^53 pass."""
+    L, K = px.L, px.K
+    i = np.array([1, 2**53, -2**53, 7, -5], dtype=np.int64)
+    f = np.array([0.5, 1.5, 2.5, np.nan, -0.0])
+    a, b = px.Column.from_numpy(i), px.Column.from_numpy(f)
+    got, ok = K.binary(L.ADD, a, b).to_numpy()
+    exp, _ = orc.binary(L.ADD, i, f)
+    assert_f64_bits(got, exp, what="int64 + float64", nan_bits=True)
+    bad = i.copy()
+    bad[3] = -(2**53) - 1
+    for call in (lambda c: K.binary(L.MUL, c, b), lambda c: K.binary(L.SUB, b, c), lambda c: K.compare(L.LT, c, b),
+                 lambda c: K.if_else(K.compare(L.GT, b, 1.0, True), c, b), lambda c: K.binary(L.ADD, c, 2.5, True)):
+        with pytest.raises(L.PdxError, match=r"Integer value -9007199254740993 not in range: -9007199254740992 to 9007199254740992") as e:
+            call(px.Column.from_numpy(bad))
+        assert e.value.status == L.INVALID
+    valid = np.array([True, True, True, False, True])
+    got, ok = K.binary(L.ADD, px.Column.from_numpy(bad, valid), b).to_numpy()
+    exp, eok = orc.binary(L.ADD, bad, f, va=valid)
+    assert np.array_equal(ok, eok) and np.array_equal(got[eok].view(np.uint64), exp[eok].view(np.uint64))
+    # same dtypes never pay the check; int64 (op) int64 wraps as before
+    got, _ = K.binary(L.ADD, px.Column.from_numpy(bad), px.Column.from_numpy(bad)).to_numpy()
+    assert np.array_equal(got, bad + bad)
+
+
+def test_sort_index_makes_group_results_order_independent(px):
+    """DataFrame::sort_index (src/dataframe.cpp:1062-1071) in the python facade: a group-by result sorted by key is the frame a consumer
+    compares with the reference's (whose Grouper numbers groups in a bounded permutation of first-occurrence order)"""
+    api = px.api
+    rng = np.random.default_rng(2)
+    n = 50_000
+    k = rng.integers(-300, 300, n).astype(np.int64)
+    v = rng.standard_normal(n)
+    df = api.DataFrame({"k": px.Column.from_numpy(k), "v": px.Column.from_numpy(v)})
+    res = df.group_by("k").sum("v")
+    by_key = api.DataFrame({"v": res.col}, index=res.index).sort_index()
+    ids, uniq, _, _ = orc.group_ids(k)
+    exp, _ = orc.groupby_agg(SUM, ids, len(uniq), v, None, nthreads=4)
+    order = np.argsort(uniq, kind="stable")
+    assert np.array_equal(by_key.index.to_numpy()[0], uniq[order])
+    assert np.array_equal(by_key["v"].col.to_numpy()[0].view(np.uint64), exp[order].view(np.uint64))
+    sk = res.sort_index(ascending=False)
+    assert np.array_equal(sk.index.to_numpy()[0], uniq[order][::-1]) and np.array_equal(sk.col.to_numpy()[0].view(np.uint64), exp[order][::-1].view(np.uint64))
+    noidx = api.DataFrame({"v": res.col}, index=res.index).sort_index(ignore_index=True)
+    assert noidx.index is None
