@@ -224,7 +224,8 @@ __device__ __forceinline__ void acc_walk(const KT* __restrict__ keys, const uint
 
 template <typename T, typename KT, bool NULLABLE>
 __global__ void __launch_bounds__(kAccBlock) k_acc(const KT* __restrict__ keys, const uint64_t* __restrict__ vals, const uint8_t* __restrict__ valid, int64_t voff,
-                                                   int64_t n, const uint32_t* __restrict__ bstart, int B, int S, int64_t span, int vec, unsigned want, AccTables P) {
+                                                   int64_t n, const uint32_t* __restrict__ bstart, int B, int S, int64_t span, int vec, unsigned want, AccTables P,
+                                                   int combine) {
   extern __shared__ unsigned long long acc_lds[];
   constexpr bool F = __is_same(T, double);
   const bool flags = acc_has_flags(want, F, NULLABLE);
@@ -253,6 +254,50 @@ __global__ void __launch_bounds__(kAccBlock) k_acc(const KT* __restrict__ keys, 
       },
       [&](uint32_t k, uint64_t v, int64_t, bool isnull) {
         const uint32_t bit = 1u << (k & 31);
+        // Hot keys: LDS atomics on ONE address serialise (a key holding 30 % of the rows fills its bucket: 64 turns per wave instruction).
+        // The lanes that share the slot of the wave's first lane -- when there are at least eight of them -- combine their rows with
+        // shuffles (the other lanes contribute identities) and their first lane applies ONE update per table; the rest of the wave goes
+        // on lane by lane.  A compare, a ballot and a population count per row otherwise (`combine` = 0: diagnostic, always per lane).
+        if (combine && __ballot(1) == ~0ull) {
+          const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+          const bool mine = k == k0 && !(NULLABLE && isnull);
+          const unsigned long long m = __ballot(mine);
+          if (__popcll(m) >= 8) {
+            const bool leader = (tid & 63) == __ffsll((long long)m) - 1;
+            const uint32_t bit0 = 1u << (k0 & 31);
+            if ((want & kAccCnt) && leader) atomicAdd(&lcnt[k0], (uint32_t)__popcll(m));
+            if (want & kAccSum) {
+              unsigned long long sacc = mine ? (unsigned long long)v : 0ull;
+#pragma unroll
+              for (int d = 32; d >= 1; d >>= 1) sacc += (unsigned long long)__shfl_xor((long long)sacc, d, 64);
+              if (leader) atomicAdd(&lsum[k0], sacc);
+            }
+            if (want & (kAccMin | kAccMax)) {
+              // min / max are idempotent: the sharing lanes READ the slot first (one address: a broadcast, no bank conflict) and send an
+              // atomic only when their value improves it -- after a hot key's first rows almost none does.  (A shuffle reduction of two
+              // 64-bit values costs as many LDS-crossbar trips as the serialised atomics it replaces: measured 5.2 vs 3.4 ms.)
+              unsigned long long omn = ~0ull, omx = 0ull;
+              if constexpr (F) {
+                const double x = __longlong_as_double((long long)v);
+                const bool nan = x != x;
+                const unsigned long long bn = __ballot(mine && nan), bpz = __ballot(mine && x == 0.0 && (long long)v >= 0),
+                                         bnz = __ballot(mine && x == 0.0 && (long long)v < 0);
+                if (leader) {
+                  if (bn) atomicOr(&fl[2 * SW + (k0 >> 5)], bit0);
+                  if (bpz) atomicOr(&fl[k0 >> 5], bit0);
+                  if (bnz) atomicOr(&fl[SW + (k0 >> 5)], bit0);
+                }
+                if (mine && !nan) omn = omx = acc_ord(x);
+              } else {
+                if (NULLABLE && leader && !(fl[2 * SW + (k0 >> 5)] & bit0)) atomicOr(&fl[2 * SW + (k0 >> 5)], bit0);
+                if (mine) omn = omx = acc_ord((long long)v);
+              }
+              if ((want & kAccMin) && omn < lmin[k0]) atomicMin(&lmin[k0], omn);
+              if ((want & kAccMax) && omx > lmax[k0]) atomicMax(&lmax[k0], omx);
+            }
+            if (mine) return;
+          }
+        }
         if (NULLABLE && isnull) {
           if (F && flags) atomicOr(&fl[3 * SW + (k >> 5)], bit);
           return;
@@ -451,7 +496,8 @@ static int acc_launch(const KT* keys, const uint64_t* vals, const uint8_t* valid
   const size_t lds = (size_t)acc_lds_layout(want, g.S, acc_has_flags(want, __is_same(T, double), NULLABLE)).total;
   auto kfn = k_acc<T, KT, NULLABLE>;
   PDX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kfn, dim3((unsigned)W), dim3(kAccBlock), lds, st, keys, vals, valid, voff, n, bstart, g.B, g.S, span, vec ? 1 : 0, want, P);
+  static const int combine = [] { const char* e = getenv("PDX_ACC_WAVE_COMBINE"); return (e && e[0] == '0') ? 0 : 1; }();
+  hipLaunchKernelGGL(kfn, dim3((unsigned)W), dim3(kAccBlock), lds, st, keys, vals, valid, voff, n, bstart, g.B, g.S, span, vec ? 1 : 0, want, P, combine);
   PDX_LAUNCH_CHECK();
   return PDX_OK;
 }

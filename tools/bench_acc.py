@@ -11,6 +11,11 @@ nk = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000
 lib = L.load()
 L.check(lib.pdx_init(0))
 keys, vals = K.synth_keys(0, n, nk), K.synth_vals(0, n)
+hot_share = float(os.environ.get("PDX_BENCH_HOT_SHARE", "0"))  # this share of the rows moves to ONE key
+if hot_share > 0:
+    sel = K.synth_keys(5, n, 1000).values < int(hot_share * 1000)
+    keys = K.Column(L.INT64, n, torch.where(sel, 4242, keys.values), None, 0, 0)
+    del sel
 ivals = K.Column(L.INT64, n, keys.values, None, 0, 0)
 valid = K.compare(L.NE, K.synth_keys(3, n, 20), 0)
 vals_n = K.Column(L.FLOAT64, n, vals.values, valid.values, 0, -1)
