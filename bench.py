@@ -386,6 +386,14 @@ def main():
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
+    # librccl prints a version banner on STDOUT when a communicator is created ("RCCL version : ..."): stdout must carry exactly one
+    # JSON line, so file descriptor 1 points at stderr until the timed region is over (communicators are created lazily, at the first
+    # collective) and is restored before rank 0 prints.
+    saved_stdout = None
+    if sharded:
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
     if sharded:
         if "MASTER_ADDR" not in os.environ:  # FORCE_DIST outside a launcher
             with socket.socket() as sk:
@@ -589,6 +597,10 @@ def main():
         if not same:
             raise SystemExit(f"HIP result differs from the oracle on the production-chain sample: {chain}")
 
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if rank == 0:
         line = {
             "metric": "Grows/sec hash group-by-sum, 1e9 int64 rows x 1e6 keys", "value": value, "unit": "Grows/s", "n_gpus": world,
