@@ -75,6 +75,24 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+TRAFFIC_FILES = ("r04_pmc_traffic.json", "r04_pmc_traffic_general.json")
+
+
+def load_traffic(slots, n_total, world):
+    """The counter-traffic file under profiles/ that was measured on THIS configuration: same rows, GPU count, key -> slot plan
+    ('dense' / 'hash_lds') and library sources.  None when there is none (a stale or foreign number is worse than none)."""
+    for name in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                pmc = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if pmc.get("rows") == n_total and pmc.get("n_gpus") == world and pmc.get("slots") == slots and pmc.get("source_hash") == source_hash():
+            pmc["file"] = "profiles/" + name
+            return pmc
+    return None
+
+
 def profile_report(lib):
     buf = C.create_string_buffer(1 << 16)
     from pandasarrow_amd import _lib as L
@@ -178,7 +196,9 @@ def secondary_runs(torch, L, K, api, keys, vals, kinds, n_total, nkeys, steps):
     try:
         dt_hash = timeit(gb_step, reps=max(2, min(steps, 3)))
         gbh, _ = gb_step()
+        trg = load_traffic(gbh.last_plan().get("slots"), n_total, 1)
         put("groupby_general_keys_hash_path", n_total, ALGO_BYTES_PER_ROW * n_total, dt_hash, plan=gbh.last_plan(),
+            traffic=None if trg is None else trg.get("step_hbm_bytes"), traffic_source=None if trg is None else trg["file"],
             workload=f"same {n_total:.3g} rows / {nkeys:.3g} keys with PDX_GROUPBY_DENSE=0 (every key through the hash table)")
         del gbh
     finally:  # (the caller's own setting comes back: a general-keys collection run must stay general for the rows below)
@@ -511,20 +531,18 @@ def main():
         roof["kernel_ms_per_step"] = {k: round(v[1] / args.steps, 3) for k, v in sorted(prof.items())}
         roof["kernel_ms_sum"] = round(sum(v[1] for v in prof.values()) / args.steps, 3)
         # HBM traffic per launch from PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes, tools/collect_profiles.sh):
-        # only valid for the configuration AND the sources it was measured on
-        try:
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            # (the counters were collected on the single-GPU step: the sharded step -- also when forced at world size 1 -- runs other passes)
-            if pmc.get("rows") == n_total and pmc.get("n_gpus") == world and pmc.get("source_hash") == source_hash() and not sharded:
-                by_tag = pmc["by_bench_tag_hbm_bytes_per_launch"]
-                dk["traffic"] = by_tag.get(tag)
-                roof["traffic"] = pmc.get("step_hbm_bytes")
-                roof["traffic_source"] = "profiles/r03_pmc_traffic.json (source_hash %s)" % pmc["source_hash"]
-            else:
-                roof["traffic_note"] = "profiles/r03_pmc_traffic.json was measured on another configuration or build: dropped"
-        except (OSError, ValueError, KeyError):
-            pass
+        # only valid for the configuration, the PLAN (dense slots / hash-partitioned slots run different passes) AND the sources it was
+        # measured on (the sharded step -- also when forced at world size 1 -- runs other passes: never attached)
+        slots = None
+        if not sharded and res is not None:
+            slots = res[0].last_plan().get("slots")
+        tr = None if sharded else load_traffic(slots, n_total, world)
+        if tr is not None:
+            dk["traffic"] = tr["by_bench_tag_hbm_bytes_per_launch"].get(tag)
+            roof["traffic"] = tr.get("step_hbm_bytes")
+            roof["traffic_source"] = "%s (slots=%s, source_hash %s)" % (tr["file"], tr.get("slots"), tr["source_hash"])
+        elif not sharded:
+            roof["traffic_note"] = "no counter traffic under profiles/ for this configuration, plan (slots=%s) and build: dropped" % slots
 
     # size-independent checks on the last result (outside the timed region)
     check = None

@@ -56,8 +56,9 @@ __global__ void __launch_bounds__(kCompactBlock) k_compact_write(int64_t n, Pred
 
 // total (host) = number of selected rows; emit is called once per selected row with its output position (ordered).
 template <typename Pred, typename Emit>
-int compact_indices(int64_t n, Pred pred, Emit emit, int64_t* total_host, Scratch& s, hipStream_t st) {
-  *total_host = 0;
+int compact_indices(int64_t n, Pred pred, Emit emit, int64_t* total_host /* nullptr: the count is not read back, no host wait */, Scratch& s,
+                    hipStream_t st) {
+  if (total_host) *total_host = 0;
   if (n <= 0) return PDX_OK;
   int64_t nblocks = ceil_div(n, kCompactTile);
   int64_t* counts = s.get<int64_t>((size_t)nblocks);
@@ -67,6 +68,7 @@ int compact_indices(int64_t n, Pred pred, Emit emit, int64_t* total_host, Scratc
   PDX_TRY((device_exclusive_scan<int64_t, SumOp>(counts, counts, nblocks, total, s, st)));
   hipLaunchKernelGGL((k_compact_write<Pred, Emit>), dim3((unsigned)nblocks), dim3(kCompactBlock), 0, st, n, pred, emit, counts);
   PDX_LAUNCH_CHECK();
+  if (!total_host) return PDX_OK;
   PDX_HIP(hipMemcpyAsync(total_host, total, sizeof(int64_t), hipMemcpyDeviceToHost, st));
   PDX_HIP(hipStreamSynchronize(st));
   return PDX_OK;

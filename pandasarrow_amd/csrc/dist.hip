@@ -15,6 +15,8 @@
 // built-in table is RCCL (ncclAllGather, grouped ncclSend / ncclRecv); pdx_dist_init_custom takes the caller's own (the tests run the
 // same orchestration across three processes that share one GPU, where RCCL refuses duplicate devices).
 #include <dlfcn.h>
+#include <chrono>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <memory>
@@ -185,11 +187,12 @@ __global__ void k_count_prefix(const int64_t* __restrict__ allc, int W, int rank
     total[g] = t;
   }
 }
-// first record whose key is >= bounds[d] * 64, d = 0..W (records are sorted by key = global id * 64 + level + 1)
-__global__ void k_record_cuts(const int64_t* __restrict__ rec_key, int64_t m, const int64_t* __restrict__ bounds, int W, int64_t* __restrict__ cuts) {
+// first record whose key is >= bound_d * 64, d = 0..W, bound_d = G * d / W: the owners' contiguous global-id ranges (records are sorted by
+// key = global id * 64 + level + 1)
+__global__ void k_record_cuts(const int64_t* __restrict__ rec_key, int64_t m, int64_t G, int W, int64_t* __restrict__ cuts) {
   const int d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d > W) return;
-  const int64_t want = bounds[d] * 64;
+  const int64_t want = (G * d / W) * 64;
   int64_t lo = 0, hi = m;
   while (lo < hi) {
     const int64_t mid = (lo + hi) >> 1;
@@ -255,6 +258,25 @@ __global__ void k_fold_partials(const int64_t* __restrict__ part, int W, int A, 
 __global__ void k_fill_i64(int64_t* __restrict__ v, int64_t n, int64_t x) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) v[i] = x;
+}
+// recv = every rank's [keys | first rows | valid words] block back to back (rank p: 3 * n_p words from 3 * off[p]) -> the three
+// concatenations in rank order
+constexpr int kMaxPackRanks = 64;
+struct RankOffsets {
+  int64_t off[kMaxPackRanks + 1];
+};
+__global__ void k_unpack3(const int64_t* __restrict__ recv, RankOffsets ro, int W, int64_t total, int64_t* __restrict__ a, int64_t* __restrict__ b,
+                          int64_t* __restrict__ c) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    int p = 0;
+    while (p + 1 < W && ro.off[p + 1] <= i) ++p;
+    const int64_t np = ro.off[p + 1] - ro.off[p], j = i - ro.off[p];
+    const int64_t* blk = recv + 3 * ro.off[p];
+    a[i] = blk[j];
+    b[i] = blk[np + j];
+    c[i] = blk[2 * np + j];
+  }
 }
 // any i with t[i] > t[i + 1]?  (a shard's own sortedness, checked before the ranks exchange rows)
 __global__ void k_any_descent(const long long* __restrict__ t, int64_t n, unsigned int* __restrict__ flag) {
@@ -438,9 +460,32 @@ int gather_host(pdx_dist* d, const int64_t* mine, int k, std::vector<int64_t>* a
   int64_t* dsend = s.get<int64_t>((size_t)k);
   int64_t* drecv = s.get<int64_t>((size_t)k * d->world);
   PDX_SCRATCH_CHECK(s);
-  PDX_HIP(hipMemcpyAsync(dsend, mine, sizeof(int64_t) * k, hipMemcpyHostToDevice, st));
-  PDX_HIP(hipStreamSynchronize(st));  // `mine` is pageable host memory
+  // (small payloads go through this thread's pinned slot: the copy is ordered on the stream and needs no host wait of its own -- the
+  //  one synchronisation of this function is the read-back below)
+  void* pin = (size_t)k * sizeof(int64_t) <= 64 ? pinned_slot() : nullptr;
+  if (pin) {
+    memcpy(pin, mine, sizeof(int64_t) * k);
+    PDX_HIP(hipMemcpyAsync(dsend, pin, sizeof(int64_t) * k, hipMemcpyHostToDevice, st));
+  } else {
+    PDX_HIP(hipMemcpyAsync(dsend, mine, sizeof(int64_t) * k, hipMemcpyHostToDevice, st));
+    PDX_HIP(hipStreamSynchronize(st));  // `mine` is pageable host memory
+  }
   PDX_TRY(d->tr.all_gather(d->tr.ctx, dsend, drecv, sizeof(int64_t) * k, st));
+  PDX_HIP(hipMemcpyAsync(all->data(), drecv, sizeof(int64_t) * k * d->world, hipMemcpyDeviceToHost, st));
+  PDX_HIP(hipStreamSynchronize(st));
+  return PDX_OK;
+}
+// the same for k int64 values that already live on the device: [W][k] on the host with ONE synchronisation
+int gather_device(pdx_dist* d, const int64_t* dmine, int k, std::vector<int64_t>* all, Scratch& s, hipStream_t st) {
+  all->assign((size_t)d->world * k, 0);
+  if (d->world == 1 && !d->force) {
+    PDX_HIP(hipMemcpyAsync(all->data(), dmine, sizeof(int64_t) * k, hipMemcpyDeviceToHost, st));
+    PDX_HIP(hipStreamSynchronize(st));
+    return PDX_OK;
+  }
+  int64_t* drecv = s.get<int64_t>((size_t)k * d->world);
+  PDX_SCRATCH_CHECK(s);
+  PDX_TRY(d->tr.all_gather(d->tr.ctx, dmine, drecv, sizeof(int64_t) * k, st));
   PDX_HIP(hipMemcpyAsync(all->data(), drecv, sizeof(int64_t) * k * d->world, hipMemcpyDeviceToHost, st));
   PDX_HIP(hipStreamSynchronize(st));
   return PDX_OK;
@@ -462,6 +507,23 @@ int all_gather_v(pdx_dist* d, const void* mine, const std::vector<int64_t>& size
   return d->tr.all_to_all_v(d->tr.ctx, mine, so.data(), sb.data(), out, ro.data(), rb.data(), st);
 }
 
+
+// PDX_DIST_TIMING=1 (diagnostic): host time between the stages of the sharded group-by, printed per call on stderr
+struct StageTimer {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  std::string line;
+  StageTimer() : on([] { const char* e = getenv("PDX_DIST_TIMING"); return e && e[0] == '1'; }()), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char* what) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    line += std::string(what) + "=" + std::to_string((int)std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count()) + "us ";
+    t0 = t1;
+  }
+  ~StageTimer() {
+    if (on) fprintf(stderr, "[pdx_dist] %s\n", line.c_str());
+  }
+};
 
 // A rank whose shard fails a local precondition (nulls in its values, an unsorted stretch, a create that fails) must not return while
 // its peers wait for it inside the next collective: the local status travels with the first small all-gather of the call, and every
@@ -495,7 +557,9 @@ int build_dictionary(pdx_dist* d, const pdx_column* keys, int local_rc, const ch
   const int W = d->world, r = d->rank;
   const bool solo = W == 1 && !d->force;
   // ---- 1. local dictionary (a failure here is reported through the gate below, not by leaving)
+  StageTimer tm;
   if (local_rc == PDX_OK) local_rc = pdx_groupby_create(keys, st, &D->gb);
+  tm.mark("local_create");
   const int64_t Gl = local_rc == PDX_OK ? pdx_groupby_num_groups(D->gb) : 0;
   D->Gl = Gl;
   int64_t mine[2] = {Gl, local_rc};
@@ -503,13 +567,14 @@ int build_dictionary(pdx_dist* d, const pdx_column* keys, int local_rc, const ch
   const int grc = gather_host(d, mine, 2, &info, s, st);
   if (grc != PDX_OK) return local_rc != PDX_OK ? local_rc : grc;
   PDX_TRY(gate_status(info, 2, 1, W, r, local_rc, what));
+  tm.mark("gate");
   std::vector<int64_t> sizes((size_t)W);
   for (int p = 0; p < W; ++p) sizes[(size_t)p] = info[(size_t)p * 2];
-  int64_t* uk = s.get<int64_t>((size_t)Gl);
+  // the three dictionary columns of this rank side by side -- [keys | first rows | valid words] -- so that they travel in ONE exchange
+  int64_t* pack = s.get<int64_t>((size_t)3 * (size_t)std::max<int64_t>(Gl, 1));
   uint8_t* uk_bits = s.get<uint8_t>((size_t)(Gl + 7) / 8 + 16);
-  int64_t* uok = s.get<int64_t>((size_t)Gl);
-  int64_t* fr = s.get<int64_t>((size_t)Gl);
   PDX_SCRATCH_CHECK(s);
+  int64_t *uk = pack, *fr = pack + Gl, *uok = pack + 2 * Gl;
   {
     pdx_mut_column m{};
     m.dtype = keys->dtype;
@@ -552,9 +617,19 @@ int build_dictionary(pdx_dist* d, const pdx_column* keys, int local_rc, const ch
     uint8_t* cat_bits = s.get<uint8_t>((size_t)(total_u + 7) / 8 + 16);
     uint32_t* gid_cat = s.get<uint32_t>((size_t)total_u);
     PDX_SCRATCH_CHECK(s);
-    PDX_TRY(all_gather_v(d, uk, sizes, 8, cat_keys, st));
-    PDX_TRY(all_gather_v(d, fr, sizes, 8, cat_first, st));
-    PDX_TRY(all_gather_v(d, uok, sizes, 8, cat_ok, st));
+    if (W <= kMaxPackRanks) {  // one all-gather(v) of 24 bytes per local group, unpacked into the three concatenations
+      int64_t* recv = s.get<int64_t>((size_t)3 * (size_t)std::max<int64_t>(total_u, 1));
+      PDX_SCRATCH_CHECK(s);
+      PDX_TRY(all_gather_v(d, pack, sizes, 24, recv, st));
+      RankOffsets ro{};
+      for (int p = 0; p <= W; ++p) ro.off[p] = p ? ro.off[p - 1] + sizes[(size_t)p - 1] : 0;
+      if (total_u) hipLaunchKernelGGL(k_unpack3, dim3(grid_for(total_u, 256)), dim3(256), 0, st, recv, ro, W, total_u, cat_keys, cat_first, cat_ok);
+      PDX_LAUNCH_CHECK();
+    } else {
+      PDX_TRY(all_gather_v(d, uk, sizes, 8, cat_keys, st));
+      PDX_TRY(all_gather_v(d, fr, sizes, 8, cat_first, st));
+      PDX_TRY(all_gather_v(d, uok, sizes, 8, cat_ok, st));
+    }
     if (total_u) hipLaunchKernelGGL(k_i64_to_bits, dim3(grid_for((total_u + 7) / 8, 256)), dim3(256), 0, st, cat_ok, total_u, cat_bits);
     PDX_LAUNCH_CHECK();
     pdx_column cc{};
@@ -563,7 +638,9 @@ int build_dictionary(pdx_dist* d, const pdx_column* keys, int local_rc, const ch
     cc.null_count = -1;
     cc.validity = cat_bits;
     cc.values = cat_keys;
+    tm.mark("dict_exchange");
     PDX_TRY(pdx_groupby_create(&cc, st, &D->gb_cat));
+    tm.mark("cat_create");
     G = pdx_groupby_num_groups(D->gb_cat);
     D->keys = own((size_t)G);
     D->keys_ok = own((size_t)G);
@@ -586,6 +663,7 @@ int build_dictionary(pdx_dist* d, const pdx_column* keys, int local_rc, const ch
     }
     if (Gl) hipLaunchKernelGGL(k_map_from_ids, dim3(grid_for(Gl, 256)), dim3(256), 0, st, gid_cat, off, Gl, D->my_map);
     PDX_LAUNCH_CHECK();
+    tm.mark("cat_fetch");
   }
   D->G = G;
   return PDX_OK;
@@ -683,7 +761,9 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
   res->counts = res->own<int64_t>((size_t)G);
   if (!res->sums || !res->means || !res->counts) return PDX_OOM;
   // ---- 3. grouped values + rows per local group
+  StageTimer tm;
   PDX_TRY(pdx_groupby_group_values(D.gb, values, st, &h.gv));
+  tm.mark("group_values");
   int64_t* cnt_local = s.get<int64_t>((size_t)Gl);
   int64_t* prefix_local = s.get<int64_t>((size_t)Gl);
   PDX_SCRATCH_CHECK(s);
@@ -717,18 +797,21 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
     PDX_LAUNCH_CHECK();
     // records are emitted group by group in GLOBAL-id order, so they leave the kernel already partitioned by owner rank:
     // order = the local group ids sorted by their global id = an ordered compaction of the inverse map
-    int64_t found = 0;
-    PDX_TRY(compact_indices(G, InvPred{inv}, InvEmit{inv, order}, &found, s, st));
-    if (found != Gl) return fail(PDX_DEVICE, "pdx_dist_groupby_sum_mean_count: internal: the global dictionary lost a local group");
+    // (every local group has exactly one global id -- my_map is a restriction of the dictionary's own ids -- so the compaction emits Gl
+    //  entries; the count is not read back: no host wait here)
+    PDX_TRY(compact_indices(G, InvPred{inv}, InvEmit{inv, order}, nullptr, s, st));
   }
   // ---- 5. partial records of the local share of every group
+  tm.mark("counts_exchange");
   int64_t nrec = 0;
   PDX_TRY(pdx_grouped_partial_plan(h.gv, prefix_local, order, &nrec, st));
+  tm.mark("partial_plan");
   int64_t* rec_key = s.get<int64_t>((size_t)nrec);
   double* rec_val = s.get<double>((size_t)nrec);
   PDX_SCRATCH_CHECK(s);
   PDX_TRY(pdx_grouped_partial_fill(h.gv, my_map, rec_key, rec_val, st));
   res->records = nrec;
+  tm.mark("partial_fill");
   // ---- 6. one all-to-all(v) to the owners of contiguous global-id ranges
   std::vector<int64_t> bounds((size_t)W + 1);
   for (int p = 0; p <= W; ++p) bounds[(size_t)p] = G * p / W;
@@ -737,17 +820,14 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
   double* rv = rec_val;
   int64_t m = nrec;
   if (!solo) {
-    int64_t* dbounds = s.get<int64_t>((size_t)W + 1);
     int64_t* dcuts = s.get<int64_t>((size_t)W + 1);
     PDX_SCRATCH_CHECK(s);
-    PDX_HIP(hipMemcpyAsync(dbounds, bounds.data(), sizeof(int64_t) * (W + 1), hipMemcpyHostToDevice, st));
-    PDX_HIP(hipStreamSynchronize(st));
-    hipLaunchKernelGGL(k_record_cuts, dim3((unsigned)ceil_div(W + 1, 64)), dim3(64), 0, st, rec_key, nrec, dbounds, W, dcuts);
+    hipLaunchKernelGGL(k_record_cuts, dim3((unsigned)ceil_div(W + 1, 64)), dim3(64), 0, st, rec_key, nrec, G, W, dcuts);
     PDX_LAUNCH_CHECK();
-    std::vector<int64_t> my_cuts((size_t)W + 1), all_cuts;
-    PDX_HIP(hipMemcpyAsync(my_cuts.data(), dcuts, sizeof(int64_t) * (W + 1), hipMemcpyDeviceToHost, st));
-    PDX_HIP(hipStreamSynchronize(st));
-    PDX_TRY(gather_host(d, my_cuts.data(), W + 1, &all_cuts, s, st));  // every rank's cut points: what I send and what I receive
+    // every rank's cut points (what I send and what I receive) straight from the device buffers: one all-gather, one host wait
+    std::vector<int64_t> all_cuts;
+    PDX_TRY(gather_device(d, dcuts, W + 1, &all_cuts, s, st));
+    std::vector<int64_t> my_cuts(all_cuts.begin() + (size_t)r * (W + 1), all_cuts.begin() + (size_t)(r + 1) * (W + 1));
     std::vector<size_t> so((size_t)W), sb((size_t)W), ro((size_t)W), rb((size_t)W);
     size_t at = 0;
     for (int p = 0; p < W; ++p) {
@@ -766,9 +846,11 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
     PDX_TRY(d->tr.all_to_all_v(d->tr.ctx, rec_val, so.data(), sb.data(), rv, ro.data(), rb.data(), st));
   }
   // ---- 7. owners replay their groups' records in (source rank, emission) order; 8. all-gather(v) of the sums
+  tm.mark("record_exchange");
   double* sums_own = solo ? res->sums : s.get<double>((size_t)n_own);
   PDX_SCRATCH_CHECK(s);
   PDX_TRY(pdx_replay_partials(rk, rv, m, bounds[(size_t)r], n_own, sums_own, st));
+  tm.mark("replay");
   if (!solo) {
     std::vector<int64_t> own_sizes((size_t)W);
     for (int p = 0; p < W; ++p) own_sizes[(size_t)p] = bounds[(size_t)p + 1] - bounds[(size_t)p];
@@ -777,6 +859,7 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
   if (G) hipLaunchKernelGGL(k_means, dim3(grid_for(G, 256)), dim3(256), 0, st, res->sums, res->counts, G, res->means);
   PDX_LAUNCH_CHECK();
   PDX_HIP(hipStreamSynchronize(st));
+  tm.mark("gather_sums+drain");
   *out = res.release();
   return PDX_OK;
 }

@@ -284,6 +284,13 @@ class _RawDeviceBytes:
         self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
 
 
+def _unpack_bits_device(bits, n):
+    """Arrow validity bitmap (uint8 tensor on the device, LSB first) -> bool tensor of n rows, without leaving the device."""
+    b = bits[: (n + 7) // 8].to(torch.uint8)
+    shifts = torch.arange(8, dtype=torch.uint8, device=b.device)
+    return ((b[:, None] >> shifts[None, :]) & 1).reshape(-1)[:n].to(torch.bool)
+
+
 def _fetch_dist_result(lib, h, key_dtype):
     """pdx_dist_groupby* -> the result dict of the sharded entry points (device tensors); destroys the handle."""
     import ctypes as C
@@ -301,11 +308,11 @@ def _fetch_dist_result(lib, h, key_dtype):
         counts = torch.empty(max(G, 1), dtype=torch.int64, device=dev)
         L.check(lib.pdx_dist_groupby_fetch(h, C.byref(m), first.data_ptr(), sums.data_ptr(), means.data_ptr(), counts.data_ptr(), K._stream()))
         kcol._adopt(m)
-        _, kok = kcol.to_numpy()
         records = int(lib.pdx_dist_groupby_num_records(h))
     finally:
         lib.pdx_dist_groupby_destroy(h)
-    ok_t = torch.ones(G, dtype=torch.bool, device=dev) if kok is None else torch.from_numpy(kok).to(dev)
+    # the null key's flag, unpacked on the device (a to_numpy() of the key column here cost an 8 MB device-to-host copy per step)
+    ok_t = _unpack_bits_device(kcol.validity, G) if kcol.validity is not None else torch.ones(G, dtype=torch.bool, device=dev)
     return {"G": G, "keys": kcol.values[:G], "keys_ok": ok_t, "first_rows": first[:G], "kinds": [L.AGG_SUM, L.AGG_MEAN, L.AGG_COUNT],
             "outs": [(sums[:G], None), (means[:G], None), (counts[:G], None)], "records": records}
 
@@ -467,12 +474,10 @@ class CDist:
                 o._adopt(marr[i])
         finally:
             self.lib.pdx_dist_agg_destroy(h)
-        _, kok = kcol.to_numpy()
         res = []
         for o in outs:
-            _, ok = o.to_numpy() if o.null_count != 0 else (None, None)
-            res.append((o.values[:G], None if ok is None else torch.from_numpy(ok).to(dev)))
-        ok_t = torch.ones(G, dtype=torch.bool, device=dev) if kok is None else torch.from_numpy(kok).to(dev)
+            res.append((o.values[:G], _unpack_bits_device(o.validity, G) if (o.null_count != 0 and o.validity is not None) else None))
+        ok_t = _unpack_bits_device(kcol.validity, G) if kcol.validity is not None else torch.ones(G, dtype=torch.bool, device=dev)
         return {"G": G, "keys": kcol.values[:G], "keys_ok": ok_t, "first_rows": first[:G], "kinds": kinds, "outs": res}
 
     def resample(self, ts, vals, kinds, freq_ns, closed_right=False, label_right=False, origin=L.ORIGIN_START_DAY, origin_custom_ns=0, offset_ns=0):
