@@ -58,6 +58,28 @@ typedef struct {
   int root;
 } pw_state;
 
+/* NaN results, bit for bit as Arrow C++ 25 on x86-64 produces them (measured: tests/test_oracle_golden_r4.py, oracle/gen_golden_nanbits.py):
+ * an SSE add returns its FIRST NaN operand quieted (the second if only that one is NaN) and the negative default NaN for inf + -inf.
+ * Inside a 16-value leaf the accumulator -- the EARLIER rows -- is the first operand; in every merge of the tree (counter pushes, the
+ * final fold) the compiled code adds the LATER operand first.  Spelled out here so that the restatement does not depend on which
+ * operand order THIS compiler happens to pick for `a += b`. */
+static double pw_nan_of(double first, double second) {
+  uint64_t b;
+  if (first != first) memcpy(&b, &first, 8), b |= 0x0008000000000000ull;
+  else if (second != second) memcpy(&b, &second, 8), b |= 0x0008000000000000ull;
+  else b = 0xFFF8000000000000ull;
+  double r;
+  memcpy(&r, &b, 8);
+  return r;
+}
+static double pw_leaf_add(double earlier, double later) {
+  const double r = earlier + later;
+  return r == r ? r : pw_nan_of(earlier, later);
+}
+static double pw_merge(double earlier, double later) {
+  const double r = earlier + later;
+  return r == r ? r : pw_nan_of(later, earlier);
+}
 static void pw_init(pw_state* s) {
   for (int i = 0; i < 64; ++i) s->sum[i] = 0.0;
   s->mask = 0;
@@ -66,20 +88,20 @@ static void pw_init(pw_state* s) {
 static void pw_reduce(pw_state* s, double block) {
   int cur = 0;
   uint64_t m = 1;
-  s->sum[0] += block;
+  s->sum[0] = pw_merge(s->sum[0], block);
   s->mask ^= m;
   while ((s->mask & m) == 0) {
     block = s->sum[cur];
     s->sum[cur] = 0.0;
     ++cur;
     m <<= 1;
-    s->sum[cur] += block;
+    s->sum[cur] = pw_merge(s->sum[cur], block);
     s->mask ^= m;
   }
   if (cur > s->root) s->root = cur;
 }
 static double pw_finish(pw_state* s) {
-  for (int i = 1; i <= s->root; ++i) s->sum[i] += s->sum[i - 1];
+  for (int i = 1; i <= s->root; ++i) s->sum[i] = pw_merge(s->sum[i], s->sum[i - 1]);
   return s->sum[s->root];
 }
 /* feed one run of consecutive valid values */
@@ -87,13 +109,13 @@ static void pw_run(pw_state* s, const double* v, int64_t len) {
   int64_t blocks = len / 16, rem = len % 16;
   for (int64_t b = 0; b < blocks; ++b) {
     double acc = 0.0;
-    for (int j = 0; j < 16; ++j) acc += v[j];
+    for (int j = 0; j < 16; ++j) acc = pw_leaf_add(acc, v[j]);
     pw_reduce(s, acc);
     v += 16;
   }
   if (rem > 0) {
     double acc = 0.0;
-    for (int64_t j = 0; j < rem; ++j) acc += v[j];
+    for (int64_t j = 0; j < rem; ++j) acc = pw_leaf_add(acc, v[j]);
     pw_reduce(s, acc);
   }
 }

@@ -105,10 +105,10 @@ __global__ void __launch_bounds__(64) k_sum_finish(FinishArgs a, double* __restr
       if (b == 8) {
         const double q0 = wave_tree64(t[r][lane]), q1 = wave_tree64(t[r][64 + lane]), q2 = wave_tree64(t[r][128 + lane]),
                      q3 = wave_tree64(t[r][192 + lane]);
-        node = (q0 + q1) + (q2 + q3);
+        node = pw_merge(pw_merge(q0, q1), pw_merge(q2, q3));
       } else if (b == 7) {
         const double lo = wave_tree64(t[r][pos + lane]), hi = wave_tree64(t[r][pos + 64 + lane]);
-        node = lo + hi;
+        node = pw_merge(lo, hi);
       } else {
         node = wave_tree_levels(lane < (1 << b) ? t[r][pos + lane] : 0.0, b);
       }
@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(kEmitWaves * 64) k_null_seg_emit(const T* __re
     double tail = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-      if (q >= 16 - pend) tail += x[q];
+      if (q >= 16 - pend) tail = pw_leaf_add(tail, x[q]);
     double acc = __shfl_up(tail, 1, 64);
     {  // lane 0: the rows in front of the segment sit one per lane in pt (lanes 0..15): scalar reads, sequential adds
       double a0 = 0.0;
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(kEmitWaves * 64) k_null_seg_emit(const T* __re
         const int lo = __builtin_amdgcn_readlane((int)(__double_as_longlong(pt) & 0xFFFFFFFFll), q);
         const int hi = __builtin_amdgcn_readlane((int)(__double_as_longlong(pt) >> 32), q);
         const double t0 = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-        if (q >= 16 - p) a0 += t0;
+        if (q >= 16 - p) a0 = pw_leaf_add(a0, t0);
       }
       if (lane == 0) acc = a0;
     }
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(kEmitWaves * 64) k_null_seg_emit(const T* __re
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         if ((m >> q) & 1u) {
-          acc = (p == 0 ? 0.0 : acc) + x[q];
+          acc = pw_leaf_add(p == 0 ? 0.0 : acc, x[q]);
           if (++p == 16) { lds[lane * kLeafPad + j++] = acc; p = 0; }
         } else if (p > 0) { lds[lane * kLeafPad + j++] = acc; p = 0; }
       }
@@ -644,7 +644,7 @@ extern "C" int pdx_aggregate(int kind, const pdx_column* a, pdx_scalar* out, voi
       out->dtype = PDX_FLOAT64;
       out->count = cnt;
       out->is_valid = cnt > 0;  // ScalarAggregateOptions::min_count = 1
-      out->v.f64 = cnt ? (kind == PDX_AGG_MEAN ? sum / (double)cnt : sum) : 0.0;
+      out->v.f64 = cnt ? (kind == PDX_AGG_MEAN ? (sum == sum ? sum / (double)cnt : sum) : sum) : 0.0;  // (a NaN sum is already quiet: NaN / n keeps its bits)
       return PDX_OK;
     }
     // integer sum: wrap-around, int64 -> int64

@@ -203,7 +203,7 @@ __global__ void k_record_cuts(const int64_t* __restrict__ rec_key, int64_t m, in
 }
 __global__ void k_means(const double* __restrict__ sums, const int64_t* __restrict__ counts, int64_t G, double* __restrict__ means) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) means[g] = sums[g] / (double)counts[g];
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) { const double sg = sums[g]; means[g] = sg == sg ? sg / (double)counts[g] : __longlong_as_double(__double_as_longlong(sg) | 0x0008000000000000ll); }  // (x86: a NaN dividend comes back quieted)
 }
 // rows of a sorted int64 axis below `edge` (<= edge when inclusive): one thread, binary search
 __global__ void k_count_below(const long long* __restrict__ t, int64_t n, long long edge, int inclusive, int64_t* __restrict__ out) {

@@ -39,13 +39,13 @@ __host__ __device__ constexpr int fw_lds_bytes(bool nullable, int levels) { retu
 __device__ __forceinline__ void fw_counter_push(double* csum /* [levels][64] */, int lane, unsigned long long& cmask, int& root, double leaf) {
   int cur = 0;
   unsigned long long m = 1;
-  double v = csum[lane] + leaf;
+  double v = pw_merge(csum[lane], leaf);
   cmask ^= m;
   while ((cmask & m) == 0) {
     csum[cur * 64 + lane] = 0.0;
     ++cur;
     m <<= 1;
-    v = csum[cur * 64 + lane] + v;
+    v = pw_merge(csum[cur * 64 + lane], v);
     cmask ^= m;
   }
   csum[cur * 64 + lane] = v;
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(64) k_flr_wave(const KT* __restrict__ keys, co
           if (!NULLABLE || nb[u] == 0) {
             ++nvalid;
             if (PW_ONLY || want_pw) {
-              acc = (pos == 0 ? 0.0 : acc) + (sqdev_mean ? flr_sqdev(seg_to_f64(x), mu) : seg_to_f64(x));
+              acc = pw_leaf_add(pos == 0 ? 0.0 : acc, sqdev_mean ? flr_sqdev(seg_to_f64(x), mu) : seg_to_f64(x));
               close = ++pos == 16;
             }
             if constexpr (!PW_ONLY) {
@@ -263,11 +263,11 @@ __global__ void __launch_bounds__(64) k_flr_wave(const KT* __restrict__ keys, co
         double total = 0.0;
         if (nvalid > 0) {
           double a = csum[lane];
-          for (int i = 1; i <= root; ++i) a = csum[i * 64 + lane] + a;
+          for (int i = 1; i <= root; ++i) a = pw_merge(csum[i * 64 + lane], a);
           total = a;
         }
         if (out.sum_f) out.sum_f[oi] = total;
-        if (out.mean) out.mean[oi] = nvalid ? total / (double)nvalid : 0.0;
+        if (out.mean) out.mean[oi] = nvalid ? pw_mean(total, (double)nvalid) : 0.0;
       }
       if constexpr (!PW_ONLY) {
         if (want_is && out.sum_i) out.sum_i[oi] = (long long)isum;

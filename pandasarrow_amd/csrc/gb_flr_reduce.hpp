@@ -165,13 +165,13 @@ __device__ __forceinline__ double flr_sqdev(double v, double mu) {
 __device__ __forceinline__ void flr_counter_push(double (*csum)[1 << kFlrBits], int lane, unsigned long long& cmask, int& root, double leaf) {
   int cur = 0;
   unsigned long long m = 1;
-  double v = csum[0][lane] + leaf;
+  double v = pw_merge(csum[0][lane], leaf);
   cmask ^= m;
   while ((cmask & m) == 0) {
     csum[cur][lane] = 0.0;
     ++cur;
     m <<= 1;
-    v = csum[cur][lane] + v;
+    v = pw_merge(csum[cur][lane], v);
     cmask ^= m;
   }
   csum[cur][lane] = v;
@@ -414,6 +414,13 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
             for (int q = 0; q < 16; ++q)
               if (q >= q0 && q < q1) a += xs[q];
           }
+          if (a != a) {  // (rare) the leaf again with the x86 NaN rule of a leaf: the earlier operand's NaN wins (pairwise.hpp)
+            a = (j == 0 && p0 > 0) ? oa : 0.0;
+            const double m = sqdev_mean ? mu_s[d] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              if (q >= q0 && q < q1) a = pw_leaf_add(a, sqdev_mean ? flr_sqdev(xs[q], m) : xs[q]);
+          }
           leafsum[Lf] = a;
         }
         FLR_T(7);  // leaf sums
@@ -432,20 +439,20 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
             for (int j = 0; j < nfull; ++j) {
               double v = nxt;
               if (j + 1 < nfull) nxt = lf[j + 1];
-              v = c0 + v;
+              v = pw_merge(c0, v);
               cmask ^= 1ull;
               if (cmask & 1ull) {
                 c0 = v;
               } else {
                 c0 = 0.0;
-                v = c1 + v;
+                v = pw_merge(c1, v);
                 cmask ^= 2ull;
                 if (cmask & 2ull) {
                   c1 = v;
                   root = root > 1 ? root : 1;
                 } else {
                   c1 = 0.0;
-                  v = c2 + v;
+                  v = pw_merge(c2, v);
                   cmask ^= 4ull;
                   if (cmask & 4ull) {
                     c2 = v;
@@ -454,13 +461,13 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
                     c2 = 0.0;
                     int cur = 3;
                     unsigned long long m = 8ull;
-                    v = csum[3][lane] + v;
+                    v = pw_merge(csum[3][lane], v);
                     cmask ^= m;
                     while ((cmask & m) == 0) {
                       csum[cur][lane] = 0.0;
                       ++cur;
                       m <<= 1;
-                      v = csum[cur][lane] + v;
+                      v = pw_merge(csum[cur][lane], v);
                       cmask ^= m;
                     }
                     csum[cur][lane] = v;
@@ -558,7 +565,7 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
               }
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-              if (j < count) a += sqdev_mean ? flr_sqdev(xs[j], m) : xs[j];
+              if (j < count) a = pw_leaf_add(a, sqdev_mean ? flr_sqdev(xs[j], m) : xs[j]);  // (opt-in NULL_PW form: per-add rule)
             const bool closed = q0 + count == 16 || term == 1;  // full, or cut by a null row
             reinterpret_cast<double*>(svals)[pp] = a;
             snull[pp] = (uint8_t)(0x80 | (closed ? 0x40 : 0) | (q0 + count - 1));
@@ -628,7 +635,7 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
             if (!isnull) {
               ++nvalid;
               if (want_pw) {
-                acc = (pos == 0 ? 0.0 : acc) + (sqdev_mean ? flr_sqdev(seg_to_f64(x), mu) : seg_to_f64(x));
+                acc = pw_leaf_add(pos == 0 ? 0.0 : acc, sqdev_mean ? flr_sqdev(seg_to_f64(x), mu) : seg_to_f64(x));
                 close = ++pos == 16;
               }
               if (want_is) isum += (unsigned long long)x;
@@ -663,11 +670,11 @@ __global__ void __launch_bounds__(kSortBlock, (DENSE_PW ? kFlrDenseWaves : 1)) k
         double total = 0.0;
         if (nvalid > 0) {
           double a = csum[0][lane];
-          for (int i = 1; i <= root; ++i) a = csum[i][lane] + a;
+          for (int i = 1; i <= root; ++i) a = pw_merge(csum[i][lane], a);
           total = a;
         }
         if (out.sum_f) out.sum_f[oi] = total;
-        if (out.mean) out.mean[oi] = nvalid ? total / (double)nvalid : 0.0;
+        if (out.mean) out.mean[oi] = nvalid ? pw_mean(total, (double)nvalid) : 0.0;
       }
       if (want_is && out.sum_i) out.sum_i[oi] = (long long)isum;
       if (want_mm) {

@@ -82,6 +82,7 @@ __global__ void __launch_bounds__(256) k_partial_fill(const double* __restrict__
         double acc = 0.0;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc += lv[q * 16 + e];
+        if (acc != acc) acc = pw_leaf_redo(16, [&](int e) { return lv[q * 16 + e]; });
         cn.push(acc, 0);
       }
       rec_key[pos] = gkey + lvl + 1;
@@ -135,10 +136,11 @@ __global__ void __launch_bounds__(256) k_partial_fill_wave(const double* __restr
       double acc = 0.0;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc += lv[e];
+      if (acc != acc) acc = pw_leaf_redo(16, [&](int e) { return lv[e]; });
       t[0] = acc;
     }
 #pragma unroll
-    for (int q = 0; q < 6; ++q) t[q + 1] = t[q] + __shfl_down(t[q], 1 << q, 64);
+    for (int q = 0; q < 6; ++q) t[q + 1] = pw_merge(t[q], __shfl_down(t[q], 1 << q, 64));
     int64_t pos = pos0 + h;
     for (int64_t sidx = kf; sidx < kl;) {
       const int lvl = (int)aligned_block_level(sidx, kl);
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(256) k_replay(const uint32_t* __restrict__ seg
       uint32_t l = lvl_shift >= 0 ? (lvl[i] & kSortKeyMask) >> lvl_shift : lvl[i];
       any = true;
       if (l == 0) {  // fragment value: extend the running 16-value leaf
-        acc += val[i];
+        acc = pw_leaf_add(acc, val[i]);
         if (++fill == 16) {
           cn.push(acc, 0);
           acc = 0.0;

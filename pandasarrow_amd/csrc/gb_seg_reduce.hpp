@@ -23,13 +23,13 @@ __device__ __forceinline__ double seg_to_f64(T x) { return (double)x; }
 __device__ __forceinline__ void lds_counter_push(double* csum, uint64_t& mask, int& root, double x, int level, int lane) {
   int cur = level;
   uint64_t mb = 1ull << level;
-  double v = csum[cur] + x;
+  double v = pw_merge(csum[cur], x);
   mask ^= mb;
   while ((mask & mb) == 0) {
     if (lane == 0) csum[cur] = 0.0;
     ++cur;
     mb <<= 1;
-    v = csum[cur] + v;
+    v = pw_merge(csum[cur], v);
     mask ^= mb;
   }
   if (lane == 0) csum[cur] = v;
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
         node[sft] = 0.0;
         if ((m >> sft) & 1) node[sft] = __shfl(x, m & ~((2 << sft) - 1), 64);
         double y = __shfl_down(x, 1 << sft, 64);
-        x = x + y;
+        x = pw_merge(x, y);
       }
       node[6] = __shfl(x, 0, 64);
       if (!multi) {
@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
 #pragma unroll
         for (int sft = 0; sft <= 6; ++sft) {
           if ((m >> sft) & 1) {
-            acc = have ? node[sft] + acc : node[sft];
+            acc = have ? pw_merge(node[sft], acc) : node[sft];
             have = true;
           }
         }
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
       double total = single;
       if (WANT_PAIRWISE && multi) {
         double acc = csum[0];
-        for (int i = 1; i <= root; ++i) acc = csum[i] + acc;
+        for (int i = 1; i <= root; ++i) acc = pw_merge(csum[i], acc);
         total = acc;
       }
       if (WANT_MINMAX) {
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce(const T* __restri
       if (lane == 0 && !big) {
         if (WANT_PAIRWISE) {
           if (out.sum_f) out.sum_f[oi] = total;
-          if (out.mean) out.mean[oi] = total / (double)len;
+          if (out.mean) out.mean[oi] = pw_mean(total, (double)len);
         }
         if (WANT_ISUM && out.sum_i) out.sum_i[oi] = (long long)isum;
         if (WANT_MINMAX) {
@@ -286,7 +286,7 @@ __device__ __forceinline__ void seg_chunked(const T* __restrict__ vals, int64_t 
         node[sft] = 0.0;
         if ((m >> sft) & 1) node[sft] = __shfl(x, m & ~((2 << sft) - 1), 64);
         double y = __shfl_down(x, 1 << sft, 64);
-        x = x + y;
+        x = pw_merge(x, y);
       }
       node[6] = __shfl(x, 0, 64);
 #pragma unroll
@@ -359,14 +359,14 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_mid(const T* __re
         double total = 0.0;
         if (WANT_PAIRWISE) {
           double acc = csum[0];
-          for (int i = 1; i <= root; ++i) acc = csum[i] + acc;
+          for (int i = 1; i <= root; ++i) acc = pw_merge(csum[i], acc);
           total = acc;
         }
         if (lane == 0) {
           const uint32_t oi = out_index ? out_index[k0] : (uint32_t)k0;
           if (WANT_PAIRWISE) {
             if (out.sum_f) out.sum_f[oi] = total;
-            if (out.mean) out.mean[oi] = total / (double)glen0;
+            if (out.mean) out.mean[oi] = pw_mean(total, (double)glen0);
           }
           if (WANT_ISUM && out.sum_i) out.sum_i[oi] = (long long)isum;
           if (WANT_MINMAX) {
@@ -416,6 +416,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_mid(const T* __re
         } else {
           for (int q = 0; q < cnt; ++q) acc += seg_to_f64(stage[off + q]);
         }
+        if (acc != acc) acc = pw_leaf_redo(cnt, [&](int q) { return seg_to_f64(stage[off + q]); });
         leaf[L] = acc;
       }
       __builtin_amdgcn_wave_barrier();
@@ -426,18 +427,18 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_mid(const T* __re
         double* x = leaf + excl;
         const int m = nl;
         for (int stride = 1; stride < m; stride <<= 1)
-          for (int i = 0; i + 2 * stride <= m; i += 2 * stride) x[i] = x[i] + x[i + stride];
+          for (int i = 0; i + 2 * stride <= m; i += 2 * stride) x[i] = pw_merge(x[i], x[i + stride]);
         double acc = 0.0;
         bool have = false;
         int pos = m;
         for (int jb = 0; jb < 7; ++jb)
           if ((m >> jb) & 1) {
             pos -= 1 << jb;
-            acc = have ? x[pos] + acc : x[pos];
+            acc = have ? pw_merge(x[pos], acc) : x[pos];
             have = true;
           }
         if (out.sum_f) out.sum_f[oi] = acc;
-        if (out.mean) out.mean[oi] = acc / (double)len;
+        if (out.mean) out.mean[oi] = pw_mean(acc, (double)len);
       }
       if (WANT_MINMAX || WANT_ISUM) {
         const T* v = stage + (int)(b0 - S);
@@ -612,7 +613,7 @@ __global__ void __launch_bounds__(64) k_seg_combine_big(const uint32_t* __restri
   if (WANT_PAIRWISE) {
     const double total = c.finish();
     if (out.sum_f) out.sum_f[oi] = total;
-    if (out.mean) out.mean[oi] = total / (double)len;
+    if (out.mean) out.mean[oi] = pw_mean(total, (double)len);
   }
   if (WANT_ISUM && out.sum_i) out.sum_i[oi] = (long long)isum;
   if (WANT_MINMAX) {
@@ -705,7 +706,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_nullable(const T*
       // sequential sum of this window's last rows that stay in an open leaf (handed to the next window)
       const int cnt_tail = full ? pos : t;
       double tail = 0.0;
-      for (int q = 16 - cnt_tail; q < 16; ++q) tail += lds[lane * 17 + q];
+      for (int q = 16 - cnt_tail; q < 16; ++q) tail = pw_leaf_add(tail, lds[lane * 17 + q]);
       double acc = __shfl_up(tail, 1, 64);
       if (lane == 0) acc = carry_acc;
       // pass 1: number of leaves this window finishes
@@ -727,7 +728,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_nullable(const T*
         double a = pos > 0 ? acc : 0.0;
         for (int q = 0; q < 16; ++q) {
           if ((m >> q) & 1u) {
-            a = (p == 0 ? 0.0 : a) + lds[lane * 17 + q];
+            a = pw_leaf_add(p == 0 ? 0.0 : a, lds[lane * 17 + q]);
             if (++p == 16) { leaves[w++] = a; p = 0; }
           } else if (p > 0) { leaves[w++] = a; p = 0; }
         }
@@ -759,11 +760,11 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_nullable(const T*
     // the queue's tail (< 64 leaves, aligned to a multiple of 64): its perfect subtrees, highest first
     if (pend > 0) {
       double x0 = lane < pend ? leaves[lane] : 0.0;
-      double x1 = x0 + __shfl_down(x0, 1, 64);
-      double x2 = x1 + __shfl_down(x1, 2, 64);
-      double x3 = x2 + __shfl_down(x2, 4, 64);
-      double x4 = x3 + __shfl_down(x3, 8, 64);
-      double x5 = x4 + __shfl_down(x4, 16, 64);
+      double x1 = pw_merge(x0, __shfl_down(x0, 1, 64));
+      double x2 = pw_merge(x1, __shfl_down(x1, 2, 64));
+      double x3 = pw_merge(x2, __shfl_down(x2, 4, 64));
+      double x4 = pw_merge(x3, __shfl_down(x3, 8, 64));
+      double x5 = pw_merge(x4, __shfl_down(x4, 16, 64));
       for (int sidx = 0; sidx < pend;) {
         int lg = 31 - __builtin_clz((unsigned)(pend - sidx));
         int tz = sidx == 0 ? 6 : __builtin_ctz((unsigned)sidx);
@@ -778,7 +779,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_nullable(const T*
     double total = 0.0;
     if (nvalid > 0) {
       double a = csum[0];
-      for (int i = 1; i <= croot; ++i) a = csum[i] + a;
+      for (int i = 1; i <= croot; ++i) a = pw_merge(csum[i], a);
       total = a;
     }
     for (int d = 32; d > 0; d >>= 1) {
@@ -791,7 +792,7 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_nullable(const T*
     }
     if (lane == 0) {
       if (out.sum_f) out.sum_f[oi] = total;
-      if (out.mean) out.mean[oi] = nvalid ? total / (double)nvalid : 0.0;
+      if (out.mean) out.mean[oi] = nvalid ? pw_mean(total, (double)nvalid) : 0.0;
       if (out.sum_i) out.sum_i[oi] = (long long)isum;
       T nanv = T(0);
       if constexpr (__is_same(T, double)) nanv = __builtin_nan("");

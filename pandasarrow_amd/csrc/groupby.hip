@@ -956,7 +956,7 @@ static int reduce_fused(const pdx_groupby* gb, const GroupedLayout& L, const Agg
 
 __global__ void k_mean_from_cache(const double* __restrict__ sum, const long long* __restrict__ cnt, int64_t G, double* __restrict__ out) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G; i += stride) out[i] = cnt[i] ? sum[i] / (double)cnt[i] : 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < G; i += stride) out[i] = cnt[i] ? pw_mean(sum[i], (double)cnt[i]) : 0.0;
 }
 
 static GroupedLayout* find_bound(pdx_groupby* gb, const pdx_column* values) {

@@ -14,6 +14,39 @@
 
 namespace pdx {
 
+// ---- NaN results carry the bits the reference's x86 host produces (round 4; measured against Arrow C++ 25, tests/test_oracle_golden_r4.py):
+// an SSE add hands back its FIRST NaN operand (quieted), the second if only that is NaN, and the negative default NaN 0xFFF8000000000000 for
+// inf + -inf; CDNA's v_add_f64 does neither reliably.  Which operand is "first" follows from how Arrow's loops were compiled:
+//   inside a 16-value leaf (sum += value, the accumulator first)  : the EARLIER rows' NaN wins
+//   in every merge of the tree (counter pushes, the final fold)    : the LATER operand's NaN wins (sum[cur] += b compiles to b + sum[cur])
+// Every add of the tree code is written earlier + later; these two functions are that add with the NaN rule of its site.  The fix is a
+// select on the (rare) NaN result: one compare per add on the fast path.
+__device__ __forceinline__ double pw_quiet(double x) { return __longlong_as_double(__double_as_longlong(x) | 0x0008000000000000ll); }
+__device__ __forceinline__ double pw_nan_of(double first, double second) {
+  return first != first ? pw_quiet(first) : (second != second ? pw_quiet(second) : __longlong_as_double((long long)0xFFF8000000000000ull));
+}
+// (the test is made wave-uniform with a ballot: the fast path is the add, one compare and one scalar branch; the selects run only in a wave
+//  that actually produced a NaN)
+__device__ __forceinline__ double pw_leaf_add(double earlier, double later) {
+  double r = earlier + later;
+  if (__builtin_expect(__ballot(r != r) != 0ull, 0)) r = r == r ? r : pw_nan_of(earlier, later);
+  return r;
+}
+__device__ __forceinline__ double pw_merge(double earlier, double later) {
+  double r = earlier + later;
+  if (__builtin_expect(__ballot(r != r) != 0ull, 0)) r = r == r ? r : pw_nan_of(later, earlier);
+  return r;
+}
+// mean = sum / count: the x86 divide hands a NaN dividend back (quieted); the count is a positive number
+__device__ __forceinline__ double pw_mean(double sum, double count) { return sum == sum ? sum / count : pw_quiet(sum); }
+// a leaf sum that came out NaN, recomputed with the leaf rule (the plain chain is the fast path: NaN-ness never disappears in a sum)
+template <typename Load>
+__device__ __forceinline__ double pw_leaf_redo(int cnt, Load value_at) {
+  double acc = 0.0;
+  for (int q = 0; q < cnt; ++q) acc = pw_leaf_add(acc, value_at(q));
+  return acc;
+}
+
 // literal replay of Arrow's counter for pushes at arbitrary levels (levels only ever decrease across calls within
 // one logical array: top-level tails first, then lower-level tails -- see aggregate.hip)
 struct PairwiseCounter {
@@ -28,20 +61,20 @@ struct PairwiseCounter {
   __device__ void push(double x, int level) {
     int cur = level;
     uint64_t m = 1ull << level;
-    sum[cur] += x;
+    sum[cur] = pw_merge(sum[cur], x);
     mask ^= m;
     while ((mask & m) == 0) {
       x = sum[cur];
       sum[cur] = 0.0;
       ++cur;
       m <<= 1;
-      sum[cur] += x;
+      sum[cur] = pw_merge(sum[cur], x);
       mask ^= m;
     }
     if (cur > root) root = cur;
   }
   __device__ double finish() {
-    for (int i = 1; i <= root; ++i) sum[i] += sum[i - 1];
+    for (int i = 1; i <= root; ++i) sum[i] = pw_merge(sum[i], sum[i - 1]);
     return sum[root];
   }
 };
@@ -51,7 +84,7 @@ __device__ __forceinline__ double wave_tree64(double x) {
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     double y = __shfl_down(x, d, 64);
-    x = x + y;  // lanes that are multiples of 2d hold left + right; other lanes compute garbage that is never used
+    x = pw_merge(x, y);  // lanes that are multiples of 2d hold left + right; other lanes compute garbage that is never used
   }
   return x;
 }
@@ -59,7 +92,7 @@ __device__ __forceinline__ double wave_tree64(double x) {
 __device__ __forceinline__ double wave_tree_levels(double x, int levels) {
   for (int s = 0; s < levels; ++s) {
     double y = __shfl_down(x, 1 << s, 64);
-    x = x + y;
+    x = pw_merge(x, y);
   }
   return x;
 }
@@ -71,7 +104,7 @@ __device__ __forceinline__ double block_tree256(double x, double* smem) {
   if (lane == 0) smem[wave] = w;
   __syncthreads();
   double r = 0.0;
-  if (threadIdx.x == 0) r = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+  if (threadIdx.x == 0) r = pw_merge(pw_merge(smem[0], smem[1]), pw_merge(smem[2], smem[3]));
   __syncthreads();
   return r;
 }
@@ -85,6 +118,7 @@ __device__ __forceinline__ double leaf_sum(const double* v, int cnt, int stride 
   } else {
     for (int q = 0; q < cnt; ++q) acc += v[q * stride];
   }
+  if (acc != acc) acc = pw_leaf_redo(cnt, [&](int q) { return v[q * stride]; });
   return acc;
 }
 

@@ -86,10 +86,11 @@ def bits_equal(a, b):
     return a.shape == b.shape and bool(np.all(a == b))
 
 
-def assert_f64_bits(a, b, valid=None, what="", nan_bits=False):
-    """bit-exact float64 comparison.  nan_bits=False: any NaN equals any NaN (results of the sum trees, where only NaN-ness is
-    guaranteed: a group holding +inf and -inf sums to -qNaN on x86 and +qNaN on CDNA); nan_bits=True: sign and payload of a NaN
-    must match too (element-wise kernels, which spell out the x86 operand rule the golden vectors were produced under)."""
+def assert_f64_bits(a, b, valid=None, what="", nan_bits=True):
+    """bit-exact float64 comparison.  nan_bits=True (the default since round 4): sign and payload of a NaN must match too -- the
+    element-wise kernels AND the sum trees spell out the x86 operand rules the reference's Arrow kernels were compiled to (leaf: the
+    earlier NaN, merges: the later operand's, inf + -inf: the negative default NaN; tests/golden/nan_bits_golden.npz).  nan_bits=False:
+    any NaN equals any NaN (variance / stddev: Arrow's own two-pass formula, where only NaN-ness is pinned)."""
     a = np.ascontiguousarray(a, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
     assert a.shape == b.shape, f"{what}: shape {a.shape} != {b.shape}"

@@ -53,7 +53,14 @@ def _make_case(seed):
     if rng.random() < 0.5:
         vals = rng.standard_normal(n) * 10.0 ** rng.integers(-3, 6, n)
         if rng.random() < 0.3:
-            vals[rng.random(n) < 0.01] = np.nan
+            # NaNs of both signs with distinct payloads (quiet and signalling) and a few infinities: the sum trees must hand on the bits
+            # Arrow's x86 adds do (leaf: the earlier NaN, merges: the later operand's, inf + -inf: the negative default NaN)
+            m = rng.random(n) < 0.01
+            k = int(m.sum())
+            vals[m] = (rng.integers(1, 2**51, k).astype(np.uint64) | np.uint64(0x7FF0000000000000) | (rng.integers(0, 2, k).astype(np.uint64) << np.uint64(63))
+                       | (rng.integers(0, 2, k).astype(np.uint64) << np.uint64(51))).view(np.float64)
+            mi = rng.random(n) < 0.002
+            vals[mi] = rng.choice(np.array([np.inf, -np.inf]), int(mi.sum()))
     else:
         vals = rng.integers(-50, 50, n).astype(np.int64)
     vvalid = (rng.random(n) > rng.choice([0.02, 0.5])) if rng.random() < 0.4 else None

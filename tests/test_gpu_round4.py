@@ -318,3 +318,65 @@ def test_sort_index_makes_group_results_order_independent(px):
     assert np.array_equal(sk.index.to_numpy()[0], uniq[order][::-1]) and np.array_equal(sk.col.to_numpy()[0].view(np.uint64), exp[order][::-1].view(np.uint64))
     noidx = api.DataFrame({"v": res.col}, index=res.index).sort_index(ignore_index=True)
     assert noidx.index is None
+
+
+# ---------------------------------------------------------------- NaN sign / payload of the fp64 sum trees (Arrow's x86 bits, section 9e)
+def _nan_golden():
+    import json
+    import os
+
+    from conftest import GOLDEN_DIR
+
+    z = np.load(os.path.join(GOLDEN_DIR, "nan_bits_golden.npz"))
+    return z
+
+
+def test_sum_tree_nan_bits_whole_column(px):
+    """pdx_aggregate(sum / mean): dense and nullable kernels, 130 seeded arrays with quiet / signalling NaNs of both signs, +-inf and
+    nulls, against Arrow C++ 25's results BIT for bit -- NaN sign and payload included"""
+    import _nanbits_inputs as inp
+
+    z = _nan_golden()
+    for name, v, valid in inp.whole_cases():
+        es, em, eok = z[name]
+        col = px.Column.from_numpy(v, valid)
+        s, _ = px.K.aggregate(SUM, col)
+        m, _ = px.K.aggregate(MEAN, col)
+        if not eok:
+            assert s is None and m is None, name
+            continue
+        for got, exp, what in ((s, es, "sum"), (m, em, "mean")):
+            g, e = np.float64(got).view(np.uint64), np.float64(exp).view(np.uint64)
+            assert g == e, (name, what, hex(int(g)), hex(int(e)))
+
+
+@pytest.mark.parametrize("path", ["default", "hash", "bound_full_layout", "no_fused"])
+def test_sum_tree_nan_bits_per_group(px, monkeypatch, path):
+    """per-group sum / mean through every reducer family -- fused last digit (dense + nullable replay), classic segment reducers
+    (short / mid / long groups), hash slots -- with NaN bits held to Arrow's"""
+    import _nanbits_inputs as inp
+
+    if path == "hash":
+        monkeypatch.setenv("PDX_GROUPBY_DENSE", "0")
+    if path == "no_fused":
+        monkeypatch.setenv("PDX_FUSED_LAST_DIGIT", "0")
+    if path == "default":
+        monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_MIN_ROWS", "1000")
+        monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_MIN_RUN", "0")
+        monkeypatch.setenv("PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS", "1")
+    z = _nan_golden()
+    for name, keys, v, valid in inp.group_cases():
+        exp = z[name]
+        eok = exp[2] != 0
+        kcol, vcol = px.Column.from_numpy(keys), px.Column.from_numpy(v, valid)
+        gb = px.K.GroupByHandle.create(kcol)
+        assert np.array_equal(gb.unique_keys().to_numpy()[0], z[name + "/uniq"]), name
+        if path == "bound_full_layout":
+            gb.bind(vcol)
+            gb.agg(vcol, [FIRST])   # builds the fully sorted layout: the classic reducers serve the sums
+        outs = gb.agg(vcol, [SUM, MEAN])
+        for out, row, what in ((outs[0], 0, "sum"), (outs[1], 1, "mean")):
+            got, ok = out.to_numpy()
+            assert ok is None or np.array_equal(ok, eok), (name, what, path)
+            g, e = got.view(np.uint64)[eok], exp[row].view(np.uint64)[eok]
+            assert np.array_equal(g, e), (name, what, path, gb.last_plan(), int((g != e).sum()), [hex(int(x)) for x in g[g != e][:3]], [hex(int(x)) for x in e[g != e][:3]])

@@ -75,3 +75,51 @@ def test_mixed_type_promotion_is_a_checked_cast():
     v, ok = orc.binary(0, bad, f, va=valid)
     want = pc.add(pa.array(bad, mask=~valid), pa.array(f))
     assert np.array_equal(ok, valid) and np.array_equal(v[valid], want.to_numpy(zero_copy_only=False)[valid])
+
+
+# ---------------------------------------------------------------- NaN sign / payload of the fp64 sum trees
+def _nan_golden():
+    import json
+    import os
+
+    from conftest import GOLDEN_DIR
+
+    z = np.load(os.path.join(GOLDEN_DIR, "nan_bits_golden.npz"))
+    return z, json.loads(str(z["manifest"]))["cases"]
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def test_sum_tree_nan_bits_whole_column():
+    """Arrow's pairwise sum hands NaNs on the way its compiled SSE adds do (leaf: the earlier NaN, merges: the later operand's, inf + -inf:
+    the negative default NaN); the oracle spells that rule out.  130 seeded arrays with quiet / signalling NaNs of both signs, +-inf,
+    nulls: sum and mean BIT for bit, NaN bits included."""
+    import _nanbits_inputs as inp
+
+    z, cases = _nan_golden()
+    for name, v, valid in inp.whole_cases():
+        es, em, eok = z[name]
+        s, cnt = orc.agg(0, v, valid)
+        m, _ = orc.agg(1, v, valid)
+        if not eok:
+            assert s is None and m is None, name
+            continue
+        assert _bits([s])[0] == _bits([es])[0], (name, hex(_bits([s])[0]), hex(_bits([es])[0]))
+        assert _bits([m])[0] == _bits([em])[0], (name, hex(_bits([m])[0]), hex(_bits([em])[0]))
+
+
+def test_sum_tree_nan_bits_per_group():
+    import _nanbits_inputs as inp
+
+    z, cases = _nan_golden()
+    for name, keys, v, valid in inp.group_cases():
+        exp = z[name]
+        ids, uniq, _, _ = orc.group_ids(keys)
+        assert np.array_equal(uniq, z[name + "/uniq"]), name
+        eok = exp[2] != 0
+        for kind, row in ((0, 0), (1, 1)):
+            got, ok = orc.groupby_agg(kind, ids, len(uniq), v, valid, nthreads=8)
+            assert np.array_equal(np.asarray(ok, bool), eok), (name, kind)
+            assert np.array_equal(_bits(got)[eok], _bits(exp[row])[eok]), (name, kind, int((_bits(got)[eok] != _bits(exp[row])[eok]).sum()))
