@@ -416,7 +416,6 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_mid(const T* __re
         } else {
           for (int q = 0; q < cnt; ++q) acc += seg_to_f64(stage[off + q]);
         }
-        if (acc != acc) acc = pw_leaf_redo(cnt, [&](int q) { return seg_to_f64(stage[off + q]); });
         leaf[L] = acc;
       }
       __builtin_amdgcn_wave_barrier();
@@ -426,17 +425,31 @@ __global__ void __launch_bounds__(kSegWaves * 64) k_seg_reduce_mid(const T* __re
       if (WANT_PAIRWISE) {
         double* x = leaf + excl;
         const int m = nl;
-        for (int stride = 1; stride < m; stride <<= 1)
-          for (int i = 0; i + 2 * stride <= m; i += 2 * stride) x[i] = pw_merge(x[i], x[i + stride]);
-        double acc = 0.0;
-        bool have = false;
-        int pos = m;
-        for (int jb = 0; jb < 7; ++jb)
-          if ((m >> jb) & 1) {
-            pos -= 1 << jb;
-            acc = have ? pw_merge(x[pos], acc) : x[pos];
-            have = true;
+        // plain adds on the fast path: a NaN anywhere in the group's tree reaches the total, and only then is the tree walked again with
+        // the x86 NaN rules of its adds (pairwise.hpp) -- the group's rows are still staged, its leaf slots are reused
+        auto tree = [&](auto merge) {
+          for (int stride = 1; stride < m; stride <<= 1)
+            for (int i = 0; i + 2 * stride <= m; i += 2 * stride) x[i] = merge(x[i], x[i + stride]);
+          double a = 0.0;
+          bool have = false;
+          int pos = m;
+          for (int jb = 0; jb < 7; ++jb)
+            if ((m >> jb) & 1) {
+              pos -= 1 << jb;
+              a = have ? merge(x[pos], a) : x[pos];
+              have = true;
+            }
+          return a;
+        };
+        double acc = tree([](double e, double l) { return e + l; });
+        if (acc != acc) {
+          const T* gv = stage + (int)(b0 - S);
+          for (int j = 0; j < m; ++j) {
+            const int cnt = len - 16 * j < 16 ? len - 16 * j : 16;
+            x[j] = pw_leaf_redo(cnt, [&](int q) { return seg_to_f64(gv[16 * j + q]); });
           }
+          acc = tree([](double e, double l) { return pw_merge(e, l); });
+        }
         if (out.sum_f) out.sum_f[oi] = acc;
         if (out.mean) out.mean[oi] = pw_mean(acc, (double)len);
       }
