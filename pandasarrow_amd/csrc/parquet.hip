@@ -224,16 +224,22 @@ __global__ void __launch_bounds__(64) k_pq_unpack(const uint8_t* __restrict__ fi
     const int64_t iend = sg.src_size, oend = sg.dst_size;
     const uint32_t ulen = rd_varint(src, &ip, iend);
     bool bad = (int64_t)ulen != oend;
+    // (round 4: the stream position and everything decoded from the tags are wave-uniform; handing them over through readfirstlane keeps
+    //  them in scalar registers, so the tag / length / offset bytes are fetched with scalar loads through the constant cache instead of a
+    //  64-lane vector load of one byte each)
+    ip = ((int64_t)__builtin_amdgcn_readfirstlane((int)(ip >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)ip);
     while (!bad && ip < iend) {
-      const uint32_t tag = src[ip++];
+      const uint64_t w8 = ld_u64(src + ip);  // the tag and the <= 4 bytes behind it in one (scalar) read; 64 bytes of slack follow the file
+      const uint64_t w = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(w8 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)w8);
+      const uint32_t tag = (uint32_t)(w & 0xFF);
+      ++ip;
       uint32_t len, off = 0;
       if ((tag & 3) == 0) {
         len = tag >> 2;
         if (len >= 60) {
           const int nb = (int)len - 59;
           if (ip + nb > iend) { bad = true; break; }
-          len = 0;
-          for (int k = 0; k < nb; ++k) len |= (uint32_t)src[ip + k] << (8 * k);
+          len = (uint32_t)((w >> 8) & (nb == 4 ? 0xFFFFFFFFull : ((1ull << (8 * nb)) - 1ull)));
           ip += nb;
         }
         ++len;
@@ -244,17 +250,17 @@ __global__ void __launch_bounds__(64) k_pq_unpack(const uint8_t* __restrict__ fi
         if ((tag & 3) == 1) {
           if (ip + 1 > iend) { bad = true; break; }
           len = 4 + ((tag >> 2) & 7);
-          off = ((tag >> 5) << 8) | src[ip];
+          off = ((tag >> 5) << 8) | (uint32_t)((w >> 8) & 0xFF);
           ip += 1;
         } else if ((tag & 3) == 2) {
           if (ip + 2 > iend) { bad = true; break; }
           len = (tag >> 2) + 1;
-          off = (uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8);
+          off = (uint32_t)((w >> 8) & 0xFFFF);
           ip += 2;
         } else {
           if (ip + 4 > iend) { bad = true; break; }
           len = (tag >> 2) + 1;
-          off = (uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8) | ((uint32_t)src[ip + 2] << 16) | ((uint32_t)src[ip + 3] << 24);
+          off = (uint32_t)((w >> 8) & 0xFFFFFFFFull);
           ip += 4;
         }
         if (off == 0 || (int64_t)off > op || op + (int64_t)len > oend) { bad = true; break; }
