@@ -1351,6 +1351,35 @@ inline DataFrame group_by_sum_mean_count(Communicator& comm, const DataFrame& sh
                                         static_cast<int64_t*>(counts.values->ptr), nullptr));
   return DataFrame({"sum", "mean", "count"}, {sums, means, counts}, keys);
 }
+// shard.group_by(key).{min, max, count}(col) -- and the sum of an int64 column -- over all shards (pdx_dist_groupby_order_free: every rank reduces
+// its shard without a value sort, dense per-group partials, one all-gather, fold in rank order): a frame indexed by the global unique keys with
+// one column per kind, named "sum" / "min" / "max" / "count".  Values may carry nulls.
+inline DataFrame group_by_order_free(Communicator& comm, const DataFrame& shard, const std::string& key, const std::string& col, const std::vector<int>& kinds,
+                                     int64_t row_offset) {
+  const Array& k = shard.m_columns[(size_t)shard.column_index(key)];
+  const Array& v = shard.m_columns[(size_t)shard.column_index(col)];
+  auto ck = k.c(), cv = v.c();
+  pdx_dist_agg* raw = nullptr;
+  ThrowOnFailure(pdx_dist_groupby_order_free(comm.h, &ck, &cv, kinds.data(), (int)kinds.size(), row_offset, nullptr, &raw));
+  std::shared_ptr<pdx_dist_agg> g(raw, [](pdx_dist_agg* p) { pdx_dist_agg_destroy(p); });
+  const int64_t G = pdx_dist_agg_num_groups(raw);
+  Array keys = Array::Empty(k.dtype, G, true);
+  std::vector<Array> outs;
+  std::vector<std::string> names;
+  std::vector<pdx_mut_column> mo;
+  for (int kind : kinds) {
+    outs.push_back(Array::Empty(kind == PDX_AGG_COUNT || kind == PDX_AGG_SUM ? PDX_INT64 : v.dtype, G, true));
+    names.push_back(kind == PDX_AGG_SUM ? "sum" : kind == PDX_AGG_MIN ? "min" : kind == PDX_AGG_MAX ? "max" : "count");
+  }
+  for (auto& o : outs) mo.push_back(o.mut());
+  auto mk = keys.mut();
+  ThrowOnFailure(pdx_dist_agg_fetch(raw, &mk, nullptr, mo.data(), nullptr));
+  for (size_t i = 0; i < outs.size(); ++i) {
+    outs[i].null_count = mo[i].null_count;
+    if (mo[i].null_count == 0) outs[i].validity.reset();
+  }
+  return DataFrame(names, outs, keys);
+}
 // pd::resample(shard, rule).agg(kind)(col) over a sorted axis sharded by row ranges: a Series of the aggregate indexed by the labels of the
 // non-empty bins of the WHOLE axis (every rank gets all of it)
 inline Series resample_agg(Communicator& comm, const Array& ts_shard, const Array& values_shard, int kind, int64_t freq_ns, bool closed_right = false,

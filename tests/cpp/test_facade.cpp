@@ -403,6 +403,12 @@ static void test_sharded_groupby_from_cpp() {
   REQUIRE((res["sum"].values<double>() == g.sum("v").values<double>()));
   REQUIRE((res["mean"].values<double>() == g.mean("v").values<double>()));
   REQUIRE((res["count"].values<long>() == g.count("v").values<long>()));
+  // the order-free kinds over the "shards" (dense partials + all-gather + fold) == the single-GPU GroupBy
+  DataFrame of = dist::group_by_order_free(comm, df, "k", "v", {PDX_AGG_MIN, PDX_AGG_MAX, PDX_AGG_COUNT}, 0);
+  REQUIRE((of.m_index->values_as<long>() == g.unique().values_as<long>()));
+  REQUIRE((of["min"].values<double>() == g.min("v").values<double>()));
+  REQUIRE((of["max"].values<double>() == g.max("v").values<double>()));
+  REQUIRE((of["count"].values<long>() == g.count("v").values<long>()));
   Array cat = dist::concat(comm, df.m_columns[1], n);
   REQUIRE(cat.length == n && (cat.values_as<double>() == val));
   Series withnull(std::vector<double>{1.0, std::nan(""), 3.0});
