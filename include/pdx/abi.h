@@ -503,6 +503,9 @@ int pdx_dist_resampled_destroy(pdx_dist_resampled* g);
  * pass small values), every chunk plays one rank of the exchange above on a host thread of its own, and the partial-tree records merge
  * the chunks' sums bit-identically to ONE pairwise tree over the whole column.  Result handle as pdx_dist_groupby_sum_mean_count. */
 int pdx_groupby_sum_mean_count_chunked(const pdx_column* keys, const pdx_column* values, int64_t chunk_rows, void* stream, pdx_dist_groupby** out);
+/* The same for the order-free kinds (PDX_AGG_MIN / MAX / COUNT, PDX_AGG_SUM of int64 values; values may carry nulls): chunks play the ranks of
+ * pdx_dist_groupby_order_free, dense per-group partials folded in chunk order.  Result handle as pdx_dist_groupby_order_free (pdx_dist_agg_fetch). */
+int pdx_groupby_order_free_chunked(const pdx_column* keys, const pdx_column* values, const int* kinds, int nk, int64_t chunk_rows, void* stream, pdx_dist_agg** out);
 
 /* ---------------------------------------------------------------- Parquet files -> device columns
  * Replaces, for the column types of this path, DataFrame::readParquet (src/dataframe.cpp:646-683: parquet::arrow::OpenFile ->

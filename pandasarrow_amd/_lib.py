@@ -147,6 +147,7 @@ ABI_SYMBOLS = {
     "pdx_dist_agg_num_groups": (C.c_int64, [_P]),
     "pdx_dist_agg_fetch": (C.c_int, [_P, _MUT, _P, _MUT, _P]),
     "pdx_dist_agg_destroy": (C.c_int, [_P]),
+    "pdx_groupby_order_free_chunked": (C.c_int, [_COL, _COL, C.POINTER(C.c_int), C.c_int, C.c_int64, _P, C.POINTER(_P)]),
     "pdx_dist_resample": (C.c_int, [_P, _COL, _COL, C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _P, C.POINTER(_P)]),
     "pdx_dist_resampled_num_bins": (C.c_int64, [_P]),
     "pdx_dist_resampled_fetch": (C.c_int, [_P, _MUT, _MUT, _P]),

@@ -1439,4 +1439,83 @@ int pdx_groupby_sum_mean_count_chunked(const pdx_column* keys, const pdx_column*
   return PDX_OK;
 }
 
+// The order-free kinds (min / max / count, int64 sum) for inputs of more than 2^31 - 1 rows: chunks play the ranks of pdx_dist_groupby_order_free on
+// host threads of their own (as pdx_groupby_sum_mean_count_chunked does for the partial-tree exchange): every chunk reduces its rows without a value
+// sort, the dense per-group partials are folded in chunk order.  chunk_rows = 0: the largest chunk the 32-bit row ids allow.
+int pdx_groupby_order_free_chunked(const pdx_column* keys, const pdx_column* values, const int* kinds, int nk, int64_t chunk_rows, void* stream, pdx_dist_agg** out) {
+  if (!out || !kinds || nk <= 0) return fail(PDX_INVALID, "pdx_groupby_order_free_chunked: null argument");
+  *out = nullptr;
+  PDX_TRY(check_column(keys, "pdx_groupby_order_free_chunked"));
+  PDX_TRY(check_column(values, "pdx_groupby_order_free_chunked"));
+  if (values->length != keys->length) return fail(PDX_INVALID, "pdx_groupby_order_free_chunked: keys and values differ in length");
+  const int64_t n = keys->length, kMaxChunk = 0x7FFFF000ll;
+  if (chunk_rows <= 0 || chunk_rows > kMaxChunk) chunk_rows = kMaxChunk;
+  const int W = (int)std::max<int64_t>(1, ceil_div(n, chunk_rows));
+  if (W > 64) return fail(PDX_INVALID, "pdx_groupby_order_free_chunked: more than 64 chunks");
+  int device = 0;
+  PDX_HIP(hipGetDevice(&device));
+  (void)stream;  // (every chunk runs on a stream of its own; the call returns when all of them have finished)
+  LocalShared sh;
+  sh.W = W;
+  sh.send.assign((size_t)W, nullptr);
+  sh.soff.assign((size_t)W, nullptr);
+  sh.sbytes.assign((size_t)W, nullptr);
+  std::vector<int> rcs((size_t)W, PDX_OK);
+  std::vector<std::string> errs((size_t)W);
+  std::vector<pdx_dist_agg*> results((size_t)W, nullptr);
+  auto work = [&](int r) {
+    int rc = PDX_OK;
+    hipStream_t st = nullptr;
+    pdx_dist* d = nullptr;
+    LocalCtx ctx{&sh, r};
+    do {
+      if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+        rc = fail(PDX_DEVICE, "chunked group-by: no stream for a chunk");
+        break;
+      }
+      pdx_dist_transport tr{&ctx, local_all_gather, local_all_to_all_v};
+      if ((rc = pdx_dist_init_custom(&tr, W, r, &d)) != PDX_OK) break;
+      const int64_t lo = (int64_t)r * chunk_rows, len = std::min<int64_t>(chunk_rows, n - lo);
+      pdx_column k = *keys, v = *values;
+      k.offset += lo;
+      k.length = len;
+      v.offset += lo;
+      v.length = len;
+      rc = pdx_dist_groupby_order_free(d, &k, &v, kinds, nk, lo, st, &results[(size_t)r]);
+    } while (false);
+    if (rc != PDX_OK) {
+      errs[(size_t)r] = pdx_last_error();
+      sh.abort();
+    }
+    rcs[(size_t)r] = rc;
+    if (d) pdx_dist_destroy(d);
+    if (st) {
+      (void)hipStreamSynchronize(st);
+      if (results[(size_t)r]) results[(size_t)r]->stream = nullptr;  // the chunk's stream dies with this thread
+      (void)hipStreamDestroy(st);
+    }
+  };
+  if (W == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> threads;
+    for (int r = 0; r < W; ++r) threads.emplace_back(work, r);
+    for (auto& t : threads) t.join();
+  }
+  int rc = PDX_OK;
+  for (int r = 0; r < W; ++r)
+    if (rcs[(size_t)r] != PDX_OK && (rc == PDX_OK || errs[(size_t)r].find("another chunk failed") == std::string::npos)) {
+      rc = rcs[(size_t)r];
+      set_error(errs[(size_t)r]);
+    }
+  for (int r = 1; r < W; ++r) delete results[(size_t)r];  // every chunk holds the full result: keep the first
+  if (rc != PDX_OK) {
+    delete results[0];
+    return rc;
+  }
+  *out = results[0];
+  return PDX_OK;
+}
+
+
 }  // extern "C"

@@ -317,6 +317,46 @@ def _fetch_dist_result(lib, h, key_dtype):
             "outs": [(sums[:G], None), (means[:G], None), (counts[:G], None)], "records": records}
 
 
+def _fetch_agg_result(lib, h, key_dtype, val_dtype, kinds):
+    """pdx_dist_agg* -> the result dict of the order-free sharded / chunked entry points (device tensors); destroys the handle."""
+    import ctypes as C
+
+    from . import column as K
+
+    try:
+        G = int(lib.pdx_dist_agg_num_groups(h))
+        dev = K._device()
+        kcol = K.Column.empty(key_dtype, G, with_validity=True)
+        first = torch.empty(max(G, 1), dtype=torch.int64, device=dev)
+        outs = [K.Column.empty(K._AGG_OUT_DT[k](val_dtype), G, with_validity=True) for k in kinds]
+        km, marr = kcol.mut(), K._mut_array(outs)
+        L.check(lib.pdx_dist_agg_fetch(h, C.byref(km), first.data_ptr(), marr, K._stream()))
+        kcol._adopt(km)
+        for i, o in enumerate(outs):
+            o._adopt(marr[i])
+    finally:
+        lib.pdx_dist_agg_destroy(h)
+    res = [(o.values[:G], _unpack_bits_device(o.validity, G) if (o.null_count != 0 and o.validity is not None) else None) for o in outs]
+    ok_t = _unpack_bits_device(kcol.validity, G) if kcol.validity is not None else torch.ones(G, dtype=torch.bool, device=dev)
+    return {"G": G, "keys": kcol.values[:G], "keys_ok": ok_t, "first_rows": first[:G], "kinds": list(kinds), "outs": res}
+
+
+def groupby_order_free_chunked(keys, vals, kinds, chunk_rows=0):
+    """min / max / count (int64 sum) on one GPU for inputs beyond 2^31 - 1 rows (pdx_groupby_order_free_chunked): chunks of `chunk_rows`
+    rows (0 = the largest allowed) reduced without a value sort, their dense per-group partials folded in chunk order."""
+    import ctypes as C
+
+    from . import column as K
+
+    lib = L.load()
+    kinds = list(kinds)
+    h = C.c_void_p()
+    ck, cv = keys.c(), vals.c()
+    karr = (C.c_int * len(kinds))(*kinds)
+    L.check(lib.pdx_groupby_order_free_chunked(C.byref(ck), C.byref(cv), karr, len(kinds), int(chunk_rows), K._stream(), C.byref(h)))
+    return _fetch_agg_result(lib, h, keys.dtype, vals.dtype, kinds)
+
+
 def groupby_sum_mean_count_chunked(keys, vals, chunk_rows=0):
     """The headline query on one GPU for inputs beyond 2^31 - 1 rows (pdx_groupby_sum_mean_count_chunked): chunks of `chunk_rows` rows
     (0 = the largest allowed) merged exactly through the partial-tree records.  Same result dict as the sharded entry points."""
@@ -461,24 +501,7 @@ class CDist:
         ck, cv = keys.c(), vals.c()
         karr = (C.c_int * len(kinds))(*kinds)
         L.check(self.lib.pdx_dist_groupby_order_free(self._h, C.byref(ck), C.byref(cv), karr, len(kinds), int(row_offset), K._stream(), C.byref(h)))
-        try:
-            G = int(self.lib.pdx_dist_agg_num_groups(h))
-            dev = K._device()
-            kcol = K.Column.empty(keys.dtype, G, with_validity=True)
-            first = torch.empty(max(G, 1), dtype=torch.int64, device=dev)
-            outs = [K.Column.empty(K._AGG_OUT_DT[k](vals.dtype), G, with_validity=True) for k in kinds]
-            km, marr = kcol.mut(), K._mut_array(outs)
-            L.check(self.lib.pdx_dist_agg_fetch(h, C.byref(km), first.data_ptr(), marr, K._stream()))
-            kcol._adopt(km)
-            for i, o in enumerate(outs):
-                o._adopt(marr[i])
-        finally:
-            self.lib.pdx_dist_agg_destroy(h)
-        res = []
-        for o in outs:
-            res.append((o.values[:G], _unpack_bits_device(o.validity, G) if (o.null_count != 0 and o.validity is not None) else None))
-        ok_t = _unpack_bits_device(kcol.validity, G) if kcol.validity is not None else torch.ones(G, dtype=torch.bool, device=dev)
-        return {"G": G, "keys": kcol.values[:G], "keys_ok": ok_t, "first_rows": first[:G], "kinds": kinds, "outs": res}
+        return _fetch_agg_result(self.lib, h, keys.dtype, vals.dtype, kinds)
 
     def resample(self, ts, vals, kinds, freq_ns, closed_right=False, label_right=False, origin=L.ORIGIN_START_DAY, origin_custom_ns=0, offset_ns=0):
         """pd::resample(...).{kinds}(col) over a sorted axis sharded by row ranges, inside the library (pdx_dist_resample).

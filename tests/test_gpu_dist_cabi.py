@@ -382,3 +382,39 @@ def test_c_abi_order_free_one_rank_rccl_on_the_wire():
     p.join(timeout=120)
     assert p.exitcode == 0
     _check_order_free(got, 1)
+
+
+@pytest.mark.parametrize("shape", ["four_chunks_f64_nulls", "ragged_int64", "one_chunk"])
+def test_chunked_order_free_beyond_the_row_limit(shape, monkeypatch):
+    """pdx_groupby_order_free_chunked: min / max / count / int64 sum for inputs of more than 2^31 - 1 rows, exercised with small chunks:
+    every chunk is a virtual rank on a host thread of its own, dense partials folded in chunk order, equal to the oracle"""
+    import torch
+
+    from pandasarrow_amd import _lib as L
+    from pandasarrow_amd import dist as pdist
+    from pandasarrow_amd.column import Column
+
+    monkeypatch.setenv("PDX_ACC_MIN_ROWS", "1")
+    L.check(L.load().pdx_init(0))
+    dtype, nulls, kinds, chunk = {"four_chunks_f64_nulls": ("f64", True, [2, 3, 4], 70_001), "ragged_int64": ("i64", False, [0, 2, 3, 4], 41_000),
+                                  "one_chunk": ("f64", False, [3, 2], 0)}[shape]
+    keys, vals, valid = _order_free_data(dtype)
+    res = pdist.groupby_order_free_chunked(Column.from_numpy(keys), Column.from_numpy(vals, valid if nulls else None), kinds, chunk)
+    got = {(dtype, nulls): {"keys": res["keys"].cpu().numpy(), "first_rows": res["first_rows"].cpu().numpy(),
+                            "outs": [(a.cpu().numpy(), None if b is None else b.cpu().numpy()) for a, b in res["outs"]]}}
+    ids, uniq, _, first = orc.group_ids(keys)
+    g = got[(dtype, nulls)]
+    assert np.array_equal(g["keys"], uniq) and np.array_equal(g["first_rows"], first)
+    for kind, (gv, gok) in zip(kinds, g["outs"]):
+        ev, eok = orc.groupby_agg(kind, ids, len(uniq), vals, valid if nulls else None, nthreads=4)
+        eok = np.asarray(eok, bool)
+        assert (gok is None and eok.all()) or np.array_equal(gok, eok), (shape, kind)
+        if ev.dtype == np.float64:
+            a, b = gv[eok], ev[eok]
+            same = (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))
+            if kind == 3 and nulls:
+                same |= (a == 0.0) & (b == 0.0)  # the documented corner: a maximum that is a tie of zeros across chunks in a group with a null
+            assert same.all(), (shape, kind, int((~same).sum()))
+        else:
+            assert np.array_equal(gv[eok], ev[eok]), (shape, kind)
+    torch.cuda.synchronize()

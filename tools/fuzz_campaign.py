@@ -16,7 +16,9 @@ MODES = {"default": {}, "fused_dense": {"PDX_FUSED_LAST_DIGIT_MIN_ROWS": "0", "P
          "hash_tail": {"PDX_GROUPBY_DENSE": "0", "PDX_HASH_HEAD_ROWS": "4096"}, "null_pw": {"PDX_FLR_NULL_PW": "1", "PDX_FUSED_LAST_DIGIT_MIN_ROWS": "0",
          "PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS": "4", "PDX_FUSED_LAST_DIGIT_MIN_RUN": "0"},
          # hot keys: runs over 20 000 rows are "long" -> the side form of the fused layout (or the classic route when there are too many)
-         "side": {"PDX_FLR_MAX_RUN": "20000", "PDX_FUSED_LAST_DIGIT_MIN_ROWS": "0", "PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS": "4", "PDX_FUSED_LAST_DIGIT_MIN_RUN": "0"}}
+         "side": {"PDX_FLR_MAX_RUN": "20000", "PDX_FUSED_LAST_DIGIT_MIN_ROWS": "0", "PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS": "4", "PDX_FUSED_LAST_DIGIT_MIN_RUN": "0"},
+         # round 4: requests of order-free kinds only (count / min / max / int64 sum) -> the accumulate path (gb_acc.hpp), dense and hash slots
+         "acc": {"PDX_ACC_MIN_ROWS": "1"}, "acc_hash": {"PDX_ACC_MIN_ROWS": "1", "PDX_GROUPBY_DENSE": "0"}}
 ALL_ENV = sorted({k for m in MODES.values() for k in m})
 bad = 0
 plans = {}
@@ -43,6 +45,13 @@ for i in range(count):
         if rng.random() < 0.5:
             kinds = [0, 1, 4]
     mode = list(MODES)[seed % len(MODES)]
+    if mode.startswith("acc"):
+        pool = [2, 3, 4] + ([0] if vals.dtype == np.int64 else [])
+        kinds = [k for k in pool if rng.random() < 0.6] or [2, 3]
+        if rng.random() < 0.5 and vals.dtype == np.float64:  # tied zeros of both signs: the zero-ties pass
+            z = rng.random(len(vals)) < 0.3
+            vals = vals.copy()
+            vals[z] = rng.choice(np.array([0.0, -0.0]), int(z.sum()))
     for k in ALL_ENV:
         os.environ.pop(k, None)
     os.environ.update(MODES[mode])
@@ -55,8 +64,9 @@ for i in range(count):
         ok_all = ok_all and np.array_equal(rows.cpu().numpy(), np.argsort(ids, kind="stable")) and np.array_equal(
             off.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(ids, minlength=G))]))
     outs = gb.agg(K.Column.from_numpy(vals, vvalid, offset=seed % 5), kinds)
-    plans[(mode, gb.last_plan().get("layout"), "side" if "side" in gb.last_plan() else gb.last_plan().get("skew", ""))] = plans.get(
-        (mode, gb.last_plan().get("layout"), "side" if "side" in gb.last_plan() else gb.last_plan().get("skew", "")), 0) + 1
+    pl = gb.last_plan()
+    pkey = (mode, pl.get("layout", "").split(":")[0], pl.get("reducer"), "side" if "side" in pl else pl.get("skew", ""), "ties" if "zero_ties" in pl else "")
+    plans[pkey] = plans.get(pkey, 0) + 1
     for kind, out in zip(kinds, outs):
         got, ok = out.to_numpy()
         exp, eok = orc.groupby_agg(kind, ids, G, vals, vvalid, nthreads=8)
