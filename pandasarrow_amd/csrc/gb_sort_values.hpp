@@ -53,6 +53,7 @@ static int sort_values_by_slot(pdx_groupby* gb, const uint64_t* vals, const uint
     if (vvalid) {
       uint32_t* fk = static_cast<uint32_t*>(alloc((size_t)n * 4));
       if (!fk) return PDX_OOM;
+      PDX_TRY(ensure_rows_part(gb, st));
       hipLaunchKernelGGL(k_flag_keys_part, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, gb->slot_part, gb->rows_part, vvalid, voff, n, fk);
       kin = fk;
     }

@@ -64,6 +64,16 @@ static int ensure_slot_part(pdx_groupby* gb, hipStream_t st) {
   return PDX_OK;
 }
 
+// the original row of every partitioned row (no null keys: the hash build's partition moves the keys alone and finds the groups' first rows
+// from positions; the few callers that want every row's origin -- group ids per row, validity flags of nullable values, the memory-side /
+// split / skewed-bucket forms of the build -- replay the partition with the row number as the payload)
+static int ensure_rows_part(pdx_groupby* gb, hipStream_t st) {
+  if (gb->rows_part || !gb->bucket8) return PDX_OK;
+  gb->rows_part = gb->own<uint32_t>((size_t)gb->n);
+  if (!gb->rows_part) return PDX_OOM;
+  return radix_scatter_iota<kPartBits, uint8_t>(gb->bucket8, nullptr, gb->rows_part, gb->n, 0, false, gb->part_off, nullptr, 0, st);
+}
+
 namespace pdx {
 #include "gb_sort_values.hpp"
 #include "gb_flr_reduce.hpp"
@@ -415,12 +425,14 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     gb->bucket8 = gb->own<uint8_t>((size_t)n);
     gb->part_off = gb->own<uint32_t>((size_t)ntiles << kPartBits);
     gb->slot_part = gb->own<uint32_t>((size_t)n);
-    gb->rows_part = gb->own<uint32_t>((size_t)n);
+    // row ids ride through the partition only when there are null keys (their flag is bit 31 of the row id); otherwise on demand
+    const bool rows_in_partition = valid != nullptr || [] { const char* e = getenv("PDX_HASH_ROWS"); return e && e[0] == '1'; }();
+    if (rows_in_partition) gb->rows_part = gb->own<uint32_t>((size_t)n);
     gb->idx16_part = gb->own<uint16_t>((size_t)n);
     bool idx16_written = false;  // by the attempt that succeeded (the LDS build at the first partition level)
     uint32_t* chunk_sum = s.get<uint32_t>((size_t)(nchunks + 1) << kPartBits);  // + digit totals row
     long long* keys_part = s.get<long long>((size_t)n);
-    if (s.failed || !gb->bucket8 || !gb->part_off || !gb->slot_part || !gb->rows_part || !gb->idx16_part) return PDX_OOM;
+    if (s.failed || !gb->bucket8 || !gb->part_off || !gb->slot_part || (rows_in_partition && !gb->rows_part) || !gb->idx16_part) return PDX_OOM;
     {
       // one pass over the keys: bucket byte per row (kept: it is the digit of the value partition of every later aggregation)
       // + the partition histogram
@@ -428,9 +440,12 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
       hipLaunchKernelGGL(k_hash_bucket_hist, dim3((unsigned)ntiles), dim3(kSortBlock), 0, st, keys, valid, key->offset, n, gb->bucket8, gb->part_off);
     }
     int rcp = radix_scan_only<kPartBits>(gb->part_off, ntiles, chunk_sum, true, st);
-    if (rcp == PDX_OK)  // keys and row ids in ONE scatter (they used to be two kernels ranking the same bucket bytes: 5.0 + 2.5 ms per 1e9 rows)
+    if (rcp == PDX_OK && rows_in_partition)  // keys and row ids in ONE scatter (they used to be two kernels ranking the same bucket bytes: 5.0 + 2.5 ms per 1e9 rows)
       rcp = radix_scatter_with_rows<kPartBits>(gb->bucket8, reinterpret_cast<const uint64_t*>(keys), reinterpret_cast<uint64_t*>(keys_part),
                                                gb->rows_part, n, gb->part_off, valid, key->offset, st);
+    else if (rcp == PDX_OK)  // the keys alone: 17 instead of 21 B/row, and the pass of the value partition (4 waves per SIMD)
+      rcp = radix_scatter_only<kPartBits, uint64_t, uint8_t>(gb->bucket8, reinterpret_cast<const uint64_t*>(keys), nullptr, reinterpret_cast<uint64_t*>(keys_part), n,
+                                                             0, false, gb->part_off, st);
     if (rcp != PDX_OK) return rcp;
     uint64_t want = std::max<uint64_t>(next_pow2((uint64_t)n * 2), 1u << 16);
     unsigned int cap = (unsigned int)std::min<uint64_t>(want, 1u << 21);
@@ -468,12 +483,17 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
         }
         uint16_t* idx16 = pb == (unsigned)kPartBits ? gb->idx16_part : nullptr;
         idx16_written = idx16 != nullptr;
+        if (!chunks.empty() || pb != (unsigned)kPartBits) PDX_TRY(ensure_rows_part(gb, st));  // (the tail kernel tracks first rows per row)
+        const bool first_as_pos = !valid && !gb->rows_part;
         if (valid)
           hipLaunchKernelGGL((k_hash_probe_lds<true>), dim3(1u << pb), dim3(kProbeBlock), 0, st, keys_part, gb->rows_part, boff, n, table, cap, region,
                              gb->slot_part, ctl, pb, head_rows, idx16);
         else  // no null keys: rows_part is not read per row (first rows as positions), and with idx16 the 4-byte slot is not written
           hipLaunchKernelGGL((k_hash_probe_lds<false>), dim3(1u << pb), dim3(kProbeBlock), 0, st, keys_part, gb->rows_part, boff, n, table, cap, region,
                              gb->slot_part, ctl, pb, head_rows, idx16);
+        if (first_as_pos)
+          hipLaunchKernelGGL(k_first_rows_from_pos, dim3((unsigned)(((int64_t)cap + 2 + 255) / 256)), dim3(256), 0, st, table, cap, region,
+                             gb->part_off, ntiles, gb->bucket8, n);
         if (!chunks.empty()) {
           TailChunk* dchunks = s.get<TailChunk>(chunks.size());
           if (s.failed) {
@@ -487,6 +507,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
         }
       } else {
         idx16_written = false;
+        PDX_TRY(ensure_rows_part(gb, st));
         PDX_PROFILE("hash_probe_part", st);
         constexpr unsigned int kWindowBits = 16;  // 2^16 slots = 1 MB per bucket window; about two buckets are active at a time
         const unsigned int nsweeps = region > (1u << kWindowBits) ? region >> kWindowBits : 1u;
@@ -538,6 +559,7 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
         while (extra < 8 && groups / (double)((uint64_t)1 << (kPartBits + extra)) > 2800.0) ++extra;  // ~35 % load when there is room ...
         if (groups / (double)((uint64_t)1 << (kPartBits + extra)) <= 4200.0) {  // ... up to ~51 % at the last level (2.7e8 groups)
           const int64_t ntiles2 = ntiles, nchunks2 = nchunks;
+          PDX_TRY(ensure_rows_part(gb, st));
           gb->digit2 = gb->own<uint8_t>((size_t)n);
           gb->part_off2 = gb->own<uint32_t>((size_t)ntiles2 << extra);
           uint32_t* chunk_sum2 = s.get<uint32_t>((size_t)(nchunks2 + 1) << extra);
@@ -731,6 +753,7 @@ int pdx_groupby_group_ids(pdx_groupby* gb, uint32_t* out_ids, void* stream) {
   gb->use_on(st);  // ordered behind the handle's creation; frees of its blocks are ordered behind this stream
   if (gb->n == 0) return PDX_OK;
   if (gb->mode == 0 && gb->slot_part) PDX_TRY(ensure_slot_part(gb, st));
+  if (gb->mode == 0 && gb->slot_part) PDX_TRY(ensure_rows_part(gb, st));
   if (gb->mode == 0 && gb->slot_part)
     hipLaunchKernelGGL(k_part_row_gids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->gid_of_slot, gb->slot_part, gb->rows_part, gb->n,
                        (const int64_t*)nullptr, out_ids, (int64_t*)nullptr);
@@ -749,6 +772,7 @@ int pdx_groupby_map_ids(pdx_groupby* gb, const int64_t* map, int64_t* out, void*
   gb->use_on(st);  // ordered behind the handle's creation; frees of its blocks are ordered behind this stream
   if (gb->n == 0) return PDX_OK;
   if (gb->mode == 0 && gb->slot_part) PDX_TRY(ensure_slot_part(gb, st));
+  if (gb->mode == 0 && gb->slot_part) PDX_TRY(ensure_rows_part(gb, st));
   if (gb->mode == 0 && gb->slot_part)
     hipLaunchKernelGGL(k_part_row_gids, dim3(grid_for(gb->n, 256, 4)), dim3(256), 0, st, gb->gid_of_slot, gb->slot_part, gb->rows_part, gb->n, map,
                        (uint32_t*)nullptr, out);

@@ -380,3 +380,39 @@ def test_sum_tree_nan_bits_per_group(px, monkeypatch, path):
             assert ok is None or np.array_equal(ok, eok), (name, what, path)
             g, e = got.view(np.uint64)[eok], exp[row].view(np.uint64)[eok]
             assert np.array_equal(g, e), (name, what, path, gb.last_plan(), int((g != e).sum()), [hex(int(x)) for x in g[g != e][:3]], [hex(int(x)) for x in e[g != e][:3]])
+
+
+@pytest.mark.parametrize("form", ["keys_only", "rows_in_partition", "skewed_tail"])
+def test_hash_build_without_row_ids(px, monkeypatch, form):
+    """No null keys: the hash build's partition moves the keys alone, the groups' first rows come from positions inside the buckets
+    (k_first_rows_from_pos) and the row ids are replayed only for the callers that want them (group ids per row, validity flags of
+    nullable values, the skewed-bucket tail).  Arbitrary int64 keys incl. INT64_MIN (its own slot); ids / uniques / first rows and
+    the aggregates against the oracle, and the old form (PDX_HASH_ROWS=1) as a cross-check of the switch."""
+    monkeypatch.setenv("PDX_GROUPBY_DENSE", "0")
+    if form == "rows_in_partition":
+        monkeypatch.setenv("PDX_HASH_ROWS", "1")
+    if form == "skewed_tail":
+        monkeypatch.setenv("PDX_HASH_HEAD_ROWS", "4096")
+    n, nk = 700_001, 30_000
+    rng = np.random.default_rng(11)
+    pool = rng.integers(-(2 ** 62), 2 ** 62, nk).astype(np.int64)
+    pool[7] = np.iinfo(np.int64).min
+    pool[8] = np.iinfo(np.int64).max
+    keys = pool[rng.integers(0, nk, n)]
+    keys[n - 5:] = np.array([3, 1, 4, 1, 5], dtype=np.int64)  # keys whose first row sits in the ragged last tile
+    if form == "skewed_tail":
+        keys[rng.random(n) < 0.3] = pool[99]
+    ids, uniq, uok, first = orc.group_ids(keys, None)
+    G = len(uniq)
+    gb = px.K.GroupByHandle.create(px.Column.from_numpy(keys))
+    assert np.array_equal(gb.first_rows().cpu().numpy(), first)
+    ukeys, _ = gb.unique_keys().to_numpy()
+    assert np.array_equal(ukeys, uniq)
+    vals = rng.standard_normal(n)
+    vvalid = rng.random(n) > 0.1
+    for vv in (None, vvalid):  # (nullable values: the flags are looked up by original row -> the replayed row ids)
+        kinds = [SUM, MEAN, COUNT, MIN, MAX]
+        outs = gb.agg(px.Column.from_numpy(vals, vv), kinds)
+        assert gb.last_plan()["slots"] == "hash_lds", gb.last_plan()
+        _check(kinds, outs, ids, G, vals, vv, f"{form} nulls={vv is not None}")
+    assert np.array_equal(gb.group_ids().cpu().numpy(), ids)
