@@ -277,6 +277,429 @@ __global__ void __launch_bounds__(64) k_pq_unpack(const uint8_t* __restrict__ fi
   }
 }
 
+// ---------------------------------------------------------------- Snappy, one WORKGROUP per segment (the product path)
+// The wave-per-page kernel above walks the element stream one element at a time (a dependent tag read and, for copies, a read of bytes it
+// has just stored: ~420 cycles per element, 46 ms for a 1 MB page of int64 values below 2^24 -- 262 K elements).  Here the sequential
+// parts become logarithmic:
+//   parse   a window of 4 KB of the stream lies in LDS; EVERY byte is decoded as if an element began there (next[i] = i + its size);
+//           the true element starts are the nodes on the path from the window's first byte, marked by pointer jumping (<= 12 rounds
+//           of mark[next^(2^k)(i)] |= mark[i], next^(2^(k+1)) = next^(2^k) o next^(2^k));
+//   place   output position of every element = exclusive scan of the marked elements' lengths;
+//   copy    the window's output is produced in tiles of 8 K bytes, one LDS word per byte: a literal byte is known at once, a copy byte
+//           whose source lies in front of the tile is read back from the output (written and fenced by earlier tiles), a copy byte whose
+//           source lies inside the tile starts as a pointer to it and is resolved by pointer doubling (tile[j] = tile[tile[j]]: the
+//           pointers only point backwards, chains of overlapping copies halve every round).  Long literals (incompressible pages: one
+//           64 KB literal per Snappy block) are moved global -> global in 16-byte pieces without the tile.
+// Malformed input (lengths past either buffer, offsets before the start, a length prefix that does not match) sets the error word.
+constexpr int kUsThreads = 1024, kUsWin = 4096, kUsTile = 8192, kUsMaxEl = kUsWin / 2 + 2, kUsPerThread = kUsWin / kUsThreads;
+constexpr uint32_t kUsResolved = 0x80000000u;
+constexpr int kUsTail = 256, kUsAhead = 64;
+static_assert(kUsPerThread == 4 && kUsTile % kUsThreads == 0, "window / tile shares per thread");
+// element that would begin at byte i of the window: header bytes, output length, copy offset (0: literal)
+__device__ __forceinline__ void us_decode(const uint8_t* c, int i, uint32_t* hdr, uint64_t* len, uint32_t* off) {
+  const uint32_t tag = c[i];
+  const uint32_t ext = (uint32_t)c[i + 1] | ((uint32_t)c[i + 2] << 8) | ((uint32_t)c[i + 3] << 16) | ((uint32_t)c[i + 4] << 24);
+  switch (tag & 3) {
+    case 0: {
+      uint32_t l = tag >> 2;
+      *hdr = 1;
+      if (l >= 60) {
+        const int nb = (int)l - 59;
+        l = nb == 4 ? ext : (ext & ((1u << (8 * nb)) - 1u));
+        *hdr = 1 + nb;
+      }
+      *len = (uint64_t)l + 1;
+      *off = 0;
+      return;
+    }
+    case 1:
+      *hdr = 2;
+      *len = 4 + ((tag >> 2) & 7);
+      *off = ((tag >> 5) << 8) | (ext & 0xFF);
+      break;
+    case 2:
+      *hdr = 3;
+      *len = (tag >> 2) + 1;
+      *off = ext & 0xFFFF;
+      break;
+    default:
+      *hdr = 5;
+      *len = (tag >> 2) + 1;
+      *off = ext;
+      break;
+  }
+  if (*off == 0) *off = 0xFFFFFFFFu;  // a copy with offset 0 is malformed: an offset no output can satisfy (off == 0 means "literal" to the callers)
+}
+// scans over the workgroup's threads (16 waves)
+// two exclusive sums in the same three barriers (element counts and output bytes)
+__device__ __forceinline__ void us_excl_sum2(uint32_t a, uint32_t b, uint32_t* part /* >= 34 words */, uint32_t* ea, uint32_t* eb, uint32_t* ta, uint32_t* tb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t ia = a, ib = b;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t ua = __shfl_up(ia, d, 64), ub = __shfl_up(ib, d, 64);
+    if (lane >= d) {
+      ia += ua;
+      ib += ub;
+    }
+  }
+  if (lane == 63) {
+    part[wave] = ia;
+    part[17 + wave] = ib;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const uint32_t wa = lane < 16 ? part[lane] : 0, wb = lane < 16 ? part[17 + lane] : 0;
+    uint32_t xa = wa, xb = wb;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const uint32_t ua = __shfl_up(xa, d, 64), ub = __shfl_up(xb, d, 64);
+      if (lane >= d) {
+        xa += ua;
+        xb += ub;
+      }
+    }
+    if (lane < 16) {
+      part[lane] = xa - wa;
+      part[17 + lane] = xb - wb;
+    }
+    if (lane == 15) {
+      part[16] = xa;
+      part[33] = xb;
+    }
+  }
+  __syncthreads();
+  *ea = part[wave] + ia - a;
+  *eb = part[17 + wave] + ib - b;
+  *ta = part[16];
+  *tb = part[33];
+  __syncthreads();
+}
+__device__ __forceinline__ uint32_t us_incl_max(uint32_t v, uint32_t* part) {  // returns the maximum over all threads IN FRONT of this one
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t u = __shfl_up(incl, d, 64);
+    if (lane >= d) incl = incl > u ? incl : u;
+  }
+  if (lane == 63) part[wave] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+  for (int w = 0; w < wave; ++w) before = before > part[w] ? before : part[w];
+  uint32_t prev = __shfl_up(incl, 1, 64);
+  if (lane == 0) prev = 0;
+  __syncthreads();
+  return before > prev ? before : prev;
+}
+#ifdef PDX_US_TIMING  // per-phase cycle sums of every workgroup (diagnostic build: tools/build_variant.py), err[4 + phase] in units of 1024 cycles
+#define US_T(k)                                     \
+  do {                                              \
+    if (threadIdx.x == 0) {                         \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+      acc_[k] += now_ - last_;                      \
+      last_ = now_;                                 \
+    }                                               \
+  } while (0)
+#else
+#define US_T(k) do { } while (0)
+#endif
+__global__ void __launch_bounds__(kUsThreads) k_pq_unsnap(const uint8_t* __restrict__ file, uint8_t* __restrict__ raw, const PqSegment* __restrict__ segs,
+                                                          int nsegs, unsigned int* __restrict__ err) {
+  __shared__ __attribute__((aligned(16))) uint8_t cbuf[kUsWin + 16];
+  __shared__ __attribute__((aligned(16))) uint16_t ja[kUsWin + 8], jb[kUsWin + 8];
+  __shared__ __attribute__((aligned(16))) uint8_t mark[kUsWin + 8];
+  __shared__ uint8_t tailb[kUsTail];  // the last bytes produced before the current tile (copies with short offsets read them here)
+  __shared__ uint16_t el_cpos[kUsMaxEl];
+  __shared__ uint32_t el_opos[kUsMaxEl];
+  __shared__ __attribute__((aligned(16))) uint32_t tile[kUsTile];
+  __shared__ uint32_t part[36];
+  __shared__ int s_bad;
+  __shared__ long long s_next;
+  const int tid = threadIdx.x;
+#ifdef PDX_US_TIMING
+  unsigned long long acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+#endif
+  for (int si = blockIdx.x; si < nsegs; si += gridDim.x) {
+    const PqSegment sg = segs[si];
+    const uint8_t* src = file + sg.src_off;
+    uint8_t* dst = raw + sg.dst_off;
+    if (!sg.snappy) {
+      for (int64_t i = tid; i < sg.src_size; i += kUsThreads) dst[i] = src[i];
+      continue;
+    }
+    __syncthreads();  // (the previous segment's last reads of the shared words)
+    if (tid == 0) s_bad = 0;
+    int64_t ip = 0, op = 0;
+    const int64_t iend = sg.src_size, oend = sg.dst_size;
+    const uint32_t ulen = rd_varint(src, &ip, iend);
+    bool bad = (int64_t)ulen != oend;
+    constexpr int kPfLen = kUsWin + 16 + 2 * kUsAhead, kPf = (kPfLen + kUsThreads - 1) / kUsThreads;
+    uint8_t pf[kPf];
+    int64_t pf_at = -1;
+#pragma unroll
+    for (int q = 0; q < kPf; ++q) pf[q] = 0;
+    __syncthreads();
+    while (!bad && ip < iend) {
+      // ---- the window [ip, ip + 4 KB) of the stream (+ the <= 4 header bytes of an element that begins on its last byte)
+      const int64_t s = ip;
+      const int wlen = (int)(iend - s < kUsWin ? iend - s : kUsWin);
+      // the bytes requested while the previous window was at work (pf_at: where they begin) cover this window unless a long literal
+      // jumped ahead; whatever they do not cover comes straight from the stream
+      {
+        const int64_t shift = pf_at - s;  // cbuf index of the first prefetched byte
+        const bool usable = pf_at >= 0 && shift <= 0 && shift > -2 * kUsAhead;
+#pragma unroll
+        for (int q = 0; q < kPf; ++q) {
+          const int64_t k = (int64_t)tid + (int64_t)q * kUsThreads;  // byte k of the prefetched range
+          const int64_t i = k + shift;
+          if (usable && k < kPfLen && i >= 0 && i < kUsWin + 16) cbuf[i] = pf[q];
+        }
+        const int covered = usable ? (int)(kPfLen + shift) : 0;  // cbuf[0, covered) is filled
+        for (int i = (covered > 0 ? covered : 0) + tid; i < kUsWin + 16; i += kUsThreads) cbuf[i] = s + i < iend ? src[s + i] : (uint8_t)0;
+      }
+      __syncthreads();
+      pf_at = s + kUsWin - kUsAhead;  // the next window begins within a few bytes of s + 4 KB (an element straddles the end) unless a literal runs on
+#pragma unroll
+      for (int q = 0; q < kPf; ++q) {
+        const int64_t a = pf_at + tid + (int64_t)q * kUsThreads;
+        pf[q] = (tid + q * kUsThreads < kPfLen && a < iend) ? src[a] : (uint8_t)0;
+      }
+      US_T(0);
+      // ---- parse: next[] of every byte, then the path from byte 0
+#pragma unroll
+      for (int q = 0; q < kUsPerThread; ++q) {
+        const int i = tid * kUsPerThread + q;
+        uint32_t nx = kUsWin;
+        if (i < wlen) {
+          uint32_t hdr, off;
+          uint64_t len;
+          us_decode(cbuf, i, &hdr, &len, &off);
+          const uint64_t e = (uint64_t)i + hdr + (off ? 0 : len);
+          nx = e < (uint64_t)kUsWin ? (uint32_t)e : (uint32_t)kUsWin;
+        }
+        ja[i] = (uint16_t)nx;
+        mark[i] = i == 0 ? 1 : 0;
+      }
+      if (tid == 0) ja[kUsWin] = jb[kUsWin] = kUsWin;
+      __syncthreads();
+      US_T(1);
+      {
+        // round k: j0 = next^(2^k).  The path from byte 0 has left the window within 2^k elements when j0[0] is the exit: the rounds so
+        // far marked its first 2^k nodes, i.e. all of them (a window of one long literal needs no round at all).
+        uint16_t *j0 = ja, *j1 = jb;
+        for (int round = 0; round < 12; ++round) {
+          if (j0[0] == kUsWin) break;
+          const ushort4 jv = *reinterpret_cast<const ushort4*>(j0 + kUsPerThread * tid);
+          const uint32_t mv = *reinterpret_cast<const uint32_t*>(mark + kUsPerThread * tid);
+          ushort4 nv;
+          nv.x = j0[jv.x];  // (j0[exit] = exit)
+          nv.y = j0[jv.y];
+          nv.z = j0[jv.z];
+          nv.w = j0[jv.w];
+          if ((mv & 0xFFu) && jv.x < kUsWin) mark[jv.x] = 1;
+          if ((mv & 0xFF00u) && jv.y < kUsWin) mark[jv.y] = 1;
+          if ((mv & 0xFF0000u) && jv.z < kUsWin) mark[jv.z] = 1;
+          if ((mv & 0xFF000000u) && jv.w < kUsWin) mark[jv.w] = 1;
+          *reinterpret_cast<ushort4*>(j1 + kUsPerThread * tid) = nv;
+          __syncthreads();
+          uint16_t* t = j0;
+          j0 = j1;
+          j1 = t;
+        }
+      }
+      US_T(2);
+      // ---- place: the marked bytes are the elements, in order; their output positions by a scan of the lengths
+      uint32_t cnt[kUsPerThread], ol[kUsPerThread], my_cnt = 0, my_len = 0;
+      int my_bad = 0;
+      int64_t my_next = -1;
+#pragma unroll
+      for (int q = 0; q < kUsPerThread; ++q) {
+        const int i = tid * kUsPerThread + q;
+        cnt[q] = 0;
+        ol[q] = 0;
+        if (i < wlen && mark[i]) {
+          uint32_t hdr, off;
+          uint64_t len;
+          us_decode(cbuf, i, &hdr, &len, &off);
+          cnt[q] = 1;
+          if (s + i + hdr + (int64_t)(off ? 0 : len) > iend || (int64_t)len > oend) {
+            my_bad = 1;
+            len = 0;
+          }
+          ol[q] = (uint32_t)len;
+          my_next = s + i + hdr + (int64_t)(off ? 0 : len);  // (the thread's LAST element wins below)
+        }
+        my_cnt += cnt[q];
+        my_len += ol[q];
+      }
+      uint32_t nel, total, e0, o0;
+      us_excl_sum2(my_cnt, my_len, part, &e0, &o0, &nel, &total);
+#pragma unroll
+      for (int q = 0; q < kUsPerThread; ++q) {
+        const int i = tid * kUsPerThread + q;
+        if (cnt[q]) {
+          uint32_t hdr, off;
+          uint64_t len;
+          us_decode(cbuf, i, &hdr, &len, &off);
+          // a copy must begin inside what has been produced so far, and nothing may be produced behind the announced length
+          if (off && (off > (uint64_t)op + o0)) my_bad = 1;
+          if (op + (int64_t)o0 + (int64_t)ol[q] > oend) my_bad = 1;
+          el_cpos[e0] = (uint16_t)i;
+          el_opos[e0] = o0;
+          if (e0 + 1 == nel) s_next = my_next;
+          ++e0;
+          o0 += ol[q];
+        }
+      }
+      if (my_bad) s_bad = 1;
+      if (tid == 0) el_opos[nel] = total;
+      __syncthreads();
+      if (s_bad || op + (int64_t)total > oend) {
+        bad = true;
+        break;
+      }
+      US_T(3);
+      // ---- copy: the window's output [op, op + total) in tiles
+      uint32_t t0 = 0;
+      while (t0 < total) {
+        // the element that covers output byte t0 (the same search in every thread)
+        uint32_t lo = 0, hi = nel - 1;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi + 1) >> 1;
+          if (el_opos[mid] <= t0) lo = mid;
+          else hi = mid - 1;
+        }
+        const uint32_t efirst = lo;
+        {
+          uint32_t hdr, off;
+          uint64_t len;
+          us_decode(cbuf, el_cpos[efirst], &hdr, &len, &off);
+          const uint32_t rem = el_opos[efirst] + (uint32_t)len - t0;
+          if (!off && rem >= 2048) {  // a long literal: straight from the stream to the output, 16 bytes per thread and step
+            const uint8_t* from = src + s + el_cpos[efirst] + hdr + (t0 - el_opos[efirst]);
+            uint8_t* to = dst + op + t0;
+            const uint32_t head = (uint32_t)((16 - (reinterpret_cast<uintptr_t>(to) & 15)) & 15);
+            if ((uint32_t)tid < head) to[tid] = from[tid];
+            const uint32_t body = (rem - head) >> 4;
+            for (uint32_t k = tid; k < body; k += kUsThreads) {
+              const uint8_t* f = from + head + ((size_t)k << 4);
+              ulonglong2 v;
+              v.x = ld_u64(f);
+              v.y = ld_u64(f + 8);
+              *reinterpret_cast<ulonglong2*>(to + head + ((size_t)k << 4)) = v;
+            }
+            for (uint32_t k = head + (body << 4) + tid; k < rem; k += kUsThreads) to[k] = from[k];
+            if (tid < kUsTail) tailb[tid] = from[rem - kUsTail + tid];  // (rem >= 2048)
+            t0 += rem;
+            __threadfence_block();
+            __syncthreads();
+            US_T(8);
+            continue;
+          }
+        }
+        const uint32_t t1 = total - t0 < (uint32_t)kUsTile ? total : t0 + kUsTile, tl = t1 - t0;
+        constexpr int kOwn = kUsTile / kUsThreads;  // 16 consecutive bytes per thread for the element lookup
+        {
+          uint4* tz = reinterpret_cast<uint4*>(tile + tid * kOwn);
+#pragma unroll
+          for (int q = 0; q < kOwn / 4; ++q) tz[q] = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+        // heads: element e begins at tile byte el_opos[e] - t0 (value e + 1); the element that reaches in from the left sits on byte 0
+        for (uint32_t e = efirst + tid; e < nel && el_opos[e] < t1; e += kUsThreads) tile[el_opos[e] > t0 ? el_opos[e] - t0 : 0] = e + 1;
+        __syncthreads();
+        uint32_t own[kOwn];
+        {
+          const uint4* tz = reinterpret_cast<const uint4*>(tile + tid * kOwn);
+#pragma unroll
+          for (int q = 0; q < kOwn / 4; ++q) {
+            const uint4 v = tz[q];
+            own[4 * q] = v.x;
+            own[4 * q + 1] = v.y;
+            own[4 * q + 2] = v.z;
+            own[4 * q + 3] = v.w;
+          }
+        }
+        uint32_t run = 0;
+#pragma unroll
+        for (int q = 0; q < kOwn; ++q) {
+          run = own[q] > run ? own[q] : run;
+          own[q] = run;
+        }
+        const uint32_t before = us_incl_max(run, part);
+        US_T(4);
+        // one word per byte: its value (resolved) or the tile byte it repeats
+#pragma unroll
+        for (int q = 0; q < kOwn; ++q) {
+          const uint32_t jj = tid * kOwn + q;
+          uint32_t word = kUsResolved;
+          if (jj < tl) {
+            const uint32_t e = (own[q] > before ? own[q] : before) - 1;
+            const uint32_t cp = el_cpos[e];
+            uint32_t hdr, off;
+            uint64_t len;
+            us_decode(cbuf, cp, &hdr, &len, &off);
+            const uint32_t j = t0 + jj;  // output byte, relative to the window's first
+            if (!off) {
+              const uint32_t lp = cp + hdr + (j - el_opos[e]);  // literal byte: in the window's LDS copy or further along the stream
+              word = kUsResolved | (lp < (uint32_t)kUsWin + 16 ? (uint32_t)cbuf[lp] : (uint32_t)src[s + lp]);
+            } else if (off > jj) {  // in front of the tile: among the last bytes kept in LDS, or read back (produced and fenced earlier)
+              word = kUsResolved | (off - jj <= (uint32_t)kUsTail ? (uint32_t)tailb[kUsTail + jj - off] : (uint32_t)dst[op + j - off]);
+            } else {
+              word = jj - off;
+            }
+          }
+          own[q] = word;
+        }
+        {
+          uint4* tz = reinterpret_cast<uint4*>(tile + tid * kOwn);
+#pragma unroll
+          for (int q = 0; q < kOwn / 4; ++q) tz[q] = make_uint4(own[4 * q], own[4 * q + 1], own[4 * q + 2], own[4 * q + 3]);
+        }
+        __syncthreads();
+        US_T(5);
+        for (int round = 0; round < 16; ++round) {  // pointer doubling: chains of <= 8 K bytes need <= 13 rounds
+          int open = 0;
+          for (uint32_t jj = tid; jj < tl; jj += kUsThreads) {
+            const uint32_t w = tile[jj];
+            if (!(w & kUsResolved)) {
+              const uint32_t w2 = tile[w];
+              tile[jj] = w2;
+              open |= !(w2 & kUsResolved);
+            }
+          }
+          if (!__syncthreads_or(open)) break;
+        }
+        US_T(6);
+        for (uint32_t jj = tid; jj < tl; jj += kUsThreads) dst[op + t0 + jj] = (uint8_t)tile[jj];
+        if (tl >= (uint32_t)kUsTail) {  // the tile's last bytes for the next tile's short-offset copies (tailb is not read between the
+          if (tid < kUsTail) tailb[tid] = (uint8_t)tile[tl - kUsTail + tid];  // words above and the barrier below)
+        } else {
+          uint8_t keep = 0;
+          if (tid < kUsTail && tid + tl < (uint32_t)kUsTail) keep = tailb[tid + tl];
+          __syncthreads();
+          if (tid < kUsTail) tailb[tid] = tid + tl < (uint32_t)kUsTail ? keep : (uint8_t)tile[tid + tl - kUsTail];
+        }
+        t0 = t1;
+        __threadfence_block();
+        __syncthreads();
+        US_T(7);
+      }
+      op += total;
+      ip = s_next;
+      __syncthreads();
+    }
+    if (bad || op != oend || ip != iend) {
+      if (tid == 0) atomicMax(err, (unsigned int)kPqErrSnappy);
+    }
+  }
+#ifdef PDX_US_TIMING
+  if (tid == 0)
+    for (int k = 0; k < 10; ++k) atomicAdd(&err[4 + k], (unsigned int)(acc_[k] >> 10));
+#endif
+}
+
 // ---------------------------------------------------------------- RLE / bit-packed hybrid runs (definition levels, dictionary indices)
 // Calls emit(k, v) for the first `need` values of the stream in [pos, end); every lane walks the run headers, the values of a run are
 // spread over the lanes.  Returns false when the stream ends early or a run header is malformed.
@@ -1006,7 +1429,14 @@ int pdx_parquet_load(pdx_parquet_file* f, void* stream) {
   if (!all_pages.empty()) PQ_HIP(hipMemcpyAsync(dpages, all_pages.data(), all_pages.size() * sizeof(PqPage), hipMemcpyHostToDevice, st));
   if (!segs.empty()) {
     PQ_HIP(hipMemcpyAsync(dsegs, segs.data(), segs.size() * sizeof(PqSegment), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_pq_unpack, dim3((unsigned)std::min<size_t>(segs.size(), (size_t)kCUs * 16)), dim3(64), 0, st, dfile, draw, dsegs, (int)segs.size(), derr);
+    // (PDX_PQ_SNAPPY_WAVE=1: the wave-per-page decoder, kept as the cross-check of the workgroup-parallel one)
+    const char* wenv = getenv("PDX_PQ_SNAPPY_WAVE");
+    const bool wave_form = wenv && wenv[0] == '1';
+    if (wave_form)
+      hipLaunchKernelGGL(k_pq_unpack, dim3((unsigned)std::min<size_t>(segs.size(), (size_t)kCUs * 16)), dim3(64), 0, st, dfile, draw, dsegs, (int)segs.size(), derr);
+    else
+      hipLaunchKernelGGL(k_pq_unsnap, dim3((unsigned)std::min<size_t>(segs.size(), (size_t)kCUs * 8)), dim3(kUsThreads), 0, st, dfile, draw, dsegs,
+                         (int)segs.size(), derr);
   }
   // ---- per column: levels -> valid bytes, dictionary, values (dense per page), expansion of the pages with nulls, bitmaps
   std::vector<uint8_t*> valid_bytes(f->cols.size(), nullptr);
@@ -1060,6 +1490,15 @@ int pdx_parquet_load(pdx_parquet_file* f, void* stream) {
   }
   // ---- results of the device-side checks + the null counts
   unsigned int herr = 0;
+#ifdef PDX_US_TIMING
+  {
+    unsigned int t[16];
+    PQ_HIP(hipMemcpyAsync(t, derr, sizeof(t), hipMemcpyDeviceToHost, st));
+    PQ_HIP(hipStreamSynchronize(st));
+    fprintf(stderr, "[pdx] k_pq_unsnap Kcycles: load %u decode %u mark %u place %u heads %u words %u resolve %u (sum over workgroups) writeout %u literal %u\n", t[4], t[5], t[6], t[7],
+            t[8], t[9], t[10], t[11], t[12]);
+  }
+#endif
   PQ_HIP(hipMemcpyAsync(&herr, derr, sizeof(herr), hipMemcpyDeviceToHost, st));
   if (!all_pages.empty()) PQ_HIP(hipMemcpyAsync(all_pages.data(), dpages, all_pages.size() * sizeof(PqPage), hipMemcpyDeviceToHost, st));
   PQ_HIP(hipStreamSynchronize(st));

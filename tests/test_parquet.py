@@ -238,3 +238,41 @@ def test_to_parquet_from_device_and_round_trip(px, tmp_path):
         assert (gok is None and ok is None) or np.array_equal(gok, ok), name
         sel = slice(None) if ok is None else ok
         assert np.array_equal(np.asarray(got)[sel], np.asarray(exp)[sel]), name
+
+
+def _snappy_patterns(rng, n):
+    """int64 / float64 columns whose PLAIN pages make Snappy emit every element shape the decoder has: long literals (random bits), a
+    literal + a copy per value (small integers: the ingest bench's keys), overlapping copies with offsets below their length (runs of one
+    byte / one value), copies with two-byte offsets that reach back tens of kilobytes -- across the decoder's 16 KB output tiles and
+    4 KB stream windows -- and chains of copies of copies (a period repeated through the page)."""
+    period = np.arange(5000, dtype=np.int64) * 7919 + 12345
+    blocks = np.concatenate([rng.integers(0, 2 ** 62, n // 8), np.zeros(n // 8, np.int64), np.tile(period, n // 8 // 5000 + 1)[:n // 8],
+                             rng.integers(0, 1 << 24, n // 8), np.full(n // 8, 0x0101010101010101, np.int64), np.arange(n // 8, dtype=np.int64),
+                             np.repeat(rng.integers(0, 2 ** 40, n // 8 // 37 + 1), 37)[:n // 8], rng.integers(-3, 3, n - 7 * (n // 8))]).astype(np.int64)
+    return {"random_bits": rng.integers(-(2 ** 62), 2 ** 62, n), "zeros": np.zeros(n, np.int64), "small_ints": rng.integers(0, 1 << 24, n),
+            "arange": np.arange(n, dtype=np.int64) * 3, "period_40k_bytes": np.tile(period, n // 5000 + 1)[:n], "one_byte": np.full(n, 0x0101010101010101, np.int64),
+            "blocks": blocks, "normal_f64": rng.standard_normal(n), "few_values_f64": rng.choice(rng.standard_normal(300), n)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("page_bytes,use_dict,version", [(1 << 20, False, "1.0"), (8 << 20, False, "2.0"), (1 << 14, False, "1.0"), (1 << 20, True, "2.0")])
+def test_snappy_decoder_element_shapes(px, monkeypatch, page_bytes, use_dict, version):
+    """pyarrow-written Snappy pages of the patterns above -> device columns, bit for bit; the workgroup-parallel decoder (pointer-jumping
+    parse, pointer-doubling copies) and the wave-per-page one it replaced (PDX_PQ_SNAPPY_WAVE=1) must agree with the source"""
+    pa = pytest.importorskip("pyarrow")
+    pq = pytest.importorskip("pyarrow.parquet")
+    import io
+    n = 600_011
+    cols = _snappy_patterns(np.random.default_rng(page_bytes + use_dict), n)
+    sink = io.BytesIO()
+    pq.write_table(pa.table(cols), sink, compression="snappy", use_dictionary=use_dict, data_page_size=page_bytes, row_group_size=n,
+                   data_page_version=version)
+    blob = sink.getvalue()
+    for wave in ("0", "1"):
+        monkeypatch.setenv("PDX_PQ_SNAPPY_WAVE", wave)
+        df = px.api.DataFrame.readParquet(blob)
+        assert df.num_rows() == n
+        for name, src in cols.items():
+            got, ok = df[name].col.to_numpy()
+            assert ok is None or ok.all(), name
+            assert np.array_equal(np.ascontiguousarray(got).view(np.uint64), np.ascontiguousarray(src).view(np.uint64)), (name, wave)
