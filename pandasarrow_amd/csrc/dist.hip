@@ -762,6 +762,7 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
   if (!res->sums || !res->means || !res->counts) return PDX_OOM;
   // ---- 3. grouped values + rows per local group
   StageTimer tm;
+  DeferSyncScope no_stage_waits;  // (the stages below hand device buffers on; the host waits where it reads a size back, and at the end)
   PDX_TRY(pdx_groupby_group_values(D.gb, values, st, &h.gv));
   tm.mark("group_values");
   int64_t* cnt_local = s.get<int64_t>((size_t)Gl);

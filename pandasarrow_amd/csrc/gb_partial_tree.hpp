@@ -98,14 +98,20 @@ __global__ void __launch_bounds__(256) k_partial_fill(const double* __restrict__
 // sums interior leaf l (16 contiguous values), six shuffle steps build every aligned perfect subtree at once (t[k] at lane r = the tree
 // over leaves [r, r + 2^k), left + right as the counter merges them), the boundary-leaf fragments are copied by the lanes.  The thread
 // form walks each group with one thread and a 64-entry counter in scratch memory (2.2 ms per 5e8 rows).
+// LPG lanes per group: 64 (one wave per group, <= 64 interior leaves), or 16 -- four groups per wave for the short groups of a sharded
+// run (8 GPUs x 1e6 keys: ~125 rows = 6-8 interior leaves per group and rank; the 64-lane form left 7/8 of every wave idle: 0.71 ms per
+// 1.25e8 rows).  A group whose interior leaves do not fit LPG lanes is left to the wider form (LPG = 16: `wide_too`) or to the thread form.
+template <int LPG>
 __global__ void __launch_bounds__(256) k_partial_fill_wave(const double* __restrict__ vals, const uint32_t* __restrict__ seg_start,
                                                            const uint32_t* __restrict__ occ_of_gid, const int64_t* __restrict__ order, int64_t G,
                                                            const int64_t* __restrict__ prefix, const int64_t* __restrict__ gid_map,
                                                            const int64_t* __restrict__ rec_off, int64_t* __restrict__ rec_key,
                                                            double* __restrict__ rec_val) {
-  const int lane = threadIdx.x & 63;
-  const int64_t nw = (int64_t)gridDim.x * 4;
-  for (int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); j < G; j += nw) {
+  static_assert(LPG == 16 || LPG == 64, "head / tail fragments (<= 15 rows) take one lane each");
+  constexpr int kLevels = LPG == 64 ? 6 : 4, kPerBlock = 256 / LPG;
+  const int lane = threadIdx.x & (LPG - 1);
+  const int64_t nw = (int64_t)gridDim.x * kPerBlock;
+  for (int64_t j = (int64_t)blockIdx.x * kPerBlock + (threadIdx.x / LPG); j < G; j += nw) {
     const int64_t lg = order ? order[j] : j;
     const uint32_t k = occ_of_gid[lg];
     const double* v = vals + seg_start[k];
@@ -116,20 +122,22 @@ __global__ void __launch_bounds__(256) k_partial_fill_wave(const double* __restr
     const int64_t gkey = gid_map[lg] * 64;
     const int64_t pos0 = rec_off[j];
     if (kf > kl) {  // the whole range lies inside one leaf (< 31 rows): fragments only
-      for (int64_t i = lane; i < c; i += 64) {
+      if (LPG == 64) continue;  // (emitted by the 16-lane form, which always runs)
+      for (int64_t i = lane; i < c; i += LPG) {
         rec_key[pos0 + i] = gkey;
         rec_val[pos0 + i] = v[i];
       }
       continue;
     }
     const int nint = (int)(kl - kf);
-    if (kl - kf > 64) continue;  // long group: k_partial_fill
+    if (kl - kf > LPG) continue;                    // wider form / long group: k_partial_fill
+    if (LPG == 64 && kl - kf <= 16) continue;       // (the 16-lane form's)
     const int h = (int)(16 * kf - a);
     if (lane < h) {
       rec_key[pos0 + lane] = gkey;
       rec_val[pos0 + lane] = v[lane];
     }
-    double t[7];
+    double t[kLevels + 1];
     t[0] = 0.0;
     if (lane < nint) {
       const double* lv = v + h + 16 * lane;
@@ -139,15 +147,18 @@ __global__ void __launch_bounds__(256) k_partial_fill_wave(const double* __restr
       if (acc != acc) acc = pw_leaf_redo(16, [&](int e) { return lv[e]; });
       t[0] = acc;
     }
+    // (a source lane outside the group's LPG lanes hands back the reader's own value: those subtrees reach past the last leaf and are
+    //  never emitted.  All lanes of the wave take part in the shuffles of their own group: the loop above is left only by whole groups,
+    //  and __shfl_down with a width reads inside the width-aligned lane group)
 #pragma unroll
-    for (int q = 0; q < 6; ++q) t[q + 1] = pw_merge(t[q], __shfl_down(t[q], 1 << q, 64));
+    for (int q = 0; q < kLevels; ++q) t[q + 1] = pw_merge(t[q], __shfl_down(t[q], 1 << q, LPG));
     int64_t pos = pos0 + h;
     for (int64_t sidx = kf; sidx < kl;) {
       const int lvl = (int)aligned_block_level(sidx, kl);
       if (lane == (int)(sidx - kf)) {
         double val = t[0];
 #pragma unroll
-        for (int q = 1; q < 7; ++q) val = lvl == q ? t[q] : val;
+        for (int q = 1; q <= kLevels; ++q) val = lvl == q ? t[q] : val;
         rec_key[pos] = gkey + lvl + 1;
         rec_val[pos] = val;
       }
@@ -269,7 +280,7 @@ int pdx_groupby_group_values(pdx_groupby* gb, const pdx_column* values, void* st
     g->vals_sorted = vc;
     hipLaunchKernelGGL(k_occ_of_gid, dim3(grid_for(G, 256)), dim3(256), 0, st, gb->gid_of_occ, G, g->occ_of_gid);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && !defer_sync()) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return hip_fail(e, "pdx_groupby_group_values");
   } else if (n > 0) {
     Scratch s;
@@ -288,7 +299,7 @@ int pdx_groupby_group_values(pdx_groupby* gb, const pdx_column* values, void* st
     g->vals_sorted = reinterpret_cast<const double*>(vs);
     hipLaunchKernelGGL(k_occ_of_gid, dim3(grid_for(G, 256)), dim3(256), 0, st, gb->gid_of_occ, G, g->occ_of_gid);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && !defer_sync()) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return hip_fail(e, "pdx_groupby_group_values");
   }
   *out = gowner.release();
@@ -304,7 +315,7 @@ int pdx_grouped_counts(pdx_grouped* g, int64_t* out_counts, void* stream) {
   g->stream = st;  // frees of the handle's blocks are ordered behind this stream
   if (g->G) hipLaunchKernelGGL(k_grouped_counts, dim3(grid_for(g->G, 256)), dim3(256), 0, st, g->seg_start, g->gb->gid_of_occ, g->G, out_counts);
   PDX_LAUNCH_CHECK();
-  PDX_HIP(hipStreamSynchronize(st));
+  if (!defer_sync()) PDX_HIP(hipStreamSynchronize(st));
   return PDX_OK;
 }
 int pdx_grouped_partial_plan(pdx_grouped* g, const int64_t* prefix, const int64_t* order, int64_t* out_total, void* stream) {
@@ -337,15 +348,18 @@ int pdx_grouped_partial_fill(pdx_grouped* g, const int64_t* gid_map, int64_t* re
     PDX_PROFILE("partial_fill", st);
     {
       const int wave_form = [] { const char* e = getenv("PDX_PARTIAL_FILL_WAVE"); return !(e && e[0] == '0'); }() ? 1 : 0;
-      if (wave_form)
-        hipLaunchKernelGGL(k_partial_fill_wave, dim3((unsigned)std::min<int64_t>(ceil_div(g->G, 4), (int64_t)kCUs * 32)), dim3(256), 0, st, g->vals_sorted,
-                           g->seg_start, g->occ_of_gid, g->order, g->G, g->prefix, gid_map, g->rec_off, rec_key, rec_val);
+      if (wave_form) {  // groups of <= 16 interior leaves (and the ones inside one leaf): 16 lanes each; <= 64: a wave each; longer: a thread each
+        hipLaunchKernelGGL((k_partial_fill_wave<16>), dim3((unsigned)std::min<int64_t>(ceil_div(g->G, 16), (int64_t)kCUs * 32)), dim3(256), 0, st,
+                           g->vals_sorted, g->seg_start, g->occ_of_gid, g->order, g->G, g->prefix, gid_map, g->rec_off, rec_key, rec_val);
+        hipLaunchKernelGGL((k_partial_fill_wave<64>), dim3((unsigned)std::min<int64_t>(ceil_div(g->G, 4), (int64_t)kCUs * 32)), dim3(256), 0, st,
+                           g->vals_sorted, g->seg_start, g->occ_of_gid, g->order, g->G, g->prefix, gid_map, g->rec_off, rec_key, rec_val);
+      }
   hipLaunchKernelGGL(k_partial_fill, dim3(grid_for(g->G, 256)), dim3(256), 0, st, g->vals_sorted, g->seg_start, g->occ_of_gid, g->order, g->G, g->prefix,
                        gid_map, g->rec_off, rec_key, rec_val, wave_form);
     }
   }
   PDX_LAUNCH_CHECK();
-  PDX_HIP(hipStreamSynchronize(st));
+  if (!defer_sync()) PDX_HIP(hipStreamSynchronize(st));
   return PDX_OK;
 }
 int pdx_replay_partials(const int64_t* rec_key, const double* rec_val, int64_t m, int64_t gid_lo, int64_t n_own, double* out_sum, void* stream) {

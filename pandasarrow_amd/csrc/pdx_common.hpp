@@ -38,6 +38,15 @@ void pool_trim();
 void note_stream(hipStream_t s);  // thread-local: the stream whose queued kernels may still use blocks this thread frees
 hipStream_t current_stream();
 void* pinned_slot();  // 64 pinned bytes of this host thread (or nullptr)
+// thread-local: an orchestration inside the library (dist.hip) that drains its stream itself asks the entry points it calls to leave out
+// their trailing hipStreamSynchronize (their outputs are device buffers, stream-ordered): one host wait per stage less
+bool defer_sync();
+void set_defer_sync(bool on);
+struct DeferSyncScope {
+  bool prev;
+  DeferSyncScope() : prev(defer_sync()) { set_defer_sync(true); }
+  ~DeferSyncScope() { set_defer_sync(prev); }
+};
 
 struct Scratch {  // RAII: everything allocated through it is returned to the pool on scope exit
   static constexpr int kMax = 64;

@@ -114,6 +114,9 @@ bool block_ready(const FreeBlock& b, hipStream_t want) {
 }
 }  // namespace
 
+thread_local bool t_defer_sync = false;
+bool defer_sync() { return t_defer_sync; }
+void set_defer_sync(bool on) { t_defer_sync = on; }
 void note_stream(hipStream_t s) { t_stream = s; }
 hipStream_t current_stream() { return t_stream; }
 

@@ -291,6 +291,31 @@ def _unpack_bits_device(bits, n):
     return ((b[:, None] >> shifts[None, :]) & 1).reshape(-1)[:n].to(torch.bool)
 
 
+class _LazyResult(dict):
+    """result dict whose "keys_ok" (the null key's flag as a bool tensor) is unpacked from the key column's validity bitmap on first use:
+    the headline step never looks at it, and the unpacking is four small torch launches per step"""
+
+    def __init__(self, items, kcol, G):
+        super().__init__(items)
+        self._kcol, self._G = kcol, G
+
+    def __missing__(self, name):
+        if name != "keys_ok":
+            raise KeyError(name)
+        from . import column as K
+
+        ok = (_unpack_bits_device(self._kcol.validity, self._G) if self._kcol.validity is not None
+              else torch.ones(self._G, dtype=torch.bool, device=K._device()))
+        self[name] = ok
+        return ok
+
+    def __contains__(self, name):
+        return name == "keys_ok" or super().__contains__(name)
+
+    def get(self, name, default=None):
+        return self[name] if name in self else default
+
+
 def _fetch_dist_result(lib, h, key_dtype):
     """pdx_dist_groupby* -> the result dict of the sharded entry points (device tensors); destroys the handle."""
     import ctypes as C
@@ -311,10 +336,9 @@ def _fetch_dist_result(lib, h, key_dtype):
         records = int(lib.pdx_dist_groupby_num_records(h))
     finally:
         lib.pdx_dist_groupby_destroy(h)
-    # the null key's flag, unpacked on the device (a to_numpy() of the key column here cost an 8 MB device-to-host copy per step)
-    ok_t = _unpack_bits_device(kcol.validity, G) if kcol.validity is not None else torch.ones(G, dtype=torch.bool, device=dev)
-    return {"G": G, "keys": kcol.values[:G], "keys_ok": ok_t, "first_rows": first[:G], "kinds": [L.AGG_SUM, L.AGG_MEAN, L.AGG_COUNT],
-            "outs": [(sums[:G], None), (means[:G], None), (counts[:G], None)], "records": records}
+    # (the null key's flag is unpacked on the device, and only when somebody asks for it)
+    return _LazyResult({"G": G, "keys": kcol.values[:G], "first_rows": first[:G], "kinds": [L.AGG_SUM, L.AGG_MEAN, L.AGG_COUNT],
+                        "outs": [(sums[:G], None), (means[:G], None), (counts[:G], None)], "records": records}, kcol, G)
 
 
 def _fetch_agg_result(lib, h, key_dtype, val_dtype, kinds):
