@@ -14,7 +14,10 @@ struct AggTuning {
   bool narrow = true;       // PDX_SORT_NARROW=0: 4-byte slots through every pass
   bool null_pw = false;     // PDX_FLR_NULL_PW=1: thread-per-leaf form for nullable sum / mean / count
   int64_t min_rows = (int64_t)1 << 22;  // PDX_FUSED_LAST_DIGIT_MIN_ROWS
-  int64_t min_run = 8192;   // PDX_FUSED_LAST_DIGIT_MIN_RUN: a run is one workgroup's sequential work (1e8 groups: 119-row runs)
+  // PDX_FUSED_LAST_DIGIT_MIN_RUN: a run is one workgroup's sequential work (1e8 groups: 119-row runs).  Was 8192 until round 4: the
+  // 1e6-key query at an 8-GPU shard's size (1.25e8 rows: 7629-row runs) fell just below it and took the classic full sort, 4.18 ms
+  // against 2.69 ms fused; fused also wins at 5e7 / 2e7 / 3e7 rows (tools/sweep_min_run.sh: 2.25 -> 1.61, 1.60 -> 1.28, 1.46 -> 1.07 ms)
+  int64_t min_run = 1024;
   int min_low = 10;         // PDX_FUSED_LAST_DIGIT_MIN_LOW_BITS
   int flr_wgs_per_cu = 24;  // PDX_FLR_WGS_PER_CU
   int fw_wgs_per_cu = 48;   // PDX_FLR_WAVE_WGS_PER_CU

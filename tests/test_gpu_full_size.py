@@ -135,13 +135,9 @@ def test_c3_against_the_oracle_at_1e8_rows(px, monkeypatch, dense):
     plan = gb.last_plan()
     hk, hv = orc.synth_keys(0, n, nk), orc.synth_vals(0, n)
     ek, es, em, ec = orc.groupby_sum_mean_count(hk, hv, nthreads=threads)
-    # (100 rows per group: 6103 rows per run of the fused layout is under its 8192-row threshold, so the DEFAULT plan at this size is the
-    #  full sort + the classic segment reducers; the narrowing sort + fused last digit the bench times is held to the oracle at 1.35e8 /
-    #  2.7e8 rows by tests/test_gpu_round3.py::test_production_chain_headline_geometry / _hash_path)
-    if dense == "1":
-        assert plan["slots"] == "dense" and plan["layout"] == "full" and plan["reducer"] == "seg_reduce", plan
-    else:
-        assert plan["slots"] == "hash_lds" and plan["layout"] == "full" and plan["reducer"] == "seg_reduce", plan
+    # (100 rows per group = 6103-row runs: since round 4's lower run threshold the DEFAULT plan at this size is the narrowing sort + the
+    #  fused last digit, i.e. the kernels the bench times at 1e9 rows)
+    assert plan["slots"] == ("dense" if dense == "1" else "hash_lds") and plan["layout"] == "fused" and plan["reducer"].startswith("flr_reduce"), plan
     assert np.array_equal(gb.unique_keys().to_numpy()[0], ek)
     assert np.array_equal(s.to_numpy()[0].view(np.uint64), es.view(np.uint64))
     assert np.array_equal(m.to_numpy()[0].view(np.uint64), em.view(np.uint64))
