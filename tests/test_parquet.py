@@ -268,8 +268,12 @@ def test_snappy_decoder_element_shapes(px, monkeypatch, page_bytes, use_dict, ve
     pq.write_table(pa.table(cols), sink, compression="snappy", use_dictionary=use_dict, data_page_size=page_bytes, row_group_size=n,
                    data_page_version=version)
     blob = sink.getvalue()
-    for wave in ("0", "1"):
-        monkeypatch.setenv("PDX_PQ_SNAPPY_WAVE", wave)
+    # ("pieces": the file goes up in 1 MB pieces and the pages of a piece are decoded on a side stream while the next piece is copied -- the
+    #  form files of >= 64 MB take by default)
+    for wave in ("0", "1", "pieces"):
+        monkeypatch.setenv("PDX_PQ_SNAPPY_WAVE", "1" if wave == "1" else "0")
+        if wave == "pieces":
+            monkeypatch.setenv("PDX_PQ_UPLOAD_PIECE_MB", "1")
         df = px.api.DataFrame.readParquet(blob)
         assert df.num_rows() == n
         for name, src in cols.items():
