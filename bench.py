@@ -646,6 +646,16 @@ def main():
         # first multi-rank RCCL run of this build: the library's orchestration against the older one over torch.distributed's collectives,
         # same shards, bit for bit on every rank -- after the line is out; the verdict goes to stderr and into the exit status
         lres, lkeys, lvals, llo = late_inputs
+        # (a watchdog: the line is out; a stall of this second orchestration must end the run, not hang it until the driver's limit)
+        import threading
+
+        def _give_up():
+            print("[bench] late cross-check did not finish within 120 s: abandoned (the JSON line above stands)", file=sys.stderr, flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(float(os.environ.get("PDX_BENCH_LATE_CHECK_LIMIT_S", "120")), _give_up)
+        watchdog.daemon = True
+        watchdog.start()
         ref = pdist.groupby_sum_mean_count_sharded(pdist.HipEngine(), lkeys, lvals, row_offset=llo)
         same = (int(ref["G"]) == int(lres["G"]) and torch.equal(ref["keys"], lres["keys"]) and torch.equal(ref["first_rows"], lres["first_rows"])
                 and all(torch.equal(a[0].view(torch.int64), b[0].view(torch.int64)) for a, b in zip(ref["outs"], lres["outs"])))
@@ -654,6 +664,7 @@ def main():
         if rank == 0:
             print(f"[bench] cross-check of the C-ABI orchestration (raw RCCL calls) against torch.distributed's collectives on all {world} ranks: "
                   + ("bit-identical" if flag.item() else "MISMATCH"), file=sys.stderr, flush=True)
+        watchdog.cancel()
         if not flag.item():
             raise SystemExit(3)
     if sharded:
