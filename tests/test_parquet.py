@@ -280,3 +280,42 @@ def test_snappy_decoder_element_shapes(px, monkeypatch, page_bytes, use_dict, ve
             got, ok = df[name].col.to_numpy()
             assert ok is None or ok.all(), name
             assert np.array_equal(np.ascontiguousarray(got).view(np.uint64), np.ascontiguousarray(src).view(np.uint64)), (name, wave)
+
+
+@pytest.mark.gpu
+def test_snappy_decoders_agree_on_damaged_streams(px, monkeypatch):
+    """A few bytes of a Snappy file flipped at random, 160 times: the workgroup-parallel decoder and the wave-per-page one must come to the
+    same verdict -- both refuse the file, or both decode it to the same bits (a flip inside a literal run changes values, not the shape).
+    Nothing may fault or hang: every length / offset of the damaged stream is checked against both buffers before it is used."""
+    pa = pytest.importorskip("pyarrow")
+    pq = pytest.importorskip("pyarrow.parquet")
+    import io
+    n = 120_000
+    rng = np.random.default_rng(77)
+    cols = {k: v for k, v in _snappy_patterns(rng, n).items() if k in ("small_ints", "blocks", "period_40k_bytes", "few_values_f64")}
+    sink = io.BytesIO()
+    pq.write_table(pa.table(cols), sink, compression="snappy", use_dictionary=False, data_page_size=1 << 16, row_group_size=n)
+    good = sink.getvalue()
+    verdicts = {"both_refuse": 0, "both_decode": 0}
+    for trial in range(160):
+        bad = bytearray(good)
+        for _ in range(int(rng.integers(1, 5))):
+            at = int(rng.integers(64, len(good) - 4096))  # (the footer stays: the damage is in the pages and their headers)
+            bad[at] = int(rng.integers(0, 256))
+        outs = []
+        for wave in ("0", "1"):
+            monkeypatch.setenv("PDX_PQ_SNAPPY_WAVE", wave)
+            try:
+                df = px.api.DataFrame.readParquet(bytes(bad))
+                outs.append([np.ascontiguousarray(df[name].col.to_numpy()[0]).view(np.uint64).copy() for name in cols])
+            except RuntimeError as e:
+                assert "pdx_parquet" in str(e)
+                outs.append(None)
+        assert (outs[0] is None) == (outs[1] is None), (trial, "one decoder refused what the other accepted")
+        if outs[0] is None:
+            verdicts["both_refuse"] += 1
+        else:
+            verdicts["both_decode"] += 1
+            for a, b, name in zip(outs[0], outs[1], cols):
+                assert np.array_equal(a, b), (trial, name)
+    assert verdicts["both_refuse"] >= 10 and verdicts["both_decode"] >= 10, verdicts
