@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <functional>
 #include <memory>
 #include <condition_variable>
 #include <mutex>
@@ -377,7 +378,31 @@ struct pdx_dist {
   pdx_dist_transport tr{};
   std::unique_ptr<RcclCtx> rccl_ctx;  // built-in transport
   bool force = false;
+  // a second stream of this communicator: the local value sort of a sharded group-by runs on it while the dictionary exchange (collectives
+  // and the regrouping of W dictionaries) occupies the caller's stream -- neither needs the other's result.  Created on first use.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_ok() {
+    if (side) return true;
+    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      if (ev_fork) (void)hipEventDestroy(ev_fork);
+      if (ev_join) (void)hipEventDestroy(ev_join);
+      if (side) (void)hipStreamDestroy(side);
+      side = nullptr;
+      ev_fork = ev_join = nullptr;
+      return false;
+    }
+    return true;
+  }
   ~pdx_dist() {
+    if (side) {
+      (void)hipStreamSynchronize(side);
+      (void)hipEventDestroy(ev_fork);
+      (void)hipEventDestroy(ev_join);
+      (void)hipStreamDestroy(side);
+    }
     if (rccl_ctx && rccl_ctx->comm && rccl().CommDestroy) (void)rccl().CommDestroy(rccl_ctx->comm);
   }
 };
@@ -551,14 +576,17 @@ struct GlobalDict {
     if (gb) pdx_groupby_destroy(gb);
   }
 };
+// after_create (may be empty): called once the local handle exists and before the first collective -- work that needs only the local handle
+// (the value sort) is started there on the communicator's side stream; its status joins the gate like the create's own
 template <typename Own>
 int build_dictionary(pdx_dist* d, const pdx_column* keys, int local_rc, const char* what, int64_t row_offset, Scratch& s, hipStream_t st, Own&& own,
-                     GlobalDict* D) {
+                     GlobalDict* D, const std::function<int(pdx_groupby*)>& after_create = {}) {
   const int W = d->world, r = d->rank;
   const bool solo = W == 1 && !d->force;
   // ---- 1. local dictionary (a failure here is reported through the gate below, not by leaving)
   StageTimer tm;
   if (local_rc == PDX_OK) local_rc = pdx_groupby_create(keys, st, &D->gb);
+  if (local_rc == PDX_OK && after_create) local_rc = after_create(D->gb);
   tm.mark("local_create");
   const int64_t Gl = local_rc == PDX_OK ? pdx_groupby_num_groups(D->gb) : 0;
   D->Gl = Gl;
@@ -749,7 +777,41 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
       if (gv) pdx_grouped_destroy(gv);
     }
   } h;
-  PDX_TRY(build_dictionary(d, keys, lrc, "pdx_dist_groupby_sum_mean_count", row_offset, s, st, [&](size_t c) { return res->own<int64_t>(c); }, &D));
+  // the local value sort starts on the side stream as soon as the local handle exists; the caller's stream joins it before the counts
+  // (PDX_DIST_OVERLAP=0: everything on the caller's stream, one stage after the other)
+  static const bool overlap_on = [] { const char* e = getenv("PDX_DIST_OVERLAP"); return !(e && e[0] == '0'); }();
+  struct SideJoin {  // declared after D and h: runs before their destructors, so nothing they free is still read on the side stream
+    pdx_dist* d;
+    hipStream_t st;
+    bool pending = false;
+    void join() {
+      if (pending) (void)hipStreamWaitEvent(st, d->ev_join, 0);
+      pending = false;
+    }
+    ~SideJoin() { join(); }
+  } side_join{d, st};
+  std::function<int(pdx_groupby*)> start_sort;
+  if (!solo && overlap_on && d->side_ok())
+    start_sort = [&](pdx_groupby* gb) -> int {
+      if (hipEventRecord(d->ev_fork, st) != hipSuccess || hipStreamWaitEvent(d->side, d->ev_fork, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return PDX_OK;  // (no fork: the sort runs on the caller's stream below)
+      }
+      int rc;
+      {
+        StreamNote on_side(d->side);  // (this thread's frees inside the call are ordered behind the side stream; restored on leaving)
+        DeferSyncScope no_wait;
+        rc = pdx_groupby_group_values(gb, values, d->side, &h.gv);
+      }
+      note_stream(st);
+      if (hipEventRecord(d->ev_join, d->side) == hipSuccess) side_join.pending = true;
+      else {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(d->side);
+      }
+      return rc;
+    };
+  PDX_TRY(build_dictionary(d, keys, lrc, "pdx_dist_groupby_sum_mean_count", row_offset, s, st, [&](size_t c) { return res->own<int64_t>(c); }, &D, start_sort));
   res->keys = D.keys;
   res->keys_ok = D.keys_ok;
   res->first_rows = D.first_rows;
@@ -763,7 +825,8 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
   // ---- 3. grouped values + rows per local group
   StageTimer tm;
   DeferSyncScope no_stage_waits;  // (the stages below hand device buffers on; the host waits where it reads a size back, and at the end)
-  PDX_TRY(pdx_groupby_group_values(D.gb, values, st, &h.gv));
+  if (h.gv) side_join.join();  // sorted on the side stream meanwhile
+  else PDX_TRY(pdx_groupby_group_values(D.gb, values, st, &h.gv));
   tm.mark("group_values");
   int64_t* cnt_local = s.get<int64_t>((size_t)Gl);
   int64_t* prefix_local = s.get<int64_t>((size_t)Gl);
