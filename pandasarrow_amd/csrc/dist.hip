@@ -801,6 +801,7 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
       {
         StreamNote on_side(d->side);  // (this thread's frees inside the call are ordered behind the side stream; restored on leaving)
         DeferSyncScope no_wait;
+        FusedEmitScope records_only;  // (two sort passes: the last digit is left to the kernel that emits the records)
         rc = pdx_groupby_group_values(gb, values, d->side, &h.gv);
       }
       note_stream(st);
@@ -825,8 +826,12 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
   // ---- 3. grouped values + rows per local group
   StageTimer tm;
   DeferSyncScope no_stage_waits;  // (the stages below hand device buffers on; the host waits where it reads a size back, and at the end)
-  if (h.gv) side_join.join();  // sorted on the side stream meanwhile
-  else PDX_TRY(pdx_groupby_group_values(D.gb, values, st, &h.gv));
+  if (h.gv) {
+    side_join.join();  // sorted on the side stream meanwhile
+  } else {
+    FusedEmitScope records_only;
+    PDX_TRY(pdx_groupby_group_values(D.gb, values, st, &h.gv));
+  }
   tm.mark("group_values");
   int64_t* cnt_local = s.get<int64_t>((size_t)Gl);
   int64_t* prefix_local = s.get<int64_t>((size_t)Gl);

@@ -173,6 +173,263 @@ __global__ void __launch_bounds__(256) k_partial_fill_wave(const double* __restr
   }
 }
 
+// ---------------------------------------------------------------- fused last digit that EMITS partial-tree records (sharded sums)
+// The dense path of k_flr_reduce with another ending: instead of one sum per group, the local share of every group leaves as the records
+// of the partial-tree exchange (gb_partial_tree.hpp) -- the rows of the group's first and last global leaf as raw values, the leaves in
+// between as the aligned blocks of Arrow's tree over the group's GLOBAL row numbering.  a = rows of the group on lower ranks: the open
+// leaf starts with a % 16 virtual rows, so the leaf grid of the staging is the global one; the counter starts at kf = ceil(a / 16) with
+// those bits VIRTUAL: a finished node whose left sibling is virtual is an "orphan" (a right child whose left sibling lives on a lower
+// rank) and is emitted as it stands; orphans come out in ascending level = row order, then the pending nodes in descending level.
+// Replaces the third sort pass + k_partial_fill of the sharded group-by (25 B/row) by this kernel's 9 B/row.
+constexpr int kEmLevels = 16;  // real nodes only: a run of <= 2^19 rows (kFlrMaxRun, checked by the host) holds <= 2^15 leaves
+__global__ void __launch_bounds__(kSortBlock, 3) k_flr_emit(const uint8_t* __restrict__ keys, const double* __restrict__ vals, const uint32_t* __restrict__ run_start,
+                                                         int64_t nruns, int low_bits, const uint32_t* __restrict__ gid_of_slot, int64_t nslots, int64_t G,
+                                                         const int64_t* __restrict__ prefix, const uint32_t* __restrict__ seg_start,
+                                                         const uint32_t* __restrict__ occ_of_gid, const uint32_t* __restrict__ occ_slot,
+                                                         const int64_t* __restrict__ rec_off_lg,
+                                                         const int64_t* __restrict__ gid_map, int64_t* __restrict__ rec_key, double* __restrict__ rec_val) {
+  constexpr int R = 1 << kFlrBits;
+  __shared__ __attribute__((aligned(16))) double svals[16 * kFlrLeafStride];
+  __shared__ __attribute__((aligned(8))) double leafsum[kFlrMaxLeaves + 1];
+  __shared__ uint32_t cnt[kSortWaves][R];
+  __shared__ unsigned long long match[kSortWaves][R];
+  __shared__ double csum[kEmLevels][R];
+  __shared__ double open_acc[R];
+  __shared__ int lp[R + 1];
+  __shared__ uint8_t leaf_d[kFlrLeafStride + 3];
+  __shared__ uint32_t dinfo[R];
+  // per group (digit) of the run and tile: the leaf coordinates [lo, hi) of its rows that are NOT raw records (lo | hi << 16; rows of the
+  // group's first and last global leaf leave raw), and what a raw row needs: rows before the tile, head rows, first tail row, offsets
+  __shared__ uint32_t g_mid[R], g_before[R], g_head[R], g_tail0[R];
+  __shared__ int g_tailbase[R];
+  __shared__ long long g_roff[R], g_gkey[R];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  for (int d = tid; d < kSortWaves * R; d += kSortBlock) {
+    (&cnt[0][0])[d] = 0;
+    (&match[0][0])[d] = 0;
+  }
+  __syncthreads();
+  for (int64_t run = blockIdx.x; run < nruns; run += gridDim.x) {
+    const int64_t s = run_start[run], e = run_start[run + 1];
+    if (s == e) continue;
+    // ---- per-group parameters (wave 0, lane = top digit)
+    int pos = 0;
+    unsigned long long cmask = 0, vmask = 0;
+    long long nrows = 0, my_roff = 0, my_gkey = 0, rec_at = 0;
+    uint32_t my_head = 0, my_tail0 = 0;
+    bool head_partial = false, first_leaf_seen = false, live = false;
+    int tile_c = 0, tile_lp = 0;
+    if (wave == 0) {
+      const uint32_t slot = ((uint32_t)lane << low_bits) | (uint32_t)run;
+      // (a digit beyond the handle's slots -- the top digit of a slot space that is not a power of two -- has no rows and no entry)
+      const uint32_t lg = (int64_t)slot < nslots ? gid_of_slot[slot] : 0xFFFFFFFFu;
+      long long a = 0, C = 0;
+      // (gid_of_slot is only defined on occupied slots: the entry counts when the group it names sits on this very slot)
+      if ((int64_t)lg < G && occ_slot[occ_of_gid[lg]] == slot) {
+        const uint32_t k = occ_of_gid[lg];
+        C = (long long)seg_start[k + 1] - (long long)seg_start[k];
+        a = prefix[lg];
+        my_roff = rec_off_lg[lg];
+        my_gkey = gid_map[lg] * 64;
+        live = C > 0;
+      }
+      const long long b = a + C, kf = (a + 15) >> 4, kl = b >> 4;
+      const bool allraw = kf > kl;
+      const long long h = allraw ? C : 16 * kf - a, ntail = allraw ? 0 : b - 16 * kl;
+      long long nnodes = 0;
+      if (!allraw)
+        for (long long sidx = kf; sidx < kl; ++nnodes) sidx += 1ll << aligned_block_level(sidx, kl);
+      pos = (int)(a & 15);
+      head_partial = pos != 0 || allraw;  // the first leaf this group finishes is not a node (its rows leave raw)
+      cmask = vmask = allraw ? 0ull : (unsigned long long)kf;
+      my_head = (uint32_t)h;
+      my_tail0 = (uint32_t)(C - ntail);
+      rec_at = my_roff + h;  // the next node record (orphans leave as they arise, the pending nodes at the end of the run)
+      g_head[lane] = my_head;
+      g_tail0[lane] = my_tail0;
+      g_tailbase[lane] = (int)(h + nnodes - (C - ntail));
+      g_roff[lane] = my_roff;
+      g_gkey[lane] = my_gkey;
+      open_acc[lane] = 0.0;
+#pragma unroll
+      for (int l = 0; l < kEmLevels; ++l) csum[l][lane] = 0.0;
+    }
+    uint32_t key[kFlrItems];
+    double val[kFlrItems];
+    auto load_tile = [&](int64_t t0) {
+      const int rows = (int)(e - t0 < kFlrTile ? e - t0 : kFlrTile);
+#pragma unroll
+      for (int q = 0; q < kFlrItems; ++q) {
+        const int r = wave * (64 * kFlrItems) + q * 64 + lane;
+        const int rr = r < rows ? r : rows - 1;
+        key[q] = keys[t0 + rr];
+        val[q] = vals[t0 + rr];
+      }
+    };
+    load_tile(s);
+    for (int64_t t0 = s; t0 < e; t0 += kFlrTile) {
+      const int rows = (int)(e - t0 < kFlrTile ? e - t0 : kFlrTile);
+      uint32_t rank[kFlrItems];
+#pragma unroll
+      for (int q = 0; q < kFlrItems; ++q) {
+        const int r = wave * (64 * kFlrItems) + q * 64 + lane;
+        rank[q] = wave_match_rank(match[wave], cnt[wave], key[q] & (R - 1), r < rows, lane, lt_mask);
+      }
+      __syncthreads();
+      if (tid < R) {
+        uint32_t cw[kSortWaves];
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) cw[w] = cnt[w][tid];
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) {
+          const uint32_t c = cw[w];
+          cw[w] = tot;
+          tot += c;
+        }
+        const int c = (int)tot;
+        const uint32_t nl = c > 0 ? (uint32_t)(pos + c + 15) >> 4 : 0u;
+        const uint32_t both = wave_inclusive_scan(tot | (nl << 16), SumOp());
+        const uint32_t lincl = both >> 16, lex = lincl - nl;
+        const uint32_t base = 16u * lex + (uint32_t)pos;
+        tile_c = c;
+        tile_lp = (int)lex;
+        dinfo[tid] = lex | ((uint32_t)pos << 12) | ((uint32_t)c << 16);
+        if (c > 0) leaf_d[lex] = (uint8_t)tid;
+        if (tid == R - 1) lp[R] = (int)lincl;
+        // rows of this tile with group-local index in [head, tail0) stay inside: in leaf coordinates (base + index - rows before the tile)
+        const long long before = nrows;
+        long long lo = (long long)base + ((long long)my_head - before), hi = (long long)base + ((long long)my_tail0 - before);
+        lo = lo < 0 ? 0 : (lo > 65535 ? 65535 : lo);
+        hi = hi < 0 ? 0 : (hi > 65535 ? 65535 : hi);
+        g_mid[tid] = (uint32_t)lo | ((uint32_t)hi << 16);
+        g_before[tid] = (uint32_t)before;
+        nrows += c;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) cnt[w][tid] = cw[w] + base;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < kFlrItems; ++q) rank[q] += cnt[wave][key[q] & (R - 1)];
+      uint32_t mid[kFlrItems];
+#pragma unroll
+      for (int q = 0; q < kFlrItems; ++q) mid[q] = g_mid[key[q] & (R - 1)];
+#pragma unroll
+      for (int q = 0; q < kFlrItems; ++q) {
+        const int r = wave * (64 * kFlrItems) + q * 64 + lane;
+        if (r < rows) {
+          const uint32_t d = key[q] & (R - 1);
+          const uint32_t p = rank[q];
+          if ((p & 15u) == 0) leaf_d[p >> 4] = (uint8_t)d;  // this row opens a leaf
+          svals[((p & 14u) >> 1) * (2 * kFlrLeafStride) + (p >> 4) * 2 + (p & 1u)] = val[q];
+          if (p < (mid[q] & 0xFFFFu) || p >= (mid[q] >> 16)) {  // a row of the group's first or last global leaf: a raw record
+            const uint32_t di = dinfo[d];
+            const uint32_t i = g_before[d] + (p - (16u * (di & 0xFFFu) + ((di >> 12) & 15u)));
+            const long long idx = i < g_head[d] ? (long long)i : (long long)i + g_tailbase[d];
+            const long long at = g_roff[d] + idx;
+            rec_key[at] = g_gkey[d];
+            rec_val[at] = val[q];
+          }
+        }
+      }
+      if (t0 + kFlrTile < e) load_tile(t0 + kFlrTile);
+      __syncthreads();
+      for (int d = tid; d < kSortWaves * R; d += kSortBlock) (&cnt[0][0])[d] = 0;
+      {
+        const int NL = lp[R];
+        for (int Lf = tid; Lf < NL; Lf += kSortBlock) {
+          const int d = leaf_d[Lf];
+          double xs[16];
+#pragma unroll
+          for (int el = 0; el < 8; ++el) {
+            struct alignas(16) Pair { double x, y; };
+            const Pair pr = *reinterpret_cast<const Pair*>(svals + el * (2 * kFlrLeafStride) + 2 * Lf);
+            xs[2 * el] = pr.x;
+            xs[2 * el + 1] = pr.y;
+          }
+          const uint32_t di = dinfo[d];
+          const double oa = open_acc[d];
+          const int j = Lf - (int)(di & 0xFFFu), p0 = (int)((di >> 12) & 15u), c = (int)(di >> 16);
+          const int q0 = j == 0 ? p0 : 0;
+          int q1 = p0 + c - 16 * j;
+          q1 = q1 < 16 ? q1 : 16;
+          double a = (j == 0 && p0 > 0) ? oa : 0.0;
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (q >= q0 && q < q1) a += xs[q];
+          if (a != a) {
+            a = (j == 0 && p0 > 0) ? oa : 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              if (q >= q0 && q < q1) a = pw_leaf_add(a, xs[q]);
+          }
+          leafsum[Lf] = a;
+        }
+      }
+      __syncthreads();
+      if (wave == 0 && tile_c > 0) {
+        const int p0 = pos, c = tile_c;
+        const int nl = (p0 + c + 15) >> 4, nfull = (p0 + c) >> 4;
+        const double* lf = leafsum + tile_lp;
+        const double last = lf[nl - 1];
+        for (int j = 0; j < nfull; ++j) {
+          if (!first_leaf_seen && head_partial) {  // the group's first global leaf, incomplete on this rank: its rows left raw
+            first_leaf_seen = true;
+            continue;
+          }
+          first_leaf_seen = true;
+          // push at the global leaf index: real pending sibling -> merge and carry; virtual sibling -> this node is an orphan (a record,
+          // at once: orphans arise in row order), the carry is virtual; free level -> the node (or the virtual carry) waits there
+          double v = lf[j];
+          bool real = true;
+          int cur = 0;
+          unsigned long long m = 1ull;
+          for (;;) {
+            if (!(cmask & m)) {
+              cmask |= m;
+              if (real) csum[cur][lane] = v;
+              else vmask |= m;
+              break;
+            }
+            if (vmask & m) {
+              if (real) {
+                rec_key[rec_at] = my_gkey + cur + 1;
+                rec_val[rec_at] = v;
+                ++rec_at;
+                real = false;
+              }
+              vmask &= ~m;
+            } else {
+              v = pw_merge(csum[cur][lane], v);  // (a virtual carry never meets a real pending node: that node would begin before kf)
+            }
+            cmask &= ~m;
+            ++cur;
+            m <<= 1;
+          }
+        }
+        const int rem = (p0 + c) & 15;
+        pos = rem;
+        if (rem) open_acc[lane] = last;
+      }
+    }
+    if (wave == 0 && live) {
+      const unsigned long long pend = cmask & ~vmask;
+      for (int l = kEmLevels - 1; l >= 0; --l)
+        if ((pend >> l) & 1ull) {
+          rec_key[rec_at] = my_gkey + l + 1;
+          rec_val[rec_at] = csum[l][lane];
+          ++rec_at;
+        }
+    }
+    __syncthreads();
+  }
+}
+// record offsets of the plan (emission order j, local group order[j]) by local group id
+__global__ void k_rec_off_by_group(const int64_t* __restrict__ rec_off, const int64_t* __restrict__ order, int64_t G, int64_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < G; j += stride) out[order ? order[j] : j] = rec_off[j];
+}
 __global__ void k_replay_keys(const int64_t* __restrict__ rec_key, int64_t m, int64_t gid_lo, int64_t n_own, uint32_t* __restrict__ slot,
                               uint32_t* __restrict__ lvl, unsigned int* __restrict__ bad, int pack_shift) {
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -236,6 +493,11 @@ struct pdx_grouped {
   const int64_t* prefix = nullptr;
   const int64_t* order = nullptr;
   int64_t total = -1;
+  // fused record emission (k_flr_emit): the values sorted by the low slot bits only; vals_sorted is filled by the third pass on demand
+  bool two_pass = false;
+  NarrowTwo two{};
+  unsigned int* dmax = nullptr;      // device: rows of the longest run (+ two unused words of k_run_max_len)
+  unsigned int hmax[3] = {0, 0, 0};  // read back with the plan's total
   mutable hipStream_t stream = nullptr;
   std::vector<void*> owned;
   template <typename T>
@@ -287,9 +549,20 @@ int pdx_groupby_group_values(pdx_groupby* gb, const pdx_column* values, void* st
     const uint32_t* ks = nullptr;
     const uint64_t* vs = nullptr;
     bool narrow_done = false;
+    // (inside the sharded orchestration, which only wants the records: two passes, the last digit is left to the emitting kernel)
+    static const bool emit_env = [] { const char* e = getenv("PDX_DIST_FUSED_EMIT"); return !(e && e[0] == '0'); }();
+    const bool want_two = emit_env && fused_emit_wanted();
     int rc = sort_values_narrow_full(gb, static_cast<const uint64_t*>(values->values) + values->offset,
-                                     [&](size_t bytes) { return (void*)g->own<uint8_t>(bytes); }, s, st, &vs, g->seg_start, &narrow_done);
+                                     [&](size_t bytes) { return (void*)g->own<uint8_t>(bytes); }, s, st, &vs, g->seg_start, &narrow_done,
+                                     want_two ? &g->two : nullptr);
     if (rc != PDX_OK) return rc;
+    if (narrow_done && g->two.k8) {
+      g->two_pass = true;
+      g->dmax = g->own<unsigned int>(3);
+      if (!g->dmax) return PDX_OOM;
+      PDX_HIP(hipMemsetAsync(g->dmax, 0, 3 * sizeof(unsigned int), st));
+      hipLaunchKernelGGL(k_run_max_len, dim3(grid_for(g->two.nruns, 256)), dim3(256), 0, st, g->two.run_start, g->two.nruns, g->dmax, kFlrMaxRun);
+    }
     if (!narrow_done) {
       rc = sort_values_by_slot(gb, static_cast<const uint64_t*>(values->values) + values->offset, nullptr, 0,
                                [&](size_t bytes) { return (void*)g->own<uint8_t>(bytes); }, s, st, &ks, &vs);
@@ -334,6 +607,7 @@ int pdx_grouped_partial_plan(pdx_grouped* g, const int64_t* prefix, const int64_
   PDX_SCRATCH_CHECK(s);
   hipLaunchKernelGGL(k_partial_plan, dim3(grid_for(g->G, 256)), dim3(256), 0, st, g->seg_start, g->occ_of_gid, order, g->G, prefix, g->rec_off);
   PDX_TRY((device_exclusive_scan<int64_t, SumOp>(g->rec_off, g->rec_off, g->G, total, s, st)));
+  if (g->two_pass) PDX_HIP(hipMemcpyAsync(g->hmax, g->dmax, sizeof(g->hmax), hipMemcpyDeviceToHost, st));
   PDX_HIP(hipMemcpyAsync(&g->total, total, sizeof(int64_t), hipMemcpyDeviceToHost, st));
   PDX_HIP(hipStreamSynchronize(st));
   *out_total = g->total;
@@ -344,7 +618,23 @@ int pdx_grouped_partial_fill(pdx_grouped* g, const int64_t* gid_map, int64_t* re
   if (g->total < 0 || !g->prefix) return fail(PDX_INVALID, "pdx_grouped_partial_fill: call pdx_grouped_partial_plan first");
   hipStream_t st = as_stream(stream);
   g->stream = st;  // frees of the handle's blocks are ordered behind this stream
-  if (g->G) {
+  static_assert(kFlrBits == 6, "NarrowTwo stops in front of a last digit of <= 6 bits");
+  if (g->G && g->two_pass && g->hmax[0] <= kFlrMaxRun) {
+    // the last digit and the records in one kernel over the runs (workgroup per run); record offsets by LOCAL group id for it
+    PDX_PROFILE("partial_fill", st);
+    Scratch s;
+    int64_t* rec_off_lg = s.get<int64_t>((size_t)g->G);
+    PDX_SCRATCH_CHECK(s);
+    hipLaunchKernelGGL(k_rec_off_by_group, dim3(grid_for(g->G, 256)), dim3(256), 0, st, g->rec_off, g->order, g->G, rec_off_lg);
+    const int grid = (int)std::min<int64_t>(g->two.nruns, (int64_t)kCUs * 8);
+    hipLaunchKernelGGL(k_flr_emit, dim3(grid), dim3(kSortBlock), 0, st, g->two.k8, reinterpret_cast<const double*>(g->two.v1), g->two.run_start, g->two.nruns,
+                       g->two.low_bits, g->gb->gid_of_slot, g->gb->nslots, g->G, g->prefix, g->seg_start, g->occ_of_gid, g->gb->occ_slot, rec_off_lg, gid_map, rec_key, rec_val);
+  } else if (g->G) {
+    if (g->two_pass && !g->vals_sorted) {  // a run too long for one workgroup (skewed keys): the third pass after all, then the per-group kernels
+      Scratch s;
+      PDX_TRY(finish_narrow_sort(g->two, g->n, s, st));
+      g->vals_sorted = reinterpret_cast<const double*>(g->two.v0);
+    }
     PDX_PROFILE("partial_fill", st);
     {
       const int wave_form = [] { const char* e = getenv("PDX_PARTIAL_FILL_WAVE"); return !(e && e[0] == '0'); }() ? 1 : 0;

@@ -95,9 +95,37 @@ static int narrow_pass(int bits, const K* kin, const uint64_t* vin, KO* kout, ui
 // Full stable sort of the values by dense slot with narrowing keys (three passes: 4 -> 2 -> 1 byte keys -> none) and every group's
 // offset from the scatter offsets (two levels of k_level_starts): 22 + 19 + 17 B/row instead of 3 x 24 + 2 x 4 (histograms) and no
 // search in sorted slots.  Returns PDX_OK with *done = false when the handle's layout does not fit (the caller takes the classic sort).
+// `two` (the sharded sums' fused record emission, k_flr_emit): stop after the second pass -- the values stay sorted by the low b0 + b1 slot
+// bits with the last digit beside them in a byte, the group offsets still come from the last digit's scatter offsets (its histogram is one
+// pass over the bytes), and the kernel that reads the runs does the last digit itself.  finish_narrow_sort() makes up for the third pass.
+struct NarrowTwo {
+  const uint8_t* k8 = nullptr;   // last digit of every row (rows sorted by the low bits)
+  const uint64_t* v1 = nullptr;  // the values in that order
+  uint64_t* v0 = nullptr;        // target of the third pass, should it be needed
+  uint32_t* run_start = nullptr; // starts of the 2^low_bits runs (+ n)
+  int64_t nruns = 0;
+  int low_bits = 0, last_bits = 0;
+};
+static int last_digit_offsets(int bits, const uint8_t* k8, int64_t n, uint32_t* hist, uint32_t* chunk, hipStream_t st) {
+  switch (bits) {
+    case 4: return radix_offsets<4, uint8_t>(k8, n, 0, hist, chunk, true, st);
+    case 5: return radix_offsets<5, uint8_t>(k8, n, 0, hist, chunk, true, st);
+    case 6: return radix_offsets<6, uint8_t>(k8, n, 0, hist, chunk, true, st);
+    case 7: return radix_offsets<7, uint8_t>(k8, n, 0, hist, chunk, true, st);
+    case 8: return radix_offsets<8, uint8_t>(k8, n, 0, hist, chunk, true, st);
+    default: return fail(PDX_INVALID, "narrowing sort: unsupported digit width");
+  }
+}
+static int finish_narrow_sort(const NarrowTwo& two, int64_t n, Scratch& s, hipStream_t st) {
+  const int64_t ntiles = ceil_div(n, kSortTile), nchunks = ceil_div(ntiles, kColChunk);
+  uint32_t* hist = s.get<uint32_t>((size_t)ntiles << 8);
+  uint32_t* chunk = s.get<uint32_t>((size_t)(nchunks + 1) << 8);
+  PDX_SCRATCH_CHECK(s);
+  return narrow_pass<uint8_t, uint8_t>(two.last_bits, two.k8, two.v1, (uint8_t*)nullptr, two.v0, n, nullptr, hist, chunk, st);
+}
 template <typename Alloc>
 static int sort_values_narrow_full(pdx_groupby* gb, const uint64_t* vin, Alloc&& alloc, Scratch& s, hipStream_t st, const uint64_t** vals_sorted,
-                                   uint32_t* seg_start_out, bool* done) {
+                                   uint32_t* seg_start_out, bool* done, NarrowTwo* two = nullptr) {
   *done = false;
   const int64_t n = gb->n, G = gb->G;
   const SortPlan plan = make_sort_plan(gb->slot_bits, sort_max_bits());
@@ -106,25 +134,36 @@ static int sort_values_narrow_full(pdx_groupby* gb, const uint64_t* vin, Alloc&&
   const int b0 = plan.bits[0], b1 = plan.bits[1], b2 = plan.bits[2];
   if (b0 > 8 || b1 > 8 || b2 > 8 || gb->slot_bits - b0 > 16 || b2 > 8 || gb->slot_bits != b0 + b1 + b2) return PDX_OK;
   const int64_t ntiles = ceil_div(n, kSortTile), nchunks = ceil_div(ntiles, kColChunk);
+  const bool stop_at_two = two != nullptr && b2 <= 6;  // (= kFlrBits: one lane per value of the last digit in k_flr_emit; asserted there)
   uint16_t* k16 = s.get<uint16_t>((size_t)n);
-  uint8_t* k8 = s.get<uint8_t>((size_t)n);
+  uint8_t* k8 = stop_at_two ? static_cast<uint8_t*>(alloc((size_t)n)) : s.get<uint8_t>((size_t)n);
   uint32_t* hist = s.get<uint32_t>((size_t)ntiles << 8);
   uint32_t* chunk = s.get<uint32_t>((size_t)(nchunks + 1) << 8);
-  uint32_t* starts1 = s.get<uint32_t>(((size_t)1 << (b0 + b1)) + 1);
+  uint32_t* starts1 = stop_at_two ? static_cast<uint32_t*>(alloc((((size_t)1 << (b0 + b1)) + 1) * 4)) : s.get<uint32_t>(((size_t)1 << (b0 + b1)) + 1);
   uint32_t* slot_start = s.get<uint32_t>(((size_t)1 << gb->slot_bits) + 1);
   PDX_SCRATCH_CHECK(s);
   uint64_t* v0 = static_cast<uint64_t*>(alloc((size_t)n * 8));
   uint64_t* v1 = static_cast<uint64_t*>(alloc((size_t)n * 8));
-  if (!v0 || !v1) return PDX_OOM;
+  if (!v0 || !v1 || !k8 || !starts1) return PDX_OOM;
   PDX_TRY((narrow_pass<uint32_t, uint16_t>(b0, gb->slot_of_row, vin, k16, v0, n, gb->pass0_off, hist, chunk, st)));
   PDX_TRY((narrow_pass<uint16_t, uint8_t>(b1, k16, v0, k8, v1, n, nullptr, hist, chunk, st)));
   hipLaunchKernelGGL((k_level_starts<uint16_t>), dim3(1u << b0), dim3(256), 0, st, k16, n, gb->pass0_off, (int64_t)1 << b0, b0, b1, hist, starts1);
-  PDX_TRY((narrow_pass<uint8_t, uint8_t>(b2, k8, v1, (uint8_t*)nullptr, v0, n, nullptr, hist, chunk, st)));
+  if (stop_at_two) PDX_TRY(last_digit_offsets(b2, k8, n, hist, chunk, st));  // (the offsets of the third pass without its scatter)
+  else PDX_TRY((narrow_pass<uint8_t, uint8_t>(b2, k8, v1, (uint8_t*)nullptr, v0, n, nullptr, hist, chunk, st)));
   hipLaunchKernelGGL((k_level_starts<uint8_t>), dim3((unsigned)std::min<int64_t>((int64_t)1 << (b0 + b1), 65536)), dim3(256), 0, st, k8, n, starts1,
                      (int64_t)1 << (b0 + b1), b0 + b1, b2, hist, slot_start);
   hipLaunchKernelGGL(k_seg_starts_from_slots, dim3(grid_for(G + 1, 256)), dim3(256), 0, st, slot_start, n, gb->occ_slot, G, seg_start_out);
   PDX_LAUNCH_CHECK();
-  *vals_sorted = v0;
+  *vals_sorted = stop_at_two ? nullptr : v0;
+  if (stop_at_two) {
+    two->k8 = k8;
+    two->v1 = v1;
+    two->v0 = v0;
+    two->run_start = starts1;
+    two->nruns = (int64_t)1 << (b0 + b1);
+    two->low_bits = b0 + b1;
+    two->last_bits = b2;
+  }
   *done = true;
   return PDX_OK;
 }

@@ -42,6 +42,15 @@ void* pinned_slot();  // 64 pinned bytes of this host thread (or nullptr)
 // their trailing hipStreamSynchronize (their outputs are device buffers, stream-ordered): one host wait per stage less
 bool defer_sync();
 void set_defer_sync(bool on);
+// thread-local: the sharded orchestration only wants the records of pdx_groupby_group_values' layout (never the sorted values themselves):
+// the layout may stop one sort pass early (gb_partial_tree.hpp, k_flr_emit)
+bool fused_emit_wanted();
+void set_fused_emit_wanted(bool on);
+struct FusedEmitScope {
+  bool prev;
+  FusedEmitScope() : prev(fused_emit_wanted()) { set_fused_emit_wanted(true); }
+  ~FusedEmitScope() { set_fused_emit_wanted(prev); }
+};
 struct DeferSyncScope {
   bool prev;
   DeferSyncScope() : prev(defer_sync()) { set_defer_sync(true); }

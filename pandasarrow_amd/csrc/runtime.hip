@@ -114,6 +114,9 @@ bool block_ready(const FreeBlock& b, hipStream_t want) {
 }
 }  // namespace
 
+thread_local bool t_fused_emit = false;
+bool fused_emit_wanted() { return t_fused_emit; }
+void set_fused_emit_wanted(bool on) { t_fused_emit = on; }
 thread_local bool t_defer_sync = false;
 bool defer_sync() { return t_defer_sync; }
 void set_defer_sync(bool on) { t_defer_sync = on; }

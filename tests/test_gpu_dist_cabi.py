@@ -418,3 +418,31 @@ def test_chunked_order_free_beyond_the_row_limit(shape, monkeypatch):
         else:
             assert np.array_equal(gv[eok], ev[eok]), (shape, kind)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("shape", ["three_full_chunks", "ragged_million_keys", "one_key_a_third_of_the_rows"])
+def test_chunked_groupby_fused_record_emission(shape):
+    """Dense keys and chunks of more than 2^22 rows: inside the orchestration the value sort stops after two passes and k_flr_emit does the
+    last digit and the partial-tree records in one kernel (the open leaf of every group starts with prefix % 16 virtual rows, the counter at
+    ceil(prefix / 16) with virtual bits: orphans and pending nodes).  Every chunk but the first has non-zero prefixes, the last chunk of the
+    ragged case is too small for the narrowing sort (classic sort + per-group fill in the same exchange), and the skewed case holds a run
+    longer than one workgroup takes (third pass after all).  NaN / inf values ride along.  Bit-identical to ONE tree over the column."""
+    import torch
+
+    from pandasarrow_amd import _lib as L
+    from pandasarrow_amd import dist as pdist
+    from pandasarrow_amd.column import Column
+
+    L.check(L.load().pdx_init(0))
+    n, nk, chunk = {"three_full_chunks": (12_900_000, 300_000, 4_300_000), "ragged_million_keys": (17_000_003, 1_000_000, 4_250_001),
+                    "one_key_a_third_of_the_rows": (9_000_000, 200_000, 4_500_000)}[shape]
+    rng = np.random.default_rng(len(shape))
+    keys = orc.synth_keys(0, n, nk) + 1000
+    if shape == "one_key_a_third_of_the_rows":
+        keys[rng.random(n) < 0.33] = 1234
+    vals = orc.synth_vals(0, n) - 0.5
+    m = rng.integers(0, n, n // 2000)
+    vals[m] = rng.choice(np.array([np.nan, -np.nan, np.inf, -np.inf, 1e300, -1e300]), m.size)
+    res = pdist.groupby_sum_mean_count_chunked(Column.from_numpy(keys), Column.from_numpy(vals), chunk)
+    _check(_to_host(res), keys, vals, None)
+    torch.cuda.synchronize()
