@@ -621,7 +621,7 @@ int pdx_grouped_partial_fill(pdx_grouped* g, const int64_t* gid_map, int64_t* re
   static_assert(kFlrBits == 6, "NarrowTwo stops in front of a last digit of <= 6 bits");
   if (g->G && g->two_pass && g->hmax[0] <= kFlrMaxRun) {
     // the last digit and the records in one kernel over the runs (workgroup per run); record offsets by LOCAL group id for it
-    PDX_PROFILE("partial_fill", st);
+    PDX_PROFILE("partial_fill_fused", st);
     Scratch s;
     int64_t* rec_off_lg = s.get<int64_t>((size_t)g->G);
     PDX_SCRATCH_CHECK(s);

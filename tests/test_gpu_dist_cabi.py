@@ -420,7 +420,7 @@ def test_chunked_order_free_beyond_the_row_limit(shape, monkeypatch):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("shape", ["three_full_chunks", "ragged_million_keys", "one_key_a_third_of_the_rows"])
+@pytest.mark.parametrize("shape", ["three_full_chunks", "ragged_million_keys", "one_key_a_third_of_the_rows", "few_large_groups"])
 def test_chunked_groupby_fused_record_emission(shape):
     """Dense keys and chunks of more than 2^22 rows: inside the orchestration the value sort stops after two passes and k_flr_emit does the
     last digit and the partial-tree records in one kernel (the open leaf of every group starts with prefix % 16 virtual rows, the counter at
@@ -434,15 +434,32 @@ def test_chunked_groupby_fused_record_emission(shape):
     from pandasarrow_amd.column import Column
 
     L.check(L.load().pdx_init(0))
-    n, nk, chunk = {"three_full_chunks": (12_900_000, 300_000, 4_300_000), "ragged_million_keys": (17_000_003, 1_000_000, 4_250_001),
-                    "one_key_a_third_of_the_rows": (9_000_000, 200_000, 4_500_000)}[shape]
+    n, nk, chunk = {"three_full_chunks": (12_900_000, 300_000, 4_300_000), "ragged_million_keys": (17_500_003, 1_000_000, 4_250_001),
+                    "one_key_a_third_of_the_rows": (9_000_000, 200_000, 4_500_000), "few_large_groups": (13_100_000, 3_000, 4_333_333)}[shape]
     rng = np.random.default_rng(len(shape))
     keys = orc.synth_keys(0, n, nk) + 1000
+    if shape == "few_large_groups":  # 3000 keys spread over a 19-bit dense domain: ~1400 rows per group and chunk -> orphans up to level 6
+        keys = (keys - 1000) * 97 + 1000
     if shape == "one_key_a_third_of_the_rows":
         keys[rng.random(n) < 0.33] = 1234
     vals = orc.synth_vals(0, n) - 0.5
     m = rng.integers(0, n, n // 2000)
     vals[m] = rng.choice(np.array([np.nan, -np.nan, np.inf, -np.inf, 1e300, -1e300]), m.size)
-    res = pdist.groupby_sum_mean_count_chunked(Column.from_numpy(keys), Column.from_numpy(vals), chunk)
+    import ctypes as C
+
+    lib = L.load()
+    L.check(lib.pdx_profile_enable(1))
+    L.check(lib.pdx_profile_reset())
+    try:
+        res = pdist.groupby_sum_mean_count_chunked(Column.from_numpy(keys), Column.from_numpy(vals), chunk)
+        buf = C.create_string_buffer(1 << 16)
+        L.check(lib.pdx_profile_report(buf, len(buf)))
+    finally:
+        lib.pdx_profile_enable(0)
+    tags = {ln.split()[0]: int(ln.split()[1]) for ln in buf.value.decode().splitlines() if ln.strip()}
+    # (the path under test did run: the fused emission in every chunk that is large enough and not skewed, the per-group kernels elsewhere)
+    fused, classic = tags.get("partial_fill_fused", 0), tags.get("partial_fill", 0)
+    assert (fused, classic) == {"three_full_chunks": (3, 0), "ragged_million_keys": (4, 1), "one_key_a_third_of_the_rows": (0, 2),
+                                "few_large_groups": (3, 1)}[shape], tags
     _check(_to_host(res), keys, vals, None)
     torch.cuda.synchronize()
