@@ -8,24 +8,7 @@
 // =====================================================================================================================
 namespace pdx {
 
-__device__ __forceinline__ int64_t aligned_block_level(int64_t s, int64_t kl) {
-  // largest j with s % 2^j == 0 and s + 2^j <= kl
-  int tz = s == 0 ? 62 : __ffsll((unsigned long long)s) - 1;
-  int64_t room = kl - s;
-  int lg = 63 - __clzll((unsigned long long)room);
-  return tz < lg ? tz : lg;
-}
-__device__ __forceinline__ int64_t partial_record_count(int64_t a, int64_t c) {
-  if (c <= 0) return 0;
-  int64_t b = a + c, kf = (a + 15) >> 4, kl = b >> 4;
-  if (kf > kl) return c;  // the whole range lies inside one leaf
-  int64_t cnt = (16 * kf - a) + (b - 16 * kl);
-  for (int64_t s = kf; s < kl;) {
-    s += (int64_t)1 << aligned_block_level(s, kl);
-    ++cnt;
-  }
-  return cnt;
-}
+// (aligned_block_level / partial_record_count: pairwise.hpp, shared with the owners' replay in dist.hip)
 
 __global__ void k_grouped_counts(const uint32_t* __restrict__ seg_start, const uint32_t* __restrict__ gid_of_occ, int64_t G,
                                  int64_t* __restrict__ out) {

@@ -79,6 +79,27 @@ struct PairwiseCounter {
   }
 };
 
+// ---- the partial-tree records of a group's rows [a, a + c) in its global row numbering (multi-GPU exchange, gb_partial_tree.hpp): the rows in
+// front of the first and behind the last 16-row leaf boundary one by one, the leaves in between as the aligned blocks of the tree
+__device__ __forceinline__ int64_t aligned_block_level(int64_t s, int64_t kl) {
+  // largest j with s % 2^j == 0 and s + 2^j <= kl
+  int tz = s == 0 ? 62 : __ffsll((unsigned long long)s) - 1;
+  int64_t room = kl - s;
+  int lg = 63 - __clzll((unsigned long long)room);
+  return tz < lg ? tz : lg;
+}
+__device__ __forceinline__ int64_t partial_record_count(int64_t a, int64_t c) {
+  if (c <= 0) return 0;
+  int64_t b = a + c, kf = (a + 15) >> 4, kl = b >> 4;
+  if (kf > kl) return c;  // the whole range lies inside one leaf
+  int64_t cnt = (16 * kf - a) + (b - 16 * kl);
+  for (int64_t s = kf; s < kl;) {
+    s += (int64_t)1 << aligned_block_level(s, kl);
+    ++cnt;
+  }
+  return cnt;
+}
+
 // perfect pairwise tree over the 64 lanes of a wave: lane 0 ends with ((l0+l1)+(l2+l3))+...  (6 levels)
 __device__ __forceinline__ double wave_tree64(double x) {
 #pragma unroll
