@@ -304,7 +304,8 @@ int pdx_groupby_last_plan(const pdx_groupby* gb, char* buf, size_t buf_len);
  * rank holds the global ranks [P, P+c) of a group.  Instead of shipping its rows to the group's owner, a rank ships
  *   - the raw values of the (at most two) 16-value leaves it shares with its neighbours ("fragments"), and
  *   - one node per maximal ALIGNED power-of-two block of the leaves that lie completely inside its range,
- * as records (key = global_gid * 64 + level + 1; level + 1 == 0 marks a fragment value).  The owner replays the records of a
+ * as records (key = global_gid * 64 + code; code 0 = one row of a leaf begun on a lower rank, 1..28 = a tree node of level code - 1,
+ * 32 + k = the first k rows of a leaf as their sequential sum).  The owner replays the records of a
  * group in (rank, emission) order through Arrow's binary counter: bit-identical to the single-process result, with
  * O(32 + 2 log c) instead of c values per group and rank.
  *

@@ -248,6 +248,10 @@ __global__ void __launch_bounds__(256) k_replay_ranked(const int64_t* __restrict
             acc = 0.0;
             fill = 0;
           }
+        } else if (l > kPartialLeafCode) {  // the first l - 32 rows of a leaf, already summed in order
+          if (fill != 0) atomicExch(bad, 2u);
+          acc = rec_val[i];
+          fill = l - kPartialLeafCode;
         } else {
           if (fill != 0) atomicExch(bad, 2u);  // a node must start on a leaf boundary
           cn.push(rec_val[i], l - 1);

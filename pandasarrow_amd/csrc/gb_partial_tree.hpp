@@ -73,7 +73,12 @@ __global__ void __launch_bounds__(256) k_partial_fill(const double* __restrict__
       ++pos;
       sidx += nleaf;
     }
-    for (int64_t i = 16 * kl - a; i < c; ++i) { rec_key[pos] = gkey; rec_val[pos] = v[i]; ++pos; }
+    if (b > 16 * kl) {  // the rows that begin the last leaf: their sequential sum
+      double acc = 0.0;
+      for (int64_t i = 16 * kl - a; i < c; ++i) acc = pw_leaf_add(acc, v[i]);
+      rec_key[pos] = gkey + kPartialLeafCode + (b - 16 * kl);
+      rec_val[pos] = acc;
+    }
   }
 }
 
@@ -149,9 +154,11 @@ __global__ void __launch_bounds__(256) k_partial_fill_wave(const double* __restr
       sidx += (int64_t)1 << lvl;
     }
     const int ntail = (int)(b - 16 * kl);
-    if (lane < ntail) {
-      rec_key[pos + lane] = gkey;
-      rec_val[pos + lane] = v[16 * kl - a + lane];
+    if (lane == 0 && ntail > 0) {  // the rows that begin the last leaf: their sequential sum, one record
+      double acc = 0.0;
+      for (int q = 0; q < ntail; ++q) acc = pw_leaf_add(acc, v[16 * kl - a + q]);
+      rec_key[pos] = gkey + kPartialLeafCode + ntail;
+      rec_val[pos] = acc;
     }
   }
 }
@@ -201,6 +208,7 @@ __global__ void __launch_bounds__(kSortBlock, 3) k_flr_emit(const uint8_t* __res
     unsigned long long cmask = 0, vmask = 0;
     long long nrows = 0, my_roff = 0, my_gkey = 0, rec_at = 0;
     uint32_t my_head = 0, my_tail0 = 0;
+    int my_ntail = 0;
     bool head_partial = false, first_leaf_seen = false, live = false;
     int tile_c = 0, tile_lp = 0;
     if (wave == 0) {
@@ -227,11 +235,13 @@ __global__ void __launch_bounds__(kSortBlock, 3) k_flr_emit(const uint8_t* __res
       head_partial = pos != 0 || allraw;  // the first leaf this group finishes is not a node (its rows leave raw)
       cmask = vmask = allraw ? 0ull : (unsigned long long)kf;
       my_head = (uint32_t)h;
-      my_tail0 = (uint32_t)(C - ntail);
+      my_tail0 = 0xFFFFFFFFu;  // (the rows that begin the last leaf stay inside: the open leaf's sum is their record)
+      my_ntail = (int)ntail;
       rec_at = my_roff + h;  // the next node record (orphans leave as they arise, the pending nodes at the end of the run)
       g_head[lane] = my_head;
       g_tail0[lane] = my_tail0;
-      g_tailbase[lane] = (int)(h + nnodes - (C - ntail));
+      g_tailbase[lane] = 0;
+      (void)nnodes;
       g_roff[lane] = my_roff;
       g_gkey[lane] = my_gkey;
       open_acc[lane] = 0.0;
@@ -404,6 +414,10 @@ __global__ void __launch_bounds__(kSortBlock, 3) k_flr_emit(const uint8_t* __res
           rec_val[rec_at] = csum[l][lane];
           ++rec_at;
         }
+      if (my_ntail > 0) {  // the open leaf: the rows behind the last leaf boundary, summed in order by the leaf phase
+        rec_key[rec_at] = my_gkey + kPartialLeafCode + my_ntail;
+        rec_val[rec_at] = open_acc[lane];
+      }
     }
     __syncthreads();
   }
@@ -449,6 +463,10 @@ __global__ void __launch_bounds__(256) k_replay(const uint32_t* __restrict__ seg
           acc = 0.0;
           fill = 0;
         }
+      } else if (l > (uint32_t)kPartialLeafCode) {  // the first l - 32 rows of a leaf, already summed in order
+        if (fill != 0) atomicExch(bad, 2u);
+        acc = val[i];
+        fill = (int)l - kPartialLeafCode;
       } else {
         if (fill != 0) atomicExch(bad, 2u);  // a node must start on a leaf boundary
         cn.push(val[i], (int)l - 1);

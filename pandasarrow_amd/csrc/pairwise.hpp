@@ -88,11 +88,16 @@ __device__ __forceinline__ int64_t aligned_block_level(int64_t s, int64_t kl) {
   int lg = 63 - __clzll((unsigned long long)room);
   return tz < lg ? tz : lg;
 }
+// record codes (key & 63): 0 = one row of a leaf begun on a lower rank; 1 .. 28 = a tree node of level code - 1; kPartialLeafCode + k = the
+// first k rows (1 <= k <= 15) of a leaf as their sequential sum -- the owner continues that leaf with the next rank's rows.  (Until round 4
+// these rows travelled one by one: with 125 rows per group and rank that was 7.5 of 17.5 records.)
+constexpr int kPartialLeafCode = 32;
 __device__ __forceinline__ int64_t partial_record_count(int64_t a, int64_t c) {
   if (c <= 0) return 0;
   int64_t b = a + c, kf = (a + 15) >> 4, kl = b >> 4;
-  if (kf > kl) return c;  // the whole range lies inside one leaf
-  int64_t cnt = (16 * kf - a) + (b - 16 * kl);
+  if (kf > kl) return c;  // the whole range lies inside one leaf (begun on a lower rank): every row is a record
+  // the rows behind the last leaf boundary BEGIN a leaf: they leave as ONE record, their sequential sum (kPartialLeafCode + rows)
+  int64_t cnt = (16 * kf - a) + (b > 16 * kl ? 1 : 0);
   for (int64_t s = kf; s < kl;) {
     s += (int64_t)1 << aligned_block_level(s, kl);
     ++cnt;

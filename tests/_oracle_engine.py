@@ -123,8 +123,12 @@ class OracleEngine:
                 keys.append(gkey + j + 1)
                 vals.append(cn.sum[j])
             t0 = 16 * kl - a
-            keys += [gkey] * (c - t0)
-            vals += list(v[t0:])
+            if c > t0:  # the rows that begin the last leaf: ONE record, their sequential sum (code 32 + rows)
+                acc = 0.0
+                for x in v[t0:]:
+                    acc = acc + float(x)
+                keys.append(gkey + 32 + (c - t0))
+                vals.append(acc)
         return torch.tensor(keys, dtype=torch.int64), torch.tensor(vals, dtype=torch.float64)
 
     def replay(self, rec_key, rec_val, gid_lo, n_own):
@@ -143,6 +147,9 @@ class OracleEngine:
                     if fill == 16:
                         cn.push(acc, 0)
                         acc, fill = 0.0, 0
+                elif lvl > 32:  # the first lvl - 32 rows of a leaf, already summed in order
+                    assert fill == 0
+                    acc, fill = val, lvl - 32
                 else:
                     assert fill == 0
                     cn.push(val, lvl - 1)
