@@ -240,7 +240,12 @@ int pdx_groupby_create(const pdx_column* key, void* stream, pdx_groupby** out) {
     // per-tile histogram of the first sort digit
     const int64_t ntiles = ceil_div(n, kSortTile), nchunks = ceil_div(ntiles, kColChunk);
     const int bits0 = make_sort_plan(ilog2((uint64_t)nslots), sort_max_bits()).bits[0];
-    int64_t prefix = std::min<int64_t>(n, std::max<int64_t>((int64_t)1 << 22, 16 * nslots));
+    // rows that go through the full first-row protocol before the tail's bitmap is taken: a slot unseen by then costs one global atomic per
+    // later row of its key.  16 rows per slot leave e^-16 of uniformly spread keys unseen; below 2^29 rows 8 per slot (e^-8 = 3e-4 of the
+    // slots, a few 10^4 atomics) -- the prefix pass is the slow one (60 Grows/s: a random read of first[] per row) and at an 8-GPU shard's
+    // size 16 per slot was 13 % of the rows, 0.28 ms of a 0.84 ms create
+    const int64_t per_slot = [n] { const char* e = getenv("PDX_DENSE_PREFIX_PER_SLOT"); return e && atoi(e) > 0 ? (int64_t)atoi(e) : (n < ((int64_t)1 << 29) ? 8 : 16); }();
+    int64_t prefix = std::min<int64_t>(n, std::max<int64_t>((int64_t)1 << 22, per_slot * nslots));
     prefix = std::min<int64_t>(n, round_up(prefix, kSortTile));
     const bool fuse = bits0 >= 4 && bits0 <= 8;
     const int64_t nwords = (nslots + 31) >> 5;
