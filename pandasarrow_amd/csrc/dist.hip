@@ -176,13 +176,19 @@ __global__ void k_scatter_iota(const int64_t* __restrict__ idx, int64_t n, int64
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[idx[i]] = i;
 }
+// the counts travel as 32-bit words (a rank holds < 2^31 rows): half the bytes of the one collective that sits between the sort and the emission
+__global__ void k_scatter_i64_to_u32(const int64_t* __restrict__ src, const int64_t* __restrict__ idx, int64_t n, uint32_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[idx[i]] = (uint32_t)src[i];
+}
 // allc[W][G] -> rows of group g on lower ranks, rows of group g on all ranks
-__global__ void k_count_prefix(const int64_t* __restrict__ allc, int W, int rank, int64_t G, int64_t* __restrict__ prefix, int64_t* __restrict__ total) {
+template <typename CT>
+__global__ void k_count_prefix(const CT* __restrict__ allc, int W, int rank, int64_t G, int64_t* __restrict__ prefix, int64_t* __restrict__ total) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < G; g += stride) {
     int64_t p = 0, t = 0;
     for (int s = 0; s < W; ++s) {
-      const int64_t c = allc[(int64_t)s * G + g];
+      const int64_t c = (int64_t)allc[(int64_t)s * G + g];
       if (s < rank) p += c;
       t += c;
     }
@@ -209,14 +215,15 @@ __global__ void k_record_cuts(const int64_t* __restrict__ rec_key, int64_t m, in
 // holds anyway (allc[p][g] rows of group g on rank p: a = the rows on lower ranks, c = its own): the segment of (p, g) starts at the
 // exclusive sum of the record counts in (p, g) order -- which is also the order of the received buffer.  (The records used to be sorted by
 // group with three radix passes: 0.36 of the 3.9 ms per-rank step.)
-__global__ void k_record_counts(const int64_t* __restrict__ allc, int W, int64_t G, int64_t gid_lo, int64_t n_own, int64_t* __restrict__ out) {
+template <typename CT>
+__global__ void k_record_counts(const CT* __restrict__ allc, int W, int64_t G, int64_t gid_lo, int64_t n_own, int64_t* __restrict__ out) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x, total = (int64_t)W * n_own;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int p = (int)(i / n_own);
     const int64_t g = gid_lo + i % n_own;
     int64_t a = 0;
-    for (int q = 0; q < p; ++q) a += allc[(int64_t)q * G + g];
-    out[i] = partial_record_count(a, allc[(int64_t)p * G + g]);
+    for (int q = 0; q < p; ++q) a += (int64_t)allc[(int64_t)q * G + g];
+    out[i] = partial_record_count(a, (int64_t)allc[(int64_t)p * G + g]);
   }
 }
 __global__ void __launch_bounds__(256) k_replay_ranked(const int64_t* __restrict__ rec_key, const double* __restrict__ rec_val, int64_t m,
@@ -899,7 +906,7 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
   PDX_SCRATCH_CHECK(s);
   PDX_TRY(pdx_grouped_counts(h.gv, cnt_local, st));
   int64_t* order = nullptr;
-  const int64_t* counts_by_rank = cnt_local;  // [W][G] rows of every group on every rank (one rank: the local counts, local id = global id)
+  const uint32_t* counts_by_rank = nullptr;  // [W][G] rows of every group on every rank (null on one rank: the local counts, local id = global id)
   if (solo) {
     if (G) {
       PDX_HIP(hipMemcpyAsync(res->counts, cnt_local, (size_t)G * 8, hipMemcpyDeviceToDevice, st));
@@ -907,24 +914,24 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
     }
   } else {
     // ---- 4. rows per (global group, rank): dense count vectors, all-gathered; prefix over the lower ranks
-    int64_t* dense = s.get<int64_t>((size_t)G);
-    int64_t* allc = s.get<int64_t>((size_t)G * W);
+    uint32_t* dense = s.get<uint32_t>((size_t)G);
+    uint32_t* allc = s.get<uint32_t>((size_t)G * W);
     int64_t* prefix_g = s.get<int64_t>((size_t)G);
     int64_t* inv = s.get<int64_t>((size_t)G);
     order = s.get<int64_t>((size_t)Gl);
     PDX_SCRATCH_CHECK(s);
     if (G) {
-      PDX_HIP(hipMemsetAsync(dense, 0, (size_t)G * 8, st));
+      PDX_HIP(hipMemsetAsync(dense, 0, (size_t)G * 4, st));
       PDX_HIP(hipMemsetAsync(inv, 0xFF, (size_t)G * 8, st));
     }
     if (Gl) {
-      hipLaunchKernelGGL(k_scatter_i64, dim3(grid_for(Gl, 256)), dim3(256), 0, st, cnt_local, my_map, Gl, dense);
+      hipLaunchKernelGGL(k_scatter_i64_to_u32, dim3(grid_for(Gl, 256)), dim3(256), 0, st, cnt_local, my_map, Gl, dense);
       hipLaunchKernelGGL(k_scatter_iota, dim3(grid_for(Gl, 256)), dim3(256), 0, st, my_map, Gl, inv);
     }
     PDX_LAUNCH_CHECK();
-    PDX_TRY(d->tr.all_gather(d->tr.ctx, dense, allc, (size_t)G * 8, st));
+    PDX_TRY(d->tr.all_gather(d->tr.ctx, dense, allc, (size_t)G * 4, st));
     counts_by_rank = allc;
-    if (G) hipLaunchKernelGGL(k_count_prefix, dim3(grid_for(G, 256)), dim3(256), 0, st, allc, W, r, G, prefix_g, res->counts);
+    if (G) hipLaunchKernelGGL((k_count_prefix<uint32_t>), dim3(grid_for(G, 256)), dim3(256), 0, st, allc, W, r, G, prefix_g, res->counts);
     if (Gl) hipLaunchKernelGGL(k_gather_i64, dim3(grid_for(Gl, 256)), dim3(256), 0, st, prefix_g, my_map, Gl, prefix_local);
     PDX_LAUNCH_CHECK();
     // records are emitted group by group in GLOBAL-id order, so they leave the kernel already partitioned by owner rank:
@@ -991,7 +998,10 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
     unsigned int* bad = s.get<unsigned int>(1);
     PDX_SCRATCH_CHECK(s);
     PDX_HIP(hipMemsetAsync(bad, 0, sizeof(unsigned int), st));
-    hipLaunchKernelGGL(k_record_counts, dim3(grid_for(cells, 256)), dim3(256), 0, st, counts_by_rank, W, G, bounds[(size_t)r], n_own, seg);
+    if (counts_by_rank)
+      hipLaunchKernelGGL((k_record_counts<uint32_t>), dim3(grid_for(cells, 256)), dim3(256), 0, st, counts_by_rank, W, G, bounds[(size_t)r], n_own, seg);
+    else
+      hipLaunchKernelGGL((k_record_counts<int64_t>), dim3(grid_for(cells, 256)), dim3(256), 0, st, cnt_local, W, G, bounds[(size_t)r], n_own, seg);
     PDX_LAUNCH_CHECK();
     PDX_TRY((device_exclusive_scan<int64_t, SumOp>(seg, seg, cells, seg_total, s, st)));
     PDX_HIP(hipMemcpyAsync(seg + cells, seg_total, sizeof(int64_t), hipMemcpyDeviceToDevice, st));
