@@ -322,7 +322,11 @@ int pdx_groupby_group_values(pdx_groupby* gb, const pdx_column* values, void* st
 int pdx_grouped_destroy(pdx_grouped* g);
 int pdx_grouped_counts(pdx_grouped* g, int64_t* out_counts, void* stream);
 int pdx_grouped_partial_plan(pdx_grouped* g, const int64_t* prefix, const int64_t* order, int64_t* out_total, void* stream);
-int pdx_grouped_partial_fill(pdx_grouped* g, const int64_t* gid_map, int64_t* rec_key, double* rec_val, void* stream);
+int pdx_grouped_partial_fill(pdx_grouped* g, const int64_t* gid_map, int64_t* rec_key /* may be null: values only */, double* rec_val, void* stream);
+/* cuts[d], d = 0..world (device): where the records of owner d's groups -- global ids [G * d / world, G * (d + 1) / world) -- begin in this
+ * rank's record stream (emitted in global-id order: pass `order` to the plan).  With the rows every rank holds of every group known to all
+ * ranks, the codes of the records follow from (rows on lower ranks, own rows): only the values need to travel. */
+int pdx_grouped_record_cuts(pdx_grouped* g, const int64_t* gid_map, int64_t num_global_groups, int world, int64_t* cuts, void* stream);
 int pdx_replay_partials(const int64_t* rec_key, const double* rec_val, int64_t m, int64_t gid_lo, int64_t n_own, double* out_sum, void* stream);
 
 /* ---------------------------------------------------------------- resample

@@ -112,6 +112,7 @@ ABI_SYMBOLS = {
     "pdx_grouped_counts": (C.c_int, [_P, _P, _P]),
     "pdx_grouped_partial_plan": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int64), _P]),
     "pdx_grouped_partial_fill": (C.c_int, [_P, _P, _P, _P, _P]),
+    "pdx_grouped_record_cuts": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P]),
     "pdx_replay_partials": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "pdx_resample_create": (C.c_int, [_COL, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, _P, C.POINTER(_P)]),
     "pdx_resample_grid": (C.c_int, [C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

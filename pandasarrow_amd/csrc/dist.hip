@@ -226,9 +226,13 @@ __global__ void k_record_counts(const CT* __restrict__ allc, int W, int64_t G, i
     out[i] = partial_record_count(a, (int64_t)allc[(int64_t)p * G + g]);
   }
 }
-__global__ void __launch_bounds__(256) k_replay_ranked(const int64_t* __restrict__ rec_key, const double* __restrict__ rec_val, int64_t m,
-                                                       const int64_t* __restrict__ seg /* [W][n_own] exclusive, + total at the end */, int W,
-                                                       int64_t gid_lo, int64_t n_own, double* __restrict__ out, unsigned int* __restrict__ bad) {
+// A thread per owned group walks its W segments.  VALUES ONLY travel: the codes of rank p's records of group g follow from the rows it holds -- a = rows on lower ranks, c = its
+// own: the rows up to the first leaf boundary one by one, the aligned blocks of the leaves inside [a, a + c), the sum of the rows that begin
+// the last leaf -- exactly the order the emitting kernels use.  Halves the bytes of the record exchange (one all-to-all instead of two).
+template <typename CT>
+__global__ void __launch_bounds__(256) k_replay_ranked_values(const double* __restrict__ rec_val, int64_t m, const int64_t* __restrict__ seg,
+                                                              const CT* __restrict__ counts /* [W][G] */, int W, int64_t G, int64_t gid_lo,
+                                                              int64_t n_own, double* __restrict__ out, unsigned int* __restrict__ bad) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_own; j += stride) {
     PairwiseCounter cn;
@@ -236,34 +240,43 @@ __global__ void __launch_bounds__(256) k_replay_ranked(const int64_t* __restrict
     double acc = 0.0;
     int fill = 0;
     bool any = false;
+    int64_t a = 0;
     for (int p = 0; p < W; ++p) {
+      const int64_t c = (int64_t)counts[(int64_t)p * G + gid_lo + j];
       const int64_t at = (int64_t)p * n_own + j;
-      const int64_t i0 = seg[at], i1 = seg[at + 1];
-      if (i0 < 0 || i1 > m || i1 < i0) {
+      int64_t i = seg[at];
+      const int64_t i1 = seg[at + 1];
+      if (i < 0 || i1 > m || i1 < i || i1 - i != partial_record_count(a, c)) {
         atomicExch(bad, 4u);
         break;
       }
-      for (int64_t i = i0; i < i1; ++i) {
-        const int64_t key = rec_key[i];
-        if ((key >> 6) != gid_lo + j) atomicExch(bad, 1u);  // not this group's record: the counts and the records disagree
-        const int l = (int)(key & 63);
+      if (c > 0) {
         any = true;
-        if (l == 0) {  // fragment value: extend the running 16-value leaf
-          acc = pw_leaf_add(acc, rec_val[i]);
+        const int64_t b = a + c, kf = (a + 15) >> 4, kl = b >> 4;
+        const int64_t raw = kf > kl ? c : 16 * kf - a;  // rows that continue a leaf begun on a lower rank
+        for (int64_t q = 0; q < raw; ++q) {
+          acc = pw_leaf_add(acc, rec_val[i++]);
           if (++fill == 16) {
             cn.push(acc, 0);
             acc = 0.0;
             fill = 0;
           }
-        } else if (l > kPartialLeafCode) {  // the first l - 32 rows of a leaf, already summed in order
-          if (fill != 0) atomicExch(bad, 2u);
-          acc = rec_val[i];
-          fill = l - kPartialLeafCode;
-        } else {
-          if (fill != 0) atomicExch(bad, 2u);  // a node must start on a leaf boundary
-          cn.push(rec_val[i], l - 1);
+        }
+        if (kf <= kl) {
+          if (fill != 0) atomicExch(bad, 2u);  // the nodes start on a leaf boundary
+          for (int64_t sidx = kf; sidx < kl;) {
+            const int lvl = (int)aligned_block_level(sidx, kl);
+            cn.push(rec_val[i++], lvl);
+            sidx += (int64_t)1 << lvl;
+          }
+          if (b > 16 * kl) {  // the first rows of the next leaf, summed in order by their rank
+            acc = rec_val[i++];
+            fill = (int)(b - 16 * kl);
+          }
         }
       }
+      a += c;
+      if (p == W - 1 && j == n_own - 1 && i1 != m) atomicExch(bad, 5u);  // (the received buffer holds exactly what the counts announce)
     }
     if (fill) cn.push(acc, 0);
     if (!any) atomicExch(bad, 3u);
@@ -945,7 +958,9 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
   int64_t nrec = 0;
   PDX_TRY(pdx_grouped_partial_plan(h.gv, prefix_local, order, &nrec, st));
   tm.mark("partial_plan");
-  int64_t* rec_key = s.get<int64_t>((size_t)nrec);
+  // values only (PDX_DIST_REPLAY_SORT=1, the sorting replay, needs the keys as well)
+  static const bool ranked_replay = [] { const char* e = getenv("PDX_DIST_REPLAY_SORT"); return !(e && e[0] == '1'); }();
+  int64_t* rec_key = ranked_replay ? nullptr : s.get<int64_t>((size_t)nrec);
   double* rec_val = s.get<double>((size_t)nrec);
   PDX_SCRATCH_CHECK(s);
   PDX_TRY(pdx_grouped_partial_fill(h.gv, my_map, rec_key, rec_val, st));
@@ -961,8 +976,12 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
   if (!solo) {
     int64_t* dcuts = s.get<int64_t>((size_t)W + 1);
     PDX_SCRATCH_CHECK(s);
-    hipLaunchKernelGGL(k_record_cuts, dim3((unsigned)ceil_div(W + 1, 64)), dim3(64), 0, st, rec_key, nrec, G, W, dcuts);
-    PDX_LAUNCH_CHECK();
+    if (rec_key) {
+      hipLaunchKernelGGL(k_record_cuts, dim3((unsigned)ceil_div(W + 1, 64)), dim3(64), 0, st, rec_key, nrec, G, W, dcuts);
+      PDX_LAUNCH_CHECK();
+    } else {
+      PDX_TRY(pdx_grouped_record_cuts(h.gv, my_map, G, W, dcuts, st));
+    }
     // every rank's cut points (what I send and what I receive) straight from the device buffers: one all-gather, one host wait
     std::vector<int64_t> all_cuts;
     PDX_TRY(gather_device(d, dcuts, W + 1, &all_cuts, s, st));
@@ -978,17 +997,16 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
       at += rb[(size_t)p];
     }
     m = (int64_t)(at / 8);
-    rk = s.get<int64_t>((size_t)m);
+    rk = rec_key ? s.get<int64_t>((size_t)m) : nullptr;
     rv = s.get<double>((size_t)m);
     PDX_SCRATCH_CHECK(s);
-    PDX_TRY(d->tr.all_to_all_v(d->tr.ctx, rec_key, so.data(), sb.data(), rk, ro.data(), rb.data(), st));
+    if (rec_key) PDX_TRY(d->tr.all_to_all_v(d->tr.ctx, rec_key, so.data(), sb.data(), rk, ro.data(), rb.data(), st));
     PDX_TRY(d->tr.all_to_all_v(d->tr.ctx, rec_val, so.data(), sb.data(), rv, ro.data(), rb.data(), st));
   }
   // ---- 7. owners replay their groups' records in (source rank, emission) order; 8. all-gather(v) of the sums
   tm.mark("record_exchange");
   double* sums_own = solo ? res->sums : s.get<double>((size_t)n_own);
   PDX_SCRATCH_CHECK(s);
-  static const bool ranked_replay = [] { const char* e = getenv("PDX_DIST_REPLAY_SORT"); return !(e && e[0] == '1'); }();
   if (!ranked_replay) {
     PDX_TRY(pdx_replay_partials(rk, rv, m, bounds[(size_t)r], n_own, sums_own, st));  // (sorts the records by group first)
   } else if (n_own > 0) {
@@ -1007,7 +1025,12 @@ int pdx_dist_groupby_sum_mean_count(pdx_dist* d, const pdx_column* keys, const p
     PDX_HIP(hipMemcpyAsync(seg + cells, seg_total, sizeof(int64_t), hipMemcpyDeviceToDevice, st));
     {
       PDX_PROFILE("replay_partials", st);
-      hipLaunchKernelGGL(k_replay_ranked, dim3(grid_for(n_own, 256)), dim3(256), 0, st, rk, rv, m, seg, W, bounds[(size_t)r], n_own, sums_own, bad);
+      if (counts_by_rank)
+        hipLaunchKernelGGL((k_replay_ranked_values<uint32_t>), dim3(grid_for(n_own, 256)), dim3(256), 0, st, rv, m, seg, counts_by_rank, W, G,
+                           bounds[(size_t)r], n_own, sums_own, bad);
+      else
+        hipLaunchKernelGGL((k_replay_ranked_values<int64_t>), dim3(grid_for(n_own, 256)), dim3(256), 0, st, rv, m, seg, cnt_local, W, G, bounds[(size_t)r],
+                           n_own, sums_own, bad);
     }
     PDX_LAUNCH_CHECK();
     unsigned int hbad = 0;

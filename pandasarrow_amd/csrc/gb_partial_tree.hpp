@@ -49,11 +49,11 @@ __global__ void __launch_bounds__(256) k_partial_fill(const double* __restrict__
     const int64_t gkey = gid_map[lg] * 64;
     int64_t pos = rec_off[j];
     if (kf > kl) {
-      for (int64_t i = 0; i < c; ++i) { rec_key[pos] = gkey; rec_val[pos] = v[i]; ++pos; }
+      for (int64_t i = 0; i < c; ++i) { if (rec_key) rec_key[pos] = gkey; rec_val[pos] = v[i]; ++pos; }
       continue;
     }
     const int64_t h = 16 * kf - a;
-    for (int64_t i = 0; i < h; ++i) { rec_key[pos] = gkey; rec_val[pos] = v[i]; ++pos; }
+    for (int64_t i = 0; i < h; ++i) { if (rec_key) rec_key[pos] = gkey; rec_val[pos] = v[i]; ++pos; }
     for (int64_t sidx = kf; sidx < kl;) {
       const int lvl = (int)aligned_block_level(sidx, kl);
       const int64_t nleaf = (int64_t)1 << lvl;
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) k_partial_fill(const double* __restrict__
         if (acc != acc) acc = pw_leaf_redo(16, [&](int e) { return lv[q * 16 + e]; });
         cn.push(acc, 0);
       }
-      rec_key[pos] = gkey + lvl + 1;
+      if (rec_key) rec_key[pos] = gkey + lvl + 1;
       rec_val[pos] = cn.sum[lvl];
       ++pos;
       sidx += nleaf;
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) k_partial_fill(const double* __restrict__
     if (b > 16 * kl) {  // the rows that begin the last leaf: their sequential sum
       double acc = 0.0;
       for (int64_t i = 16 * kl - a; i < c; ++i) acc = pw_leaf_add(acc, v[i]);
-      rec_key[pos] = gkey + kPartialLeafCode + (b - 16 * kl);
+      if (rec_key) rec_key[pos] = gkey + kPartialLeafCode + (b - 16 * kl);
       rec_val[pos] = acc;
     }
   }
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) k_partial_fill_wave(const double* __restr
     if (kf > kl) {  // the whole range lies inside one leaf (< 31 rows): fragments only
       if (LPG == 64) continue;  // (emitted by the 16-lane form, which always runs)
       for (int64_t i = lane; i < c; i += LPG) {
-        rec_key[pos0 + i] = gkey;
+        if (rec_key) rec_key[pos0 + i] = gkey;
         rec_val[pos0 + i] = v[i];
       }
       continue;
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) k_partial_fill_wave(const double* __restr
     if (LPG == 64 && kl - kf <= 16) continue;       // (the 16-lane form's)
     const int h = (int)(16 * kf - a);
     if (lane < h) {
-      rec_key[pos0 + lane] = gkey;
+      if (rec_key) rec_key[pos0 + lane] = gkey;
       rec_val[pos0 + lane] = v[lane];
     }
     double t[kLevels + 1];
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) k_partial_fill_wave(const double* __restr
         double val = t[0];
 #pragma unroll
         for (int q = 1; q <= kLevels; ++q) val = lvl == q ? t[q] : val;
-        rec_key[pos] = gkey + lvl + 1;
+        if (rec_key) rec_key[pos] = gkey + lvl + 1;
         rec_val[pos] = val;
       }
       ++pos;
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) k_partial_fill_wave(const double* __restr
     if (lane == 0 && ntail > 0) {  // the rows that begin the last leaf: their sequential sum, one record
       double acc = 0.0;
       for (int q = 0; q < ntail; ++q) acc = pw_leaf_add(acc, v[16 * kl - a + q]);
-      rec_key[pos] = gkey + kPartialLeafCode + ntail;
+      if (rec_key) rec_key[pos] = gkey + kPartialLeafCode + ntail;
       rec_val[pos] = acc;
     }
   }
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(kSortBlock, 3) k_flr_emit(const uint8_t* __res
             const uint32_t i = g_before[d] + (p - (16u * (di & 0xFFFu) + ((di >> 12) & 15u)));
             const long long idx = i < g_head[d] ? (long long)i : (long long)i + g_tailbase[d];
             const long long at = g_roff[d] + idx;
-            rec_key[at] = g_gkey[d];
+            if (rec_key) rec_key[at] = g_gkey[d];
             rec_val[at] = val[q];
           }
         }
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(kSortBlock, 3) k_flr_emit(const uint8_t* __res
             }
             if (vmask & m) {
               if (real) {
-                rec_key[rec_at] = my_gkey + cur + 1;
+                if (rec_key) rec_key[rec_at] = my_gkey + cur + 1;
                 rec_val[rec_at] = v;
                 ++rec_at;
                 real = false;
@@ -410,12 +410,12 @@ __global__ void __launch_bounds__(kSortBlock, 3) k_flr_emit(const uint8_t* __res
       const unsigned long long pend = cmask & ~vmask;
       for (int l = kEmLevels - 1; l >= 0; --l)
         if ((pend >> l) & 1ull) {
-          rec_key[rec_at] = my_gkey + l + 1;
+          if (rec_key) rec_key[rec_at] = my_gkey + l + 1;
           rec_val[rec_at] = csum[l][lane];
           ++rec_at;
         }
       if (my_ntail > 0) {  // the open leaf: the rows behind the last leaf boundary, summed in order by the leaf phase
-        rec_key[rec_at] = my_gkey + kPartialLeafCode + my_ntail;
+        if (rec_key) rec_key[rec_at] = my_gkey + kPartialLeafCode + my_ntail;
         rec_val[rec_at] = open_acc[lane];
       }
     }
@@ -615,7 +615,8 @@ int pdx_grouped_partial_plan(pdx_grouped* g, const int64_t* prefix, const int64_
   return PDX_OK;
 }
 int pdx_grouped_partial_fill(pdx_grouped* g, const int64_t* gid_map, int64_t* rec_key, double* rec_val, void* stream) {
-  if (!g || !gid_map || !rec_key || !rec_val) return fail(PDX_INVALID, "pdx_grouped_partial_fill: null argument");
+  // (rec_key may be null: values only -- the owner of a group can regenerate every record's code from the rows (a, c) each rank holds)
+  if (!g || !gid_map || !rec_val) return fail(PDX_INVALID, "pdx_grouped_partial_fill: null argument");
   if (g->total < 0 || !g->prefix) return fail(PDX_INVALID, "pdx_grouped_partial_fill: call pdx_grouped_partial_plan first");
   hipStream_t st = as_stream(stream);
   g->stream = st;  // frees of the handle's blocks are ordered behind this stream
@@ -651,6 +652,32 @@ int pdx_grouped_partial_fill(pdx_grouped* g, const int64_t* gid_map, int64_t* re
   }
   PDX_LAUNCH_CHECK();
   if (!defer_sync()) PDX_HIP(hipStreamSynchronize(st));
+  return PDX_OK;
+}
+// where the records of every owner's groups begin in this rank's record stream: owner d holds the global ids [G * d / W, G * (d + 1) / W), the
+// records were emitted in global-id order (order = the local groups sorted by global id), so cut d is the record offset of the first local
+// group whose global id reaches the bound.  W + 1 values on the device (cuts[W] = all records).  After pdx_grouped_partial_plan.
+__global__ void k_record_cuts_by_group(const int64_t* __restrict__ rec_off, const int64_t* __restrict__ order, const int64_t* __restrict__ gid_map, int64_t Gl,
+                                       int64_t total, int64_t G, int W, int64_t* __restrict__ cuts) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d > W) return;
+  const int64_t bound = G * d / W;
+  int64_t lo = 0, hi = Gl;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (gid_map[order ? order[mid] : mid] < bound) lo = mid + 1;
+    else hi = mid;
+  }
+  cuts[d] = lo < Gl ? rec_off[lo] : total;
+}
+int pdx_grouped_record_cuts(pdx_grouped* g, const int64_t* gid_map, int64_t num_global_groups, int world, int64_t* cuts, void* stream) {
+  if (!g || !gid_map || !cuts || world <= 0) return fail(PDX_INVALID, "pdx_grouped_record_cuts: bad argument");
+  if (g->total < 0) return fail(PDX_INVALID, "pdx_grouped_record_cuts: call pdx_grouped_partial_plan first");
+  hipStream_t st = as_stream(stream);
+  g->stream = st;
+  hipLaunchKernelGGL(k_record_cuts_by_group, dim3((unsigned)ceil_div(world + 1, 64)), dim3(64), 0, st, g->rec_off, g->order, gid_map, g->G, g->total,
+                     num_global_groups, world, cuts);
+  PDX_LAUNCH_CHECK();
   return PDX_OK;
 }
 int pdx_replay_partials(const int64_t* rec_key, const double* rec_val, int64_t m, int64_t gid_lo, int64_t n_own, double* out_sum, void* stream) {
